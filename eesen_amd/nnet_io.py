@@ -1,0 +1,246 @@
+"""Reader / writer for Eesen's `<Nnet>` model files (Kaldi stream format, text and binary).
+
+Host-side utility: builds model files for tests / bench / the CLI mirror and reads back what the HIP
+library's own C++ serialiser (eesen_amd/csrc/nnet_format.cpp) wrote.  The format is the reference's:
+
+* stream header `\\0B` when binary (/root/reference/src/base/io-funcs-inl.h:183-187);
+* `<Nnet>` ... `</Nnet>` wrapper (src/net/net.cc:325-334);
+* per layer: marker, `<InputDim> d`, `<CellDim>`|`<OutputDim> d` (src/net/layer.cc:203-215), then
+  layer data: BiLstm(Parallel) src/net/bilstm-layer.h:317-493, Lstm(Parallel) src/net/lstm-layer.h:106-172,
+  AffineTransform src/net/affine-trans-layer.h:83-128, Softmax has none;
+* tensors: text `[ rows ]`, binary `FM `/`FV ` + sized ints + raw fp32 (src/cpucompute/matrix.cc:968-994,
+  src/cpucompute/vector.cc Write); ints/floats in binary are a size byte + LE payload
+  (src/base/io-funcs-inl.h:32-41, io-funcs.cc:51-55); bools are a bare `T`/`F` (io-funcs.cc:26-28).
+
+A model is a list of dict layers:
+  {"type": "BiLstmParallel", "input_dim": D, "output_dim": 2H, "learn_rate_coef": 1.0, "max_grad": 0.0,
+   "params": [W_x_fw, W_m_fw, b_fw, pi_fw, pf_fw, po_fw, W_x_bw, ...]}     (np.float32 arrays)
+"""
+from __future__ import annotations
+
+import io
+import struct
+from typing import BinaryIO, List
+
+import numpy as np
+
+LSTM_TYPES = ("BiLstmParallel", "LstmParallel", "BiLstm", "Lstm")
+_DROPOUT_TOKENS = [  # bilstm-layer.h:331-373, in this fixed order; (token, kind)
+    ("<ForwardDropoutFactor>", "f"), ("<ForwardTimeStepDropout>", "b"), ("<ForwardSequenceDropout>", "b"),
+    ("<RecurrentTimeStepDropout>", "b"), ("<RecurrentSequenceDropout>", "b"), ("<RNNDrop>", "b"),
+    ("<NoMemLossDropout>", "b"), ("<RecurrentDropoutFactor>", "f"), ("<TwiddleForward>", "b"),
+]
+
+
+def is_lstm(t: str) -> bool:
+    return t in LSTM_TYPES
+
+
+def param_shapes(layer_type: str, din: int, dout: int):
+    """Shapes of the parameter tensors in file order."""
+    if layer_type in ("BiLstmParallel", "BiLstm"):
+        H = dout // 2
+        one = [(4 * H, din), (4 * H, H), (4 * H,), (H,), (H,), (H,)]
+        return one + one
+    if layer_type in ("LstmParallel", "Lstm"):
+        H = dout
+        return [(4 * H, din), (4 * H, H), (4 * H,), (H,), (H,), (H,)]
+    if layer_type == "AffineTransform":
+        return [(dout, din), (dout,)]
+    if layer_type in ("Softmax", "Sigmoid", "Tanh"):
+        return []
+    raise ValueError(f"unknown layer type {layer_type}")
+
+
+# ------------------------------------------------------------------------------------------ writer
+def _fmt(x: float) -> str:
+    # the reference prints with the stream's default precision (lossy); both sides must read IDENTICAL
+    # values, so we print the shortest fp32-round-tripping string
+    # shortest decimal string that round-trips this fp32 value exactly
+    return np.format_float_scientific(np.float32(x), unique=True, trim="-") if x != 0 else "0"
+
+
+def _write_tensor_text(f, a: np.ndarray):
+    a = np.asarray(a, dtype=np.float32)
+    if a.ndim == 2:
+        f.write(" [\n")
+        for i, row in enumerate(a):
+            f.write("  " + " ".join(_fmt(v) for v in row) + (" ]\n" if i == a.shape[0] - 1 else "\n"))
+    else:
+        f.write(" [ " + " ".join(_fmt(v) for v in a) + " ]\n")
+
+
+def _wi(f: BinaryIO, v: int):
+    f.write(b"\x04" + struct.pack("<i", int(v)))
+
+
+def _wf(f: BinaryIO, v: float):
+    f.write(b"\x04" + struct.pack("<f", float(v)))
+
+
+def _write_tensor_bin(f: BinaryIO, a: np.ndarray):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 2:
+        f.write(b"FM ")
+        _wi(f, a.shape[0]); _wi(f, a.shape[1])
+    else:
+        f.write(b"FV ")
+        _wi(f, a.shape[0])
+    f.write(a.tobytes())
+
+
+def write_nnet(path: str, layers: List[dict], binary: bool = False, write_dropout_tokens: bool = True):
+    if binary:
+        with open(path, "wb") as f:
+            f.write(b"\x00B")
+            f.write(b"<Nnet> ")
+            for L in layers:
+                t = L["type"]
+                f.write(f"<{t}> ".encode()); f.write(b"<InputDim> "); _wi(f, L["input_dim"])
+                f.write(b"<CellDim> " if is_lstm(t) else b"<OutputDim> "); _wi(f, L["output_dim"])
+                if param_shapes(t, L["input_dim"], L["output_dim"]):
+                    f.write(b"<LearnRateCoef> "); _wf(f, L.get("learn_rate_coef", 1.0))
+                    f.write(b"<MaxGrad> "); _wf(f, L.get("max_grad", 0.0))
+                    if t.startswith("BiLstm") and write_dropout_tokens:
+                        for tok, kind in _DROPOUT_TOKENS:
+                            f.write(tok.encode() + b" ")
+                            if kind == "f": _wf(f, 0.0)
+                            else: f.write(b"F")
+                    for p in L["params"]:
+                        _write_tensor_bin(f, p)
+            f.write(b"</Nnet> ")
+        return
+    with open(path, "w") as f:
+        f.write("<Nnet> \n")
+        for L in layers:
+            t = L["type"]
+            f.write(f"<{t}> <InputDim> {L['input_dim']} " + ("<CellDim>" if is_lstm(t) else "<OutputDim>") + f" {L['output_dim']} \n")
+            if param_shapes(t, L["input_dim"], L["output_dim"]):
+                f.write(f"<LearnRateCoef> {_fmt(L.get('learn_rate_coef', 1.0))} <MaxGrad> {_fmt(L.get('max_grad', 0.0))} ")
+                if t.startswith("BiLstm") and write_dropout_tokens:
+                    for tok, kind in _DROPOUT_TOKENS:
+                        f.write(tok + (" 0 " if kind == "f" else " F "))
+                for p in L["params"]:
+                    _write_tensor_text(f, p)
+        f.write("</Nnet> \n")
+
+
+# ------------------------------------------------------------------------------------------ reader
+class _Text:
+    def __init__(self, s: str):
+        self.s = s; self.i = 0
+
+    def ws(self):
+        while self.i < len(self.s) and self.s[self.i].isspace(): self.i += 1
+
+    def peek(self) -> str:
+        self.ws()
+        return self.s[self.i] if self.i < len(self.s) else ""
+
+    def token(self) -> str:
+        self.ws()
+        j = self.i
+        while j < len(self.s) and not self.s[j].isspace(): j += 1
+        t = self.s[self.i:j]; self.i = j
+        return t
+
+    def tensor(self, shape):
+        self.ws()
+        assert self.s[self.i] == "[", f"expected '[' at {self.i}"
+        j = self.s.index("]", self.i)
+        body = self.s[self.i + 1:j]; self.i = j + 1
+        a = np.array(body.split(), dtype=np.float32)
+        return a.reshape(shape)
+
+
+class _Bin:
+    def __init__(self, b: bytes):
+        self.b = b; self.i = 2  # skip \0B
+
+    def peek(self) -> str:
+        return chr(self.b[self.i]) if self.i < len(self.b) else ""
+
+    def token(self) -> str:
+        j = self.b.index(b" ", self.i)
+        t = self.b[self.i:j].decode(); self.i = j + 1
+        return t
+
+    def int(self) -> int:
+        assert self.b[self.i] == 4
+        v = struct.unpack_from("<i", self.b, self.i + 1)[0]; self.i += 5
+        return v
+
+    def float(self) -> float:
+        assert self.b[self.i] == 4
+        v = struct.unpack_from("<f", self.b, self.i + 1)[0]; self.i += 5
+        return v
+
+    def bool(self) -> bool:
+        c = chr(self.b[self.i]); self.i += 1
+        return c == "T"
+
+    def tensor(self, shape):
+        t = self.token()
+        if t == "FM":
+            r, c = self.int(), self.int(); n = r * c; got = (r, c)
+        elif t == "FV":
+            n = self.int(); got = (n,)
+        else:
+            raise ValueError(f"expected FM/FV, got {t!r}")
+        assert tuple(shape) == got, f"tensor shape {got} != expected {shape}"
+        a = np.frombuffer(self.b, dtype="<f4", count=n, offset=self.i).astype(np.float32).reshape(shape)
+        self.i += 4 * n
+        return a
+
+
+def read_nnet(path: str) -> List[dict]:
+    raw = open(path, "rb").read()
+    binary = raw[:2] == b"\x00B"
+    r = _Bin(raw) if binary else _Text(raw.decode())
+    layers = []
+    while True:
+        if r.peek() == "": break
+        tok = r.token()
+        if tok == "</Nnet>": break
+        if tok == "<Nnet>": tok = r.token()
+        if tok == "</Nnet>": break
+        t = tok.strip("<>")
+        assert r.token() == "<InputDim>"
+        din = r.int() if binary else int(r.token())
+        dim_tok = r.token()
+        assert dim_tok == ("<CellDim>" if is_lstm(t) else "<OutputDim>"), dim_tok
+        dout = r.int() if binary else int(r.token())
+        L = {"type": t, "input_dim": din, "output_dim": dout, "params": []}
+        shapes = param_shapes(t, din, dout)
+        if shapes:
+            L["learn_rate_coef"], L["max_grad"] = 1.0, 0.0
+            while r.peek() == "<":
+                tk = r.token()
+                kinds = dict(_DROPOUT_TOKENS)
+                if tk == "<LearnRateCoef>": L["learn_rate_coef"] = r.float() if binary else float(r.token())
+                elif tk == "<MaxGrad>": L["max_grad"] = r.float() if binary else float(r.token())
+                elif tk in kinds:
+                    if kinds[tk] == "f":
+                        v = r.float() if binary else float(r.token())
+                    else:
+                        v = r.bool() if binary else (r.token() == "T")
+                    if v:
+                        raise ValueError(f"dropout option {tk} is set; dropout variants are out of scope")
+                else:
+                    raise ValueError(f"unsupported token {tk} in layer {t} (Adagrad/RMSProp accumulators are not handled here)")
+            for sh in shapes:
+                L["params"].append(r.tensor(sh))
+        layers.append(L)
+    return layers
+
+
+def num_params(layers: List[dict]) -> int:
+    return int(sum(p.size for L in layers for p in L["params"]))
+
+
+def flatten_params(layers: List[dict]) -> np.ndarray:
+    """Same order as Net::GetParams (src/net/net.cc:181-195): per trainable layer, the layer's GetParams —
+    BiLstm: the 12 tensors in file order, each row-major (src/net/bilstm-layer.h:1000-1031);
+    AffineTransform: linearity then bias (src/net/affine-trans-layer.h:134-141)."""
+    ps = [np.asarray(p, np.float32).ravel() for L in layers for p in L["params"]]
+    return np.concatenate(ps) if ps else np.zeros(0, np.float32)

@@ -1,0 +1,184 @@
+// oracle/ref_build/ref_driver.cc -- TEST INFRASTRUCTURE (oracle), not product code.
+//
+// A thin extern "C" driver over the REAL reference classes, compiled together with the reference's
+// own, unmodified sources (see Makefile) into oracle/_ref/libeesen_ref.so.  Nothing here restates
+// reference arithmetic: it only marshals plain float arrays into eesen::Matrix / CuMatrix (CPU
+// mode: CuDevice is never enabled, so every CuMatrix op runs the src/cpucompute branch) and calls
+//   eesen::Net::{Read,Write,SetTrainOptions,SetSeqLengths,Propagate,Backpropagate,GetParams}
+//     (/root/reference/src/net/net.h:48-161, net.cc:67-108,181-195,279-334)
+//   eesen::Ctc::ErrorRateMSeq (/root/reference/src/net/ctc-loss.cc:235-298).
+// The reference's CTC loss itself has no CPU branch; it is provided by ref_cuda_emul.cc.
+//
+// Used by: tests/ (checker), oracle/make_golden.py (fixture generation), bench.py's
+// cpu_baseline leg (kind "reference").  Never by the product path.
+
+#include <string>
+#include <vector>
+#include <cstring>
+#include <stdexcept>
+
+#include "net/net.h"
+#include "net/ctc-loss.h"
+#include "net/train-opts.h"
+#include "cpucompute/matrix.h"
+#include "gpucompute/cuda-matrix.h"
+
+using namespace eesen;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct RefNet {
+  Net net;
+  Ctc ctc;
+};
+
+void ToCu(const float* src, int rows, int cols, CuMatrix<BaseFloat>* dst) {
+  Matrix<BaseFloat> m(rows, cols, kUndefined);
+  for (int r = 0; r < rows; r++) memcpy(m.RowData(r), src + (size_t)r * cols, sizeof(float) * cols);
+  dst->Resize(rows, cols, kUndefined);
+  dst->CopyFromMat(m);
+}
+
+void FromCu(const CuMatrixBase<BaseFloat>& src, float* dst) {
+  Matrix<BaseFloat> m(src.NumRows(), src.NumCols(), kUndefined);
+  src.CopyToMat(&m);
+  for (int r = 0; r < m.NumRows(); r++) memcpy(dst + (size_t)r * m.NumCols(), m.RowData(r), sizeof(float) * m.NumCols());
+}
+
+}  // namespace
+
+#define REF_TRY try {
+#define REF_CATCH(ret)                                      \
+  } catch (const std::exception& e) {                       \
+    g_last_error = e.what();                                \
+    return ret;                                             \
+  }
+
+extern "C" {
+
+// SciPy's OpenBLAS threading control (symbol is prefixed like the rest of that library).
+void scipy_openblas_set_num_threads(int);
+int scipy_openblas_get_num_threads(void);
+
+const char* ref_last_error() { return g_last_error.c_str(); }
+
+void ref_set_blas_threads(int n) { scipy_openblas_set_num_threads(n); }
+int ref_get_blas_threads() { return scipy_openblas_get_num_threads(); }
+
+void* ref_net_read(const char* path) {
+  REF_TRY
+  RefNet* h = new RefNet();
+  h->net.Read(std::string(path));
+  // the trainer's defaults (netbin/train-ctc-parallel.cc:79,113-119); update_algorithm is otherwise uninitialised
+  h->net.SetUpdateAlgorithm("SGD");
+  h->net.SetTrainMode();
+  return h;
+  REF_CATCH(nullptr)
+}
+
+void ref_net_free(void* p) { delete static_cast<RefNet*>(p); }
+
+int ref_net_write(void* p, const char* path, int binary) {
+  REF_TRY
+  static_cast<RefNet*>(p)->net.Write(std::string(path), binary != 0);
+  return 0;
+  REF_CATCH(-1)
+}
+
+int ref_net_input_dim(void* p) { return static_cast<RefNet*>(p)->net.InputDim(); }
+int ref_net_output_dim(void* p) { return static_cast<RefNet*>(p)->net.OutputDim(); }
+int ref_net_num_params(void* p) { return static_cast<RefNet*>(p)->net.NumParams(); }
+
+int ref_net_get_params(void* p, float* out) {
+  REF_TRY
+  Vector<BaseFloat> v;
+  static_cast<RefNet*>(p)->net.GetParams(&v);
+  memcpy(out, v.Data(), sizeof(float) * v.Dim());
+  return v.Dim();
+  REF_CATCH(-1)
+}
+
+int ref_net_set_train_options(void* p, float learn_rate, float momentum) {
+  REF_TRY
+  NetTrainOptions o;
+  o.learn_rate = learn_rate;
+  o.momentum = momentum;
+  static_cast<RefNet*>(p)->net.SetTrainOptions(o);
+  return 0;
+  REF_CATCH(-1)
+}
+
+int ref_net_set_update_algorithm(void* p, const char* alg) {
+  REF_TRY
+  static_cast<RefNet*>(p)->net.SetUpdateAlgorithm(std::string(alg));
+  return 0;
+  REF_CATCH(-1)
+}
+
+int ref_net_set_seq_lengths(void* p, const int* lens, int S) {
+  REF_TRY
+  std::vector<int> v(lens, lens + S);
+  static_cast<RefNet*>(p)->net.SetSeqLengths(v);
+  return 0;
+  REF_CATCH(-1)
+}
+
+// in: [rows x InputDim] (row = t*S+s), out: [rows x OutputDim]
+int ref_net_propagate(void* p, const float* in, int rows, float* out) {
+  REF_TRY
+  RefNet* h = static_cast<RefNet*>(p);
+  CuMatrix<BaseFloat> cin, cout;
+  ToCu(in, rows, h->net.InputDim(), &cin);
+  h->net.Propagate(cin, &cout);
+  FromCu(cout, out);
+  return 0;
+  REF_CATCH(-1)
+}
+
+// out_diff: [rows x OutputDim]; in_diff (nullable): [rows x InputDim].  Includes the per-layer Update
+// (net.cc:101-104), exactly like the reference trainer.
+int ref_net_backpropagate(void* p, const float* out_diff, int rows, float* in_diff) {
+  REF_TRY
+  RefNet* h = static_cast<RefNet*>(p);
+  CuMatrix<BaseFloat> cdiff, cin_diff;
+  ToCu(out_diff, rows, h->net.OutputDim(), &cdiff);
+  h->net.Backpropagate(cdiff, in_diff ? &cin_diff : NULL);
+  if (in_diff) FromCu(cin_diff, in_diff);
+  return 0;
+  REF_CATCH(-1)
+}
+
+// Copies layer `layer`'s input activation buffer (propagate_buf_[layer]) — layer==NumLayers gives the output.
+int ref_net_get_propagate_buf(void* p, int layer, float* out, int capacity) {
+  REF_TRY
+  const std::vector<CuMatrix<BaseFloat> >& b = static_cast<RefNet*>(p)->net.PropagateBuffer();
+  if (layer < 0 || layer >= (int)b.size()) return -1;
+  if ((long)b[layer].NumRows() * b[layer].NumCols() > capacity) return -2;
+  FromCu(b[layer], out);
+  return b[layer].NumCols();
+  REF_CATCH(-1)
+}
+
+// Real Ctc::ErrorRateMSeq (argmax → collapse repeats → drop blanks → Levenshtein), ctc-loss.cc:235-298.
+int ref_ctc_error_rate_mseq(void* p, const float* net_out, int T, int S, int K, const int* frame_num_utt,
+                            const int* label_ids, const int* label_off, float* num_err, int* num_ref) {
+  REF_TRY
+  RefNet* h = static_cast<RefNet*>(p);
+  CuMatrix<BaseFloat> cout;
+  ToCu(net_out, T * S, K, &cout);
+  std::vector<int> lens(frame_num_utt, frame_num_utt + S);
+  std::vector<std::vector<int> > labels(S);
+  for (int s = 0; s < S; s++) labels[s].assign(label_ids + label_off[s], label_ids + label_off[s + 1]);
+  std::string out_file;
+  float e0 = h->ctc.NumErrorTokens();
+  int r0 = h->ctc.NumRefTokens();
+  h->ctc.ErrorRateMSeq(lens, cout, labels, out_file);
+  *num_err = h->ctc.NumErrorTokens() - e0;
+  *num_ref = h->ctc.NumRefTokens() - r0;
+  return 0;
+  REF_CATCH(-1)
+}
+
+}  // extern "C"
