@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- CTC training frames/sec of the MI355X path on BASELINE.json's configuration.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of train-ctc-parallel's inner loop (/root/reference/src/netbin/train-ctc-parallel.cc:195-207)
+over one synthetic utterance mini-batch per GPU: SetSeqLengths -> Propagate -> Ctc::EvalParallel ->
+Backpropagate (+ gradient all-reduce when N > 1) -> Update.  Workload at N = 1 = BASELINE.json configs[1]:
+4 x BiLSTM (512 cells/direction), 40-d input, 46 classes, 32 utterances, T_max = 1000, fp32.
+Weak scaling: every rank runs its own 32-utterance shard (global batch 32 N = configs[2] at N = 8).
+`value` = padded frames/s of the whole job (the reference's own fps counts padded frames,
+train-ctc-parallel.cc:215,247-252), inputs resident in HBM when the timed region starts.
+
+Rank 0 prints ONE JSON line (see the task contract) with `roofline` (dominant kernel, live HIP-event timing)
+and, at N = 1, `cpu_baseline` (the reference's own CPU code from oracle/_ref when present, else the C port).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from eesen_amd import synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_frame(cfg) -> float:
+    """sum over layers of 2 dirs * 24 H (D_in + H), + 6 D_last K (+ 6 * 2H * P per projection)."""
+    nd = 2 if cfg["kind"].startswith("BiLstm") else 1
+    H, D, K = cfg["H"], cfg["D"], cfg["K"]
+    total, din = 0.0, D
+    for li in range(cfg["layers"]):
+        total += nd * 24.0 * H * (din + H)
+        din = nd * H
+        if cfg.get("proj") and li < cfg["layers"] - 1:
+            total += 6.0 * din * cfg["proj"]
+            din = cfg["proj"]
+    total += 6.0 * din * K
+    return total
+
+
+def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
+    """The reference's CPU path (oracle/_ref: src/net + src/cpucompute compiled unmodified; its CUDA-only CTC
+    kernels run through the CPU shim) or, when that library is absent, the C port; same model, a bounded
+    sample of the same workload.  Reported, never the target."""
+    from oracle import refbind, net as onet
+    from eesen_amd import nnet_io
+    ncores = os.cpu_count() or 1
+    sc = dict(cfg)
+    sc["T"] = 96  # 32 utterances x 96 frames = 3072 padded frames of the same 4x512 BiLSTM
+    layers = synth.make_model(max_grad=50.0, **sc)
+    batch = synth.make_batch(**sc)
+    frames = batch.T * batch.S
+    out = {"unit": "frames/s", "sample": f"1 step of the same model on S={batch.S} utterances x T={batch.T} frames ({frames} padded frames)"}
+    if refbind.available():
+        path = tempfile.mktemp(suffix=".nnet")
+        nnet_io.write_nnet(path, layers, binary=True)
+        res = {}
+        for thr in (ncores, 1):
+            refbind.set_blas_threads(thr)
+            r = refbind.RefNet(path)
+            r.set_train_options(4e-5, 0.9)
+            r.set_seq_lengths(batch.lens)
+            t0 = time.perf_counter()
+            o = r.propagate(batch.feats)
+            c = refbind.cuda_ctc_eval_parallel(o, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+            r.backpropagate(c["diff"], False)
+            res[thr] = frames / (time.perf_counter() - t0)
+        os.unlink(path)
+        out.update(kind="reference", value=res[ncores], cores=ncores, single_thread_value=res[1],
+                   note="reference src/net+src/cpucompute (OpenBLAS sgemm); CTC = reference CUDA kernel bodies run on the CPU, "
+                        "the reference has no CPU CTC")
+    else:
+        ora = onet.OracleNet(layers, "f32")
+        ora.set_train_options(4e-5, 0.9)
+        sc["T"] = 16
+        batch = synth.make_batch(**sc)
+        t0 = time.perf_counter()
+        onet.train_step(ora, batch, "f32")
+        out.update(kind="port", value=batch.T * batch.S / (time.perf_counter() - t0), cores=1,
+                   sample=f"1 step, S={batch.S} x T={batch.T} (scalar C port, naive GEMM loops)")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--T", type=int, default=0, help="override T_max (debug)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    from eesen_amd import _lib
+
+    cfg = synth.config(args.config)
+    if args.T:
+        cfg["T"] = args.T
+    layers = synth.make_model(max_grad=50.0, **cfg)                 # recipe settings: model_topo.py:90, run_ctc_phn.sh:84-85
+    batch = synth.make_batch(**{**cfg, "seed": 777 + rank})         # every rank its own shard of the global batch
+    dev = local if world > 1 else 0
+    net = Net.from_layers(layers, device=dev)
+    net.SetTrainOptions(4e-5, 0.9)
+    ctc = Ctc(device=dev)
+    if world > 1:
+        from eesen_amd.parallel import GradAllReducer
+        net.grad_hook = GradAllReducer(net)
+    feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # inputs resident in HBM before the timed region
+    diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
+    net.SetProfiling(True)
+
+    def step():
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(feats_dev)
+        ctc.EvalParallel(batch.lens, out, batch.labels, diff)
+        net.Backpropagate(diff)
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+        net.Synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phases = {}
+    ctc_ph = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        net.Synchronize()
+        for k, v in net.PhaseTimes().items():
+            phases[k] = phases.get(k, 0.0) + v
+        for k, v in ctc.PhaseTimes().items():
+            ctc_ph[k] = ctc_ph.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        fr = torch.tensor([float(batch.T * batch.S), float(batch.real_frames)], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        padded, real = fr.tolist()
+    else:
+        padded, real = float(batch.T * batch.S), float(batch.real_frames)
+
+    if rank == 0:
+        K = args.steps
+        value = padded * K / dt
+        fpf = flops_per_frame(cfg)
+        nd = 2 if cfg["kind"].startswith("BiLstm") else 1
+        H, S, T, nl = cfg["H"], batch.S, batch.T, cfg["layers"]
+        # per-launch algorithmic work of the three kernels that carry the step (DESIGN.md "kernels")
+        rec_flops = 2.0 * S * 4 * H * H * nd                              # one recurrence step, all directions
+        n_rec = T * nl * K
+        gemm_flops = sum(2.0 * T * S * nd * 4 * H * (cfg["D"] if li == 0 else nd * H) for li in range(nl)) / nl
+        kern = {
+            "lstm_fwd_step_kernel": dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops),
+            "lstm_bwd_step_kernel": dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops),
+            "gemm_f32_mfma_kernel(input->gates)": dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops),
+        }
+        for k in kern.values():
+            k["avg_us"] = 1e6 * k["total_s"] / k["launches"]
+            k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12
+        dom = max(kern, key=lambda n: kern[n]["total_s"])
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
+                    "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "flops_per_frame": fpf},
+                    "other_kernels": {n: {"achieved": v["achieved"], "frac": v["achieved"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": v["avg_us"]}
+                                      for n, v in kern.items() if n != dom}}
+        # CTC sweep against the HBM roofline: 4*(3K + 2L') algorithmic bytes per frame
+        Lp = 2 * max(len(l) for l in batch.labels) + 1
+        ctc_bytes = 4.0 * (3 * cfg["K"] + 2 * Lp) * T * S
+        ctc_s = (ctc_ph["alpha_beta"] + ctc_ph["error_diff"] + ctc_ph["log"]) / K
+        roofline["ctc"] = {"bound": "hbm", "achieved": ctc_bytes / ctc_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": ctc_bytes / ctc_s / 1e9 / PEAK_HBM_GBS, "ms": 1e3 * ctc_s, "sweep_ms": 1e3 * ctc_ph["alpha_beta"] / K,
+                           "note": "bounded by the 2T-step dependency chain of S lattices, not by HBM (SURVEY.md 8d caveat)"}
+        line = {
+            "metric": "CTC training frames/sec (whole node), 4x512 BiLSTM",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seed 777: N(0,1) 40-d features, lengths U{0.8T..T}, T/10 labels per utterance, U(-0.1,0.1) weights)",
+            "config": {"workload": f"{args.config}: {nl}x{H} {'Bi' if nd == 2 else ''}LSTM + affine + softmax + CTC, D={cfg['D']}, K={cfg['K']}, "
+                                   f"S={S} utterances/GPU, T_max={T}, SGD lr=4e-5 momentum=0.9 max_grad=50",
+                       "global_batch_utterances": S * world, "parallelism": f"dp{world}",
+                       "real_frames_per_s": real * K / dt, "padded_frames_per_step": padded, "real_frames_per_step": real},
+            "phase_ms_per_step": {k: 1e3 * v / K for k, v in {**phases, **{'ctc_' + a: b for a, b in ctc_ph.items()}}.items()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

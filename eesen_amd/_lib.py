@@ -1,0 +1,98 @@
+"""ctypes binding of eesen_amd/lib/libeesen_hip.so (the C-ABI of include/eesen_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "lib", "libeesen_hip.so")
+
+OK = 0
+LAYER_AFFINE, LAYER_SOFTMAX, LAYER_LSTM_PARALLEL, LAYER_BILSTM_PARALLEL = 1, 2, 3, 4
+KIND_OF = {"AffineTransform": LAYER_AFFINE, "Softmax": LAYER_SOFTMAX, "LstmParallel": LAYER_LSTM_PARALLEL,
+           "BiLstmParallel": LAYER_BILSTM_PARALLEL, "Lstm": LAYER_LSTM_PARALLEL, "BiLstm": LAYER_BILSTM_PARALLEL}
+NAME_OF = {LAYER_AFFINE: "AffineTransform", LAYER_SOFTMAX: "Softmax", LAYER_LSTM_PARALLEL: "LstmParallel",
+           LAYER_BILSTM_PARALLEL: "BiLstmParallel"}
+
+# every symbol include/eesen_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+_pi, _pf, _pl, _pd = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_long), C.POINTER(C.c_double)
+SIGNATURES = {
+    "eesen_last_error": (C.c_char_p, []),
+    "eesen_version": (C.c_char_p, []),
+    "eesen_device_count": (_i, [_pi]),
+    "eesen_net_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "eesen_net_destroy": (_i, [_vp]),
+    "eesen_net_add_layer": (_i, [_vp, _i, _i, _i, _f, _f]),
+    "eesen_net_finalize": (_i, [_vp]),
+    "eesen_net_read": (_i, [_vp, C.c_char_p]),
+    "eesen_net_write": (_i, [_vp, C.c_char_p, _i]),
+    "eesen_net_num_layers": (_i, [_vp, _pi]),
+    "eesen_net_layer_info": (_i, [_vp, _i, _pi, _pi, _pi, _pf, _pf]),
+    "eesen_net_input_dim": (_i, [_vp, _pi]),
+    "eesen_net_output_dim": (_i, [_vp, _pi]),
+    "eesen_net_num_params": (_i, [_vp, _pl]),
+    "eesen_net_get_params": (_i, [_vp, _vp, _l]),
+    "eesen_net_set_params": (_i, [_vp, _vp, _l]),
+    "eesen_net_set_train_options": (_i, [_vp, _f, _f]),
+    "eesen_net_set_seq_lengths": (_i, [_vp, _vp, _i]),
+    "eesen_net_propagate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _pi, _pi]),
+    "eesen_net_get_output": (_i, [_vp, _vp, _l]),
+    "eesen_net_backpropagate": (_i, [_vp, _vp, _i, _vp, _i]),
+    "eesen_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), _pl]),
+    "eesen_net_get_grads": (_i, [_vp, _vp, _l]),
+    "eesen_net_update": (_i, [_vp]),
+    "eesen_net_synchronize": (_i, [_vp]),
+    "eesen_net_set_profiling": (_i, [_vp, _i]),
+    "eesen_net_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_ctc_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "eesen_ctc_destroy": (_i, [_vp]),
+    "eesen_ctc_eval_parallel": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "eesen_ctc_error_rate_mseq": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _pi, _pi]),
+    "eesen_ctc_stats": (_i, [_vp, _pd, _pl, _pl, _pl, _pl]),
+    "eesen_ctc_get_alpha_beta": (_i, [_vp, _vp, _vp, _pi]),
+    "eesen_ctc_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_dev_alloc": (_i, [_i, _l, C.POINTER(_vp)]),
+    "eesen_dev_free": (_i, [_i, _vp]),
+    "eesen_dev_copy": (_i, [_i, _vp, _vp, _l, _i]),
+    "eesen_op_gemm": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),
+}
+
+
+class EesenError(RuntimeError):
+    """Mirrors the std::runtime_error thrown by KALDI_ERR (/root/reference/src/base/kaldi-error.cc:168-182)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EesenError(-2, f"{LIB_PATH} is missing: build it with `python -m eesen_amd.build` "
+                                 "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError = a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != OK:
+        raise EesenError(rc, load().eesen_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().eesen_device_count(C.byref(n)))
+    return n.value

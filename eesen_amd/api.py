@@ -1,0 +1,323 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C-ABI.
+
+Same names, argument meaning and error behaviour as the classes `train-ctc-parallel` drives
+(/root/reference/src/netbin/train-ctc-parallel.cc:111-119,195-207):
+
+  Net  : Read, Write, SetTrainOptions, SetSeqLengths, InputDim, OutputDim, NumParams, GetParams, SetParams,
+         Propagate, Backpropagate                      (/root/reference/src/net/net.h:48-161)
+  Ctc  : EvalParallel, ErrorRateMSeq, Report, NumErrorTokens, NumRefTokens
+                                                       (/root/reference/src/net/ctc-loss.h:40-63)
+  CuMatrix : a [rows x cols] fp32 device matrix with a stride, the stand-in for CuMatrix<BaseFloat>
+                                                       (/root/reference/src/gpucompute/cuda-matrix.h)
+
+Errors surface as EesenError (the reference throws std::runtime_error from KALDI_ERR).  Everything here
+is plumbing: all arithmetic happens in libeesen_hip.so.  No torch import — device memory comes from the
+library's own allocator, so the product path has no framework dependency.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import EesenError, check
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CuMatrix:
+    """Row-major fp32 device matrix {rows, cols, stride} (/root/reference/src/gpucompute/cuda-matrixdim.h:52-56).
+
+    Owns its memory when created with `CuMatrix(rows, cols)`; `CuMatrix.view(ptr, ...)` wraps memory owned
+    by a Net (Propagate output).  Rows are padded to a multiple of 4 floats so they stay 16-byte aligned.
+    """
+
+    def __init__(self, rows: int, cols: int, device: int = 0, zero: bool = True):
+        self.rows, self.cols, self.device = int(rows), int(cols), device
+        self.stride = (self.cols + 3) & ~3
+        self._own = True
+        p = C.c_void_p()
+        check(_lib.load().eesen_dev_alloc(device, max(1, self.rows * self.stride) * 4, C.byref(p)))
+        self.ptr = p.value
+        if zero and rows * cols:
+            z = np.zeros(self.rows * self.stride, np.float32)
+            check(_lib.load().eesen_dev_copy(device, C.c_void_p(self.ptr), _np_ptr(z), z.nbytes, 1))
+
+    @classmethod
+    def view(cls, ptr: int, rows: int, cols: int, stride: int, device: int = 0, keepalive=None) -> "CuMatrix":
+        m = cls.__new__(cls)
+        m.ptr, m.rows, m.cols, m.stride, m.device, m._own, m._keep = ptr, rows, cols, stride, device, False, keepalive
+        return m
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, device: int = 0) -> "CuMatrix":
+        a = np.ascontiguousarray(a, np.float32)
+        m = cls(a.shape[0], a.shape[1], device, zero=False)
+        buf = np.zeros((m.rows, m.stride), np.float32)
+        buf[:, : m.cols] = a
+        check(_lib.load().eesen_dev_copy(device, C.c_void_p(m.ptr), _np_ptr(buf), buf.nbytes, 1))
+        return m
+
+    def NumRows(self) -> int:
+        return self.rows
+
+    def NumCols(self) -> int:
+        return self.cols
+
+    def Stride(self) -> int:
+        return self.stride
+
+    def numpy(self) -> np.ndarray:
+        """CopyToMat: device -> host, dense [rows x cols]. Synchronous."""
+        buf = np.empty((self.rows, self.stride), np.float32)
+        if buf.size:
+            check(_lib.load().eesen_dev_copy(self.device, _np_ptr(buf), C.c_void_p(self.ptr), buf.nbytes, 2))
+        return np.ascontiguousarray(buf[:, : self.cols])
+
+    def __del__(self):
+        if getattr(self, "_own", False) and getattr(self, "ptr", None):
+            try:
+                _lib.load().eesen_dev_free(self.device, C.c_void_p(self.ptr))
+            except Exception:
+                pass
+            self.ptr = None
+
+
+class Net:
+    """eesen::Net for BiLstmParallel / LstmParallel / AffineTransform / Softmax stacks."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        self.device = device
+        self._stream = stream
+        self.h = C.c_void_p()
+        check(self.lib.eesen_net_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self._out = None
+        self.grad_hook = None  # callable(net) run between backprop and update: the data-parallel exchange
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            try:
+                self.lib.eesen_net_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    # ---- model I/O ---------------------------------------------------------------------------
+    def Read(self, path: str):
+        """Net::Read (net.cc:279-309). Learn rate is reset to 0: call SetTrainOptions afterwards."""
+        check(self.lib.eesen_net_read(self.h, path.encode()))
+        return self
+
+    def Write(self, path: str, binary: bool = True):
+        check(self.lib.eesen_net_write(self.h, path.encode(), int(binary)))
+
+    @classmethod
+    def from_layers(cls, layers: List[dict], device: int = 0, stream: Optional[int] = None) -> "Net":
+        """Build from the dict form of eesen_amd.nnet_io (type, input_dim, output_dim, learn_rate_coef, max_grad, params)."""
+        net = cls(device, stream)
+        for L in layers:
+            check(net.lib.eesen_net_add_layer(net.h, _lib.KIND_OF[L["type"]], int(L["input_dim"]), int(L["output_dim"]),
+                                              float(L.get("learn_rate_coef", 1.0)), float(L.get("max_grad", 0.0))))
+        check(net.lib.eesen_net_finalize(net.h))
+        flat = [np.asarray(p, np.float32).ravel() for L in layers for p in L["params"]]
+        if flat:
+            net.SetParams(np.concatenate(flat))
+        return net
+
+    def layers(self) -> List[dict]:
+        n = C.c_int()
+        check(self.lib.eesen_net_num_layers(self.h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            k, di, do, cf, mg = C.c_int(), C.c_int(), C.c_int(), C.c_float(), C.c_float()
+            check(self.lib.eesen_net_layer_info(self.h, i, C.byref(k), C.byref(di), C.byref(do), C.byref(cf), C.byref(mg)))
+            out.append(dict(type=_lib.NAME_OF[k.value], input_dim=di.value, output_dim=do.value,
+                            learn_rate_coef=cf.value, max_grad=mg.value))
+        return out
+
+    def InputDim(self) -> int:
+        d = C.c_int()
+        check(self.lib.eesen_net_input_dim(self.h, C.byref(d)))
+        return d.value
+
+    def OutputDim(self) -> int:
+        d = C.c_int()
+        check(self.lib.eesen_net_output_dim(self.h, C.byref(d)))
+        return d.value
+
+    def NumParams(self) -> int:
+        n = C.c_long()
+        check(self.lib.eesen_net_num_params(self.h, C.byref(n)))
+        return n.value
+
+    def GetParams(self) -> np.ndarray:
+        out = np.empty(self.NumParams(), np.float32)
+        check(self.lib.eesen_net_get_params(self.h, _np_ptr(out), out.size))
+        return out
+
+    def SetParams(self, flat: np.ndarray):
+        flat = np.ascontiguousarray(flat, np.float32)
+        check(self.lib.eesen_net_set_params(self.h, _np_ptr(flat), flat.size))
+
+    def GetGrads(self) -> np.ndarray:
+        """Fresh gradients of the last Backpropagate in GetParams order (parity accessor)."""
+        out = np.empty(self.NumParams(), np.float32)
+        check(self.lib.eesen_net_get_grads(self.h, _np_ptr(out), out.size))
+        return out
+
+    # ---- options -----------------------------------------------------------------------------
+    def SetTrainOptions(self, learn_rate: float, momentum: float = 0.0):
+        check(self.lib.eesen_net_set_train_options(self.h, float(learn_rate), float(momentum)))
+
+    def SetSeqLengths(self, lens: Sequence[int]):
+        a = np.ascontiguousarray(lens, np.int32)
+        check(self.lib.eesen_net_set_seq_lengths(self.h, _np_ptr(a), a.size))
+
+    # ---- compute -----------------------------------------------------------------------------
+    def Propagate(self, feats) -> CuMatrix:
+        """Net::Propagate (net.cc:67-86). feats: host ndarray [T*S x InputDim] (uploaded, as the reference's
+        CuMatrix ctor does) or a CuMatrix.  Returns a view of the net-owned output, valid until the next call."""
+        p, co, ld = C.c_void_p(), C.c_int(), C.c_int()
+        if isinstance(feats, CuMatrix):
+            check(self.lib.eesen_net_propagate(self.h, C.c_void_p(feats.ptr), feats.rows, feats.stride, 1, C.byref(p), C.byref(co), C.byref(ld)))
+            rows = feats.rows
+        else:
+            a = np.ascontiguousarray(feats, np.float32)
+            if a.ndim != 2:
+                raise EesenError(-1, "Propagate expects a [rows x dim] matrix")
+            check(self.lib.eesen_net_propagate(self.h, _np_ptr(a), a.shape[0], a.shape[1], 0, C.byref(p), C.byref(co), C.byref(ld)))
+            rows = a.shape[0]
+        self._out = CuMatrix.view(p.value, rows, co.value, ld.value, self.device, keepalive=self)
+        return self._out
+
+    def BackpropagateNoUpdate(self, out_diff: CuMatrix, in_diff: Optional[CuMatrix] = None):
+        check(self.lib.eesen_net_backpropagate(self.h, C.c_void_p(out_diff.ptr), out_diff.stride,
+                                               C.c_void_p(in_diff.ptr) if in_diff is not None else None,
+                                               in_diff.stride if in_diff is not None else 0))
+
+    def Update(self):
+        check(self.lib.eesen_net_update(self.h))
+
+    def Backpropagate(self, out_diff: CuMatrix, in_diff: Optional[CuMatrix] = None):
+        """Net::Backpropagate (net.cc:88-108): gradients, [data-parallel exchange], per-layer Update."""
+        self.BackpropagateNoUpdate(out_diff, in_diff)
+        if self.grad_hook is not None:
+            self.grad_hook(self)
+        self.Update()
+
+    def grad_buffer(self):
+        """(device pointer, float count) of the contiguous fresh-gradient buffer (all-reduce payload)."""
+        p, n = C.c_void_p(), C.c_long()
+        check(self.lib.eesen_net_grad_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def Synchronize(self):
+        check(self.lib.eesen_net_synchronize(self.h))
+
+    def SetProfiling(self, on: bool):
+        check(self.lib.eesen_net_set_profiling(self.h, int(on)))
+
+    def PhaseTimes(self) -> dict:
+        out = np.zeros(6, np.float32)
+        check(self.lib.eesen_net_get_phase_times(self.h, _np_ptr(out)))
+        return dict(zip(["input_gemm", "recurrence_fwd", "affine_softmax", "recurrence_bwd", "grad_gemm", "update"], out.tolist()))
+
+
+class Ctc:
+    """eesen::Ctc (ctc-loss.h:31-90) for the multi-sequence path."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        self.device = device
+        self.h = C.c_void_p()
+        check(self.lib.eesen_ctc_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+        self.pzx = None
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            try:
+                self.lib.eesen_ctc_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    @staticmethod
+    def _csr(label: Sequence[Sequence[int]]):
+        off = np.zeros(len(label) + 1, np.int32)
+        off[1:] = np.cumsum([len(l) for l in label])
+        ids = np.concatenate([np.asarray(l, np.int32) for l in label]) if off[-1] else np.zeros(1, np.int32)
+        return np.ascontiguousarray(ids, np.int32), off
+
+    def EvalParallel(self, frame_num_utt: Sequence[int], net_out: CuMatrix, label: Sequence[Sequence[int]],
+                     diff: Optional[CuMatrix] = None) -> CuMatrix:
+        """Ctc::EvalParallel (ctc-loss.cc:101-194). Returns diff (allocated when not given); self.pzx = ln p per sequence."""
+        fn = np.ascontiguousarray(frame_num_utt, np.int32)
+        ids, off = self._csr(label)
+        if diff is None:
+            diff = CuMatrix(net_out.rows, net_out.cols, self.device, zero=False)
+        pzx = np.empty(fn.size, np.float32)
+        check(self.lib.eesen_ctc_eval_parallel(self.h, _np_ptr(fn), fn.size, C.c_void_p(net_out.ptr), net_out.rows, net_out.cols,
+                                               net_out.stride, _np_ptr(ids), _np_ptr(off), C.c_void_p(diff.ptr), diff.stride,
+                                               _np_ptr(pzx)))
+        self.pzx = pzx
+        return diff
+
+    def ErrorRateMSeq(self, frame_num_utt: Sequence[int], net_out: CuMatrix, label: Sequence[Sequence[int]]):
+        fn = np.ascontiguousarray(frame_num_utt, np.int32)
+        ids, off = self._csr(label)
+        ne, nr = C.c_int(), C.c_int()
+        check(self.lib.eesen_ctc_error_rate_mseq(self.h, _np_ptr(fn), fn.size, C.c_void_p(net_out.ptr), net_out.rows, net_out.cols,
+                                                 net_out.stride, _np_ptr(ids), _np_ptr(off), C.byref(ne), C.byref(nr)))
+        return ne.value, nr.value
+
+    def stats(self) -> dict:
+        o, s, f, e, r = C.c_double(), C.c_long(), C.c_long(), C.c_long(), C.c_long()
+        check(self.lib.eesen_ctc_stats(self.h, C.byref(o), C.byref(s), C.byref(f), C.byref(e), C.byref(r)))
+        return dict(obj_sum=o.value, sequences=s.value, frames=f.value, err_tokens=e.value, ref_tokens=r.value)
+
+    def NumErrorTokens(self) -> int:
+        return self.stats()["err_tokens"]
+
+    def NumRefTokens(self) -> int:
+        return self.stats()["ref_tokens"]
+
+    def Report(self) -> str:
+        """Ctc::Report (ctc-loss.cc:300-304); train_ctc_parallel.sh greps this line."""
+        st = self.stats()
+        acc = 100.0 * (1.0 - st["err_tokens"] / st["ref_tokens"]) if st["ref_tokens"] else float("nan")
+        return f"\nTOKEN_ACCURACY >> {acc:g}% <<"
+
+    def alpha_beta(self):
+        """(alpha, beta) of the last EvalParallel in the reference's [T*S x L'] layout (parity accessor)."""
+        L = C.c_int()
+        check(self.lib.eesen_ctc_get_alpha_beta(self.h, None, None, C.byref(L)))
+        rows = self._rows
+        a = np.empty((rows, L.value), np.float32)
+        b = np.empty((rows, L.value), np.float32)
+        check(self.lib.eesen_ctc_get_alpha_beta(self.h, _np_ptr(a), _np_ptr(b), C.byref(L)))
+        return a, b
+
+    def PhaseTimes(self) -> dict:
+        out = np.zeros(3, np.float32)
+        check(self.lib.eesen_ctc_get_phase_times(self.h, _np_ptr(out)))
+        return dict(zip(["log", "alpha_beta", "error_diff"], out.tolist()))
+
+
+def train_step(net: Net, ctc: Ctc, batch, error_rate: bool = False) -> dict:
+    """One pass of the trainer's inner loop (train-ctc-parallel.cc:195-207) on a eesen_amd.synth.Batch."""
+    net.SetSeqLengths(batch.lens)
+    net_out = net.Propagate(batch.feats)
+    diff = ctc.EvalParallel(batch.lens, net_out, batch.labels, getattr(ctc, "_diff", None)
+                            if getattr(ctc, "_diff", None) is not None and ctc._diff.rows == net_out.rows and ctc._diff.cols == net_out.cols else None)
+    ctc._diff = diff
+    ctc._rows = net_out.rows
+    res = dict(net_out=net_out, diff=diff, pzx=ctc.pzx)
+    if error_rate:
+        res["errors"] = ctc.ErrorRateMSeq(batch.lens, net_out, batch.labels)
+    net.Backpropagate(diff)
+    return res

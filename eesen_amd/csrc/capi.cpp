@@ -1,0 +1,219 @@
+// capi.cpp -- the extern "C" boundary declared in include/eesen_hip.h.  Every wrapper converts internal
+// exceptions into a status code and a thread-local message; no exception leaves the library.
+#include <cstring>
+
+#include "net.h"
+
+using namespace eesen;
+
+struct eesen_net : public Net { using Net::Net; };
+struct eesen_ctc : public Ctc { using Ctc::Ctc; };
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int guard(F f) {
+  try {
+    f();
+    return EESEN_OK;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return EESEN_ERR_INVALID;
+  } catch (...) {
+    g_err = "unknown failure";
+    return EESEN_ERR_INVALID;
+  }
+}
+#define REQ_PTR(p) EESEN_REQUIRE((p) != nullptr, EESEN_ERR_INVALID, "null pointer argument")
+}  // namespace
+
+extern "C" {
+
+const char* eesen_last_error(void) { return g_err.c_str(); }
+const char* eesen_version(void) { return "eesen_hip 0.1.0 (gfx950)"; }
+
+int eesen_device_count(int* count) {
+  return guard([&] {
+    REQ_PTR(count);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+  });
+}
+
+int eesen_net_create(int device, void* stream, eesen_net_t** out) {
+  return guard([&] {
+    REQ_PTR(out);
+    *out = new eesen_net(device, stream);
+  });
+}
+int eesen_net_destroy(eesen_net_t* net) {
+  return guard([&] { delete net; });
+}
+int eesen_net_add_layer(eesen_net_t* net, int kind, int in_dim, int out_dim, float coef, float max_grad) {
+  return guard([&] { REQ_PTR(net); net->add_layer(kind, in_dim, out_dim, coef, max_grad); });
+}
+int eesen_net_finalize(eesen_net_t* net) {
+  return guard([&] { REQ_PTR(net); net->finalize(); });
+}
+int eesen_net_read(eesen_net_t* net, const char* path) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(path); net->read(path); });
+}
+int eesen_net_write(eesen_net_t* net, const char* path, int binary) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(path); net->write(path, binary != 0); });
+}
+int eesen_net_num_layers(eesen_net_t* net, int* n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(n); *n = (int)net->layers.size(); });
+}
+int eesen_net_layer_info(eesen_net_t* net, int idx, int* kind, int* in_dim, int* out_dim, float* coef, float* max_grad) {
+  return guard([&] {
+    REQ_PTR(net);
+    EESEN_REQUIRE(idx >= 0 && idx < (int)net->layers.size(), EESEN_ERR_INVALID, "layer index out of range");
+    const Layer& L = net->layers[idx];
+    if (kind) *kind = L.kind;
+    if (in_dim) *in_dim = L.din;
+    if (out_dim) *out_dim = L.dout;
+    if (coef) *coef = L.coef;
+    if (max_grad) *max_grad = L.max_grad;
+  });
+}
+int eesen_net_input_dim(eesen_net_t* net, int* dim) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.front().din; });
+}
+int eesen_net_output_dim(eesen_net_t* net, int* dim) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.back().dout; });
+}
+int eesen_net_num_params(eesen_net_t* net, long* n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(n); *n = net->num_params(); });
+}
+int eesen_net_get_params(eesen_net_t* net, float* host_flat, long n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(host_flat); net->get_flat(net->params, host_flat, n); });
+}
+int eesen_net_set_params(eesen_net_t* net, const float* host_flat, long n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(host_flat); net->set_params(host_flat, n); });
+}
+int eesen_net_set_train_options(eesen_net_t* net, float learn_rate, float momentum) {
+  return guard([&] { REQ_PTR(net); net->lr = learn_rate; net->mmt = momentum; });
+}
+int eesen_net_set_seq_lengths(eesen_net_t* net, const int* lens, int S) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(lens); net->set_seq_lengths(lens, S); });
+}
+int eesen_net_propagate(eesen_net_t* net, const float* in, int rows, int in_ld, int in_is_device, const float** out_dev,
+                        int* out_cols, int* out_ld) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(in);
+    net->propagate(in, rows, in_ld, in_is_device != 0);
+    if (out_dev) *out_dev = net->out_ptr;
+    if (out_cols) *out_cols = net->out_cols;
+    if (out_ld) *out_ld = net->out_ld;
+  });
+}
+int eesen_net_get_output(eesen_net_t* net, float* host_out, long n) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(host_out);
+    EESEN_REQUIRE(net->propagated, EESEN_ERR_STATE, "no Propagate output");
+    EESEN_REQUIRE(n == (long)net->rows * net->out_cols, EESEN_ERR_INVALID, "output size mismatch");
+    net->sync();
+    EESEN_HIP_CHECK(hipMemcpy2D(host_out, (size_t)net->out_cols * 4, net->out_ptr, (size_t)net->out_ld * 4, (size_t)net->out_cols * 4,
+                                net->rows, hipMemcpyDeviceToHost));
+  });
+}
+int eesen_net_backpropagate(eesen_net_t* net, const float* out_diff_dev, int out_diff_ld, float* in_diff_dev, int in_diff_ld) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(out_diff_dev); net->backpropagate(out_diff_dev, out_diff_ld, in_diff_dev, in_diff_ld); });
+}
+int eesen_net_grad_buffer(eesen_net_t* net, float** dev_ptr, long* n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(dev_ptr); REQ_PTR(n); *dev_ptr = net->fresh.p; *n = (long)net->P; });
+}
+int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(host_flat); net->get_flat(net->fresh, host_flat, n); });
+}
+int eesen_net_update(eesen_net_t* net) {
+  return guard([&] { REQ_PTR(net); net->update(); });
+}
+int eesen_net_synchronize(eesen_net_t* net) {
+  return guard([&] { REQ_PTR(net); net->sync(); });
+}
+int eesen_net_set_profiling(eesen_net_t* net, int on) {
+  return guard([&] { REQ_PTR(net); net->timer.enable(on != 0); });
+}
+int eesen_net_get_phase_times(eesen_net_t* net, float* out6) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(out6); net->timer.collect(out6, 6); });
+}
+
+int eesen_ctc_create(int device, void* stream, eesen_ctc_t** out) {
+  return guard([&] { REQ_PTR(out); *out = new eesen_ctc(device, stream); });
+}
+int eesen_ctc_destroy(eesen_ctc_t* ctc) {
+  return guard([&] { delete ctc; });
+}
+int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev, int rows, int K,
+                            int ld, const int* label_ids, const int* label_off, float* diff_dev, int diff_ld,
+                            float* pzx_host) {
+  return guard([&] {
+    REQ_PTR(ctc); REQ_PTR(frame_num_utt); REQ_PTR(net_out_dev); REQ_PTR(label_ids); REQ_PTR(label_off); REQ_PTR(diff_dev);
+    ctc->eval_parallel(frame_num_utt, S, net_out_dev, rows, K, ld, label_ids, label_off, diff_dev, diff_ld, pzx_host);
+  });
+}
+int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev, int rows, int K,
+                              int ld, const int* label_ids, const int* label_off, int* num_err, int* num_ref) {
+  return guard([&] {
+    REQ_PTR(ctc); REQ_PTR(frame_num_utt); REQ_PTR(net_out_dev); REQ_PTR(label_ids); REQ_PTR(label_off);
+    ctc->error_rate_mseq(frame_num_utt, S, net_out_dev, rows, K, ld, label_ids, label_off, num_err, num_ref);
+  });
+}
+int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* frames, long* err_tokens, long* ref_tokens) {
+  return guard([&] {
+    REQ_PTR(ctc);
+    if (obj_sum) *obj_sum = ctc->obj_sum;
+    if (sequences) *sequences = ctc->sequences;
+    if (frames) *frames = ctc->frames;
+    if (err_tokens) *err_tokens = ctc->err_tokens;
+    if (ref_tokens) *ref_tokens = ctc->ref_tokens;
+  });
+}
+int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_host, int* Lprime) {
+  return guard([&] { REQ_PTR(ctc); ctc->get_alpha_beta(alpha_host, beta_host, Lprime); });
+}
+int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3) {
+  return guard([&] { REQ_PTR(ctc); REQ_PTR(out3); ctc->phase_times(out3); });
+}
+
+int eesen_dev_alloc(int device, long bytes, void** dev_ptr) {
+  return guard([&] {
+    REQ_PTR(dev_ptr);
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    EESEN_HIP_CHECK(hipMalloc(dev_ptr, (size_t)bytes));
+  });
+}
+int eesen_dev_free(int device, void* dev_ptr) {
+  return guard([&] {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    EESEN_HIP_CHECK(hipFree(dev_ptr));
+  });
+}
+int eesen_dev_copy(int device, void* dst, const void* src, long bytes, int kind) {
+  return guard([&] {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    EESEN_HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, k));
+  });
+}
+
+int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias) {
+  return guard([&] {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // private split-K workspace for this standalone call
+    DevBuf<float> ws;
+    ws.reserve((size_t)8 << 20);
+    gemm_f32(st, a_kc != 0, b_kc != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws.p, ws.cap);
+    EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
+}  // extern "C"

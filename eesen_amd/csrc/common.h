@@ -1,0 +1,71 @@
+// common.h -- error plumbing, device buffers and launch helpers shared by the HIP sources.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/eesen_hip.h"
+
+namespace eesen {
+
+// Internal failures travel as exceptions up to the C-ABI wrappers (capi.cpp), which turn them into a
+// status code + thread-local message; nothing throws across the `extern "C"` boundary.
+struct Error : public std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define EESEN_HIP_CHECK(expr)                                                                       \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      throw ::eesen::Error(EESEN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + \
+                                              __FILE__ + ":" + std::to_string(__LINE__) + ")");     \
+  } while (0)
+
+#define EESEN_REQUIRE(cond, code, msg)                                       \
+  do {                                                                       \
+    if (!(cond)) throw ::eesen::Error((code), std::string(msg) + " [" #cond "]"); \
+  } while (0)
+
+inline void check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw Error(EESEN_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+}
+
+// Owning device allocation (fp32 / int32 elements), grow-only resize so steady-state steps allocate nothing.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // returns true when a new allocation was made (contents undefined then)
+  bool reserve(size_t n) {
+    if (n <= cap) return false;
+    release();
+    EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    cap = n;
+    return true;
+  }
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+}  // namespace eesen

@@ -1,0 +1,339 @@
+// ctc.hip -- softmax and the CTC forward-backward over a padded utterance batch, for gfx950.
+//
+// Reference arithmetic: Ctc::EvalParallel /root/reference/src/net/ctc-loss.cc:101-194 and its three
+// CUDA kernels src/gpucompute/cuda-kernels.cu:1367-1408 (alpha), :1482-1544 (beta, live branch
+// :1527-1543), :1603-1627 (error), with the log-domain helpers of src/gpucompute/ctc-utils.h:53-96
+// (-1e30 sentinel compared with ==, ExpA clamps).  The reference launches one kernel per time step per
+// sweep (2T launches, each preceded by 2-3 blocking H2D copies of the label arrays).
+//
+// Here the lattice sweep of one utterance is ONE wavefront that walks all T_s steps inside a single
+// launch: lane l owns the PL consecutive lattice positions [l*PL, (l+1)*PL), so the j-1 / j-2 (alpha) and
+// j+1 / j+2 (beta) neighbours are in-register except at the chunk edge, where two wave shuffles
+// (__shfl_up / __shfl_down) fetch them -- no LDS, no barrier on the 2T-step dependency chain.  The alpha
+// and beta sweeps of all S utterances run concurrently (2S wavefronts).  The next step's log-probability
+// gather is issued one step ahead so its latency sits under the current step's log-add-exp.  alpha/beta
+// rows are written utterance-major [S][T][64*PL] so every store is one coalesced line-aligned row.
+// The per-frame gradient is then a bulk pass (one wavefront per frame) that stages alpha+beta in LDS
+// and lets lane k fold class k's lattice positions (precomputed per utterance), emitting
+// d(-ln p)/d(logits) directly.
+#include "kernels.h"
+
+namespace eesen {
+namespace {
+
+// ---- src/gpucompute/ctc-utils.h:33-96, fp32 instantiation ------------------------------------------
+constexpr float kLogZero = -1e30f, kLogInf = 1e30f, kExpLimit = 88.722839f, kFltMax = 3.4028235e+038f;
+__device__ __forceinline__ float AddAB(float a, float b) { return (a == kLogZero || b == kLogZero) ? kLogZero : a + b; }
+__device__ __forceinline__ float SubAB(float a, float b) {
+  if (a == kLogZero) return kLogZero;
+  if (b == kLogZero) return kLogInf;
+  return a - b;
+}
+__device__ __forceinline__ float ExpA(float a) {
+  if (a <= kLogZero) return 0.f;
+  if (a >= kExpLimit) return kFltMax;
+  return expf(a);
+}
+__device__ __forceinline__ float LogAPlusB(float a, float b) {
+  if (b < a) return AddAB(a, logf(1.f + ExpA(SubAB(b, a))));
+  return AddAB(b, logf(1.f + ExpA(SubAB(a, b))));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- Softmax::PropagateFnc (softmax-layer.h:44-47): one wavefront per row ---------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                           int ldy, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * ldx;
+  float* yr = y + (size_t)r * ldy;
+  float mx = -3.4e38f;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, xr[k]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < K; k += 64) sum += expf(xr[k] - mx);
+  sum = wave_sum(sum);
+  for (int k = lane; k < K; k += 64) yr[k] = expf(xr[k] - mx) / sum;
+}
+
+__global__ __launch_bounds__(256) void log_rows_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out,
+                                                       int ldo, int rows, int K) {
+  const size_t total = (size_t)rows * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K, k = i % K;
+    out[r * ldo + k] = logf(in[r * ldi + k]);
+  }
+}
+
+template <int PL>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float (&v)[PL]) {
+  if constexpr (PL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < PL; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else if constexpr (PL == 2) {
+    *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PL; ++i) dst[i] = v[i];
+  }
+}
+
+// ---- alpha / beta sweeps: grid (S, 2), one wavefront each -------------------------------------------
+template <int PL>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, int ld, int T, int S,
+                                                            const int* __restrict__ labx, const int* __restrict__ lens,
+                                                            const int* __restrict__ lablens, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, float* __restrict__ pzx) {
+  constexpr int Lpad = 64 * PL;
+  __shared__ float last[Lpad];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const bool is_beta = blockIdx.y == 1;
+  const int len = lens[s], ll = lablens[s];
+  const int* lab = labx + (size_t)s * Lpad;
+  const int j0 = lane * PL;
+
+  int cls[PL];
+  bool three[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int j = j0 + i;
+    cls[i] = lab[j];
+    if (!is_beta) three[i] = cls[i] >= 0 && j > 1 && (j & 1) && lab[j - 2] != cls[i];                 // :1396
+    else three[i] = cls[i] >= 0 && j < ll - 2 && (j & 1) && lab[j + 2] != cls[i];                      // :1532
+  }
+  if (len <= 0) {
+    if (!is_beta && lane == 0) pzx[s] = kLogZero;
+    return;
+  }
+  float* out = (is_beta ? beta : alpha) + (size_t)s * T * Lpad + j0;
+  float cur[PL], pn[PL];
+
+  if (!is_beta) {
+    // row 0 (:1391-1393)
+    const float* lp = logp + (size_t)s * ld;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int j = j0 + i;
+      cur[i] = (cls[i] >= 0 && j < 2) ? lp[cls[i]] : kLogZero;
+    }
+    store_row<PL>(out, cur);
+    if (len > 1) {
+      const float* l1 = logp + (size_t)(1 * S + s) * ld;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? l1[cls[i]] : 0.f;
+    }
+    for (int t = 1; t < len; ++t) {
+      float p[PL];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) p[i] = pn[i];
+      if (t + 1 < len) {  // gather for the next step now; it is consumed one iteration later
+        const float* ln = logp + (size_t)((t + 1) * S + s) * ld;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? ln[cls[i]] : 0.f;
+      }
+      const float pm1 = __shfl_up(cur[PL - 1], 1);
+      const float pm2 = PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2);
+      float nxt[PL];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        const int j = j0 + i;
+        const float a0 = cur[i];
+        const float a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : pm1;
+        const float a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? pm1 : pm2);
+        float v;
+        if (cls[i] < 0) v = kLogZero;                                          // :1380-1383
+        else if (j > 1) {
+          const float tmp = LogAPlusB(a1, a0);                                  // :1397 / :1399
+          v = three[i] ? AddAB(p[i], LogAPlusB(a2, tmp)) : AddAB(p[i], tmp);    // :1400 / :1397
+        } else if (j == 1) v = AddAB(p[i], LogAPlusB(a1, a0));                 // :1403
+        else v = AddAB(p[i], a0);                                              // :1405
+        nxt[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
+      store_row<PL>(out + (size_t)t * Lpad, cur);
+    }
+    // ln p(z|x) = logadd(alpha[T_s-1][L'_s-1], alpha[T_s-1][L'_s-2])  (ctc-loss.cc:147-153)
+#pragma unroll
+    for (int i = 0; i < PL; ++i) last[j0 + i] = cur[i];
+    __syncthreads();
+    if (lane == 0) {
+      const float tmp1 = last[ll - 1], tmp2 = ll >= 2 ? last[ll - 2] : kLogZero;
+      pzx[s] = tmp1 + logf(1.f + ExpA(tmp2 - tmp1));
+    }
+  } else {
+    // row T_s - 1 (:1527-1529)
+    const float* lp = logp + (size_t)((len - 1) * S + s) * ld;
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      const int j = j0 + i;
+      cur[i] = (cls[i] >= 0 && j > ll - 3) ? lp[cls[i]] : kLogZero;
+    }
+    store_row<PL>(out + (size_t)(len - 1) * Lpad, cur);
+    if (len > 1) {
+      const float* l1 = logp + (size_t)((len - 2) * S + s) * ld;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? l1[cls[i]] : 0.f;
+    }
+    for (int t = len - 2; t >= 0; --t) {
+      float p[PL];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) p[i] = pn[i];
+      if (t > 0) {
+        const float* ln = logp + (size_t)((t - 1) * S + s) * ld;
+#pragma unroll
+        for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? ln[cls[i]] : 0.f;
+      }
+      const float nm1 = __shfl_down(cur[0], 1);
+      const float nm2 = PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2);
+      float nxt[PL];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        const int j = j0 + i;
+        const float b0 = cur[i];
+        const float b1 = i + 1 < PL ? cur[i + 1 < PL ? i + 1 : 0] : nm1;
+        const float b2 = i + 2 < PL ? cur[i + 2 < PL ? i + 2 : 0] : (i + 2 == PL ? nm1 : nm2);
+        float v;
+        if (cls[i] < 0) v = kLogZero;                                          // :1495-1498
+        else if (j < ll - 2) {
+          const float tmp = LogAPlusB(b1, b0);                                  // :1533 / :1535
+          v = three[i] ? AddAB(p[i], LogAPlusB(b2, tmp)) : AddAB(p[i], tmp);    // :1536 / :1533
+        } else if (j == ll - 2) v = AddAB(p[i], LogAPlusB(b1, b0));            // :1539
+        else v = AddAB(p[i], b0);                                              // :1541
+        nxt[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
+      store_row<PL>(out + (size_t)t * Lpad, cur);
+    }
+  }
+}
+
+// ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per frame -----
+__global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __restrict__ probs, int ld, int T, int S, int K,
+                                                             int Lpad, const int* __restrict__ lens,
+                                                             const int* __restrict__ cls_off,
+                                                             const int* __restrict__ cls_pos,
+                                                             const float* __restrict__ alpha,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ pzx, float* __restrict__ diff,
+                                                             int ldd) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + w;
+  if (r >= T * S) return;
+  const int t = r / S, s = r % S;
+  float* drow = diff + (size_t)r * ldd;
+  if (t >= lens[s]) {  // ctc_err_ stays zero there (:1613), and so does diff
+    for (int k = lane; k < K; k += 64) drow[k] = 0.f;
+    return;
+  }
+  float* ab = smem + (size_t)w * (Lpad + K);
+  float* ek = ab + Lpad;
+  const float* ar = alpha + ((size_t)s * T + t) * Lpad;
+  const float* br = beta + ((size_t)s * T + t) * Lpad;
+  for (int j = lane; j < Lpad; j += 64) ab[j] = AddAB(ar[j], br[j]);
+  __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
+  const float* yr = probs + (size_t)r * ld;
+  const int* co = cls_off + (size_t)s * (K + 1);
+  const int* cp = cls_pos + (size_t)s * Lpad;
+  const float pz = pzx[s];
+  float rsum = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float err = kLogZero;
+    const int e = co[k + 1];
+    for (int idx = co[k]; idx < e; ++idx) err = LogAPlusB(err, ab[cp[idx]]);              // :1617-1624
+    const float y = yr[k];
+    const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
+    const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
+    ek[k] = e_k;
+    rsum += e_k;
+  }
+  rsum = wave_sum(rsum);                                                                   // ctc-loss.cc:162
+  for (int k = lane; k < K; k += 64) drow[k] = ek[k] - yr[k] * rsum;                       // :164-168
+}
+
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ m, int ld, int rows, int K,
+                                                         int* __restrict__ ids) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* mr = m + (size_t)r * ld;
+  float best = -1e21f;  // cuda-matrix.cc:1045
+  int bi = -1;
+  for (int k = lane; k < K; k += 64) {
+    const float v = mr[k];
+    if (best < v) { best = v; bi = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ov; bi = oi; }
+  }
+  if (lane == 0) ids[r] = bi;
+}
+
+}  // namespace
+
+void softmax_rows(hipStream_t st, const float* x, int ldx, float* y, int ldy, int rows, int K) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, y, ldy, rows, K);
+  check_launch("softmax_rows");
+}
+
+void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int rows, int K) {
+  if (rows <= 0) return;
+  const size_t total = (size_t)rows * K;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(log_rows_kernel, dim3(blocks), dim3(256), 0, st, in, ldi, out, ldo, rows, K);
+  check_launch("log_rows");
+}
+
+void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
+                    const int* lablens, float* alpha, float* beta, float* pzx) {
+  dim3 grid(S, 2), block(64);
+#define EESEN_AB(PL)                                                                                               \
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<PL>), grid, block, 0, st, logp, ld, T, S, labx, lens, lablens, alpha, \
+                     beta, pzx)
+  switch (Lpad / 64) {
+    case 1: EESEN_AB(1); break;
+    case 2: EESEN_AB(2); break;
+    case 4: EESEN_AB(4); break;
+    case 8: EESEN_AB(8); break;
+    case 16: EESEN_AB(16); break;
+    default: throw Error(EESEN_ERR_INVALID, "ctc: expanded label length above 1024 is not supported");
+  }
+#undef EESEN_AB
+  check_launch("ctc_alpha_beta");
+}
+
+void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
+                    const int* cls_off, const int* cls_pos, const float* alpha, const float* beta, const float* pzx,
+                    float* diff, int ldd) {
+  const int rows = T * S;
+  if (rows <= 0) return;
+  const size_t smem = (size_t)4 * (Lpad + K) * sizeof(float);
+  hipLaunchKernelGGL(ctc_error_diff_kernel, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens,
+                     cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
+  check_launch("ctc_error_diff");
+}
+
+void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* ids) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, m, ld, rows, K, ids);
+  check_launch("row_argmax");
+}
+
+}  // namespace eesen

@@ -1,0 +1,205 @@
+// ctc_host.cpp -- host side of the Ctc object: label expansion, launch sequence, statistics, greedy
+// decoding.  Replaces eesen::Ctc::EvalParallel / ErrorRateMSeq (/root/reference/src/net/ctc-loss.cc:101-194,
+// :235-298).  The lattice arithmetic itself is in ctc.hip.
+#include <algorithm>
+#include <cmath>
+
+#include "net.h"
+
+namespace eesen {
+
+Ctc::Ctc(int dev, void* stream) : device(dev) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error(EESEN_ERR_HIP, "no HIP device available: this library has no CPU fallback");
+  EESEN_REQUIRE(dev >= 0 && dev < n, EESEN_ERR_INVALID, "device index out of range");
+  EESEN_HIP_CHECK(hipSetDevice(dev));
+  st = reinterpret_cast<hipStream_t>(stream);  // NULL = the device's default stream (shared with the Net)
+  for (auto& x : ev) EESEN_HIP_CHECK(hipEventCreate(&x));
+}
+
+Ctc::~Ctc() {
+  (void)hipSetDevice(device);
+  (void)hipStreamSynchronize(st);
+  for (auto& x : ev)
+    if (x) (void)hipEventDestroy(x);
+  if (own_stream) (void)hipStreamDestroy(st);
+}
+
+static void check_batch(const int* frame_num_utt, int S, int rows, int K, const int* label_ids, const int* label_off) {
+  EESEN_REQUIRE(S > 0 && rows > 0 && rows % S == 0, EESEN_ERR_INVALID, "rows must be a positive multiple of the sequence count");
+  EESEN_REQUIRE(K > 0, EESEN_ERR_INVALID, "no classes");
+  const int T = rows / S;
+  for (int s = 0; s < S; ++s) {
+    EESEN_REQUIRE(frame_num_utt[s] >= 0 && frame_num_utt[s] <= T, EESEN_ERR_INVALID, "frame_num_utt out of range");
+    EESEN_REQUIRE(label_off[s + 1] >= label_off[s], EESEN_ERR_INVALID, "label offsets must be non-decreasing");
+  }
+  for (int i = label_off[0]; i < label_off[S]; ++i)
+    EESEN_REQUIRE(label_ids[i] >= 0 && label_ids[i] < K, EESEN_ERR_INVALID, "label id outside [0, K)");
+}
+
+void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld, const int* label_ids,
+                        const int* label_off, float* diff, int ldd, float* pzx_host) {
+  check_batch(frame_num_utt, S, rows, K, label_ids, label_off);
+  EESEN_REQUIRE(ld >= K && ldd >= K, EESEN_ERR_INVALID, "leading dimension smaller than the class count");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  const int T = rows / S;
+  int maxU = 0;
+  for (int s = 0; s < S; ++s) {
+    const int U = label_off[s + 1] - label_off[s];
+    // an empty label sequence reads alpha column -1 in the reference (ctc-loss.cc:151); refuse it
+    EESEN_REQUIRE(U >= 1, EESEN_ERR_INVALID, "every sequence needs at least one label");
+    maxU = std::max(maxU, U);
+  }
+  const int Lprime = 2 * maxU + 1;  // ctc-loss.cc:118
+  int PL = 1;
+  while (64 * PL < Lprime) PL *= 2;
+  EESEN_REQUIRE(PL <= 16, EESEN_ERR_INVALID, "expanded label length above 1024 is not supported");
+  const int Lpad = 64 * PL;
+
+  // label expansion (ctc-loss.cc:116-129) + per-class position lists, all in one staging vector
+  const size_t n_labx = (size_t)S * Lpad, n_off = (size_t)S * (K + 1);
+  std::vector<int> h(n_labx + n_labx + n_off + 2 * (size_t)S);
+  int* labx_h = h.data();
+  int* pos_h = labx_h + n_labx;
+  int* off_h = pos_h + n_labx;
+  int* lens_h = off_h + n_off;
+  int* ll_h = lens_h + S;
+  std::fill(labx_h, labx_h + n_labx, -1);
+  std::fill(pos_h, pos_h + n_labx, 0);
+  std::vector<int> cnt(K + 1);
+  for (int s = 0; s < S; ++s) {
+    const int U = label_off[s + 1] - label_off[s];
+    const int* lab = label_ids + label_off[s];
+    int* lx = labx_h + (size_t)s * Lpad;
+    for (int l = 0; l < U; ++l) { lx[2 * l] = 0; lx[2 * l + 1] = lab[l]; }
+    lx[2 * U] = 0;
+    lens_h[s] = frame_num_utt[s];
+    ll_h[s] = 2 * U + 1;
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int j = 0; j < 2 * U + 1; ++j) cnt[lx[j] + 1]++;
+    int* co = off_h + (size_t)s * (K + 1);
+    co[0] = 0;
+    for (int k = 0; k < K; ++k) co[k + 1] = co[k] + cnt[k + 1];
+    std::vector<int> fill(co, co + K);
+    int* cp = pos_h + (size_t)s * Lpad;
+    for (int j = 0; j < 2 * U + 1; ++j) cp[fill[lx[j]]++] = j;  // ascending j within each class, as the error kernel's loop visits them
+  }
+  labx.reserve(h.size());
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));  // a previous call may still read the staging buffers
+  EESEN_HIP_CHECK(hipMemcpy(labx.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  const int* labx_d = labx.p;
+  const int* pos_d = labx_d + n_labx;
+  const int* off_d = pos_d + n_labx;
+  const int* lens_dd = off_d + n_off;
+  const int* ll_d = lens_dd + S;
+
+  logp.reserve((size_t)rows * K);
+  alpha.reserve((size_t)S * T * Lpad);
+  beta.reserve((size_t)S * T * Lpad);
+  pzx_d.reserve(S);
+
+  EESEN_HIP_CHECK(hipEventRecord(ev[0], st));
+  log_rows(st, net_out, ld, logp.p, K, rows, K);                                               // ctc-loss.cc:132-133
+  EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
+  ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p);  // :136-153
+  EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
+  ctc_error_diff(st, net_out, ld, T, S, K, Lpad, lens_dd, off_d, pos_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
+  EESEN_HIP_CHECK(hipEventRecord(ev[3], st));
+
+  std::vector<float> pz(S);
+  EESEN_HIP_CHECK(hipMemcpyAsync(pz.data(), pzx_d.p, S * sizeof(float), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  double sum = 0;
+  for (int s = 0; s < S; ++s) {
+    sum += pz[s];
+    frames += frame_num_utt[s];
+    if (pzx_host) pzx_host[s] = pz[s];
+  }
+  obj_sum += sum;  // ctc-loss.cc:171-177
+  sequences += S;
+  last_lens.assign(frame_num_utt, frame_num_utt + S);
+  last_T = T; last_S = S; last_Lpad = Lpad; last_Lprime = Lprime;
+}
+
+void Ctc::phase_times(float* out3) {
+  for (int i = 0; i < 3; ++i) {
+    float ms = 0.f;
+    EESEN_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    out3[i] = ms * 1e-3f;
+  }
+}
+
+void Ctc::get_alpha_beta(float* alpha_host, float* beta_host, int* Lprime) {
+  EESEN_REQUIRE(last_T > 0, EESEN_ERR_STATE, "no EvalParallel yet");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  const int T = last_T, S = last_S, Lpad = last_Lpad, Lp = last_Lprime;
+  if (Lprime) *Lprime = Lp;
+  std::vector<float> h((size_t)S * T * Lpad);
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which == 0 ? alpha_host : beta_host;
+    if (!dst) continue;
+    EESEN_HIP_CHECK(hipMemcpy(h.data(), which == 0 ? alpha.p : beta.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t)
+      for (int s = 0; s < S; ++s) {
+        float* o = dst + ((size_t)t * S + s) * Lp;
+        if (t >= last_lens[s]) {  // rows the sweep never visits; the reference leaves -1e30 there (ctc-loss.cc:138-139)
+          for (int j = 0; j < Lp; ++j) o[j] = -1e30f;
+        } else {
+          const float* src = h.data() + ((size_t)s * T + t) * Lpad;
+          for (int j = 0; j < Lp; ++j) o[j] = src[j];
+        }
+      }
+  }
+}
+
+// LevenshteinEditDistance (src/util/edit-distance-inl.h), total errors only
+static int levenshtein(const int* ref, int nr, const std::vector<int>& hyp) {
+  const int nh = (int)hyp.size();
+  std::vector<int> prev(nh + 1), cur(nh + 1);
+  for (int j = 0; j <= nh; ++j) prev[j] = j;
+  for (int i = 1; i <= nr; ++i) {
+    cur[0] = i;
+    for (int j = 1; j <= nh; ++j) {
+      const int sub = prev[j - 1] + (ref[i - 1] == hyp[j - 1] ? 0 : 1);
+      cur[j] = std::min(sub, std::min(prev[j] + 1, cur[j - 1] + 1));
+    }
+    std::swap(prev, cur);
+  }
+  return prev[nh];
+}
+
+void Ctc::error_rate_mseq(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld,
+                          const int* label_ids, const int* label_off, int* num_err, int* num_ref) {
+  check_batch(frame_num_utt, S, rows, K, label_ids, label_off);
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  ids_d.reserve(rows);
+  row_argmax(st, net_out, ld, rows, K, ids_d.p);  // FindRowMaxId, ctc-loss.cc:238-239
+  std::vector<int> ids(rows);
+  EESEN_HIP_CHECK(hipMemcpyAsync(ids.data(), ids_d.p, rows * sizeof(int), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  int err = 0, ref = 0;
+  std::vector<int> hyp;
+  for (int s = 0; s < S; ++s) {
+    hyp.clear();
+    int last = -1;
+    for (int f = 0; f < frame_num_utt[s]; ++f) {  // collapse repeats, drop blanks (ctc-loss.cc:252-275)
+      const int id = ids[(size_t)f * S + s];
+      if (f == 0 || id != last) {
+        if (id != 0) hyp.push_back(id);
+      }
+      last = id;
+    }
+    const int U = label_off[s + 1] - label_off[s];
+    err += levenshtein(label_ids + label_off[s], U, hyp);
+    ref += U;
+  }
+  err_tokens += err;
+  ref_tokens += ref;
+  if (num_err) *num_err = err;
+  if (num_ref) *num_ref = ref;
+}
+
+}  // namespace eesen

@@ -1,0 +1,243 @@
+// gemm.hip -- fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, for gfx950.
+//
+// Serves every dense contraction of the hot path that is NOT inside the time recurrence
+// (/root/reference/src/net/bilstm-parallel-layer.h:109,163 input->gates; :502,593 input gradient;
+// :505-506,596-597 weight gradients; affine-trans-layer.h:165,171,182), i.e. what the reference sends
+// to cublasSgemm through CuMatrixBase::AddMatMat (src/gpucompute/cuda-matrix.cc:604-639).
+//
+// Design (MI355X-first, not a cuBLAS call pattern):
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles
+//     of 32x32, 64 accumulator registers), BK = 16, two LDS stages with register prefetch of the next
+//     k-tile so global latency sits under 32 MFMAs (2048 matrix-pipe cycles per wave per k-tile).
+//   * LDS holds both operands k-major ([k][m] / [k][n], row padded by 4 floats): every MFMA operand read
+//     is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave, whatever the storage order
+//     of the operand in HBM (transposition happens on the LDS write, 2-way conflicts only).
+//   * exact fp32: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain (guide section 3), so results are
+//     ordinary fp32 GEMM results -- no TF32-like truncation anywhere.
+//   * split-K (deterministic two-pass: partial slabs + reduce kernel) for the weight-gradient shapes
+//     whose M x N tile count cannot fill 256 CUs (e.g. 2048 x 512 with K = T*S = 32000).
+#include "kernels.h"
+
+namespace eesen {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDP = 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K;
+  int lda, ldb, ldc;
+  float alpha, beta;
+  int splits;   // grid.y
+  int k_chunk;  // K elements per split (multiple of BK)
+  int tiles_n;
+};
+
+// Load one [rows x BK] operand tile (rows = BM or BN) from HBM into registers: 2 float4 per thread.
+// KC = true : operand stored [R x K], k contiguous.  float4 f -> (r = f >> 2, kq = f & 3)
+// KC = false: operand stored [K x R], r contiguous.  float4 f -> (k = f >> 5, rq = f & 31)
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend,
+                                          int tid, float4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * 256;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int r = r0 + (f >> 2), k = k0 + ((f & 3) << 2);
+      if (r < R) {
+        const float* src = P + (size_t)r * ld + k;
+        if (k + 3 < kend) {
+          x = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k + 0 < kend) x.x = src[0];
+          if (k + 1 < kend) x.y = src[1];
+          if (k + 2 < kend) x.z = src[2];
+        }
+      }
+    } else {
+      const int k = k0 + (f >> 5), r = r0 + ((f & 31) << 2);
+      if (k < kend) {
+        const float* src = P + (size_t)k * ld + r;
+        if (r + 3 < R) {
+          x = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (r + 0 < R) x.x = src[0];
+          if (r + 1 < R) x.y = src[1];
+          if (r + 2 < R) x.z = src[2];
+        }
+      }
+    }
+    v[i] = x;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const float4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * 256;
+    if (KC) {
+      const int r = f >> 2, k = (f & 3) << 2;
+      T[k + 0][r] = v[i].x;
+      T[k + 1][r] = v[i].y;
+      T[k + 2][r] = v[i].z;
+      T[k + 3][r] = v[i].w;
+    } else {
+      const int k = f >> 5, r = (f & 31) << 2;
+      *reinterpret_cast<float4*>(&T[k][r]) = v[i];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LDP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, tid, ra);
+    load_tile<B_KC>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+    store_tile<A_KC>(As[0], tid, ra);
+    store_tile<B_KC>(Bs[0], tid, rb);
+  }
+  __syncthreads();
+
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, tid, ra);
+      load_tile<B_KC>(p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int kr = 2 * kk + lk;
+      const float a0 = As[cur][kr][wm * 64 + lr];
+      const float a1 = As[cur][kr][wm * 64 + 32 + lr];
+      const float b0 = Bs[cur][kr][wn * 64 + lr];
+      const float b1 = Bs[cur][kr][wn * 64 + 32 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_tile<A_KC>(As[cur ^ 1], tid, ra);
+      store_tile<B_KC>(Bs[cur ^ 1], tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* C = p.C;
+  size_t ldc = p.ldc;
+  const bool partial = p.splits > 1;
+  if (partial) {  // raw partial sums into slab `split` of the workspace, dense [M x N]
+    C = p.C + (size_t)split * p.M * p.N;
+    ldc = p.N;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + lr;
+      if (col >= p.N) continue;
+      const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= p.M) continue;
+        float* dst = C + (size_t)row * ldc + col;
+        if (partial) {
+          *dst = acc[mi][ni][r];
+        } else {
+          float v = p.alpha * acc[mi][ni][r] + bv;
+          if (p.beta != 0.f) v += p.beta * *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
+// C = alpha * sum_s ws[s] + beta * C + bias
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
+                                                            float alpha, float beta, float* __restrict__ C, int ldc,
+                                                            const float* __restrict__ bias) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
+    const int row = (int)(i / N), col = (int)(i % N);
+    float v = alpha * s + (bias ? bias[col] : 0.f);
+    float* dst = C + (size_t)row * ldc + col;
+    if (beta != 0.f) v += beta * *dst;
+    *dst = v;
+  }
+}
+
+}  // namespace
+
+void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
+              const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats) {
+  if (M <= 0 || N <= 0) return;
+  EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
+  EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = alpha; p.beta = beta;
+  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+  p.tiles_n = tiles_n;
+  const long tiles = (long)tiles_m * tiles_n;
+  // split-K only when the tile grid cannot fill the chip and K is long enough to amortise the reduce pass
+  int splits = 1;
+  if (ws && tiles < 256 && K >= 2048) {
+    splits = (int)std::min<long>(512 / tiles, K / 1024);
+    splits = std::max(1, std::min(splits, 64));
+    while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
+  }
+  int k_chunk = cdiv(cdiv(K, splits), BK) * BK;
+  if (k_chunk < BK) k_chunk = BK;
+  splits = std::max(1, cdiv(K, k_chunk));
+  p.splits = splits;
+  p.k_chunk = k_chunk;
+  if (splits > 1) p.C = ws;
+  dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, true>), grid, block, 0, st, p);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, false>), grid, block, 0, st, p);
+  else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, false>), grid, block, 0, st, p);
+  check_launch("gemm_f32_mfma");
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, splits, M, N, alpha, beta,
+                       C, ldc, bias);
+    check_launch("splitk_reduce");
+  }
+}
+
+}  // namespace eesen

@@ -1,0 +1,74 @@
+// kernels.h -- host-side launchers of the gfx950 kernels (definitions in gemm.hip, lstm.hip, ctc.hip, optim.hip).
+// All pointers are device pointers; every launcher enqueues on `st` and returns without synchronising.
+#pragma once
+#include "common.h"
+
+namespace eesen {
+
+// ---------------------------------------------------------------------------------------- gemm.hip
+// C[M x N] = alpha * op(A) * op(B) + beta * C (+ bias[n]).  fp32 in, fp32 accumulate on
+// v_mfma_f32_32x32x2_f32.  a_kc: A stored [M x K] (k contiguous) else [K x M]; b_kc: B stored [N x K]
+// else [K x N].  All base pointers 16-byte aligned and all leading dimensions multiples of 4.
+// `ws`/`ws_floats`: split-K workspace (may be null => no split).  Replaces the cublasSgemm behind
+// CuMatrixBase::AddMatMat (/root/reference/src/gpucompute/cuda-matrix.cc:604-639).
+void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
+              const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+              size_t ws_floats);
+
+// ---------------------------------------------------------------------------------------- lstm.hip
+struct LstmLayerDev {
+  // geometry
+  int T, S, H, ndir;
+  // activations of this layer (see DESIGN.md "data layout")
+  float* G;         // [T*S x ndir*4H]   gate-interleaved (col = dir*4H + u*4 + q, q in g,i,f,o)
+  float* C;         // [(T+2)*S x ndir*H] cell state, row (t+1)*S+s, boundary row-blocks zero
+  float* Y;         // [(T+2)*S x ndir*H] cell output m, same indexing; rows S.. are the layer output
+  // parameters (internal layout)
+  const float* Wm;   // [ndir][4H x H]   rows gate-interleaved (u*4+q)
+  const float* WmT;  // [ndir][H x 4H]   transpose of the above
+  const float* peep; // [ndir][3][H]     p_i, p_f, p_o
+  const int* lens;   // [S]
+};
+// One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
+void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
+// One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.
+// dY: [T*S x ndir*H] gradient w.r.t. the layer output, DG: [T*S x ndir*4H] (out), DCF: [S x ndir*H] carry.
+void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float* dY, int lddy, float* DG, float* DCF);
+// bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of
+// bilstm-parallel-layer.h:507-510 / :598-601.  ws: >= red_rows_ws(...) floats.
+void lstm_bias_peep_grads(hipStream_t st, const LstmLayerDev& L, const float* DG, float* bias_grad, float* peep_grad,
+                          float* ws, size_t ws_floats);
+size_t lstm_bias_peep_ws_floats(int T, int S, int H, int ndir);
+
+// out[c] = sum_r M[r][c]  (bias gradient of AffineTransform, affine-trans-layer.h:183)
+void col_sums(hipStream_t st, const float* M, int rows, int cols, int ld, float* out, float* ws, size_t ws_floats);
+size_t col_sums_ws_floats(int rows, int cols);
+
+// ---------------------------------------------------------------------------------------- ctc.hip
+// y = softmax(x) per row (Softmax::PropagateFnc, softmax-layer.h:44-47)
+void softmax_rows(hipStream_t st, const float* x, int ldx, float* y, int ldy, int rows, int K);
+// out = log(in) elementwise on a [rows x K] matrix (CuMatrixBase::ApplyLog, ctc-loss.cc:132-133)
+void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int rows, int K);
+// alpha and beta lattice sweeps for all S sequences (2*S single-wave workgroups).
+// logp: [T*S x K] (ld), labx: [S x Lpad] expanded labels (-1 padded), lens/lablens: [S]
+// alpha/beta: [S][T][Lpad] (utterance-major), pzx: [S]
+void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
+                    const int* lablens, float* alpha, float* beta, float* pzx);
+// diff[t*S+s][k] = y*rowsum(e) - gamma ... (error kernel + softmax Jacobian, ctc-loss.cc:156-168)
+// cls_off [S x (K+1)], cls_pos [S x Lpad]: per sequence the lattice positions of each class, ascending.
+void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
+                    const int* cls_off, const int* cls_pos, const float* alpha, const float* beta, const float* pzx,
+                    float* diff, int ldd);
+// ids[r] = argmax_k m[r][k], first maximum wins (CuMatrixBase::FindRowMaxId, cuda-matrix.cc:1038-1095)
+void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* ids);
+
+// ---------------------------------------------------------------------------------------- optim.hip
+// corr = mmt*corr + fresh; clip to +-max_grad when max_grad > 0; param -= lr_coef*corr
+void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
+                float max_grad);
+// dst[c][r] = src[r][c]  (rows x cols -> cols x rows), dense
+void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst);
+// dst[r][0..cols) = src[r][0..cols) with different leading dimensions
+void copy2d(hipStream_t st, const float* src, int lds, float* dst, int ldd, int rows, int cols);
+
+}  // namespace eesen

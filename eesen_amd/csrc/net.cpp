@@ -1,0 +1,410 @@
+// net.cpp -- host orchestration of the hot path: the replacement of eesen::Net
+// (/root/reference/src/net/net.{h,cc}) for the layer kinds on the path.
+//
+//   Net::Propagate      net.cc:67-86     -> Net::propagate
+//   Net::Backpropagate  net.cc:88-108    -> Net::backpropagate (+ Net::update for the Update calls :101-104)
+//   BiLstmParallel      bilstm-parallel-layer.h:379-420 (fwd), :881-913 (bwd); Lstm twin lstm-parallel-layer.h
+//   AffineTransform     affine-trans-layer.h:161-219;  Softmax softmax-layer.h:44-57
+//
+// Differences by design: one input GEMM for both directions, gate-interleaved G layout,
+// everything asynchronous on one HIP stream, fresh gradients kept apart from the momentum buffer until
+// update() so the data-parallel all-reduce can sit between backpropagate() and update().
+#include "net.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace eesen {
+
+// ------------------------------------------------------------------------------------------ PhaseTimer
+PhaseTimer::~PhaseTimer() {
+  for (auto& s : spans_) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+}
+void PhaseTimer::begin(hipStream_t st, int phase) {
+  if (!on_) return;
+  if (used_ == spans_.size()) {
+    Span s;
+    EESEN_HIP_CHECK(hipEventCreate(&s.a));
+    EESEN_HIP_CHECK(hipEventCreate(&s.b));
+    spans_.push_back(s);
+  }
+  spans_[used_].phase = phase;
+  EESEN_HIP_CHECK(hipEventRecord(spans_[used_].a, st));
+  open_ = true;
+}
+void PhaseTimer::end(hipStream_t st) {
+  if (!on_ || !open_) return;
+  EESEN_HIP_CHECK(hipEventRecord(spans_[used_].b, st));
+  ++used_;
+  open_ = false;
+}
+void PhaseTimer::collect(float* out, int nphase) {
+  for (int i = 0; i < nphase; ++i) out[i] = 0.f;
+  for (size_t i = 0; i < used_; ++i) {
+    EESEN_HIP_CHECK(hipEventSynchronize(spans_[i].b));
+    float ms = 0.f;
+    EESEN_HIP_CHECK(hipEventElapsedTime(&ms, spans_[i].a, spans_[i].b));
+    if (spans_[i].phase >= 0 && spans_[i].phase < nphase) out[spans_[i].phase] += ms * 1e-3f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Layer
+long Layer::file_params() const {
+  if (is_lstm()) return (long)ndir * ((long)4 * H * din + (long)4 * H * H + 4 * H + 3 * H);  // bilstm-layer.h:991-998
+  if (kind == EESEN_LAYER_AFFINE) return (long)dout * din + dout;
+  return 0;
+}
+
+// Visits every parameter of a layer as (index in Net::GetParams order, offset in the internal block).
+// File / GetParams order per LSTM direction: W_x [4H x D], W_m [4H x H], bias [4H], p_i, p_f, p_o [H]
+// (bilstm-layer.h:478-492, 1000-1031), gate rows in g,i,f,o order.  Internal: rows gate-interleaved
+// (row u*4+q), both directions' W_x stacked, W_x rows padded to a multiple of 4 floats.
+template <class F>
+static void for_each_param(const Layer& L, F f) {
+  long fi = 0;
+  if (L.is_lstm()) {
+    const int H = L.H, D = L.din, D4 = pad4(L.din);
+    for (int dir = 0; dir < L.ndir; ++dir) {
+      for (int r = 0; r < 4 * H; ++r) {
+        const int q = r / H, u = r % H;
+        for (int d = 0; d < D; ++d) f(fi++, L.off_wx + ((size_t)dir * 4 * H + u * 4 + q) * D4 + d);
+      }
+      for (int r = 0; r < 4 * H; ++r) {
+        const int q = r / H, u = r % H;
+        for (int k = 0; k < H; ++k) f(fi++, L.off_wm + ((size_t)dir * 4 * H + u * 4 + q) * H + k);
+      }
+      for (int r = 0; r < 4 * H; ++r) f(fi++, L.off_bias + (size_t)dir * 4 * H + (r % H) * 4 + r / H);
+      for (int g = 0; g < 3; ++g)
+        for (int u = 0; u < H; ++u) f(fi++, L.off_peep + ((size_t)dir * 3 + g) * H + u);
+    }
+  } else if (L.kind == EESEN_LAYER_AFFINE) {
+    const int D4 = pad4(L.din);
+    for (int r = 0; r < L.dout; ++r)
+      for (int d = 0; d < L.din; ++d) f(fi++, L.off_w + (size_t)r * D4 + d);
+    for (int r = 0; r < L.dout; ++r) f(fi++, L.off_b + r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Net
+Net::Net(int dev, void* stream) : device(dev) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error(EESEN_ERR_HIP, "no HIP device available: this library has no CPU fallback (hipGetDeviceCount: " +
+                                   std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+  EESEN_REQUIRE(dev >= 0 && dev < n, EESEN_ERR_INVALID, "device index out of range");
+  EESEN_HIP_CHECK(hipSetDevice(dev));
+  // NULL selects the device's default stream, so a Net and a Ctc created without a stream are ordered
+  // against each other exactly like the reference's single-stream CuDevice.
+  st = reinterpret_cast<hipStream_t>(stream);
+}
+
+Net::~Net() {
+  (void)hipSetDevice(device);
+  (void)hipStreamSynchronize(st);
+  if (own_stream) (void)hipStreamDestroy(st);
+}
+
+void Net::sync() {
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
+  EESEN_REQUIRE(!finalized, EESEN_ERR_STATE, "net already finalized");
+  EESEN_REQUIRE(din > 0 && dout > 0, EESEN_ERR_INVALID, "layer dimensions must be positive");
+  if (!layers.empty())  // net.cc:282-286
+    EESEN_REQUIRE(layers.back().dout == din, EESEN_ERR_INVALID, "Dimensionality mismatch between consecutive layers");
+  layers.emplace_back();
+  Layer& L = layers.back();
+  L.kind = kind; L.din = din; L.dout = dout; L.coef = coef; L.max_grad = max_grad;
+  switch (kind) {
+    case EESEN_LAYER_BILSTM_PARALLEL:
+      EESEN_REQUIRE(dout % 2 == 0, EESEN_ERR_INVALID, "<CellDim> of a BiLstm layer must be even");
+      L.ndir = 2; L.H = dout / 2;
+      break;
+    case EESEN_LAYER_LSTM_PARALLEL:
+      L.ndir = 1; L.H = dout;
+      break;
+    case EESEN_LAYER_AFFINE:
+      break;
+    case EESEN_LAYER_SOFTMAX:
+      EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "Softmax needs InputDim == OutputDim");
+      break;
+    default:
+      layers.pop_back();
+      throw Error(EESEN_ERR_INVALID, "unsupported layer kind " + std::to_string(kind));
+  }
+  if (L.is_lstm()) EESEN_REQUIRE(L.H % 4 == 0, EESEN_ERR_INVALID, "LSTM cell count per direction must be a multiple of 4");
+}
+
+void Net::finalize() {
+  EESEN_REQUIRE(!finalized, EESEN_ERR_STATE, "net already finalized");
+  EESEN_REQUIRE(!layers.empty(), EESEN_ERR_INVALID, "empty net");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  size_t off = 0;
+  for (Layer& L : layers) {
+    L.p_off = off;
+    size_t n = 0;
+    if (L.is_lstm()) {
+      const size_t H = L.H, D4 = pad4(L.din), nd = L.ndir;
+      L.off_wx = n;   n += nd * 4 * H * D4;
+      L.off_bias = n; n += nd * 4 * H;
+      L.off_wm = n;   n += nd * 4 * H * H;
+      L.off_peep = n; n += nd * 3 * H;
+      L.WmT.reserve(nd * H * 4 * H);
+    } else if (L.kind == EESEN_LAYER_AFFINE) {
+      L.off_w = n; n += (size_t)L.dout * pad4(L.din);
+      L.off_b = n; n += pad4(L.dout);
+    }
+    L.p_n = (n + 3) & ~(size_t)3;
+    off += L.p_n;
+  }
+  P = off;
+  if (P) {
+    params.reserve(P); corr.reserve(P); fresh.reserve(P);
+    EESEN_HIP_CHECK(hipMemsetAsync(params.p, 0, P * sizeof(float), st));
+    EESEN_HIP_CHECK(hipMemsetAsync(corr.p, 0, P * sizeof(float), st));
+    EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, P * sizeof(float), st));
+  }
+  finalized = true;
+  refresh_derived();
+  sync();
+}
+
+long Net::num_params() const {
+  long n = 0;
+  for (const Layer& L : layers) n += L.file_params();
+  return n;
+}
+
+void Net::refresh_derived() {
+  for (Layer& L : layers)
+    if (L.is_lstm())
+      for (int dir = 0; dir < L.ndir; ++dir)
+        transpose2d(st, params.p + L.p_off + L.off_wm + (size_t)dir * 4 * L.H * L.H, 4 * L.H, L.H,
+                    L.WmT.p + (size_t)dir * L.H * 4 * L.H);
+}
+
+void Net::set_params(const float* host, long n) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(n == num_params(), EESEN_ERR_INVALID, "parameter count mismatch");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  std::vector<float> h(P, 0.f);
+  long base = 0;
+  for (const Layer& L : layers) {
+    for_each_param(L, [&](long fi, size_t io) { h[L.p_off + io] = host[base + fi]; });
+    base += L.file_params();
+  }
+  sync();
+  if (P) EESEN_HIP_CHECK(hipMemcpy(params.p, h.data(), P * sizeof(float), hipMemcpyHostToDevice));
+  refresh_derived();
+  sync();
+}
+
+void Net::get_flat(const DevBuf<float>& buf, float* host, long n) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(n == num_params(), EESEN_ERR_INVALID, "parameter count mismatch");
+  sync();
+  std::vector<float> h(P);
+  if (P) EESEN_HIP_CHECK(hipMemcpy(h.data(), buf.p, P * sizeof(float), hipMemcpyDeviceToHost));
+  long base = 0;
+  for (const Layer& L : layers) {
+    for_each_param(L, [&](long fi, size_t io) { host[base + fi] = h[L.p_off + io]; });
+    base += L.file_params();
+  }
+}
+
+void Net::set_seq_lengths(const int* l, int s) {
+  EESEN_REQUIRE(s > 0, EESEN_ERR_INVALID, "need at least one sequence");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  lens.assign(l, l + s);
+  for (int v : lens) EESEN_REQUIRE(v >= 0, EESEN_ERR_INVALID, "negative sequence length");
+  lens_d.reserve(s);
+  sync();  // the previous step may still read the old lengths
+  EESEN_HIP_CHECK(hipMemcpy(lens_d.p, lens.data(), s * sizeof(int), hipMemcpyHostToDevice));
+  S = s;
+  propagated = false;
+}
+
+static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
+  LstmLayerDev d;
+  d.T = net.T; d.S = net.S; d.H = L.H; d.ndir = L.ndir;
+  d.G = L.G.p; d.C = L.C.p; d.Y = L.Y.p;
+  d.Wm = net.params.p + L.p_off + L.off_wm;
+  d.WmT = L.WmT.p;
+  d.peep = net.params.p + L.p_off + L.off_peep;
+  d.lens = net.lens_d.p;
+  return d;
+}
+
+void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(S > 0, EESEN_ERR_STATE, "SetSeqLengths must precede Propagate");
+  EESEN_REQUIRE(nrows > 0 && nrows % S == 0, EESEN_ERR_INVALID, "row count must be a positive multiple of the sequence count");
+  const int D = layers[0].din, D4 = pad4(D);
+  EESEN_REQUIRE(ld >= D, EESEN_ERR_INVALID, "input leading dimension smaller than InputDim");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  rows = nrows;
+  T = rows / S;
+  for (int v : lens) EESEN_REQUIRE(v <= T, EESEN_ERR_INVALID, "sequence length exceeds the number of frames");
+  timer.reset();
+
+  // input -> device, rows padded to a multiple of 4 floats (GEMM operand alignment)
+  if (input.reserve((size_t)rows * D4) || D4 != D) EESEN_HIP_CHECK(hipMemsetAsync(input.p, 0, (size_t)rows * D4 * sizeof(float), st));
+  EESEN_HIP_CHECK(hipMemcpy2DAsync(input.p, (size_t)D4 * sizeof(float), in, (size_t)ld * sizeof(float), (size_t)D * sizeof(float),
+                                   rows, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  const float* x = input.p;
+  int ldx = D4;
+  for (Layer& L : layers) {
+    if (L.is_lstm()) {
+      const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
+      L.G.reserve((size_t)rows * ldG);
+      const size_t state = (size_t)(T + 2) * S * ldY;
+      L.C.reserve(state);
+      L.Y.reserve(state);
+      // boundary row blocks t = -1 and t = T (bilstm-parallel-layer.h:393-394)
+      const size_t blk = (size_t)S * ldY * sizeof(float);
+      EESEN_HIP_CHECK(hipMemsetAsync(L.C.p, 0, blk, st));
+      EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p, 0, blk, st));
+      EESEN_HIP_CHECK(hipMemsetAsync(L.C.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
+      EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
+      // all gate pre-activations of both directions in one GEMM: G = x * Wx^T + bias  (:109-110, :163-164)
+      timer.begin(st, 0);
+      gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
+               params.p + L.p_off + L.off_bias, nullptr, 0);
+      timer.end(st);
+      timer.begin(st, 1);
+      const LstmLayerDev v = lstm_view(*this, L);
+      for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
+      check_launch("lstm_fwd_step");
+      timer.end(st);
+      x = L.Y.p + (size_t)S * ldY;
+      ldx = ldY;
+    } else if (L.kind == EESEN_LAYER_AFFINE) {
+      const int ldo = pad4(L.dout);
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      timer.begin(st, 2);
+      gemm_f32(st, true, true, rows, L.dout, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, L.out.p, ldo,
+               params.p + L.p_off + L.off_b, nullptr, 0);
+      timer.end(st);
+      x = L.out.p;
+      ldx = ldo;
+    } else {  // Softmax
+      const int ldo = pad4(L.dout);
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      timer.begin(st, 2);
+      softmax_rows(st, x, ldx, L.out.p, ldo, rows, L.dout);
+      timer.end(st);
+      x = L.out.p;
+      ldx = ldo;
+    }
+  }
+  out_ptr = x;
+  out_cols = layers.back().dout;
+  out_ld = ldx;
+  propagated = true;
+}
+
+void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi) {
+  EESEN_REQUIRE(propagated, EESEN_ERR_STATE, "Backpropagate needs a preceding Propagate");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  int maxdim = 0, max_g = 0, max_y = 0;
+  size_t need_ws = 0;
+  for (const Layer& L : layers) {
+    maxdim = std::max(maxdim, std::max(pad4(L.din), pad4(L.dout)));
+    if (L.is_lstm()) {
+      max_g = std::max(max_g, L.ndir * 4 * L.H);
+      max_y = std::max(max_y, L.ndir * L.H);
+      need_ws = std::max(need_ws, lstm_bias_peep_ws_floats(T, S, L.H, L.ndir));
+    }
+    need_ws = std::max(need_ws, col_sums_ws_floats(rows, L.dout));
+  }
+  need_ws = std::max(need_ws, (size_t)16 << 20);  // 64 MB of split-K slabs
+  ws.reserve(need_ws);
+  ws_floats = ws.cap;
+  dA.reserve((size_t)rows * maxdim);
+  dB.reserve((size_t)rows * maxdim);
+  if (max_g) DG.reserve((size_t)rows * max_g);
+  if (max_y) DCF.reserve((size_t)S * max_y);
+
+  // backpropagate_buf_[L] = out_diff (net.cc:96), into a buffer whose rows are 16-byte aligned
+  const int Kout = layers.back().dout;
+  float* d = dA.p;
+  int ld_d = pad4(Kout);
+  float* dn = dB.p;
+  if (ld_d != Kout) EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
+  copy2d(st, out_diff, ldd, d, ld_d, rows, Kout);
+
+  for (int li = (int)layers.size() - 1; li >= 0; --li) {
+    Layer& L = layers[li];
+    // this layer's input activation
+    const float* x;
+    int ldx;
+    if (li == 0) { x = input.p; ldx = pad4(L.din); }
+    else {
+      const Layer& Pv = layers[li - 1];
+      if (Pv.is_lstm()) { ldx = Pv.ndir * Pv.H; x = Pv.Y.p + (size_t)S * ldx; }
+      else { ldx = pad4(Pv.dout); x = Pv.out.p; }
+    }
+    const bool want_in = li > 0 || in_diff != nullptr;
+    const int ld_n = pad4(L.din);
+    float* fr = fresh.p + L.p_off;
+    if (L.kind == EESEN_LAYER_SOFTMAX) {
+      continue;  // softmax-layer.h:49-57: CTC already delivers d/d(logits)
+    } else if (L.kind == EESEN_LAYER_AFFINE) {
+      timer.begin(st, 4);
+      if (want_in) {  // in_diff = out_diff * W  (affine-trans-layer.h:171)
+        if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
+        gemm_f32(st, true, false, rows, L.din, L.dout, 1.f, d, ld_d, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, dn, ld_n,
+                 nullptr, nullptr, 0);
+      }
+      // gradients (computed inside Update in the reference, affine-trans-layer.h:182-183)
+      gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats);
+      col_sums(st, d, rows, L.dout, ld_d, fr + L.off_b, ws.p, ws_floats);
+      timer.end(st);
+    } else {
+      const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
+      const LstmLayerDev v = lstm_view(*this, L);
+      timer.begin(st, 3);
+      for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DG.p, DCF.p);
+      check_launch("lstm_bwd_step");
+      timer.end(st);
+      timer.begin(st, 4);
+      if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction
+        if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
+        gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DG.p, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
+                 nullptr, nullptr, 0);
+      }
+      // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
+      gemm_f32(st, false, false, ldG, L.din, rows, 1.f, DG.p, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws.p, ws_floats);
+      // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
+      for (int dir = 0; dir < nd; ++dir)
+        gemm_f32(st, false, false, 4 * H, H, rows, 1.f, DG.p + (size_t)dir * 4 * H, ldG,
+                 L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws.p, ws_floats);
+      lstm_bias_peep_grads(st, v, DG.p, fr + L.off_bias, fr + L.off_peep, ws.p, ws_floats);
+      timer.end(st);
+    }
+    if (want_in) {
+      std::swap(d, dn);
+      ld_d = ld_n;
+    }
+  }
+  if (in_diff) copy2d(st, d, ld_d, in_diff, ldi, rows, layers[0].din);
+}
+
+void Net::update() {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  timer.begin(st, 5);
+  for (Layer& L : layers)
+    if (L.p_n) sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
+  refresh_derived();
+  timer.end(st);
+}
+
+}  // namespace eesen

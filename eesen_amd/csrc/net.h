@@ -1,0 +1,107 @@
+// net.h -- host-side Net / Ctc objects behind the C-ABI (include/eesen_hip.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace eesen {
+
+inline int pad4(int x) { return (x + 3) & ~3; }
+
+struct Layer {
+  int kind = 0, din = 0, dout = 0;
+  float coef = 1.f, max_grad = 0.f;
+  // parameter block inside the net-wide flat buffers (library-internal layout)
+  size_t p_off = 0, p_n = 0;
+  // LSTM kinds
+  int H = 0, ndir = 0;
+  size_t off_wx = 0, off_bias = 0, off_wm = 0, off_peep = 0;  // relative to p_off
+  DevBuf<float> WmT;      // [ndir][H x 4H], rebuilt after every parameter change
+  DevBuf<float> G, C, Y;  // activations
+  // AffineTransform
+  size_t off_w = 0, off_b = 0;
+  DevBuf<float> out;  // affine / softmax output [rows x pad4(dout)]
+  bool is_lstm() const { return kind == EESEN_LAYER_LSTM_PARALLEL || kind == EESEN_LAYER_BILSTM_PARALLEL; }
+  bool trainable() const { return kind != EESEN_LAYER_SOFTMAX; }
+  long file_params() const;
+};
+
+class PhaseTimer {
+ public:
+  ~PhaseTimer();
+  void enable(bool on) { on_ = on; }
+  bool enabled() const { return on_; }
+  void reset() { used_ = 0; }
+  void begin(hipStream_t st, int phase);
+  void end(hipStream_t st);
+  void collect(float* out, int nphase);  // seconds per phase; synchronises on the recorded events
+ private:
+  struct Span { hipEvent_t a, b; int phase; };
+  std::vector<Span> spans_;
+  size_t used_ = 0;
+  bool on_ = false, open_ = false;
+};
+
+struct Net {
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::vector<Layer> layers;
+  bool finalized = false;
+  size_t P = 0;  // floats in the flat buffers (with alignment padding)
+  DevBuf<float> params, corr, fresh;
+  float lr = 0.f, mmt = 0.f;
+  // current minibatch
+  std::vector<int> lens;
+  DevBuf<int> lens_d;
+  int T = 0, S = 0, rows = 0;
+  bool propagated = false;
+  DevBuf<float> input;  // [rows x pad4(din0)]
+  const float* out_ptr = nullptr;
+  int out_cols = 0, out_ld = 0;
+  // backward scratch
+  DevBuf<float> DG, DCF, dA, dB, ws;
+  size_t ws_floats = 0;
+  PhaseTimer timer;
+
+  Net(int device, void* stream);
+  ~Net();
+  void add_layer(int kind, int din, int dout, float coef, float max_grad);
+  void finalize();
+  long num_params() const;
+  void set_params(const float* host, long n);
+  void get_flat(const DevBuf<float>& buf, float* host, long n);  // params or fresh grads in Net::GetParams order
+  void set_seq_lengths(const int* lens, int S);
+  void propagate(const float* in, int rows, int ld, bool is_device);
+  void backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi);
+  void update();
+  void refresh_derived();  // W_m^T copies
+  void read(const std::string& path);
+  void write(const std::string& path, bool binary);
+  void sync();
+};
+
+struct Ctc {
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  DevBuf<float> logp, alpha, beta, pzx_d;
+  DevBuf<int> labx, lens_d, lablens_d, cls_off, cls_pos, ids_d;
+  std::vector<int> last_lens;
+  int last_T = 0, last_S = 0, last_Lpad = 0, last_Lprime = 0;
+  double obj_sum = 0;
+  long sequences = 0, frames = 0, err_tokens = 0, ref_tokens = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  Ctc(int device, void* stream);
+  ~Ctc();
+  void eval_parallel(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld, const int* label_ids,
+                     const int* label_off, float* diff, int ldd, float* pzx_host);
+  void error_rate_mseq(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld,
+                       const int* label_ids, const int* label_off, int* num_err, int* num_ref);
+  void get_alpha_beta(float* alpha_host, float* beta_host, int* Lprime);
+  void phase_times(float* out3);
+};
+
+}  // namespace eesen

@@ -1,0 +1,295 @@
+// nnet_format.cpp -- Eesen's <Nnet> model files (Kaldi stream format, text and binary) for the layer
+// kinds on the hot path.  Format facts (all from the reference):
+//   * stream header "\0B" when binary (/root/reference/src/base/io-funcs-inl.h:183-187), absent in text;
+//   * <Nnet> ... </Nnet> wrapper (src/net/net.cc:325-334); per layer the marker, <InputDim> d,
+//     <CellDim> (LSTM kinds) or <OutputDim> d (src/net/layer.cc:138-222);
+//   * layer data: optional <LearnRateCoef>, <MaxGrad>, nine dropout tokens, optional accumulators, then the
+//     tensors (src/net/bilstm-layer.h:317-493, lstm-layer.h:106-172, affine-trans-layer.h:83-128);
+//   * tensors: text " [ ... ]" (rows end in newlines), binary "FM " + rows + cols + raw fp32, "FV " + dim +
+//     raw fp32 (src/cpucompute/matrix.cc:968-994, vector.cc:1114-1134); binary int32 / float are a size
+//     byte followed by the little-endian payload, bool is a bare 'T' / 'F' (src/base/io-funcs.cc:26-55).
+// The parser below is a cursor over the whole file in memory; nothing of the reference's stream classes
+// is used.
+#include <cerrno>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "net.h"
+
+namespace eesen {
+namespace {
+
+struct Cursor {
+  const std::string& b;
+  size_t i = 0;
+  bool binary = false;
+  explicit Cursor(const std::string& buf) : b(buf) {
+    if (b.size() >= 2 && b[0] == '\0' && b[1] == 'B') { binary = true; i = 2; }
+  }
+  [[noreturn]] void fail(const std::string& what) const {
+    throw Error(EESEN_ERR_IO, "model file: " + what + " at byte " + std::to_string(i));
+  }
+  void ws() { while (i < b.size() && isspace((unsigned char)b[i])) ++i; }
+  int peek() {
+    if (!binary) ws();
+    return i < b.size() ? (unsigned char)b[i] : -1;
+  }
+  std::string token() {
+    if (!binary) ws();
+    size_t j = i;
+    while (j < b.size() && !isspace((unsigned char)b[j])) ++j;
+    if (j == i) fail("expected a token");
+    std::string t = b.substr(i, j - i);
+    i = j;
+    if (i < b.size()) ++i;  // the single separator after a token
+    return t;
+  }
+  void expect(const char* tok) {
+    const std::string t = token();
+    if (t != tok) fail(std::string("expected ") + tok + ", got " + t);
+  }
+  template <typename V>
+  V basic() {
+    V v;
+    if (binary) {
+      if (i + 1 + sizeof(V) > b.size() || (unsigned char)b[i] != sizeof(V)) fail("bad binary scalar");
+      memcpy(&v, b.data() + i + 1, sizeof(V));
+      i += 1 + sizeof(V);
+    } else {
+      const std::string t = token();
+      char* end = nullptr;
+      errno = 0;
+      const double d = strtod(t.c_str(), &end);
+      if (end == t.c_str() || *end) fail("bad number '" + t + "'");
+      v = (V)d;
+    }
+    return v;
+  }
+  bool boolean() {
+    const int c = peek();
+    if (c != 'T' && c != 'F') fail("expected T or F");
+    ++i;
+    return c == 'T';
+  }
+  // reads rows*cols (cols == 0: a vector of `rows`) floats into dst
+  void tensor(int rows, int cols, float* dst) {
+    const size_t n = (size_t)rows * (cols ? cols : 1);
+    if (binary) {
+      const std::string t = token();
+      if (cols) {
+        if (t != "FM") fail("expected FM, got " + t);
+        const int r = basic<int32_t>(), c = basic<int32_t>();
+        if (r != rows || c != cols) fail("matrix is " + std::to_string(r) + "x" + std::to_string(c) + ", expected " + std::to_string(rows) + "x" + std::to_string(cols));
+      } else {
+        if (t != "FV") fail("expected FV, got " + t);
+        const int d = basic<int32_t>();
+        if (d != rows) fail("vector has " + std::to_string(d) + " elements, expected " + std::to_string(rows));
+      }
+      if (i + n * 4 > b.size()) fail("truncated tensor");
+      memcpy(dst, b.data() + i, n * 4);
+      i += n * 4;
+    } else {
+      ws();
+      if (i >= b.size() || b[i] != '[') fail("expected '['");
+      ++i;
+      for (size_t k = 0; k < n; ++k) {
+        ws();
+        char* end = nullptr;
+        const float v = strtof(b.c_str() + i, &end);
+        if (end == b.c_str() + i) fail("bad float in tensor");
+        dst[k] = v;
+        i = end - b.c_str();
+      }
+      ws();
+      if (i >= b.size() || b[i] != ']') fail("tensor has more elements than its layer dimensions allow");
+      ++i;
+    }
+  }
+};
+
+struct ParsedLayer {
+  int kind, din, dout;
+  float coef = 1.f, max_grad = 0.f;
+  std::vector<float> flat;  // Net::GetParams order
+};
+
+int marker_kind(const std::string& m) {
+  // <BiLstm> / <Lstm> are the single-sequence twins with identical parameters (layer.cc:164-170)
+  if (m == "<BiLstmParallel>" || m == "<BiLstm>") return EESEN_LAYER_BILSTM_PARALLEL;
+  if (m == "<LstmParallel>" || m == "<Lstm>") return EESEN_LAYER_LSTM_PARALLEL;
+  if (m == "<AffineTransform>") return EESEN_LAYER_AFFINE;
+  if (m == "<Softmax>") return EESEN_LAYER_SOFTMAX;
+  return 0;
+}
+
+const char* kDropoutTokens[] = {"<ForwardDropoutFactor>", "<ForwardTimeStepDropout>", "<ForwardSequenceDropout>",
+                                "<RecurrentTimeStepDropout>", "<RecurrentSequenceDropout>", "<RNNDrop>",
+                                "<NoMemLossDropout>", "<RecurrentDropoutFactor>", "<TwiddleForward>"};
+const bool kDropoutIsFloat[] = {true, false, false, false, false, false, false, true, false};
+
+}  // namespace
+
+void Net::read(const std::string& path) {
+  EESEN_REQUIRE(!finalized && layers.empty(), EESEN_ERR_STATE, "Read needs an empty net");
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw Error(EESEN_ERR_IO, "cannot open model file " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string buf = ss.str();
+  Cursor c(buf);
+  std::vector<ParsedLayer> parsed;
+  while (true) {
+    if (c.peek() < 0) break;
+    std::string tok = c.token();
+    if (tok == "</Nnet>") break;
+    if (tok == "<Nnet>") {
+      if (c.peek() < 0) break;
+      tok = c.token();
+      if (tok == "</Nnet>") break;
+    }
+    ParsedLayer P;
+    P.kind = marker_kind(tok);
+    if (!P.kind) throw Error(EESEN_ERR_INVALID, "layer kind " + tok + " is outside the MI355X hot path (supported: BiLstmParallel, LstmParallel, AffineTransform, Softmax)");
+    c.expect("<InputDim>");
+    P.din = c.basic<int32_t>();
+    const bool lstm = P.kind == EESEN_LAYER_BILSTM_PARALLEL || P.kind == EESEN_LAYER_LSTM_PARALLEL;
+    c.expect(lstm ? "<CellDim>" : "<OutputDim>");
+    P.dout = c.basic<int32_t>();
+    if (P.kind != EESEN_LAYER_SOFTMAX) {
+      while (c.peek() == '<') {
+        const std::string t = c.token();
+        if (t == "<LearnRateCoef>") P.coef = c.basic<float>();
+        else if (t == "<MaxGrad>") P.max_grad = c.basic<float>();
+        else if (t == "<BiLstmAccus>" || t == "<LstmAccus>" || t == "<AffineAccus>")
+          throw Error(EESEN_ERR_INVALID, "model carries Adagrad/RMSProp accumulators (" + t + "); only the SGD rule is implemented");
+        else {
+          bool known = false;
+          for (int k = 0; k < 9; ++k)
+            if (t == kDropoutTokens[k]) {
+              known = true;
+              const bool set = kDropoutIsFloat[k] ? (c.basic<float>() != 0.f) : c.boolean();
+              if (set) throw Error(EESEN_ERR_INVALID, "dropout option " + t + " is set; dropout variants are out of scope of this path");
+            }
+          if (!known) c.fail("unexpected token " + t);
+        }
+      }
+      if (lstm) {
+        const int nd = P.kind == EESEN_LAYER_BILSTM_PARALLEL ? 2 : 1;
+        if (P.dout % nd) c.fail("odd <CellDim> for a BiLstm layer");
+        const int H = P.dout / nd;
+        P.flat.resize((size_t)nd * ((size_t)4 * H * P.din + (size_t)4 * H * H + 7 * H));
+        float* p = P.flat.data();
+        for (int d = 0; d < nd; ++d) {
+          c.tensor(4 * H, P.din, p); p += (size_t)4 * H * P.din;
+          c.tensor(4 * H, H, p);     p += (size_t)4 * H * H;
+          c.tensor(4 * H, 0, p);     p += 4 * H;
+          for (int g = 0; g < 3; ++g) { c.tensor(H, 0, p); p += H; }
+        }
+      } else {
+        P.flat.resize((size_t)P.dout * P.din + P.dout);
+        c.tensor(P.dout, P.din, P.flat.data());
+        c.tensor(P.dout, 0, P.flat.data() + (size_t)P.dout * P.din);
+      }
+    }
+    parsed.push_back(std::move(P));
+  }
+  if (parsed.empty()) throw Error(EESEN_ERR_IO, "model file " + path + " holds no layers");
+  for (const ParsedLayer& P : parsed) add_layer(P.kind, P.din, P.dout, P.coef, P.max_grad);
+  finalize();
+  std::vector<float> all;
+  for (const ParsedLayer& P : parsed) all.insert(all.end(), P.flat.begin(), P.flat.end());
+  for (float v : all)  // Net::Check, net.cc:459-468
+    if (!std::isfinite(v)) throw Error(EESEN_ERR_INVALID, "model holds NaN/Inf parameters");
+  set_params(all.data(), (long)all.size());
+  lr = 0.f;  // net.cc:294
+}
+
+namespace {
+void put_token(std::ostream& os, const char* t) { os << t << " "; }
+void put_int(std::ostream& os, bool binary, int32_t v) {
+  if (binary) { os.put((char)4); os.write(reinterpret_cast<const char*>(&v), 4); }
+  else os << v << " ";
+}
+void put_float(std::ostream& os, bool binary, float v) {
+  if (binary) { os.put((char)4); os.write(reinterpret_cast<const char*>(&v), 4); }
+  else { char s[32]; snprintf(s, sizeof s, "%.9g", v); os << s << " "; }
+}
+void put_bool(std::ostream& os, bool binary, bool v) { os << (v ? "T" : "F"); if (!binary) os << " "; }
+void put_tensor(std::ostream& os, bool binary, const float* p, int rows, int cols) {
+  const size_t n = (size_t)rows * (cols ? cols : 1);
+  if (binary) {
+    put_token(os, cols ? "FM" : "FV");
+    put_int(os, true, rows);
+    if (cols) put_int(os, true, cols);
+    os.write(reinterpret_cast<const char*>(p), n * 4);
+  } else if (cols) {
+    os << " [";
+    for (int r = 0; r < rows; ++r) {
+      os << "\n  ";
+      for (int c = 0; c < cols; ++c) { char s[32]; snprintf(s, sizeof s, "%.9g", p[(size_t)r * cols + c]); os << s << " "; }
+    }
+    os << "]\n";
+  } else {
+    os << " [ ";
+    for (int r = 0; r < rows; ++r) { char s[32]; snprintf(s, sizeof s, "%.9g", p[r]); os << s << " "; }
+    os << "]\n";
+  }
+}
+}  // namespace
+
+void Net::write(const std::string& path, bool binary) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  std::vector<float> all(num_params());
+  get_flat(params, all.data(), (long)all.size());
+  for (float v : all)
+    if (!std::isfinite(v)) throw Error(EESEN_ERR_INVALID, "refusing to write NaN/Inf parameters");  // net.cc:459-468
+  std::ofstream os(path, std::ios::binary);
+  if (!os) throw Error(EESEN_ERR_IO, "cannot open " + path + " for writing");
+  if (binary) { os.put('\0'); os.put('B'); }
+  put_token(os, "<Nnet>");
+  if (!binary) os << "\n";
+  const float* p = all.data();
+  for (const Layer& L : layers) {
+    const char* marker = L.kind == EESEN_LAYER_BILSTM_PARALLEL ? "<BiLstmParallel>"
+                         : L.kind == EESEN_LAYER_LSTM_PARALLEL ? "<LstmParallel>"
+                         : L.kind == EESEN_LAYER_AFFINE        ? "<AffineTransform>"
+                                                               : "<Softmax>";
+    put_token(os, marker);
+    put_token(os, "<InputDim>");
+    put_int(os, binary, L.din);
+    put_token(os, L.is_lstm() ? "<CellDim>" : "<OutputDim>");
+    put_int(os, binary, L.dout);
+    if (!binary) os << "\n";
+    if (L.kind == EESEN_LAYER_SOFTMAX) continue;
+    put_token(os, "<LearnRateCoef>");
+    put_float(os, binary, L.coef);
+    put_token(os, "<MaxGrad>");
+    put_float(os, binary, L.max_grad);
+    if (L.kind == EESEN_LAYER_BILSTM_PARALLEL)  // bilstm-layer.h:435-455; the uni-LSTM writes none (lstm-layer.h:147-151)
+      for (int k = 0; k < 9; ++k) {
+        put_token(os, kDropoutTokens[k]);
+        if (kDropoutIsFloat[k]) put_float(os, binary, 0.f);
+        else put_bool(os, binary, false);
+      }
+    if (L.is_lstm()) {
+      const int H = L.H;
+      for (int d = 0; d < L.ndir; ++d) {
+        put_tensor(os, binary, p, 4 * H, L.din); p += (size_t)4 * H * L.din;
+        put_tensor(os, binary, p, 4 * H, H);     p += (size_t)4 * H * H;
+        put_tensor(os, binary, p, 4 * H, 0);     p += 4 * H;
+        for (int g = 0; g < 3; ++g) { put_tensor(os, binary, p, H, 0); p += H; }
+      }
+    } else {
+      put_tensor(os, binary, p, L.dout, L.din); p += (size_t)L.dout * L.din;
+      put_tensor(os, binary, p, L.dout, 0);     p += L.dout;
+    }
+  }
+  put_token(os, "</Nnet>");
+  if (!binary) os << "\n";
+  os.close();
+  if (!os) throw Error(EESEN_ERR_IO, "write failure on " + path);
+}
+
+}  // namespace eesen

@@ -1,0 +1,92 @@
+// optim.hip -- SGD update with momentum + clipping, and small layout helpers, for gfx950.
+//
+// Reference arithmetic: BiLstm::Update /root/reference/src/net/bilstm-layer.h:846-883 (clip each *_corr_
+// to +-max_grad_ when max_grad_ > 0, then param += -lr*learn_rate_coef*corr), Lstm::Update
+// src/net/lstm-layer.h:345-369, AffineTransform::Update src/net/affine-trans-layer.h:174-195.  In the
+// reference the momentum fold (corr = mmt*corr + gradient) happens inside the gradient GEMMs
+// (bilstm-parallel-layer.h:504-510); here the fresh gradient is kept separate until this kernel so a
+// data-parallel all-reduce can sum it across ranks first.  One launch per layer
+// over its whole flat parameter block (the reference: 24 clip + 12 axpy launches per BiLSTM layer).
+#include "kernels.h"
+
+namespace eesen {
+namespace {
+
+__global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ param, float* __restrict__ corr,
+                                                         const float* __restrict__ fresh, long n, float mmt,
+                                                         float lr_coef, float max_grad) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 p = reinterpret_cast<float4*>(param)[i];
+    float4 c = reinterpret_cast<float4*>(corr)[i];
+    const float4 g = reinterpret_cast<const float4*>(fresh)[i];
+    c.x = mmt * c.x + g.x; c.y = mmt * c.y + g.y; c.z = mmt * c.z + g.z; c.w = mmt * c.w + g.w;
+    if (max_grad > 0.f) {
+      c.x = fminf(fmaxf(c.x, -max_grad), max_grad); c.y = fminf(fmaxf(c.y, -max_grad), max_grad);
+      c.z = fminf(fmaxf(c.z, -max_grad), max_grad); c.w = fminf(fmaxf(c.w, -max_grad), max_grad);
+    }
+    p.x -= lr_coef * c.x; p.y -= lr_coef * c.y; p.z -= lr_coef * c.z; p.w -= lr_coef * c.w;
+    reinterpret_cast<float4*>(corr)[i] = c;
+    reinterpret_cast<float4*>(param)[i] = p;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float c = mmt * corr[i] + fresh[i];
+    if (max_grad > 0.f) c = fminf(fmaxf(c, -max_grad), max_grad);
+    corr[i] = c;
+    param[i] -= lr_coef * c;
+  }
+}
+
+// 32x32 LDS-tiled transpose, coalesced on both sides
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, int rows, int cols,
+                                                          float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int r = r0 + ty + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i][tx] = src[(size_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int c = c0 + ty + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + i];
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
+                                                     int ldd, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols, c = i % cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
+}  // namespace
+
+void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
+                float max_grad) {
+  if (n <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(n / 4 + 1, 256), 2048);
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad);
+  check_launch("sgd_update");
+}
+
+void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst) {
+  hipLaunchKernelGGL(transpose2d_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, st, src, rows, cols, dst);
+  check_launch("transpose2d");
+}
+
+void copy2d(hipStream_t st, const float* src, int lds, float* dst, int ldd, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return;
+  const size_t total = (size_t)rows * cols;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, st, src, lds, dst, ldd, rows, cols);
+  check_launch("copy2d");
+}
+
+}  // namespace eesen

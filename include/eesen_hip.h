@@ -1,0 +1,168 @@
+/* eesen_hip.h -- C-ABI of libeesen_hip.so: the MI355X (gfx950) implementation of the hot path of
+ * Eesen's `train-ctc-parallel` (peephole (Bi-)LSTM forward/backward, affine, softmax, CTC
+ * forward-backward, SGD update) behind the reference's net/netbin operator interface.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes.  No torch / C++ types.
+ * Every entry point returns EESEN_OK (0) or a negative status; eesen_last_error() gives the message
+ * of the last failure on the calling thread (the reference throws std::runtime_error from KALDI_ERR,
+ * /root/reference/src/base/kaldi-error.cc:168-182; no exception crosses this boundary).
+ *
+ * Threading: one handle per GPU, not thread-safe per handle (the reference is single-threaded with a
+ * process-global CuDevice, src/gpucompute/cuda-device.cc:846).  All work of a handle is enqueued on the
+ * handle's HIP stream; entry points that return host data synchronise that stream, the others do not.
+ *
+ * Memory kinds: pointers marked `dev` are device pointers on the handle's GPU, `host` are host
+ * pointers.  Matrices are row-major fp32 with an explicit leading dimension `ld` (elements), exactly
+ * the reference's MatrixDim {rows, cols, stride} (src/gpucompute/cuda-matrixdim.h:52-56).
+ * Utterance batches are time-major interleaved: row t*S + s = frame t of sequence s
+ * (src/netbin/train-ctc-parallel.cc:187-193).
+ */
+#ifndef EESEN_HIP_H_
+#define EESEN_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EESEN_OK 0
+#define EESEN_ERR_INVALID -1   /* bad argument / unsupported model feature (e.g. dropout tokens)   */
+#define EESEN_ERR_HIP -2       /* a HIP runtime call or kernel launch failed                        */
+#define EESEN_ERR_STATE -3     /* call sequence violated (e.g. Backpropagate before Propagate)      */
+#define EESEN_ERR_IO -4        /* model file could not be read / written / parsed                   */
+
+/* Layer kinds: the markers of src/net/layer.cc:37-46 that are on the hot path. */
+#define EESEN_LAYER_AFFINE 1          /* <AffineTransform>  src/net/affine-trans-layer.h           */
+#define EESEN_LAYER_SOFTMAX 2         /* <Softmax>          src/net/softmax-layer.h                */
+#define EESEN_LAYER_LSTM_PARALLEL 3   /* <LstmParallel>     src/net/lstm-parallel-layer.h          */
+#define EESEN_LAYER_BILSTM_PARALLEL 4 /* <BiLstmParallel>   src/net/bilstm-parallel-layer.h        */
+
+typedef struct eesen_net eesen_net_t; /* replaces eesen::Net, src/net/net.h:37-175           */
+typedef struct eesen_ctc eesen_ctc_t; /* replaces eesen::Ctc, src/net/ctc-loss.h:31-90       */
+
+/* ---- library / device ------------------------------------------------------------------------ */
+const char* eesen_last_error(void);
+const char* eesen_version(void);
+/* replaces CuDevice::Instantiate().SelectGpuId (src/gpucompute/cuda-device.cc:73-140): number of
+ * visible HIP devices (0 is not an error here; creating a handle then fails loudly). */
+int eesen_device_count(int* count);
+
+/* ---- Net: construction, model I/O ------------------------------------------------------------ */
+/* New empty net on `device`.  `stream` is a hipStream_t to enqueue on (e.g. the caller framework's
+ * current stream) or NULL for the device's default stream.  A Net and the Ctc it feeds must share a
+ * stream (the reference has one implicit stream for everything). */
+int eesen_net_create(int device, void* stream, eesen_net_t** out);
+int eesen_net_destroy(eesen_net_t* net);
+/* Net::AppendLayer (src/net/net.cc:197-205) with the layer header of src/net/layer.cc:138-222:
+ * in_dim = <InputDim>, out_dim = <CellDim> (LSTM kinds: 2H for BiLstm, H for Lstm) or <OutputDim>. */
+int eesen_net_add_layer(eesen_net_t* net, int kind, int in_dim, int out_dim,
+                        float learn_rate_coef, float max_grad);
+/* Allocates parameters (zero) + optimiser state; must follow the last add_layer. */
+int eesen_net_finalize(eesen_net_t* net);
+/* Net::Read (src/net/net.cc:279-309): parse a Kaldi-stream <Nnet> file (text or \0B binary), build
+ * the layers and upload the weights.  Fails (EESEN_ERR_INVALID) on non-zero dropout options, Adagrad
+ * / RMSProp accumulators or layer kinds outside the list above.  Resets learn_rate to 0 as the
+ * reference does (net.cc:294). */
+int eesen_net_read(eesen_net_t* net, const char* path);
+/* Net::Write (src/net/net.cc:325-334), same byte format as the reference for these layer kinds. */
+int eesen_net_write(eesen_net_t* net, const char* path, int binary);
+
+int eesen_net_num_layers(eesen_net_t* net, int* n);
+int eesen_net_layer_info(eesen_net_t* net, int idx, int* kind, int* in_dim, int* out_dim,
+                         float* learn_rate_coef, float* max_grad);
+int eesen_net_input_dim(eesen_net_t* net, int* dim);   /* Net::InputDim  net.cc:139-142 */
+int eesen_net_output_dim(eesen_net_t* net, int* dim);  /* Net::OutputDim net.cc:134-137 */
+int eesen_net_num_params(eesen_net_t* net, long* n);   /* Net::NumParams net.cc:163-172 */
+/* Net::GetParams / SetParams order (src/net/net.cc:181-195): per trainable layer its tensors in
+ * model-file order, each row-major and dense.  host pointers, n = num_params. */
+int eesen_net_get_params(eesen_net_t* net, float* host_flat, long n);
+int eesen_net_set_params(eesen_net_t* net, const float* host_flat, long n);
+
+/* ---- Net: training options (src/net/train-opts.h:29-62, net.h:147-161) ------------------------- */
+int eesen_net_set_train_options(eesen_net_t* net, float learn_rate, float momentum);
+/* Net::SetSeqLengths (net.h:157): frame count of each of the S parallel sequences. host pointer. */
+int eesen_net_set_seq_lengths(eesen_net_t* net, const int* lens, int S);
+
+/* ---- Net: forward / backward / update -------------------------------------------------------- */
+/* Net::Propagate (src/net/net.cc:67-86).  in: [rows x input_dim], rows = T*S, `in_is_device` selects
+ * the memory kind (the reference trainer hands a host Matrix that the CuMatrix ctor uploads,
+ * train-ctc-parallel.cc:198).  The output stays on the device and is owned by the handle:
+ * *out_dev -> [rows x *out_cols] fp32 with leading dimension *out_ld, valid until the next Propagate.
+ * Rows t >= len[s] hold unspecified values (the reference computes on padding too; nothing reads them). */
+int eesen_net_propagate(eesen_net_t* net, const float* in, int rows, int in_ld, int in_is_device,
+                        const float** out_dev, int* out_cols, int* out_ld);
+/* Copy the last Propagate output to the host ([rows x output_dim], dense). Synchronises. */
+int eesen_net_get_output(eesen_net_t* net, float* host_out, long n);
+
+/* Net::Backpropagate minus Update (src/net/net.cc:88-108, with :101-104 split out so that a
+ * data-parallel gradient exchange can run between the two).  out_diff_dev: [rows x output_dim]
+ * device matrix, d(-ln p)/d(logits) as Ctc::EvalParallel returns it.  After the call every
+ * parameter has its FRESH gradient (sum over frames, momentum not yet folded in) in the gradient
+ * buffer.  in_diff_dev: optional [rows x input_dim] device matrix (NULL in the trainer,
+ * train-ctc-parallel.cc:207). */
+int eesen_net_backpropagate(eesen_net_t* net, const float* out_diff_dev, int out_diff_ld,
+                            float* in_diff_dev, int in_diff_ld);
+/* The contiguous device buffer of fresh gradients of ALL parameters (n floats, library-internal
+ * tensor layout, identical on every rank): the payload of the data-parallel all-reduce(SUM) that
+ * replaces comm_avg_weights (src/net/communicator.h:39-119). */
+int eesen_net_grad_buffer(eesen_net_t* net, float** dev_ptr, long* n);
+/* Fresh gradients in Net::GetParams order on the host (debug / parity accessor; the reference keeps
+ * *_corr_ protected, src/net/bilstm-layer.h:1076-1096). Synchronises. */
+int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n);
+/* TrainableLayer::Update for every layer, SGD rule (src/net/bilstm-layer.h:846-883,
+ * affine-trans-layer.h:174-195): corr = momentum*corr + fresh; clip corr to +-max_grad if
+ * max_grad > 0; param -= learn_rate*learn_rate_coef*corr. */
+int eesen_net_update(eesen_net_t* net);
+/* Block until everything enqueued on the handle's stream has finished. */
+int eesen_net_synchronize(eesen_net_t* net);
+/* Seconds spent (HIP events on the handle's stream) in the phases of the last step, for bench.py:
+ * out[0]=input GEMMs, [1]=recurrence fwd, [2]=affine+softmax, [3]=recurrence bwd, [4]=gradient GEMMs
+ * and reductions, [5]=update.  Enabled by eesen_net_set_profiling(net, 1). */
+int eesen_net_set_profiling(eesen_net_t* net, int on);
+int eesen_net_get_phase_times(eesen_net_t* net, float* out6);
+
+/* ---- Ctc (src/net/ctc-loss.h:31-90) ------------------------------------------------------------ */
+int eesen_ctc_create(int device, void* stream, eesen_ctc_t** out);
+int eesen_ctc_destroy(eesen_ctc_t* ctc);
+/* Ctc::EvalParallel (src/net/ctc-loss.cc:101-194).  net_out_dev: [T*S x K] softmax outputs (device),
+ * frame_num_utt: host int[S]; labels in CSR form on the host: label_off int[S+1], label_ids (no
+ * blanks, blank id is 0).  Writes diff_dev [T*S x K] (device, ld given) = d(-ln p)/d(logits), zero
+ * on rows t >= frame_num_utt[s]; pzx_host (may be NULL): ln p(z|x) per sequence.  Accumulates the
+ * objective / frame counters reported by eesen_ctc_report.  Every sequence needs >= 1 label and a
+ * feasible alignment is the caller's business (ln p ~ -1e30 otherwise, as in the reference). */
+int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
+                            int rows, int K, int ld, const int* label_ids, const int* label_off,
+                            float* diff_dev, int diff_ld, float* pzx_host);
+/* Ctc::ErrorRateMSeq (ctc-loss.cc:235-298): greedy decode (argmax on the device, collapse repeats,
+ * drop blanks) and Levenshtein distance against the references (host).  Accumulates error / ref
+ * token counts; also returns this call's counts. */
+int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
+                              int rows, int K, int ld, const int* label_ids, const int* label_off,
+                              int* num_err, int* num_ref);
+/* Running totals: Ctc::NumErrorTokens/NumRefTokens (ctc-loss.h:58-59) and the sums behind
+ * Ctc::Report (ctc-loss.cc:300-308): obj = sum of ln p, sequences, frames. */
+int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* frames, long* err_tokens,
+                    long* ref_tokens);
+/* Debug / parity accessor: alpha and beta of the last EvalParallel in the reference's layout
+ * [T*S x L'] (row t*S+s, L' = 2*max_U+1), host pointers, either may be NULL. Cells the reference
+ * leaves at -1e30 (padding) read -1e30. */
+int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_host, int* Lprime);
+/* seconds of the last EvalParallel's device work (HIP events): out[0]=log, [1]=alpha/beta sweep, [2]=error+jacobian */
+int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3);
+
+/* ---- raw device helpers for hosts that own no GPU allocator --------------------------------- */
+int eesen_dev_alloc(int device, long bytes, void** dev_ptr);
+int eesen_dev_free(int device, void* dev_ptr);
+int eesen_dev_copy(int device, void* dst, const void* src, long bytes, int kind /*1 H2D, 2 D2H, 3 D2D*/);
+
+/* ---- single-op entry points (kernel-level parity tests and microbenchmarks) ------------------- */
+/* C[MxN] = alpha*op(A)*op(B) + beta*C (+ bias[n]); fp32 MFMA GEMM on device pointers.
+ * a_kc: A stored [M x K] (k contiguous) if 1, [K x M] if 0.  b_kc: B stored [N x K] if 1, [K x N] if 0.
+ * Replaces CuMatrixBase::AddMatMat (src/gpucompute/cuda-matrix.cc:604-639). */
+int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, int K, float alpha,
+                  const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                  const float* bias);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EESEN_HIP_H_ */

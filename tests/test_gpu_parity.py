@@ -1,0 +1,213 @@
+"""-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance: 1e-4 relative (||a-b||_inf / ||b||_inf per tensor), the figure BASELINE.json's north_star
+states for fp32 loss and gradients.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from eesen_amd import synth, nnet_io
+from tests.util import rel_err, valid_mask, split_params
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 40), (257, 46, 1024), (130, 1024, 46), (128, 128, 16), (96, 64, 5000),
+                                   (33, 17, 7)])
+def test_gemm(gpu, a_kc, b_kc, M, N, K):
+    from eesen_amd.api import CuMatrix
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA = CuMatrix.from_numpy(A if a_kc else np.ascontiguousarray(A.T))
+    dB = CuMatrix.from_numpy(np.ascontiguousarray(B.T) if b_kc else B)
+    dC = CuMatrix.from_numpy(C0)
+    dbias = CuMatrix.from_numpy(bias[None, :])
+    alpha, beta = 0.75, 0.5
+    rc = gpu.eesen_op_gemm(0, None, a_kc, b_kc, M, N, K, alpha, C.c_void_p(dA.ptr), dA.stride, C.c_void_p(dB.ptr), dB.stride,
+                           beta, C.c_void_p(dC.ptr), dC.stride, C.c_void_p(dbias.ptr))
+    assert rc == 0, gpu.eesen_last_error()
+    want = alpha * (A.astype(np.float64) @ B.astype(np.float64)) + beta * C0 + bias[None, :]
+    assert rel_err(dC.numpy(), want) < 2e-6 * max(1, K ** 0.5)
+
+
+# ------------------------------------------------------------------------------------------ CTC alone
+def _random_ctc_case(S, T, K, Umax, seed, min_len_frac=0.6):
+    rng = np.random.default_rng(seed)
+    lens = np.sort(rng.integers(int(min_len_frac * T), T + 1, size=S)).astype(np.int32)
+    lens[-1] = T
+    logits = rng.standard_normal((T * S, K)).astype(np.float32) * 2
+    probs = np.exp(logits - logits.max(1, keepdims=True)); probs /= probs.sum(1, keepdims=True)
+    labels = []
+    for s in range(S):
+        U = int(rng.integers(1, min(Umax, lens[s] // 2) + 1))
+        lab = rng.integers(1, K, size=U).astype(np.int32)
+        for i in range(1, U):
+            if rng.random() < 0.2: lab[i] = lab[i - 1]
+        labels.append(lab)
+    return lens, probs.astype(np.float32), labels
+
+
+@pytest.mark.parametrize("S,T,K,Umax", [(3, 12, 7, 4), (8, 60, 46, 6), (4, 50, 31, 25), (5, 150, 46, 60), (3, 300, 46, 120),
+                                        (2, 600, 20, 250), (33, 40, 100, 10)])
+def test_ctc_vs_oracle(gpu, S, T, K, Umax):
+    from eesen_amd.api import CuMatrix, Ctc
+    from oracle import net as onet
+    lens, probs, labels = _random_ctc_case(S, T, K, Umax, seed=S * 1000 + T)
+    ids = np.concatenate(labels); off = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    want = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f32")
+    ctc = Ctc()
+    dprob = CuMatrix.from_numpy(probs)
+    diff = ctc.EvalParallel(lens, dprob, labels).numpy()
+    ctc._rows = T * S
+    a, b = ctc.alpha_beta()
+    # the lattice: exact sentinel pattern, values to fp32 round-off of the same operation order
+    for got, ref in ((a, want["alpha"]), (b, want["beta"])):
+        assert np.array_equal(got == -1e30, ref == -1e30)
+        m = ref != -1e30
+        assert np.max(np.abs(got[m] - ref[m]) / np.maximum(1.0, np.abs(ref[m]))) < 2e-6
+    assert rel_err(ctc.pzx, want["pzx"]) < 1e-6
+    assert rel_err(diff, want["diff"]) < TOL
+    assert np.all(diff[~valid_mask(lens, T, S)] == 0)
+    # against the fp64 arbiter the HIP path must be as close as the fp32 oracle is
+    arb = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f64")
+    assert rel_err(diff, arb["diff"]) <= max(2 * rel_err(want["diff"], arb["diff"]), 1e-5)
+    # greedy decode + edit distance
+    ne, nr = ctc.ErrorRateMSeq(lens, dprob, labels)
+    assert (ne, nr) == onet.ctc_error_rate_mseq(probs, T, S, lens, ids, off)
+    st = ctc.stats()
+    assert st["sequences"] == S and st["frames"] == int(lens.sum()) and st["ref_tokens"] == nr
+
+
+# ------------------------------------------------------------------------------------------ full step
+def _run_both(cfg_name, lr, mmt, max_grad, steps=1, seed=777, **over):
+    from eesen_amd.api import Net, Ctc, CuMatrix, train_step
+    from oracle import net as onet
+    cfg = synth.config(cfg_name); cfg.update(over)
+    layers = synth.make_model(max_grad=max_grad, seed=seed, **cfg)
+    batch = synth.make_batch(seed=seed, **cfg)
+    ora = onet.OracleNet(layers, "f32")
+    ora.set_train_options(lr, mmt)
+    net = Net.from_layers(layers)
+    net.SetTrainOptions(lr, mmt)
+    ctc = Ctc()
+    res = []
+    for _ in range(steps):
+        o = onet.train_step(ora, batch, "f32")
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+        in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
+        net.BackpropagateNoUpdate(diff, in_diff)
+        grads = net.GetGrads()
+        net.Update()
+        res.append(dict(o=o, net_out=out.numpy(), pzx=ctc.pzx.copy(), diff=diff.numpy(), in_diff=in_diff.numpy(), grads=grads,
+                        ora_grads=ora.fresh_grads_flat().astype(np.float32), params=net.GetParams(),
+                        ora_params=ora.get_params().astype(np.float32)))
+    return layers, batch, res
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny_bi", "small_bi", "small_uni", "cfg1"])
+def test_train_step_parity(gpu, cfg_name):
+    layers, batch, res = _run_both(cfg_name, lr=1.0, mmt=0.0, max_grad=0.0)
+    r = res[0]; o = r["o"]
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(r["net_out"][vm], o["net_out"][vm]) < TOL
+    assert rel_err(r["pzx"], o["pzx"]) < TOL
+    assert abs(r["pzx"].sum() - o["pzx"].sum()) / abs(o["pzx"].sum()) < TOL
+    assert rel_err(r["diff"], o["diff"]) < TOL
+    assert rel_err(r["in_diff"], o["in_diff"]) < TOL
+    worst = 0.0
+    for (li, name, g), (_, _, w) in zip(split_params(layers, r["grads"]), split_params(layers, r["ora_grads"])):
+        e = rel_err(g, w); worst = max(worst, e)
+        assert e < TOL, f"layer {li} {name}: gradient rel err {e:.2e}"
+    # lr = 1, momentum 0, no clipping: theta_after = theta_before - grad
+    for (li, name, p), (_, _, w) in zip(split_params(layers, r["params"]), split_params(layers, r["ora_params"])):
+        assert rel_err(p, w) < TOL, f"layer {li} {name}: parameter mismatch after update"
+
+
+def test_momentum_and_clipping(gpu):
+    """Three steps with the recipe's settings scaled so that clipping bites (bilstm-layer.h:846-883)."""
+    layers, batch, res = _run_both("small_bi", lr=1e-3, mmt=0.9, max_grad=0.05, steps=3)
+    for step, r in enumerate(res):
+        for (li, name, p), (_, _, w) in zip(split_params(layers, r["params"]), split_params(layers, r["ora_params"])):
+            assert rel_err(p, w) < TOL, f"step {step} layer {li} {name}"
+    g = res[0]["grads"]
+    assert np.max(np.abs(g)) > 0.05, "test must exercise clipping"
+
+
+def test_unaligned_dims(gpu):
+    """Input dim and class count that are not multiples of 4 exercise the padded-row paths."""
+    layers, batch, res = _run_both("small_bi", lr=1.0, mmt=0.0, max_grad=0.0, D=13, K=11, S=5, T=21, H=8)
+    r = res[0]; o = r["o"]
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(r["net_out"][vm], o["net_out"][vm]) < TOL
+    assert rel_err(r["diff"], o["diff"]) < TOL
+    assert rel_err(r["in_diff"], o["in_diff"]) < TOL
+    assert rel_err(r["grads"], r["ora_grads"]) < TOL
+
+
+def test_projection_layers(gpu):
+    """cfg4's topology at small scale: AffineTransform projections between BiLSTM layers."""
+    layers, batch, res = _run_both("small_bi", lr=1.0, mmt=0.0, max_grad=0.0, proj=24, layers=3)
+    r = res[0]; o = r["o"]
+    assert rel_err(r["pzx"], o["pzx"]) < TOL
+    for (li, name, g), (_, _, w) in zip(split_params(layers, r["grads"]), split_params(layers, r["ora_grads"])):
+        assert rel_err(g, w) < TOL, f"layer {li} {name}"
+
+
+def test_model_file_roundtrip(gpu, tmp_path):
+    """Net::Read of a text file written by the host tool; Net::Write binary and text; all agree bit for bit."""
+    from eesen_amd.api import Net
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    p_txt = str(tmp_path / "m.txt"); p_bin = str(tmp_path / "m.bin"); p_txt2 = str(tmp_path / "m2.txt")
+    nnet_io.write_nnet(p_txt, layers, binary=False)
+    net = Net().Read(p_txt)
+    assert net.InputDim() == cfg["D"] and net.OutputDim() == cfg["K"]
+    assert net.NumParams() == nnet_io.num_params(layers)
+    assert np.array_equal(net.GetParams(), nnet_io.flatten_params(layers))
+    net.Write(p_bin, binary=True); net.Write(p_txt2, binary=False)
+    for p in (p_bin, p_txt2):
+        back = nnet_io.read_nnet(p)
+        assert [l["type"] for l in back] == [l["type"] for l in layers]
+        assert np.array_equal(nnet_io.flatten_params(back), nnet_io.flatten_params(layers))
+        assert back[0]["max_grad"] == 50.0
+        assert np.array_equal(Net().Read(p).GetParams(), nnet_io.flatten_params(layers))
+    # our binary writer and the host tool's writer produce identical bytes
+    p_bin2 = str(tmp_path / "m3.bin")
+    nnet_io.write_nnet(p_bin2, layers, binary=True)
+    assert open(p_bin, "rb").read() == open(p_bin2, "rb").read()
+
+
+def test_error_behaviour(gpu, tmp_path):
+    from eesen_amd.api import Net, Ctc, CuMatrix, EesenError
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(**cfg)
+    net = Net.from_layers(layers)
+    with pytest.raises(EesenError):       # Propagate before SetSeqLengths
+        net.Propagate(np.zeros((6, cfg["D"]), np.float32))
+    net.SetSeqLengths([2, 3])
+    with pytest.raises(EesenError):       # rows not a multiple of S
+        net.Propagate(np.zeros((7, cfg["D"]), np.float32))
+    with pytest.raises(EesenError):       # Backpropagate before Propagate
+        net.Backpropagate(CuMatrix(6, cfg["K"]))
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "w").write("<Nnet>\n<BiLstmParallel> <InputDim> 4 <CellDim> 8\n<LearnRateCoef> 1 <MaxGrad> 0 <ForwardDropoutFactor> 0.2 ")
+    with pytest.raises(EesenError):       # dropout is out of scope and must be refused, not ignored
+        Net().Read(bad)
+    with pytest.raises(EesenError):
+        Net().Read(str(tmp_path / "does-not-exist"))
+    ctc = Ctc()
+    with pytest.raises(EesenError):       # label id out of range
+        ctc.EvalParallel([3, 3], CuMatrix(6, 5), [[1], [7]])
+    with pytest.raises(EesenError):       # empty label sequence (out-of-bounds read in the reference)
+        ctc.EvalParallel([3, 3], CuMatrix(6, 5), [[1], []])

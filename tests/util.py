@@ -1,0 +1,33 @@
+"""Shared helpers of the parity tests."""
+import numpy as np
+
+
+def rel_err(a, b, eps=1e-12):
+    """||a-b||_inf / max(||b||_inf, eps): the per-tensor metric of SURVEY.md section 7 (hard part ii)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), eps)) if a.size else 0.0
+
+
+def valid_mask(lens, T, S):
+    """[T*S] bool: row t*S+s is a real frame of sequence s."""
+    t = np.arange(T)[:, None]
+    return (t < np.asarray(lens)[None, :]).reshape(T * S)
+
+
+def split_params(layers, flat):
+    """Split a Net::GetParams-ordered flat vector into named tensors [(layer_idx, name, array)]."""
+    out, i = [], 0
+    names_lstm = ["Wx", "Wm", "bias", "pi", "pf", "po"]
+    for li, L in enumerate(layers):
+        t, din, dout = L["type"], L["input_dim"], L["output_dim"]
+        if t in ("BiLstmParallel", "LstmParallel"):
+            nd = 2 if t == "BiLstmParallel" else 1
+            H = dout // nd
+            for d in range(nd):
+                for nm, n in zip(names_lstm, [4 * H * din, 4 * H * H, 4 * H, H, H, H]):
+                    out.append((li, f"{nm}_{'fw' if d == 0 else 'bw'}", flat[i:i + n])); i += n
+        elif t == "AffineTransform":
+            out.append((li, "W", flat[i:i + dout * din])); i += dout * din
+            out.append((li, "b", flat[i:i + dout])); i += dout
+    assert i == flat.size
+    return out
