@@ -1,0 +1,68 @@
+"""Generates tests/golden/*.npz from THE REFERENCE ITSELF (oracle/_ref/libeesen_ref.so: the reference's
+src/net + src/cpucompute compiled unmodified, plus its CUDA CTC kernel bodies run on the CPU).
+TEST INFRASTRUCTURE.  Run in the authoring container (where /root/reference exists):
+
+    python -m oracle.make_golden
+
+Each fixture holds the inputs (so nothing depends on RNG stream stability) and the reference's outputs of one
+trainer step (train-ctc-parallel.cc:195-207) with lr = 1, momentum = 0, <MaxGrad> 0, which turns the parameter
+delta into the gradient: net_out, alpha, beta, pzx, diff, in_diff, params before / after,
+greedy-decode error counts.  The reference holds no golden vectors of its own for this path (TESTFILES empty in
+src/net/Makefile:10), so these outputs of the reference code are the pin.
+"""
+from __future__ import annotations
+
+import os
+import tempfile
+
+import numpy as np
+
+from eesen_amd import nnet_io, synth
+from oracle import refbind
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CASES = {
+    "tiny_bi": dict(cfg="tiny_bi"),
+    "small_uni": dict(cfg="small_uni"),
+    "small_bi": dict(cfg="small_bi"),
+    "proj_bi": dict(cfg="tiny_bi", layers=3, proj=12, H=12, T=20, S=4),
+    "ragged_bi": dict(cfg="tiny_bi", T=30, S=5, min_frac=0.3, K=5, repeat_frac=0.5),
+}
+
+
+def make_case(name: str, spec: dict) -> dict:
+    spec = dict(spec)
+    cfg = synth.config(spec.pop("cfg"))
+    cfg.update(spec)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    path = tempfile.mktemp(suffix=".nnet")
+    nnet_io.write_nnet(path, layers, binary=False)     # text, so the reference parses exactly these values
+    ref = refbind.RefNet(path)
+    os.unlink(path)
+    before = ref.get_params()
+    assert np.array_equal(before, nnet_io.flatten_params(layers)), "reference parsed different weights"
+    ref.set_train_options(1.0, 0.0)
+    ref.set_seq_lengths(batch.lens)
+    net_out = ref.propagate(batch.feats)
+    ctc = refbind.cuda_ctc_eval_parallel(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+    ne, nr = ref.error_rate_mseq(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+    in_diff = ref.backpropagate(ctc["diff"], True)
+    after = ref.get_params()
+    meta = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str))}
+    return dict(meta=np.array(repr(meta)), feats=batch.feats, lens=batch.lens, label_ids=batch.label_ids, label_off=batch.label_off,
+                params=before, net_out=net_out, alpha=ctc["alpha"], beta=ctc["beta"], pzx=ctc["pzx"], diff=ctc["diff"],
+                in_diff=in_diff, params_after=after, errors=np.array([ne, nr], np.int64))
+
+
+def main():
+    assert refbind.build_if_possible(), "oracle/_ref could not be built (needs /root/reference)"
+    os.makedirs(OUT, exist_ok=True)
+    for name, spec in CASES.items():
+        d = make_case(name, spec)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **d)
+        print(name, {k: getattr(v, "shape", None) for k, v in d.items() if k in ("feats", "params", "alpha")}, "pzx", d["pzx"][:3])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""CPU: libeesen_hip.so loads and exports every symbol include/eesen_hip.h declares; the ctypes table
+covers the header; without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "eesen_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(eesen_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_all_declared_symbols():
+    from eesen_amd import build, _lib
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/eesen_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    _lib.load()
+
+
+def test_version_and_device_count_do_not_need_a_gpu():
+    from eesen_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.eesen_version()
+    assert _lib.device_count() >= 0
+
+
+def test_no_silent_cpu_fallback():
+    from eesen_amd import _lib
+    from eesen_amd.api import Net, Ctc, EesenError
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(EesenError, match="no HIP device"):
+        Net()
+    with pytest.raises(EesenError, match="no HIP device"):
+        Ctc()
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "eesen_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                s = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
+                assert "liboracle" not in s and "libeesen_ref" not in s, f

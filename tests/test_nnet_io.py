@@ -1,0 +1,43 @@
+"""CPU: the <Nnet> model-file tool (text + binary round trips, header handling, refusals)."""
+import numpy as np
+import pytest
+
+from eesen_amd import nnet_io, synth
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny_bi", "small_uni"])
+@pytest.mark.parametrize("binary", [False, True])
+def test_roundtrip(tmp_path, cfg_name, binary):
+    cfg = synth.config(cfg_name)
+    layers = synth.make_model(max_grad=50.0, learn_rate_coef=0.5, **cfg)
+    p = str(tmp_path / "m.nnet")
+    nnet_io.write_nnet(p, layers, binary=binary)
+    back = nnet_io.read_nnet(p)
+    assert [(l["type"], l["input_dim"], l["output_dim"]) for l in back] == [(l["type"], l["input_dim"], l["output_dim"]) for l in layers]
+    assert np.array_equal(nnet_io.flatten_params(back), nnet_io.flatten_params(layers))   # text uses shortest round-trip digits
+    assert back[0]["max_grad"] == 50.0 and back[0]["learn_rate_coef"] == 0.5
+    assert nnet_io.num_params(back) == nnet_io.num_params(layers)
+
+
+def test_param_count_matches_reference_formula():
+    # BiLSTM layer = 2 * (4H*D + 4H*H + 4H + 3H)  (/root/reference/src/net/bilstm-layer.h:991-998); cfg2 total 21 211 182
+    cfg = synth.config("cfg2")
+    H, D, K = cfg["H"], cfg["D"], cfg["K"]
+    n = 2 * (4 * H * D + 4 * H * H + 7 * H) + 3 * 2 * (4 * H * 2 * H + 4 * H * H + 7 * H) + (K * 2 * H + K)
+    assert n == 21211182
+
+
+def test_dropout_is_refused(tmp_path):
+    p = str(tmp_path / "d.nnet")
+    open(p, "w").write("<Nnet>\n<BiLstmParallel> <InputDim> 2 <CellDim> 8\n<LearnRateCoef> 1 <MaxGrad> 0 <ForwardDropoutFactor> 0.2 <ForwardTimeStepDropout> T ")
+    with pytest.raises(ValueError, match="dropout"):
+        nnet_io.read_nnet(p)
+
+
+def test_headerless_layer_data_is_accepted(tmp_path):
+    """All header tokens are optional on read (bilstm-layer.h:322-373)."""
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(**cfg)
+    p = str(tmp_path / "m.nnet")
+    nnet_io.write_nnet(p, layers, binary=False, write_dropout_tokens=False)
+    assert np.array_equal(nnet_io.flatten_params(nnet_io.read_nnet(p)), nnet_io.flatten_params(layers))

@@ -31,3 +31,26 @@ def split_params(layers, flat):
             out.append((li, "b", flat[i:i + dout])); i += dout
     assert i == flat.size
     return out
+
+
+def load_golden(name):
+    """tests/golden/<name>.npz -> (cfg dict, layers with the fixture's weights, Batch, fixture arrays)."""
+    import ast
+    import os
+    from eesen_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    cfg = ast.literal_eval(str(g["meta"]))
+    layers = synth.make_model(**cfg)
+    flat, i = g["params"], 0
+    for L in layers:
+        for k, p in enumerate(L["params"]):
+            L["params"][k] = flat[i:i + p.size].reshape(p.shape).astype(np.float32); i += p.size
+    assert i == flat.size
+    off = g["label_off"]
+    labels = [g["label_ids"][off[s]:off[s + 1]].astype(np.int32) for s in range(len(off) - 1)]
+    S = len(g["lens"])
+    batch = synth.Batch(feats=g["feats"], lens=g["lens"].astype(np.int32), labels=labels, T=g["feats"].shape[0] // S, S=S)
+    return cfg, layers, batch, g
+
+
+GOLDEN = ["tiny_bi", "small_uni", "small_bi", "proj_bi", "ragged_bi"]
