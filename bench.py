@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--T", type=int, default=0, help="override T_max (debug)")
+    ap.add_argument("--H", type=int, default=0, help="override cells per direction (debug)")
+    ap.add_argument("--S", type=int, default=0, help="override utterances per GPU (debug)")
+    ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,8 +123,9 @@ def main():
     from eesen_amd import _lib
 
     cfg = synth.config(args.config)
-    if args.T:
-        cfg["T"] = args.T
+    for k in ("T", "H", "S", "layers"):
+        if getattr(args, k):
+            cfg[k] = getattr(args, k)
     layers = synth.make_model(max_grad=50.0, **cfg)                 # recipe settings: model_topo.py:90, run_ctc_phn.sh:84-85
     batch = synth.make_batch(**{**cfg, "seed": 777 + rank})         # every rank its own shard of the global batch
     dev = local if world > 1 else 0

@@ -41,6 +41,7 @@ __device__ __forceinline__ void ld8(const float* __restrict__ row, int k, int km
 // ------------------------------------------------------------------------------------------------
 // forward step
 // ------------------------------------------------------------------------------------------------
+template <int CPW, int PROBE = 0>  // CPW k-chunks (of 32) per wave: every operand load of the step is in flight before the first MFMA. PROBE != 0: timing probes only (EESEN_STEP_PROBE)
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, int step) {
   __shared__ __attribute__((aligned(16))) float red[NW][32][20];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,8 +58,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   float cprev = 0.f, p_i = 0.f, p_f = 0.f, p_o = 0.f;
   int len = 0;
+  const float* gptr = L.G + (size_t)(t * S + s_e) * ldG + (size_t)dir * 4 * H + (u0 + eu) * 4;
   if (e_ok) {
-    gx = *reinterpret_cast<const float4*>(L.G + (size_t)(t * S + s_e) * ldG + (size_t)dir * 4 * H + (u0 + eu) * 4);
+    gx = *reinterpret_cast<const float4*>(gptr);
     cprev = L.C[(size_t)((tp + 1) * S + s_e) * ldY + dir * H + u0 + eu];
     const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
     p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
@@ -73,18 +75,30 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
   const float* A1 = Yp + (size_t)sa1 * ldY;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int nch = (H + 31) >> 5;
-  for (int ch = wave; ch < nch; ch += NW) {
-    const int k = ch * 32 + kq * 8;
-    float b[8], a0[8], a1[8];
-    ld8(Wr, k, H, true, b);
-    ld8(A0, k, H, sa0 < S, a0);
-    ld8(A1, k, H, sa1 < S, a1);
+  for (int cb = wave; cb < nch; cb += NW * CPW) {
+    float b[CPW][8], a0[CPW][8], a1[CPW][8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b[c], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b[c], acc1, 0, 0, 0);
+    for (int c = 0; c < CPW; ++c) {
+      const int ch = cb + c * NW;
+      const int k = ch * 32 + kq * 8;  // k >= H for ch >= nch: ld8 then returns zeros
+      ld8(A0, k, H, sa0 < S && !(PROBE & 2), a0[c]);
+      ld8(A1, k, H, sa1 < S && !(PROBE & 2), a1[c]);
+      ld8(Wr, k, H, !(PROBE & 1), b[c]);
     }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (PROBE & 4) { acc0[0] += a0[c][j] * b[c][j]; acc1[0] += a1[c][j] * b[c][j]; continue; }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c][j], b[c][j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c][j], b[c][j], acc1, 0, 0, 0);
+      }
   }
+  // pull the NEXT step's gate pre-activations toward this XCD's L2 (same workgroup index = same XCD next launch);
+  // issued after every real load so no wait of this step covers it, consumed by nothing but the final keep-alive
+  float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool pf_ok = e_ok && step + 1 < T;
+  if (pf_ok) pf = *reinterpret_cast<const float4*>(dir == 0 ? gptr + (size_t)S * ldG : gptr - (size_t)S * ldG);
   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -113,11 +127,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
   const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
   L.C[o1] = c;
   L.Y[o1] = m;
+  asm volatile("" ::"v"(pf.x), "v"(pf.y), "v"(pf.z), "v"(pf.w));
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward step
 // ------------------------------------------------------------------------------------------------
+template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, int step, const float* __restrict__ dY,
                                                                 int lddy, float* __restrict__ DG,
                                                                 float* __restrict__ DCF) {
@@ -137,11 +153,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
   float4 gt = make_float4(0.f, 0.f, 0.f, 0.f), dgn = gt;
   float dy = 0.f, c_t = 0.f, c_p = 0.f, dcf = 0.f, p_i = 0.f, p_f = 0.f, p_o = 0.f;
   int len = 0;
+  const size_t gofs = (size_t)(t * S + s_e) * ldG + (size_t)dir * K4 + u_e * 4;
+  const size_t yofs = (size_t)(t * S + s_e) * lddy + dir * H + u_e;
+  const size_t cofs = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u_e;
   if (e_ok) {
-    const size_t gofs = (size_t)(t * S + s_e) * ldG + (size_t)dir * K4 + u_e * 4;
     gt = *reinterpret_cast<const float4*>(L.G + gofs);
-    dy = dY[(size_t)(t * S + s_e) * lddy + dir * H + u_e];
-    c_t = L.C[(size_t)((t + 1) * S + s_e) * ldY + dir * H + u_e];
+    dy = dY[yofs];
+    c_t = L.C[cofs];
     c_p = L.C[(size_t)((tp + 1) * S + s_e) * ldY + dir * H + u_e];
     if (has_next) {
       dgn = *reinterpret_cast<const float4*>(DG + (size_t)(tn * S + s_e) * ldG + (size_t)dir * K4 + u_e * 4);
@@ -161,18 +179,31 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
     const float* Br = L.WmT + ((size_t)dir * H + ub) * K4;
     const bool a_ok = sa < S, b_ok = ub < H;
     const int nch = (K4 + 31) >> 5;
-#pragma unroll 2
-    for (int ch = wave; ch < nch; ch += NW) {
-      const int k = ch * 32 + kq * 8;
-      float a[8], b[8];
-      ld8(Ar, k, K4, a_ok, a);
-      ld8(Br, k, K4, b_ok, b);
+    for (int cb = wave; cb < nch; cb += NW * CPW) {
+      float a[CPW][8], b[CPW][8];
 #pragma unroll
-      for (int c = 0; c < 8; c += 2) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1], b[c + 1], acc1, 0, 0, 0);
+      for (int c = 0; c < CPW; ++c) {
+        const int k = (cb + c * NW) * 32 + kq * 8;  // beyond K4: zeros
+        ld8(Ar, k, K4, a_ok, a[c]);
+        ld8(Br, k, K4, b_ok, b[c]);
       }
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
+        }
     }
+  }
+  // next step's epilogue operands -> this XCD's L2 (see the forward kernel)
+  float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+  float pf1 = 0.f, pf2 = 0.f;
+  if (e_ok && step + 1 < T) {
+    const long d = dir == 0 ? -(long)S : (long)S;  // row offset of the next processed step
+    pf = *reinterpret_cast<const float4*>(L.G + gofs + d * ldG);
+    pf1 = dY[yofs + d * lddy];
+    pf2 = L.C[cofs + 2 * d * ldY];  // its c_prev; its c_t is this step's c_prev, already here
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
@@ -192,8 +223,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
   float dg = (1.f - g * g) * (dc * i);
   float carry = dc * f;  // what the next step adds as d_c,next * f_next (:482)
   if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
-  *reinterpret_cast<float4*>(DG + (size_t)(t * S + s_e) * ldG + (size_t)dir * K4 + u_e * 4) = make_float4(dg, di, df, dob);
+  *reinterpret_cast<float4*>(DG + gofs) = make_float4(dg, di, df, dob);
   DCF[(size_t)s_e * ldY + dir * H + u_e] = carry;
+  asm volatile("" ::"v"(pf.x), "v"(pf.y), "v"(pf.z), "v"(pf.w), "v"(pf1), "v"(pf2));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -272,14 +304,41 @@ __global__ __launch_bounds__(256) void col_sums_pass2(const float* __restrict__ 
 
 }  // namespace
 
+static int pick_cpw(int nch) {  // chunks per wave so that one pass covers the K range where possible
+  const int need = (nch + NW - 1) / NW;
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+}
+
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step) {
-  dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32));
-  hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(NW * 64), 0, st, L, step);
+  dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
+  switch (std::min(4, pick_cpw((L.H + 31) / 32))) {
+    case 1: hipLaunchKernelGGL(lstm_fwd_step_kernel<1>, grid, block, 0, st, L, step); break;
+    case 2: {
+      static const int probe = getenv("EESEN_STEP_PROBE") ? atoi(getenv("EESEN_STEP_PROBE")) : 0;  // timing probes (wrong results!)
+      switch (probe) {
+        case 1: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 1>), grid, block, 0, st, L, step); break;
+        case 2: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 2>), grid, block, 0, st, L, step); break;
+        case 3: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 3>), grid, block, 0, st, L, step); break;
+        case 4: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 4>), grid, block, 0, st, L, step); break;
+        case 7: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 7>), grid, block, 0, st, L, step); break;
+        default: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 0>), grid, block, 0, st, L, step); break;
+      }
+      break;
+    }
+    default: hipLaunchKernelGGL(lstm_fwd_step_kernel<4>, grid, block, 0, st, L, step); break;
+  }
 }
 
 void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float* dY, int lddy, float* DG, float* DCF) {
-  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16));
-  hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(NW * 64), 0, st, L, step, dY, lddy, DG, DCF);
+  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16)), block(NW * 64);
+  // measured on MI355X at H = 512: 2 chunks in flight per wave (77 VGPRs) beat 8 (190 VGPRs): 10.0 vs 10.9 us per step
+  static const int cap = getenv("EESEN_BWD_CPW") ? atoi(getenv("EESEN_BWD_CPW")) : 2;
+  switch (std::min(cap, pick_cpw((4 * L.H + 31) / 32))) {
+    case 1: hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+    case 2: hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+    case 4: hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+    default: hipLaunchKernelGGL(lstm_bwd_step_kernel<8>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+  }
 }
 
 size_t lstm_bias_peep_ws_floats(int T, int S, int H, int ndir) { return (size_t)RED_RB * ndir * H * 7; }

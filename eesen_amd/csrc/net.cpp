@@ -23,8 +23,8 @@ PhaseTimer::~PhaseTimer() {
     (void)hipEventDestroy(s.b);
   }
 }
-void PhaseTimer::begin(hipStream_t st, int phase) {
-  if (!on_) return;
+int PhaseTimer::begin(hipStream_t st, int phase) {
+  if (!on_) return -1;
   if (used_ == spans_.size()) {
     Span s;
     EESEN_HIP_CHECK(hipEventCreate(&s.a));
@@ -33,13 +33,11 @@ void PhaseTimer::begin(hipStream_t st, int phase) {
   }
   spans_[used_].phase = phase;
   EESEN_HIP_CHECK(hipEventRecord(spans_[used_].a, st));
-  open_ = true;
+  return (int)used_++;
 }
-void PhaseTimer::end(hipStream_t st) {
-  if (!on_ || !open_) return;
-  EESEN_HIP_CHECK(hipEventRecord(spans_[used_].b, st));
-  ++used_;
-  open_ = false;
+void PhaseTimer::end(hipStream_t st, int idx) {
+  if (!on_ || idx < 0) return;
+  EESEN_HIP_CHECK(hipEventRecord(spans_[idx].b, st));
 }
 void PhaseTimer::collect(float* out, int nphase) {
   for (int i = 0; i < nphase; ++i) out[i] = 0.f;
@@ -100,11 +98,35 @@ Net::Net(int dev, void* stream) : device(dev) {
   // NULL selects the device's default stream, so a Net and a Ctc created without a stream are ordered
   // against each other exactly like the reference's single-stream CuDevice.
   st = reinterpret_cast<hipStream_t>(stream);
+  // side stream for work off the critical path (weight-gradient GEMMs), lowest priority so that the latency-bound
+  // recurrence kernels of the main stream are dispatched first
+  int lo = 0, hi = 0;
+  EESEN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  const int side_cus = getenv("EESEN_SIDE_CUS") ? atoi(getenv("EESEN_SIDE_CUS")) : 0;
+  if (side_cus > 0) {  // confine the side stream to a subset of the CUs (bit i of the mask = CU i)
+    hipDeviceProp_t prop;
+    EESEN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    const int stride = getenv("EESEN_SIDE_STRIDE") ? atoi(getenv("EESEN_SIDE_STRIDE")) : 1;
+    for (int k = 0, c = 0; k < side_cus && c < ncu; ++k, c += stride) mask[c / 32] |= 1u << (c % 32);
+    EESEN_HIP_CHECK(hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()));
+  } else {
+    EESEN_HIP_CHECK(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
+  }
+  EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_rec, hipEventDisableTiming));
+  for (auto& e : ev_grad) EESEN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // measured on MI355X (cfg2): running the weight-gradient GEMMs under the next layer's recurrence is neutral
+  // (105.1 vs 104.9 ms/step: the recurrence kernels slow down by what the GEMMs gain), so it is opt-in
+  overlap = getenv("EESEN_OVERLAP") && atoi(getenv("EESEN_OVERLAP"));
 }
 
 Net::~Net() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(st);
+  if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
+  if (ev_rec) (void)hipEventDestroy(ev_rec);
+  for (auto& e : ev_grad) if (e) (void)hipEventDestroy(e);
   if (own_stream) (void)hipStreamDestroy(st);
 }
 
@@ -273,32 +295,32 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
       EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
       // all gate pre-activations of both directions in one GEMM: G = x * Wx^T + bias  (:109-110, :163-164)
-      timer.begin(st, 0);
+      { const int ti_ = timer.begin(st, 0);
       gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
                params.p + L.p_off + L.off_bias, nullptr, 0);
-      timer.end(st);
-      timer.begin(st, 1);
+      timer.end(st, ti_); }
+      { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
       for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
       check_launch("lstm_fwd_step");
-      timer.end(st);
+      timer.end(st, ti_); }
       x = L.Y.p + (size_t)S * ldY;
       ldx = ldY;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       const int ldo = pad4(L.dout);
       if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
-      timer.begin(st, 2);
+      { const int ti_ = timer.begin(st, 2);
       gemm_f32(st, true, true, rows, L.dout, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, L.out.p, ldo,
                params.p + L.p_off + L.off_b, nullptr, 0);
-      timer.end(st);
+      timer.end(st, ti_); }
       x = L.out.p;
       ldx = ldo;
     } else {  // Softmax
       const int ldo = pad4(L.dout);
       if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
-      timer.begin(st, 2);
+      { const int ti_ = timer.begin(st, 2);
       softmax_rows(st, x, ldx, L.out.p, ldo, rows, L.dout);
-      timer.end(st);
+      timer.end(st, ti_); }
       x = L.out.p;
       ldx = ldo;
     }
@@ -328,8 +350,14 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   ws_floats = ws.cap;
   dA.reserve((size_t)rows * maxdim);
   dB.reserve((size_t)rows * maxdim);
-  if (max_g) DG.reserve((size_t)rows * max_g);
+  if (max_g) {
+    DGb[0].reserve((size_t)rows * max_g);
+    DGb[1].reserve((size_t)rows * max_g);
+  }
   if (max_y) DCF.reserve((size_t)S * max_y);
+  ws2.reserve(need_ws);
+  int dg_slot = 0;
+  bool side_pending[2] = {false, false};
 
   // backpropagate_buf_[L] = out_diff (net.cc:96), into a buffer whose rows are 16-byte aligned
   const int Kout = layers.back().dout;
@@ -356,7 +384,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     if (L.kind == EESEN_LAYER_SOFTMAX) {
       continue;  // softmax-layer.h:49-57: CTC already delivers d/d(logits)
     } else if (L.kind == EESEN_LAYER_AFFINE) {
-      timer.begin(st, 4);
+      { const int ti_ = timer.begin(st, 4);
       if (want_in) {  // in_diff = out_diff * W  (affine-trans-layer.h:171)
         if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
         gemm_f32(st, true, false, rows, L.din, L.dout, 1.f, d, ld_d, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, dn, ld_n,
@@ -365,29 +393,48 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // gradients (computed inside Update in the reference, affine-trans-layer.h:182-183)
       gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats);
       col_sums(st, d, rows, L.dout, ld_d, fr + L.off_b, ws.p, ws_floats);
-      timer.end(st);
+      timer.end(st, ti_); }
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
       const LstmLayerDev v = lstm_view(*this, L);
-      timer.begin(st, 3);
-      for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DG.p, DCF.p);
-      check_launch("lstm_bwd_step");
-      timer.end(st);
-      timer.begin(st, 4);
-      if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction
-        if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
-        gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DG.p, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
-                 nullptr, nullptr, 0);
+      // Gate-gradient buffers alternate between LSTM layers: while this layer's weight-gradient GEMMs (side stream)
+      // still read DGb[slot], the next-lower layer's recurrence (main stream) already fills the other one.
+      float* DGl = DGb[dg_slot].p;
+      if (side_pending[dg_slot]) {  // the layer two LSTM layers up used this buffer: its gradient GEMMs must be done
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_grad[dg_slot], 0));
+        side_pending[dg_slot] = false;
       }
+      { const int ti_ = timer.begin(st, 3);
+      for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
+      check_launch("lstm_bwd_step");
+      timer.end(st, ti_); }
+      EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
+      if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction
+        const int ti_ = timer.begin(st, 4);
+        if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
+        gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DGl, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
+                 nullptr, nullptr, 0);
+        timer.end(st, ti_);
+      }
+      // Everything that only feeds the parameter gradients leaves the critical path: it runs on the side stream,
+      // under the next layer's (latency-bound, mostly idle-chip) recurrence.
+      hipStream_t sg = overlap ? st2 : st;
+      if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
+      { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
-      gemm_f32(st, false, false, ldG, L.din, rows, 1.f, DG.p, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws.p, ws_floats);
+      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, ws2.cap);
       // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
       for (int dir = 0; dir < nd; ++dir)
-        gemm_f32(st, false, false, 4 * H, H, rows, 1.f, DG.p + (size_t)dir * 4 * H, ldG,
+        gemm_f32(sg, false, false, 4 * H, H, rows, 1.f, DGl + (size_t)dir * 4 * H, ldG,
                  L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
-                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws.p, ws_floats);
-      lstm_bias_peep_grads(st, v, DG.p, fr + L.off_bias, fr + L.off_peep, ws.p, ws_floats);
-      timer.end(st);
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, ws2.cap);
+      lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, ws2.cap);
+      timer.end(sg, ti_); }
+      if (overlap) {
+        EESEN_HIP_CHECK(hipEventRecord(ev_grad[dg_slot], st2));
+        side_pending[dg_slot] = true;
+      }
+      dg_slot ^= 1;
     }
     if (want_in) {
       std::swap(d, dn);
@@ -395,16 +442,19 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     }
   }
   if (in_diff) copy2d(st, d, ld_d, in_diff, ldi, rows, layers[0].din);
+  // the gradient buffer is complete only when the side stream has drained: make the caller's stream wait for it
+  for (int k = 0; k < 2; ++k)
+    if (side_pending[k]) EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_grad[k], 0));
 }
 
 void Net::update() {
   EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
   EESEN_HIP_CHECK(hipSetDevice(device));
-  timer.begin(st, 5);
+  { const int ti_ = timer.begin(st, 5);
   for (Layer& L : layers)
     if (L.p_n) sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
   refresh_derived();
-  timer.end(st);
+  timer.end(st, ti_); }
 }
 
 }  // namespace eesen

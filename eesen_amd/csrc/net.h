@@ -33,14 +33,14 @@ class PhaseTimer {
   void enable(bool on) { on_ = on; }
   bool enabled() const { return on_; }
   void reset() { used_ = 0; }
-  void begin(hipStream_t st, int phase);
-  void end(hipStream_t st);
+  int begin(hipStream_t st, int phase);  // returns a span index (-1 when disabled)
+  void end(hipStream_t st, int idx);
   void collect(float* out, int nphase);  // seconds per phase; synchronises on the recorded events
  private:
   struct Span { hipEvent_t a, b; int phase; };
   std::vector<Span> spans_;
   size_t used_ = 0;
-  bool on_ = false, open_ = false;
+  bool on_ = false;
 };
 
 struct Net {
@@ -61,7 +61,10 @@ struct Net {
   const float* out_ptr = nullptr;
   int out_cols = 0, out_ld = 0;
   // backward scratch
-  DevBuf<float> DG, DCF, dA, dB, ws;
+  DevBuf<float> DGb[2], DCF, dA, dB, ws, ws2;
+  hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
+  hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
+  bool overlap = true;
   size_t ws_floats = 0;
   PhaseTimer timer;
 
