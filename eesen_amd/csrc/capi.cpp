@@ -216,4 +216,27 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
   });
 }
 
+int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, int iters, float* avg_ms) {
+  return guard([&] {
+    REQ_PTR(avg_ms);
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    DevBuf<float> ws;
+    ws.reserve((size_t)16 << 20);
+    hipEvent_t e0, e1;
+    EESEN_HIP_CHECK(hipEventCreate(&e0));
+    EESEN_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap);
+    EESEN_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap);
+    EESEN_HIP_CHECK(hipEventRecord(e1, nullptr));
+    EESEN_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    EESEN_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  });
+}
+
 }  // extern "C"

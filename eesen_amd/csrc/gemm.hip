@@ -21,7 +21,12 @@
 namespace eesen {
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDP = 4;
+#ifndef EESEN_GEMM_BK
+#define EESEN_GEMM_BK 16  // measured on MI355X: BK=32 is -8 % on the k-contiguous shapes (97 vs 107 TF), +3 % on the tall-K transposed ones
+#endif
+constexpr int BM = 128, BN = 128, BK = EESEN_GEMM_BK, LDP = 4;
+constexpr int NLD = BM * BK / 4 / 256;        // float4 loads per thread per operand tile
+constexpr int KQ_BITS = BK == 16 ? 2 : 3;     // log2(BK / 4): float4 per k-contiguous row
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmParams {
@@ -37,18 +42,18 @@ struct GemmParams {
   int tiles_n;
 };
 
-// Load one [rows x BK] operand tile (rows = BM or BN) from HBM into registers: 2 float4 per thread.
-// KC = true : operand stored [R x K], k contiguous.  float4 f -> (r = f >> 2, kq = f & 3)
+// Load one [rows x BK] operand tile (rows = BM or BN) from HBM into registers: NLD float4 per thread.
+// KC = true : operand stored [R x K], k contiguous.  float4 f -> (r = f / (BK/4), kq = f % (BK/4))
 // KC = false: operand stored [K x R], r contiguous.  float4 f -> (k = f >> 5, rq = f & 31)
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend,
-                                          int tid, float4 (&v)[2]) {
+                                          int tid, float4 (&v)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + i * 256;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
-      const int r = r0 + (f >> 2), k = k0 + ((f & 3) << 2);
+      const int r = r0 + (f >> KQ_BITS), k = k0 + ((f & ((1 << KQ_BITS) - 1)) << 2);
       if (r < R) {
         const float* src = P + (size_t)r * ld + k;
         if (k + 3 < kend) {
@@ -77,12 +82,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const float4 (&v)[2]) {
+__device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const float4 (&v)[NLD]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NLD; ++i) {
     const int f = tid + i * 256;
     if (KC) {
-      const int r = f >> 2, k = (f & 3) << 2;
+      const int r = f >> KQ_BITS, k = (f & ((1 << KQ_BITS) - 1)) << 2;
       T[k + 0][r] = v[i].x;
       T[k + 1][r] = v[i].y;
       T[k + 2][r] = v[i].z;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[NLD], rb[NLD];
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     load_tile<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, tid, ra);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
 // ------------------------------------------------------------------------------------------------
 // backward step
 // ------------------------------------------------------------------------------------------------
-template <int CPW>
+template <int CPW, int PROBE = 0>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, int step, const float* __restrict__ dY,
                                                                 int lddy, float* __restrict__ DG,
                                                                 float* __restrict__ DCF) {
@@ -184,13 +184,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (cb + c * NW) * 32 + kq * 8;  // beyond K4: zeros
-        ld8(Ar, k, K4, a_ok, a[c]);
-        ld8(Br, k, K4, b_ok, b[c]);
+        ld8(Ar, k, K4, a_ok && !(PROBE & 2), a[c]);
+        ld8(Br, k, K4, b_ok && !(PROBE & 1), b[c]);
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
+          if (PROBE & 4) { acc0[0] += a[c][j] * b[c][j] + a[c][j + 1] * b[c][j + 1]; continue; }
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
         }
@@ -335,7 +336,18 @@ void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float*
   static const int cap = getenv("EESEN_BWD_CPW") ? atoi(getenv("EESEN_BWD_CPW")) : 2;
   switch (std::min(cap, pick_cpw((4 * L.H + 31) / 32))) {
     case 1: hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-    case 2: hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+    case 2: {
+      static const int probe = getenv("EESEN_BSTEP_PROBE") ? atoi(getenv("EESEN_BSTEP_PROBE")) : 0;  // timing probes (wrong results!)
+      switch (probe) {
+        case 1: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 1>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+        case 2: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 2>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+        case 3: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 3>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+        case 4: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 4>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+        case 7: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 7>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+        default: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 0>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
+      }
+      break;
+    }
     case 4: hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
     default: hipLaunchKernelGGL(lstm_bwd_step_kernel<8>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
   }

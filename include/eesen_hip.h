@@ -162,6 +162,11 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
                   const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                   const float* bias);
 
+/* Average milliseconds (HIP events) of `iters` back-to-back launches of the same GEMM (beta = 0, no bias);
+ * microbenchmark entry point used by scripts/gemm_bench.py. */
+int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda,
+                        const float* B, int ldb, float* C, int ldc, int iters, float* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif
