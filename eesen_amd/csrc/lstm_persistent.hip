@@ -1,0 +1,347 @@
+// lstm_persistent.hip -- the whole time recurrence of one (Bi-)LSTM layer in ONE launch, for gfx950.
+//
+// Why this exists (measured, profiles/r01b_pmc_T250.md + tools/l2_probe.hip): the XCD L2s are invalidated at every
+// kernel boundary, so the one-launch-per-step kernels of lstm.hip re-stream the whole recurrent matrix W_m
+// (2 x 4 MB at H = 512) through the Infinity Fabric on EVERY step (TCC_MISS ~ 115 k lines = 15 MB per step), which is
+// 2-3 us of a 6.5 us forward step and ~5 us of a 10 us backward step.  Here each workgroup loads its slice of W_m
+// ONCE into VGPRs (as MFMA B operands) and keeps it there for all T steps; per step only the new cell outputs
+// m_t (forward, 64 KB per direction) or gate gradients DG_t (backward, 256 KB per direction) cross the chip.
+//
+// Cross-workgroup hand-off per step (the placement-independent recipe of the CDNA4 guide, section 6 G16, form R1):
+//   producer: payload with write-through (sc1) stores -> every storing wave drains vmcnt -> workgroup barrier ->
+//             ONE lane bumps the (direction, sequence-tile) arrival counter with a relaxed agent-scope atomic;
+//   consumer: ONE lane polls that counter (relaxed, agent scope, s_sleep between polls, BOUNDED spin) -> workgroup
+//             barrier -> every wave reads the payload with sc1 loads (served from L2 / memory, never from a stale L1).
+// Every step writes row blocks that no one has read before in this launch, so no cache can hold a stale copy.
+// A workgroup can run at most one step ahead of the slowest one of its (direction, sequence-tile) group, and step t
+// writes row block t while laggards still read row block t-1, so there is no write-after-read hazard.
+// All workgroups must be co-resident: the host launches cooperatively after an occupancy check with margin and
+// otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an error word instead of hanging.
+//
+// Arithmetic is identical to lstm.hip (same MFMA order, same LDS reduction order, same cell equations), so results
+// are bit-identical to the per-step path; tests assert exactly that.
+#include "kernels.h"
+
+namespace eesen {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NW = 8;
+constexpr int kSc1 = 16;  // cache-policy bit of the raw-buffer builtins: sc1 = write-through store / L1-bypassing load
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + expf(2.f * x)); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+// 8 consecutive floats at row[k..k+7] (k, kmax multiples of 4) through the sc1 path; zeros outside
+__device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int k, int kmax, bool ok, float (&v)[8]) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+  if (ok && k < kmax) a = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kSc1);
+  if (ok && k + 4 < kmax) b = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, kSc1);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void ld8_plain(const float* __restrict__ row, int k, int kmax, bool ok, float (&v)[8]) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (ok && k < kmax) a = *reinterpret_cast<const float4*>(row + k);
+  if (ok && k + 4 < kmax) b = *reinterpret_cast<const float4*>(row + k + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Arrival counters are sharded 8 ways (shard = blockIdx.x & 7, one 128-byte line each) so that the increments of a
+// step do not serialise on one address.  Lanes 0-7 of wave 0 each poll one shard until it reaches its own target
+// (workgroups in that shard x steps).  Returns false (and raises *err) when the bound is hit or a peer gave up.
+constexpr int kShards = 8, kShardStride = 32;  // words
+__device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
+                                              int lane) {
+  const unsigned mine = lane < kShards ? ((nblk - lane + kShards - 1) / kShards) * step : 0u;
+  for (int spins = 0; spins < spin_limit; ++spins) {
+    bool ok = true;
+    if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
+    if (__all(ok)) return true;
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (H/4, ndir, ceil(S/32)), 512 threads -- the decomposition of lstm_fwd_step_kernel
+// ------------------------------------------------------------------------------------------------
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
+                                                                      int spin_limit) {
+  __shared__ __attribute__((aligned(16))) float red[NW][32][20];
+  __shared__ int s_go;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
+  const int u0 = blockIdx.x * 4, dir = blockIdx.y, s0 = blockIdx.z * 32;
+  unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
+  const unsigned nblk = gridDim.x;
+
+  const int li = lane & 15, kq = lane >> 4;
+  // this wave's part of the workgroup's 16 gate rows of W_m: resident in registers for the whole layer pass
+  float b[CPW][8];
+  {
+    const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + li) * H;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, b[c]);
+  }
+  const int es = tid >> 2, eu = tid & 3;
+  const int s_e = s0 + es;
+  const bool e_ok = tid < 128 && s_e < S;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;  // c_{t-1} of this thread's (sequence, unit) never leaves the register
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  const int sa0 = s0 + li, sa1 = s0 + 16 + li;
+  const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
+  float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
+      if (wave == 0) {
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y + (size_t)(tp + 1) * S * ldY + dir * H);
+      float a0[CPW][8], a1[CPW][8];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int k = (wave + c * NW) * 32 + kq * 8;
+        ld8_sc1(rY, (unsigned)(((size_t)sa0 * ldY + k) * 4), k, H, sa0 < S, a0[c]);
+        ld8_sc1(rY, (unsigned)(((size_t)sa1 * ldY + k) * 4), k, H, sa1 < S, a1[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c][j], b[c][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c][j], b[c][j], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][4 * kq + r][li] = acc0[r];
+      red[wave][16 + 4 * kq + r][li] = acc1[r];
+    }
+    __syncthreads();
+    if (e_ok) {
+      float4 pre = gx;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
+        pre.x += v.x; pre.y += v.y; pre.z += v.z; pre.w += v.w;
+      }
+      float g = tanhf_(pre.x);
+      float i = sigmoidf_(pre.y + p_i * cprev);
+      float f = sigmoidf_(pre.z + p_f * cprev);
+      float c = g * i + cprev * f;
+      float h = tanhf_(c);
+      float o = sigmoidf_(pre.w + p_o * c);
+      float m = h * o;
+      if (t >= len) { g = i = f = o = c = m = 0.f; }
+      *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e) * ldG + gcol) = make_float4(g, i, f, o);
+      const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
+      L.C[o1] = c;
+      __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: other XCDs read it next step
+      cprev = c;
+    }
+    if (step + 1 < T) {
+      if (tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+      __syncthreads();                                                 // (also fences `red` for the next step)
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok)  // next step's gate pre-activations: issued AFTER the publish so the drain above never waits for HBM
+        gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: grid (ceil(H/16), ndir, ceil(S/16)), 512 threads -- the decomposition of lstm_bwd_step_kernel
+// ------------------------------------------------------------------------------------------------
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
+                                                                      int lddy, float* __restrict__ DG, unsigned* cnt,
+                                                                      unsigned* err, int spin_limit) {
+  __shared__ float red[NW][16][17];
+  __shared__ int s_go;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
+  const int u0 = blockIdx.x * 16, dir = blockIdx.y, s0 = blockIdx.z * 16;
+  unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
+  const unsigned nblk = gridDim.x;
+
+  const int li = lane & 15, kq = lane >> 4;
+  const int sa = s0 + li, ub = u0 + li;
+  float b[CPW][8];  // this wave's part of the workgroup's 16 rows of W_m^T, resident for the whole layer pass
+  {
+    const float* Br = L.WmT + ((size_t)dir * H + ub) * K4;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, K4, ub < H, b[c]);
+  }
+  const int es = tid >> 4, eu = tid & 15;
+  const int s_e = s0 + es, u_e = u0 + eu;
+  const bool e_ok = tid < 256 && s_e < S && u_e < H;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  // carried in registers between steps: d_c * f of the previous step and its d_i, d_f (the peephole terms, :483-484)
+  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
+  const size_t gcol = (size_t)dir * K4 + u_e * 4;
+  const size_t ycol = (size_t)dir * H + u_e;
+  // this step's epilogue operands are loaded one step ahead
+  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dy = 0.f, c_t = 0.f, c_p = 0.f;
+  {
+    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
+    if (e_ok) {
+      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
+      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
+      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
+      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);  // DG is at most rows * ldG * 4 bytes < 2 GB (checked on the host)
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+      if (wave == 0) {
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      const size_t arow = ((size_t)(tn * S + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row
+      float a[CPW][8];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int k = (wave + c * NW) * 32 + kq * 8;
+        ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, sa < S, a[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
+    __syncthreads();
+    if (e_ok) {
+      float dm = dy;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dm += red[w][es][eu];
+      const float g = gt.x, i = gt.y, f = gt.z, o = gt.w;
+      const float h = tanhf_(c_t);
+      const float dh = (1.f - h * h) * (dm * o);
+      float dob = o * (1.f - o) * (dm * h);
+      float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
+      float df = f * (1.f - f) * (dc * c_p);
+      float di = i * (1.f - i) * (dc * g);
+      float dg = (1.f - g * g) * (dc * i);
+      float carry = dc * f;
+      if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
+      const f32x4 out = {dg, di, df, dob};
+      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4), 0, kSc1);
+      dcf = carry; dn_i = di; dn_f = df;
+    }
+    if (step + 1 < T) {
+      if (tid < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {  // next step's operands, issued after the publish
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;  // the next step's cell is this step's recurrence source
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      }
+    }
+  }
+}
+
+template <class K>
+bool fits(K kernel, dim3 grid, int threads) {
+  int dev = 0, ncu = 0, nb = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) return false;
+  // the occupancy query can over-report by one workgroup per CU (CDNA4 guide): keep a margin of one
+  const long cap = (long)ncu * std::max(1, nb - 1);
+  return (long)grid.x * grid.y * grid.z <= cap;
+}
+
+template <class K, class... Args>
+void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) {
+  void* argv[] = {(void*)&args...};
+  EESEN_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, 0, st));
+}
+
+}  // namespace
+
+// ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
+bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit) {
+  const int nch = (L.H + 31) / 32;
+  const int need = (nch + NW - 1) / NW;
+  dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
+  if (need > 4 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+#define EESEN_FP(CPW)                                                                   \
+  do {                                                                                   \
+    if (!fits(lstm_fwd_persistent_kernel<CPW>, grid, NW * 64)) return false;             \
+    coop_launch(st, lstm_fwd_persistent_kernel<CPW>, grid, block, L, cnt, err, spin_limit); \
+  } while (0)
+  if (need <= 1) EESEN_FP(1);
+  else if (need <= 2) EESEN_FP(2);
+  else EESEN_FP(4);
+#undef EESEN_FP
+  return true;
+}
+
+bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
+                         unsigned* err, int spin_limit) {
+  const int nch = (4 * L.H + 31) / 32;
+  const int need = (nch + NW - 1) / NW;
+  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16)), block(NW * 64);
+  if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets
+  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+#define EESEN_BP(CPW)                                                                              \
+  do {                                                                                              \
+    if (!fits(lstm_bwd_persistent_kernel<CPW>, grid, NW * 64)) return false;                        \
+    coop_launch(st, lstm_bwd_persistent_kernel<CPW>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit); \
+  } while (0)
+  if (need <= 1) EESEN_BP(1);
+  else if (need <= 2) EESEN_BP(2);
+  else if (need <= 4) EESEN_BP(4);
+  else EESEN_BP(8);
+#undef EESEN_BP
+  return true;
+}
+
+}  // namespace eesen

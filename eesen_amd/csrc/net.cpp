@@ -16,6 +16,8 @@
 
 namespace eesen {
 
+constexpr size_t kCtlWords = 16384 + 32;  // counters [0, 8192) forward, [8192, 16384) backward, last word = error flag
+
 // ------------------------------------------------------------------------------------------ PhaseTimer
 PhaseTimer::~PhaseTimer() {
   for (auto& s : spans_) {
@@ -119,6 +121,10 @@ Net::Net(int dev, void* stream) : device(dev) {
   // measured on MI355X (cfg2): running the weight-gradient GEMMs under the next layer's recurrence is neutral
   // (105.1 vs 104.9 ms/step: the recurrence kernels slow down by what the GEMMs gain), so it is opt-in
   overlap = getenv("EESEN_OVERLAP") && atoi(getenv("EESEN_OVERLAP"));
+  if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
+  if (getenv("EESEN_SPIN_LIMIT")) spin_limit = atoi(getenv("EESEN_SPIN_LIMIT"));
+  ctl.reserve(kCtlWords);
+  EESEN_HIP_CHECK(hipMemset(ctl.p, 0, kCtlWords * sizeof(unsigned)));
 }
 
 Net::~Net() {
@@ -133,6 +139,18 @@ Net::~Net() {
 void Net::sync() {
   EESEN_HIP_CHECK(hipSetDevice(device));
   EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  check_device_error();
+}
+
+void Net::check_device_error() {
+  if (!ctl.p) return;
+  unsigned e = 0;
+  EESEN_HIP_CHECK(hipMemcpy(&e, ctl.p + kCtlWords - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (e) {
+    EESEN_HIP_CHECK(hipMemset(ctl.p + kCtlWords - 1, 0, sizeof(unsigned)));
+    throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
+                               "resident?); rerun with EESEN_PERSISTENT=0");
+  }
 }
 
 void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
@@ -301,8 +319,9 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       timer.end(st, ti_); }
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
-      for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
-      check_launch("lstm_fwd_step");
+      if (!(persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit)))
+        for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
+      check_launch("lstm_fwd");
       timer.end(st, ti_); }
       x = L.Y.p + (size_t)S * ldY;
       ldx = ldY;
@@ -405,8 +424,9 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         side_pending[dg_slot] = false;
       }
       { const int ti_ = timer.begin(st, 3);
-      for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
-      check_launch("lstm_bwd_step");
+      if (!(persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit)))
+        for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
+      check_launch("lstm_bwd");
       timer.end(st, ti_); }
       EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
       if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction

@@ -65,6 +65,10 @@ struct Net {
   hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;
+  DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
+  int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
+  int spin_limit = 400000;
+  void check_device_error();
   size_t ws_floats = 0;
   PhaseTimer timer;
 

@@ -214,3 +214,36 @@ def test_error_behaviour(gpu, tmp_path):
         ctc.EvalParallel([3, 3], CuMatrix(6, 5), [[1], [7]])
     with pytest.raises(EesenError):       # empty label sequence (out-of-bounds read in the reference)
         ctc.EvalParallel([3, 3], CuMatrix(6, 5), [[1], []])
+
+
+@pytest.mark.parametrize("cfg_name,over", [("small_bi", {}), ("small_uni", {}), ("cfg1", {}), ("small_bi", dict(S=37, T=33, H=40)),
+                                           ("cfg2", dict(T=50, layers=2))])
+def test_persistent_recurrence_matches_step_kernels(gpu, cfg_name, over, monkeypatch):
+    """lstm_persistent.hip (one cooperative launch per layer pass, W_m resident in registers, in-kernel hand-off of
+    m_t / DG_t) against the one-launch-per-step kernels: same MFMA and reduction order, so the forward pass is bit
+    identical; the backward cell equations may be FMA-contracted differently by the compiler (last-bit differences)."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config(cfg_name); cfg.update(over)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EESEN_PERSISTENT", mode)
+        net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+        outs = []
+        for it in range(6):  # repeated on unchanged weights: a hand-off race would show up as run-to-run differences
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            idf = CuMatrix(batch.T * batch.S, cfg["D"])
+            net.BackpropagateNoUpdate(diff, idf)
+            outs.append((out.numpy(), diff.numpy(), idf.numpy(), net.GetGrads()))
+        net.Update()
+        res[mode] = (outs, net.GetParams())
+    ref = res["0"][0][0]
+    for mode in ("0", "1"):
+        for o in res[mode][0]:
+            assert np.array_equal(o[0], ref[0]) and np.array_equal(o[1], ref[1])   # net_out, diff: bit-identical, every run
+            assert np.array_equal(o[2], res[mode][0][0][2]) and np.array_equal(o[3], res[mode][0][0][3])   # deterministic
+            assert rel_err(o[2], ref[2]) < 5e-6 and rel_err(o[3], ref[3]) < 5e-6     # in_diff, gradients
+    assert rel_err(res["1"][1], res["0"][1]) < 1e-6
