@@ -37,9 +37,10 @@ void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float*
 // The whole recurrence of one layer in ONE cooperative launch with W_m resident in registers (lstm_persistent.hip).
 // cnt: >= ndir * ceil(S/16) zero-initialisable counters, err: one word raised when a bounded spin gives up.
 // Return false (nothing launched) when the shape does not fit the resident-workgroup budget: use the step kernels then.
-bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit);
+bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
+                         unsigned long long* trace = nullptr);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
-                         unsigned* err, int spin_limit);
+                         unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of
 // bilstm-parallel-layer.h:507-510 / :598-601.  ws: >= red_rows_ws(...) floats.
 void lstm_bias_peep_grads(hipStream_t st, const LstmLayerDev& L, const float* DG, float* bias_grad, float* peep_grad,

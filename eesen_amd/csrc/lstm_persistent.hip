@@ -36,10 +36,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
 // 8 consecutive floats at row[k..k+7] (k, kmax multiples of 4) through the sc1 path; zeros outside
+// EESEN_SC1_LOADS=1 (build flag): consumers read the handed-off rows with sc1 (L1-bypassing) loads.  Measured on MI355X
+// this makes every workgroup pull its own copy through the Infinity Fabric (16 MB per backward step, ~27 GB/s per CU).
+// Default: plain loads.  They are safe HERE because (i) every step reads row blocks that were never read before in this
+// launch, so neither the CU's L1 nor the XCD's L2 can hold an older copy, (ii) the producers' sc1 stores write through
+// and drop the line from their L2, and (iii) no load is issued before the arrival counters say every producer has
+// drained its stores -- and they let the 16 workgroups of an XCD share one fabric fetch through the L2.
+#ifndef EESEN_SC1_LOADS
+#define EESEN_SC1_LOADS 0
+#endif
 __device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int k, int kmax, bool ok, float (&v)[8]) {
   f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-  if (ok && k < kmax) a = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kSc1);
-  if (ok && k + 4 < kmax) b = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, kSc1);
+  constexpr int pol = EESEN_SC1_LOADS ? kSc1 : 0;
+  if (ok && k < kmax) a = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, pol);
+  if (ok && k + 4 < kmax) b = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, pol);
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
@@ -63,18 +73,24 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
     if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
     if (__all(ok)) return true;
     if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+#ifndef EESEN_POLL_NOSLEEP
     __builtin_amdgcn_s_sleep(1);
+#endif
   }
   if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
 }
+
+// Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
+#define EESEN_STAMP(i) do { if (trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && step < 128) \
+    trace[step * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (H/4, ndir, ceil(S/32)), 512 threads -- the decomposition of lstm_fwd_step_kernel
 // ------------------------------------------------------------------------------------------------
 template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
-                                                                      int spin_limit) {
+                                                                      int spin_limit, unsigned long long* trace) {
   __shared__ __attribute__((aligned(16))) float red[NW][32][20];
   __shared__ int s_go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
       if (wave == 0) {
         const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       }
       __syncthreads();
       if (!s_go) return;
+      EESEN_STAMP(1);
       const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y + (size_t)(tp + 1) * S * ldY + dir * H);
       float a0[CPW][8], a1[CPW][8];
 #pragma unroll
@@ -140,6 +158,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       red[wave][16 + 4 * kq + r][li] = acc1[r];
     }
     __syncthreads();
+    EESEN_STAMP(2);
     if (e_ok) {
       float4 pre = gx;
 #pragma unroll
@@ -161,9 +180,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: other XCDs read it next step
       cprev = c;
     }
+    EESEN_STAMP(3);
     if (step + 1 < T) {
       if (tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
       __syncthreads();                                                 // (also fences `red` for the next step)
+      EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok)  // next step's gate pre-activations: issued AFTER the publish so the drain above never waits for HBM
         gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
-                                                                      unsigned* err, int spin_limit) {
+                                                                      unsigned* err, int spin_limit, unsigned long long* trace) {
   __shared__ float red[NW][16][17];
   __shared__ int s_go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -227,6 +248,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    EESEN_STAMP(0);
     if (step > 0) {
       if (wave == 0) {
         const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
@@ -234,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       }
       __syncthreads();
       if (!s_go) return;
+      EESEN_STAMP(1);
       const size_t arow = ((size_t)(tn * S + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row
       float a[CPW][8];
 #pragma unroll
@@ -252,6 +275,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
     __syncthreads();
+    EESEN_STAMP(2);
     if (e_ok) {
       float dm = dy;
 #pragma unroll
@@ -270,9 +294,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4), 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
+    EESEN_STAMP(3);
     if (step + 1 < T) {
       if (tid < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok) {  // next step's operands, issued after the publish
         const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
@@ -305,7 +331,8 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 }  // namespace
 
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
-bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit) {
+bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
+                         unsigned long long* trace) {
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
   dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
@@ -314,7 +341,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
 #define EESEN_FP(CPW)                                                                   \
   do {                                                                                   \
     if (!fits(lstm_fwd_persistent_kernel<CPW>, grid, NW * 64)) return false;             \
-    coop_launch(st, lstm_fwd_persistent_kernel<CPW>, grid, block, L, cnt, err, spin_limit); \
+    coop_launch(st, lstm_fwd_persistent_kernel<CPW>, grid, block, L, cnt, err, spin_limit, trace); \
   } while (0)
   if (need <= 1) EESEN_FP(1);
   else if (need <= 2) EESEN_FP(2);
@@ -324,7 +351,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
 }
 
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
-                         unsigned* err, int spin_limit) {
+                         unsigned* err, int spin_limit, unsigned long long* trace) {
   const int nch = (4 * L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
   dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16)), block(NW * 64);
@@ -334,7 +361,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
 #define EESEN_BP(CPW)                                                                              \
   do {                                                                                              \
     if (!fits(lstm_bwd_persistent_kernel<CPW>, grid, NW * 64)) return false;                        \
-    coop_launch(st, lstm_bwd_persistent_kernel<CPW>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit); \
+    coop_launch(st, lstm_bwd_persistent_kernel<CPW>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit, trace); \
   } while (0)
   if (need <= 1) EESEN_BP(1);
   else if (need <= 2) EESEN_BP(2);

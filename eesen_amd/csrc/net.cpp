@@ -118,11 +118,16 @@ Net::Net(int dev, void* stream) : device(dev) {
   }
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_rec, hipEventDisableTiming));
   for (auto& e : ev_grad) EESEN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  // measured on MI355X (cfg2): running the weight-gradient GEMMs under the next layer's recurrence is neutral
-  // (105.1 vs 104.9 ms/step: the recurrence kernels slow down by what the GEMMs gain), so it is opt-in
-  overlap = getenv("EESEN_OVERLAP") && atoi(getenv("EESEN_OVERLAP"));
   if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
+  // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on MI355X, cfg2: with the
+  // one-launch-per-step recurrence it is neutral (105.1 vs 104.9 ms/step: the step kernels slow down by what the
+  // GEMMs gain); with the persistent recurrence, whose workgroups mostly wait on hand-offs, it pays: 78.3 -> 73.0 ms.
+  overlap = getenv("EESEN_OVERLAP") ? atoi(getenv("EESEN_OVERLAP")) != 0 : persistent != 0;
   if (getenv("EESEN_SPIN_LIMIT")) spin_limit = atoi(getenv("EESEN_SPIN_LIMIT"));
+  if (getenv("EESEN_TRACE") && atoi(getenv("EESEN_TRACE"))) {
+    trace.reserve(1280);
+    EESEN_HIP_CHECK(hipMemset(trace.p, 0, 1280 * sizeof(unsigned long long)));
+  }
   ctl.reserve(kCtlWords);
   EESEN_HIP_CHECK(hipMemset(ctl.p, 0, kCtlWords * sizeof(unsigned)));
 }
@@ -130,6 +135,23 @@ Net::Net(int dev, void* stream) : device(dev) {
 Net::~Net() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(st);
+  if (trace.p) {  // EESEN_TRACE=1: timeline of workgroup 0 of the last persistent launches (shader-clock ticks)
+    std::vector<unsigned long long> h(1280);
+    if (hipMemcpy(h.data(), trace.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int pass = 0; pass < 2; ++pass) {
+        double seg[5] = {0, 0, 0, 0, 0};
+        int n = 0;
+        for (int s = 8; s < 120; ++s) {
+          const unsigned long long* a = h.data() + pass * 640 + s * 5;
+          if (!a[0] || !a[5]) continue;
+          seg[0] += (double)(a[1] - a[0]); seg[1] += (double)(a[2] - a[1]); seg[2] += (double)(a[3] - a[2]);
+          seg[3] += (double)(a[4] - a[3]); seg[4] += (double)(a[5] - a[4]);
+          ++n;
+        }
+        if (n) fprintf(stderr, "EESEN_TRACE %s: wait %.0f | A-load+MFMA+reduce %.0f | epilogue %.0f | drain+barrier %.0f | publish->next %.0f ticks/step (%d steps)\n",
+                       pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
+      }
+  }
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
   if (ev_rec) (void)hipEventDestroy(ev_rec);
   for (auto& e : ev_grad) if (e) (void)hipEventDestroy(e);
@@ -319,7 +341,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       timer.end(st, ti_); }
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
-      if (!(persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit)))
+      if (!(persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p)))
         for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
       check_launch("lstm_fwd");
       timer.end(st, ti_); }
@@ -424,7 +446,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         side_pending[dg_slot] = false;
       }
       { const int ti_ = timer.begin(st, 3);
-      if (!(persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit)))
+      if (!(persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr)))
         for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
       check_launch("lstm_bwd");
       timer.end(st, ti_); }

@@ -68,6 +68,7 @@ struct Net {
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
   int spin_limit = 400000;
+  DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error();
   size_t ws_floats = 0;
   PhaseTimer timer;
