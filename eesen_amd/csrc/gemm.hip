@@ -236,8 +236,9 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   const long tiles = (long)tiles_m * tiles_n;
   // split-K only when the tile grid cannot fill the chip and K is long enough to amortise the reduce pass
   int splits = 1;
-  if (ws && tiles < 256 && K >= 2048) {
-    splits = (int)std::min<long>(512 / tiles, K / 1024);
+  static const int target = getenv("EESEN_GEMM_TARGET_BLOCKS") ? atoi(getenv("EESEN_GEMM_TARGET_BLOCKS")) : 1024;  // >= 4 workgroups per CU (measured: tall-K W_x gradient 92 -> 110 TF)
+  if (ws && tiles < target && K >= 2048) {
+    splits = (int)std::min<long>((target + tiles - 1) / tiles, K / 1024);
     splits = std::max(1, std::min(splits, 64));
     while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
   }
