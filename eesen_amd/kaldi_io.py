@@ -1,0 +1,186 @@
+"""Kaldi tables for the trainer's two inputs: float feature matrices and int32 label vectors.
+
+Host-side data loading for the CLI mirror (eesen_amd/train_ctc_parallel.py); formats follow the reference:
+  * archive entry = `key` + space + object (/root/reference/src/util/kaldi-table-inl.h TableWriterArchiveImpl::Write);
+  * binary objects start with `\\0B` (src/base/io-funcs-inl.h:183-187);
+  * float matrix: `FM ` + int32 rows + int32 cols (each preceded by a size byte 4) + raw little-endian fp32
+    (src/cpucompute/matrix.cc:968-994); text: ` [` newline-separated rows ` ]`;
+  * int32 vector (BasicVectorHolder, src/util/kaldi-holder-inl.h:190-260): binary = sized int32 count, then every
+    element as a sized int32; text = `1 2 3\\n`;
+  * script files: `key path[:byte_offset]` per line, the offset pointing at the object (src/util/kaldi-table.h).
+Supported specifiers: `ark:path`, `ark,t:path`, `scp:path`, and `ark:-` for stdin.  Compressed matrices (`CM`), pipes
+and double-precision matrices are outside the hot path and raise.
+"""
+from __future__ import annotations
+
+import io
+import struct
+import sys
+from typing import BinaryIO, Dict, Iterator, List, Tuple
+
+import numpy as np
+
+
+class KaldiIOError(RuntimeError):
+    pass
+
+
+def _parse_specifier(spec: str) -> Tuple[str, str, bool]:
+    if ":" not in spec:
+        raise KaldiIOError(f"bad table specifier '{spec}' (expected ark:... or scp:...)")
+    head, path = spec.split(":", 1)
+    opts = head.split(",")
+    kind = opts[0]
+    if kind not in ("ark", "scp"):
+        raise KaldiIOError(f"unsupported table kind in '{spec}'")
+    if path.endswith("|") or path.startswith("|"):
+        raise KaldiIOError("pipes in table specifiers are not supported by this reader")
+    return kind, path, "t" in opts[1:]
+
+
+def _read_token(f: BinaryIO) -> str:
+    """Key of the next archive entry: bytes up to the first space; '' at EOF. Leading newlines (text mode) are skipped."""
+    out = bytearray()
+    while True:
+        c = f.read(1)
+        if not c:
+            return out.decode()
+        if c in b" \t":
+            if out:
+                return out.decode()
+            continue
+        if c in b"\r\n" and not out:
+            continue
+        out += c
+
+
+def _read_sized_int(f: BinaryIO) -> int:
+    b = f.read(5)
+    if len(b) != 5 or b[0] != 4:
+        raise KaldiIOError("bad binary int32")
+    return struct.unpack("<i", b[1:])[0]
+
+
+def _read_matrix(f: BinaryIO) -> np.ndarray:
+    hdr = f.read(2)
+    if hdr == b"\x00B":
+        tok = f.read(3)
+        if tok == b"CM " or tok[:2] == b"CM":
+            raise KaldiIOError("compressed matrices (CM) are not supported; run copy-feats --compress=false")
+        if tok == b"DM ":
+            raise KaldiIOError("double-precision matrices are not supported (the path is BaseFloat = float)")
+        if tok != b"FM ":
+            raise KaldiIOError(f"expected FM, got {tok!r}")
+        rows, cols = _read_sized_int(f), _read_sized_int(f)
+        buf = f.read(4 * rows * cols)
+        if len(buf) != 4 * rows * cols:
+            raise KaldiIOError("truncated matrix")
+        return np.frombuffer(buf, dtype="<f4").reshape(rows, cols).astype(np.float32)
+    # text: "[" rows "]" ; hdr holds the first two characters already
+    txt = bytearray(hdr)
+    while b"]" not in txt:
+        chunk = f.readline()
+        if not chunk:
+            raise KaldiIOError("unterminated text matrix")
+        txt += chunk
+    s = txt.decode()
+    body = s[s.index("[") + 1: s.index("]")]
+    rows = [r.split() for r in body.strip().split("\n") if r.strip()]
+    if not rows:
+        return np.zeros((0, 0), np.float32)
+    return np.array(rows, dtype=np.float32)
+
+
+def _read_int_vector(f: BinaryIO) -> np.ndarray:
+    c0 = f.read(1)
+    if c0 == b"\n" or not c0:       # text mode, empty vector
+        return np.zeros(0, np.int32)
+    hdr = c0 + (f.read(1) if c0 == b"\x00" else b"")
+    if hdr == b"\x00B":
+        n = _read_sized_int(f)
+        buf = f.read(5 * n)
+        if len(buf) != 5 * n:
+            raise KaldiIOError("truncated int vector")
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(n, 5)
+        if n and not np.all(a[:, 0] == 4):
+            raise KaldiIOError("bad element size in int vector")
+        return np.ascontiguousarray(a[:, 1:]).view("<i4").reshape(n).astype(np.int32)
+    line = hdr + f.readline()
+    return np.array(line.split(), dtype=np.int32)
+
+
+def _open(path: str) -> BinaryIO:
+    return sys.stdin.buffer if path == "-" else open(path, "rb")
+
+
+def _iter_table(spec: str, read_obj) -> Iterator[Tuple[str, np.ndarray]]:
+    kind, path, _ = _parse_specifier(spec)
+    if kind == "ark":
+        with _open(path) as f:
+            while True:
+                key = _read_token(f)
+                if not key:
+                    return
+                yield key, read_obj(f)
+    else:
+        with open(path) as scp:
+            for line in scp:
+                line = line.strip()
+                if not line:
+                    continue
+                key, loc = line.split(None, 1)
+                off = 0
+                if ":" in loc and loc.rsplit(":", 1)[1].isdigit():
+                    loc, o = loc.rsplit(":", 1)
+                    off = int(o)
+                with open(loc, "rb") as f:
+                    f.seek(off)
+                    yield key, read_obj(f)
+
+
+def read_mat_table(spec: str) -> Iterator[Tuple[str, np.ndarray]]:
+    """SequentialBaseFloatMatrixReader (train-ctc-parallel.cc:124)."""
+    return _iter_table(spec, _read_matrix)
+
+
+def read_vec_int_table(spec: str) -> Dict[str, np.ndarray]:
+    """RandomAccessInt32VectorReader (train-ctc-parallel.cc:125): the whole table as a dict."""
+    return dict(_iter_table(spec, _read_int_vector))
+
+
+# ---------------------------------------------------------------------------------------------- writers
+def write_mat_ark(path: str, items, text: bool = False, scp_path: str = None):
+    """BaseFloatMatrixWriter to `ark:path` (optionally also an scp with byte offsets, like ark,scp:)."""
+    scp = open(scp_path, "w") if scp_path else None
+    with open(path, "wb") as f:
+        for key, m in items:
+            m = np.ascontiguousarray(m, np.float32)
+            f.write(key.encode() + b" ")
+            if scp:
+                scp.write(f"{key} {path}:{f.tell()}\n")
+            if text:
+                f.write(b" [")
+                for r in m:
+                    f.write(b"\n  " + " ".join(repr(float(np.float32(v))) for v in r).encode() + b" ")
+                f.write(b"]\n")
+            else:
+                f.write(b"\x00BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]))
+                f.write(m.tobytes())
+    if scp:
+        scp.close()
+
+
+def write_vec_int_ark(path: str, items, text: bool = False):
+    """Int32VectorWriter to `ark:path` / `ark,t:path`."""
+    with open(path, "wb") as f:
+        for key, v in items:
+            v = np.ascontiguousarray(v, np.int32)
+            f.write(key.encode() + b" ")
+            if text:
+                f.write((" ".join(str(int(x)) for x in v) + " \n").encode())
+            else:
+                f.write(b"\x00B\x04" + struct.pack("<i", v.size))
+                out = np.empty((v.size, 5), np.uint8)
+                out[:, 0] = 4
+                out[:, 1:] = v.astype("<i4").view(np.uint8).reshape(v.size, 4)
+                f.write(out.tobytes())

@@ -22,6 +22,9 @@
 #include "net/train-opts.h"
 #include "cpucompute/matrix.h"
 #include "gpucompute/cuda-matrix.h"
+#include "util/kaldi-table.h"
+#include "util/kaldi-holder.h"
+#include "util/table-types.h"
 
 using namespace eesen;
 
@@ -178,6 +181,58 @@ int ref_ctc_error_rate_mseq(void* p, const float* net_out, int T, int S, int K, 
   *num_err = h->ctc.NumErrorTokens() - e0;
   *num_ref = h->ctc.NumRefTokens() - r0;
   return 0;
+  REF_CATCH(-1)
+}
+
+// ---- Kaldi tables through the reference's OWN reader / writer classes (util/kaldi-table.h, util/table-types.h) --------
+// Used to pin eesen_amd/kaldi_io.py: files written here must be read identically by our reader and vice versa.
+int ref_write_feats(const char* wspecifier, int n, const char** keys, const float** mats, const int* rows, int cols) {
+  REF_TRY
+  BaseFloatMatrixWriter w(wspecifier);
+  for (int i = 0; i < n; i++) {
+    Matrix<BaseFloat> m(rows[i], cols, kUndefined);
+    for (int r = 0; r < rows[i]; r++) memcpy(m.RowData(r), mats[i] + (size_t)r * cols, sizeof(float) * cols);
+    w.Write(keys[i], m);
+  }
+  return 0;
+  REF_CATCH(-1)
+}
+
+int ref_write_labels(const char* wspecifier, int n, const char** keys, const int** labs, const int* lens) {
+  REF_TRY
+  Int32VectorWriter w(wspecifier);
+  for (int i = 0; i < n; i++) w.Write(keys[i], std::vector<int32>(labs[i], labs[i] + lens[i]));
+  return 0;
+  REF_CATCH(-1)
+}
+
+// Sequential read of a feature table: number of utterances, total rows, and sum over all elements of value * (1 + col).
+int ref_read_feats_summary(const char* rspecifier, int* n_utts, long* total_rows, double* checksum, char* keys_out, int keys_cap) {
+  REF_TRY
+  SequentialBaseFloatMatrixReader r(rspecifier);
+  int n = 0; long rows = 0; double cs = 0; std::string keys;
+  for (; !r.Done(); r.Next()) {
+    const Matrix<BaseFloat>& m = r.Value();
+    for (int i = 0; i < m.NumRows(); i++)
+      for (int j = 0; j < m.NumCols(); j++) cs += (double)m(i, j) * (1 + j);
+    rows += m.NumRows(); n++;
+    keys += r.Key(); keys += " ";
+  }
+  *n_utts = n; *total_rows = rows; *checksum = cs;
+  if (keys_out && keys_cap > 0) { strncpy(keys_out, keys.c_str(), keys_cap - 1); keys_out[keys_cap - 1] = 0; }
+  return 0;
+  REF_CATCH(-1)
+}
+
+// Random-access read of one label vector (RandomAccessInt32VectorReader, as train-ctc-parallel.cc:125 uses it).
+int ref_read_labels(const char* rspecifier, const char* key, int* out, int cap) {
+  REF_TRY
+  RandomAccessInt32VectorReader r(rspecifier);
+  if (!r.HasKey(key)) return -2;
+  const std::vector<int32>& v = r.Value(key);
+  if ((int)v.size() > cap) return -3;
+  for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+  return (int)v.size();
   REF_CATCH(-1)
 }
 

@@ -1,0 +1,73 @@
+"""-m gpu: the command-line mirror of train-ctc-parallel end to end (Kaldi tables in, <Nnet> out, TOKEN_ACCURACY on
+stderr) against the oracle driven through the same minibatch assembly."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from eesen_amd import kaldi_io, nnet_io, synth
+from eesen_amd.batching import assemble
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dataset(tmp_path, n=14, D=8, K=7, seed=5):
+    rng = np.random.default_rng(seed)
+    feats = [(f"spk{i % 3}_utt{i:02d}", rng.standard_normal((int(rng.integers(8, 30)), D)).astype(np.float32)) for i in range(n)]
+    feats.sort(key=lambda kv: kv[1].shape[0])                   # recipes sort by length (train_ctc_parallel.sh:84-89)
+    labs = {k: rng.integers(1, K, size=max(1, m.shape[0] // 5)).astype(np.int32) for k, m in feats}
+    ark, scp, lab = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp"), str(tmp_path / "labels.ark")
+    kaldi_io.write_mat_ark(ark, feats, scp_path=scp)
+    kaldi_io.write_vec_int_ark(lab, labs.items())
+    return feats, labs, scp, lab
+
+
+def _run(args):
+    return subprocess.run([sys.executable, "-m", "eesen_amd.train_ctc_parallel"] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
+
+
+def test_training_iteration_matches_oracle(gpu, tmp_path):
+    from oracle import net as onet
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    feats, labs, scp, lab = _dataset(tmp_path, D=cfg["D"], K=cfg["K"])
+    m_in, m_out = str(tmp_path / "nnet.init"), str(tmp_path / "nnet.iter1")
+    nnet_io.write_nnet(m_in, layers, binary=True)
+    opts = ["--learn-rate=0.01", "--momentum=0.9", "--num-sequence=4", "--frame-limit=90", "--report-step=4", "--verbose=1"]
+    r = _run(opts + ["scp:" + scp, "ark:" + lab, m_in, m_out])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "TRAINING STARTED" in r.stderr and re.search(r"TOKEN_ACCURACY >> [-0-9.e]+% <<", r.stderr)
+    assert re.search(r"Done 14 files, 0 with no targets", r.stderr) and "Obj(log[Pzx])" in r.stderr
+    got = nnet_io.read_nnet(m_out)
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(0.01, 0.9)
+    errs = refs = 0
+    for mb in assemble(iter(feats), labs, 4, 90, cfg["D"]):
+        ora.set_seq_lengths(mb.lens)
+        out = ora.propagate(mb.feats)
+        ids = np.concatenate(mb.labels); off = np.concatenate([[0], np.cumsum([len(l) for l in mb.labels])]).astype(np.int32)
+        c = onet.ctc_eval_parallel(out, mb.T, mb.S, mb.lens, ids, off, "f32")
+        e, n = onet.ctc_error_rate_mseq(out, mb.T, mb.S, mb.lens, ids, off); errs += e; refs += n
+        ora.backpropagate(c["diff"])
+    assert rel_err(nnet_io.flatten_params(got), ora.get_params()) < 1e-4
+    acc = float(re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r.stderr).group(1))
+    assert abs(acc - 100.0 * (1.0 - errs / refs)) < 1e-3
+    # cross-validation: no model written, no parameter change, same report line
+    r2 = _run(["--cross-validate=true", "--num-sequence=4", "--frame-limit=90", "scp:" + scp, "ark:" + lab, m_out])
+    assert r2.returncode == 0 and "CROSS-VALIDATION STARTED" in r2.stderr and "TOKEN_ACCURACY" in r2.stderr
+
+
+def test_cli_error_contract(gpu, tmp_path):
+    cfg = synth.config("tiny_bi")
+    feats, labs, scp, lab = _dataset(tmp_path, D=cfg["D"], K=cfg["K"])
+    r = _run(["scp:" + scp, "ark:" + lab])                       # wrong argument count: usage, exit 1 (:81-84)
+    assert r.returncode == 1 and "usage" in r.stderr.lower()
+    r = _run(["scp:" + scp, "ark:" + lab, str(tmp_path / "missing.nnet"), str(tmp_path / "o")])
+    assert r.returncode == 255 and "cannot open model file" in r.stderr
+    m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(**cfg), binary=False)
+    r = _run(["--opt-algorithm=Adagrad", "scp:" + scp, "ark:" + lab, m_in, str(tmp_path / "o")])
+    assert r.returncode == 255

@@ -1,0 +1,110 @@
+"""CPU: Kaldi table I/O against the reference's own table classes (oracle/_ref, skipped where absent), and the
+minibatch assembly rule of train-ctc-parallel.cc:144-193."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from eesen_amd import kaldi_io
+from eesen_amd.batching import assemble, interleave, AssemblyStats
+from oracle import refbind
+
+
+def _utts(n, D=5, seed=0, lo=3, hi=12):
+    rng = np.random.default_rng(seed)
+    feats = [(f"utt{i:03d}", rng.standard_normal((int(rng.integers(lo, hi)), D)).astype(np.float32)) for i in range(n)]
+    labs = {k: rng.integers(1, 9, size=max(1, m.shape[0] // 3)).astype(np.int32) for k, m in feats}
+    return feats, labs
+
+
+@pytest.mark.parametrize("text", [False, True])
+def test_roundtrip_ark_and_scp(tmp_path, text):
+    feats, labs = _utts(7)
+    ark, scp, lab = str(tmp_path / "f.ark"), str(tmp_path / "f.scp"), str(tmp_path / "l.ark")
+    kaldi_io.write_mat_ark(ark, feats, text=text, scp_path=None if text else scp)
+    kaldi_io.write_vec_int_ark(lab, labs.items(), text=text)
+    back = list(kaldi_io.read_mat_table(("ark,t:" if text else "ark:") + ark))
+    assert [k for k, _ in back] == [k for k, _ in feats]
+    for (_, a), (_, b) in zip(back, feats):
+        assert np.array_equal(a, b)
+    if not text:
+        for (ka, a), (kb, b) in zip(kaldi_io.read_mat_table("scp:" + scp), feats):
+            assert ka == kb and np.array_equal(a, b)
+    lb = kaldi_io.read_vec_int_table(("ark,t:" if text else "ark:") + lab)
+    assert set(lb) == set(labs) and all(np.array_equal(lb[k], labs[k]) for k in labs)
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("text", [False, True])
+def test_against_the_reference_table_classes(tmp_path, text):
+    lib = refbind._load()
+    feats, labs = _utts(5, D=4, seed=3)
+    mode = "ark,t:" if text else "ark:"
+    # (1) written by the reference's BaseFloatMatrixWriter / Int32VectorWriter, read by us
+    ark, lab = str(tmp_path / "ref.ark"), str(tmp_path / "ref_lab.ark")
+    keys = (C.c_char_p * len(feats))(*[k.encode() for k, _ in feats])
+    mats = (C.c_void_p * len(feats))(*[m.ctypes.data for _, m in feats])
+    rows = (C.c_int * len(feats))(*[m.shape[0] for _, m in feats])
+    assert lib.ref_write_feats((mode + ark).encode(), len(feats), keys, mats, rows, 4) == 0
+    lv = [np.ascontiguousarray(labs[k]) for k, _ in feats]
+    lp = (C.c_void_p * len(lv))(*[v.ctypes.data for v in lv])
+    ll = (C.c_int * len(lv))(*[v.size for v in lv])
+    assert lib.ref_write_labels((mode + lab).encode(), len(lv), keys, lp, ll) == 0
+    back = list(kaldi_io.read_mat_table(mode + ark))
+    assert [k for k, _ in back] == [k for k, _ in feats]
+    for (_, a), (_, b) in zip(back, feats):
+        assert np.allclose(a, b, rtol=1e-6 if text else 0, atol=0)
+    lb = kaldi_io.read_vec_int_table(mode + lab)
+    assert all(np.array_equal(lb[k], labs[k]) for k in labs)
+    # (2) written by us, read by the reference's SequentialBaseFloatMatrixReader / RandomAccessInt32VectorReader
+    ours, ours_lab = str(tmp_path / "ours.ark"), str(tmp_path / "ours_lab.ark")
+    kaldi_io.write_mat_ark(ours, feats, text=text)
+    kaldi_io.write_vec_int_ark(ours_lab, labs.items(), text=text)
+    n, tot, cs = C.c_int(), C.c_long(), C.c_double()
+    kb = C.create_string_buffer(4096)
+    assert lib.ref_read_feats_summary((mode + ours).encode(), C.byref(n), C.byref(tot), C.byref(cs), kb, 4096) == 0
+    want = sum(float((m.astype(np.float64) * (1 + np.arange(m.shape[1]))).sum()) for _, m in feats)
+    assert n.value == len(feats) and tot.value == sum(m.shape[0] for _, m in feats)
+    assert abs(cs.value - want) < 1e-4 * max(1.0, abs(want))
+    assert kb.value.decode().split() == [k for k, _ in feats]
+    out = np.zeros(64, np.int32)
+    for k in labs:
+        cnt = lib.ref_read_labels((mode + ours_lab).encode(), k.encode(), out.ctypes.data_as(C.c_void_p), 64)
+        assert cnt == labs[k].size and np.array_equal(out[:cnt], labs[k])
+
+
+def test_interleave_is_time_major_zero_padded():
+    mats = [np.full((2, 3), 1, np.float32), np.full((4, 3), 2, np.float32), np.full((1, 3), 3, np.float32)]
+    feats, lens, T = interleave(mats, 3)
+    assert T == 4 and lens.tolist() == [2, 4, 1] and feats.shape == (12, 3)
+    f = feats.reshape(4, 3, 3)
+    assert np.all(f[:2, 0] == 1) and np.all(f[2:, 0] == 0) and np.all(f[:, 1] == 2) and np.all(f[0, 2] == 3) and np.all(f[1:, 2] == 0)
+
+
+def test_grouping_rule():
+    """Lengths 10,10,10,30,5,5 with --num-sequence=3 --frame-limit=60: [10,10,10] (full) | 30 alone would be 30*1<=60 ok, then
+    5: max 30 * 2 = 60 <= 60 fits, then 5: 30 * 3 = 90 > 60 opens the next group."""
+    lens = [10, 10, 10, 30, 5, 5]
+    feats = [(f"u{i}", np.zeros((n, 2), np.float32)) for i, n in enumerate(lens)]
+    labs = {k: np.array([1], np.int32) for k, _ in feats}
+    got = [mb.lens.tolist() for mb in assemble(iter(feats), labs, 3, 60, 2)]
+    assert got == [[10, 10, 10], [30, 5], [5]]
+
+
+def test_skips_and_counts():
+    feats = [("a", np.zeros((4, 2), np.float32)), ("nolab", np.zeros((4, 2), np.float32)), ("huge", np.zeros((50, 2), np.float32)),
+             ("b", np.zeros((6, 2), np.float32))]
+    labs = {"a": np.array([1], np.int32), "huge": np.array([1], np.int32), "b": np.array([2, 3], np.int32)}
+    st = AssemblyStats()
+    mbs = list(assemble(iter(feats), labs, 5, 40, 2, st))
+    assert [mb.keys for mb in mbs] == [["a", "b"]] and st.num_no_tgt_mat == 1 and st.num_too_long == 1
+    assert mbs[0].T == 6 and mbs[0].feats.shape == (12, 2)
+
+
+def test_every_utterance_lands_in_exactly_one_group():
+    feats, labs = _utts(40, seed=9, lo=5, hi=60)
+    for ns, fl in [(1, 100), (4, 100), (10, 250), (64, 1e5)]:
+        mbs = list(assemble(iter(feats), labs, ns, fl, 5))
+        assert [k for mb in mbs for k in mb.keys] == [k for k, _ in feats]
+        assert all(mb.S <= ns and mb.T * mb.S <= fl for mb in mbs)
