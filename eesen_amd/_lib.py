@@ -38,6 +38,10 @@ SIGNATURES = {
     "eesen_net_get_params": (_i, [_vp, _vp, _l]),
     "eesen_net_set_params": (_i, [_vp, _vp, _l]),
     "eesen_net_set_train_options": (_i, [_vp, _f, _f]),
+    "eesen_net_set_update_algorithm": (_i, [_vp, C.c_char_p]),
+    "eesen_net_set_adaptive_options": (_i, [_vp, _f, _f]),
+    "eesen_net_get_accumulators": (_i, [_vp, _vp, _l]),
+    "eesen_net_set_accumulators": (_i, [_vp, _vp, _l]),
     "eesen_net_set_seq_lengths": (_i, [_vp, _vp, _i]),
     "eesen_net_propagate": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_vp), _pi, _pi]),
     "eesen_net_get_output": (_i, [_vp, _vp, _l]),

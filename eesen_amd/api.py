@@ -174,6 +174,20 @@ class Net:
     def SetTrainOptions(self, learn_rate: float, momentum: float = 0.0):
         check(self.lib.eesen_net_set_train_options(self.h, float(learn_rate), float(momentum)))
 
+    def SetUpdateAlgorithm(self, name: str, adagrad_epsilon: float = 1e-6, rmsprop_rho: float = 0.9):
+        """Net::SetUpdateAlgorithm (net.cc:481-497) + the adaptive hyper-parameters of NetTrainOptions."""
+        check(self.lib.eesen_net_set_update_algorithm(self.h, name.encode()))
+        check(self.lib.eesen_net_set_adaptive_options(self.h, float(adagrad_epsilon), float(rmsprop_rho)))
+
+    def GetAccumulators(self) -> np.ndarray:
+        out = np.empty(self.NumParams(), np.float32)
+        check(self.lib.eesen_net_get_accumulators(self.h, _np_ptr(out), out.size))
+        return out
+
+    def SetAccumulators(self, flat: np.ndarray):
+        flat = np.ascontiguousarray(flat, np.float32)
+        check(self.lib.eesen_net_set_accumulators(self.h, _np_ptr(flat), flat.size))
+
     def SetSeqLengths(self, lens: Sequence[int]):
         a = np.ascontiguousarray(lens, np.int32)
         check(self.lib.eesen_net_set_seq_lengths(self.h, _np_ptr(a), a.size))

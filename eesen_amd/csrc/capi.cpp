@@ -99,6 +99,25 @@ int eesen_net_set_params(eesen_net_t* net, const float* host_flat, long n) {
 int eesen_net_set_train_options(eesen_net_t* net, float learn_rate, float momentum) {
   return guard([&] { REQ_PTR(net); net->lr = learn_rate; net->mmt = momentum; });
 }
+int eesen_net_set_update_algorithm(eesen_net_t* net, const char* name) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(name);
+    const std::string a(name);  // Net::SetUpdateAlgorithm, net.cc:481-497
+    if (a == "SGD") net->rule = 0;
+    else if (a == "Adagrad") net->rule = 1;
+    else if (a == "RMSProp") net->rule = 2;
+    else throw Error(EESEN_ERR_INVALID, "unknown optimization algorithm '" + a + "' (SGD|Adagrad|RMSProp)");
+  });
+}
+int eesen_net_set_adaptive_options(eesen_net_t* net, float adagrad_epsilon, float rmsprop_rho) {
+  return guard([&] { REQ_PTR(net); net->ada_eps = adagrad_epsilon; net->rms_rho = rmsprop_rho; net->rms_one_minus_rho = 1.0f - rmsprop_rho; });
+}
+int eesen_net_get_accumulators(eesen_net_t* net, float* host_flat, long n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(host_flat); net->init_accu(); net->get_flat(net->accu, host_flat, n); });
+}
+int eesen_net_set_accumulators(eesen_net_t* net, const float* host_flat, long n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(host_flat); net->set_accu(host_flat, n); });
+}
 int eesen_net_set_seq_lengths(eesen_net_t* net, const int* lens, int S) {
   return guard([&] { REQ_PTR(net); REQ_PTR(lens); net->set_seq_lengths(lens, S); });
 }

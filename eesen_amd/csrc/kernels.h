@@ -73,6 +73,9 @@ void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* id
 // corr = mmt*corr + fresh; clip to +-max_grad when max_grad > 0; param -= lr_coef*corr
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
                 float max_grad);
+// Adagrad (rmsprop = false) / RMSProp update of one flat parameter block, see optim.hip
+void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop);
 // dst[c][r] = src[r][c]  (rows x cols -> cols x rows), dense
 void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst);
 // dst[r][0..cols) = src[r][0..cols) with different leading dimensions

@@ -243,6 +243,13 @@ long Net::num_params() const {
   return n;
 }
 
+void Net::init_accu() {  // InitAdaBuffers (bilstm-layer.h:66-100, affine-trans-layer.h:74-81): zeros
+  if (accu_init) return;
+  accu.reserve(P);
+  EESEN_HIP_CHECK(hipMemsetAsync(accu.p, 0, P * sizeof(float), st));
+  accu_init = true;
+}
+
 void Net::refresh_derived() {
   for (Layer& L : layers)
     if (L.is_lstm())
@@ -251,20 +258,29 @@ void Net::refresh_derived() {
                     L.WmT.p + (size_t)dir * L.H * 4 * L.H);
 }
 
-void Net::set_params(const float* host, long n) {
-  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
-  EESEN_REQUIRE(n == num_params(), EESEN_ERR_INVALID, "parameter count mismatch");
-  EESEN_HIP_CHECK(hipSetDevice(device));
-  std::vector<float> h(P, 0.f);
+static void upload_flat(Net& net, DevBuf<float>& dst, const float* host, long n) {
+  EESEN_REQUIRE(net.finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(n == net.num_params(), EESEN_ERR_INVALID, "parameter count mismatch");
+  EESEN_HIP_CHECK(hipSetDevice(net.device));
+  std::vector<float> h(net.P, 0.f);
   long base = 0;
-  for (const Layer& L : layers) {
+  for (const Layer& L : net.layers) {
     for_each_param(L, [&](long fi, size_t io) { h[L.p_off + io] = host[base + fi]; });
     base += L.file_params();
   }
-  sync();
-  if (P) EESEN_HIP_CHECK(hipMemcpy(params.p, h.data(), P * sizeof(float), hipMemcpyHostToDevice));
+  net.sync();
+  if (net.P) EESEN_HIP_CHECK(hipMemcpy(dst.p, h.data(), net.P * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void Net::set_params(const float* host, long n) {
+  upload_flat(*this, params, host, n);
   refresh_derived();
   sync();
+}
+
+void Net::set_accu(const float* host, long n) {
+  init_accu();
+  upload_flat(*this, accu, host, n);
 }
 
 void Net::get_flat(const DevBuf<float>& buf, float* host, long n) {
@@ -494,7 +510,15 @@ void Net::update() {
   EESEN_HIP_CHECK(hipSetDevice(device));
   { const int ti_ = timer.begin(st, 5);
   for (Layer& L : layers)
-    if (L.p_n) sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
+    if (L.p_n) {
+      if (rule == 0) {
+        sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
+      } else {  // the adaptive rules do not apply learn_rate_coef (bilstm-layer.h:865-869 multiplies only in the SGD branch)
+        init_accu();
+        adaptive_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, accu.p + L.p_off, (long)L.p_n, mmt, lr,
+                        L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2);
+      }
+    }
   refresh_derived();
   timer.end(st, ti_); }
 }

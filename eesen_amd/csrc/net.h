@@ -52,6 +52,13 @@ struct Net {
   size_t P = 0;  // floats in the flat buffers (with alignment padding)
   DevBuf<float> params, corr, fresh;
   float lr = 0.f, mmt = 0.f;
+  // UpdateRule (trainable-layer.h:38) + NetTrainOptions::adagrad_epsilon / rmsprop_rho (train-opts.h:33-42)
+  int rule = 0;  // 0 SGD, 1 Adagrad, 2 RMSProp
+  float ada_eps = 1e-6f, rms_rho = 0.9f, rms_one_minus_rho = 0.1f;
+  DevBuf<float> accu;         // squared-gradient accumulators, parameter layout; allocated on first use / Read
+  bool accu_init = false;
+  void init_accu();
+  void set_accu(const float* host, long n);
   // current minibatch
   std::vector<int> lens;
   DevBuf<int> lens_d;

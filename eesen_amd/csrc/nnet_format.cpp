@@ -113,6 +113,7 @@ struct ParsedLayer {
   int kind, din, dout;
   float coef = 1.f, max_grad = 0.f;
   std::vector<float> flat;  // Net::GetParams order
+  std::vector<float> accu;  // same order; empty unless the file carries <...Accus>
 };
 
 int marker_kind(const std::string& m) {
@@ -158,13 +159,35 @@ void Net::read(const std::string& path) {
     c.expect(lstm ? "<CellDim>" : "<OutputDim>");
     P.dout = c.basic<int32_t>();
     if (P.kind != EESEN_LAYER_SOFTMAX) {
+      const int nd = P.kind == EESEN_LAYER_BILSTM_PARALLEL ? 2 : 1;
+      if (lstm && P.dout % nd) c.fail("odd <CellDim> for a BiLstm layer");
+      const int H = lstm ? P.dout / nd : 0;
+      const size_t count = lstm ? (size_t)nd * ((size_t)4 * H * P.din + (size_t)4 * H * H + 7 * H) : (size_t)P.dout * P.din + P.dout;
+      auto read_tensors = [&](std::vector<float>& dst) {  // the layer's tensor list, identical for weights and accumulators
+        dst.resize(count);
+        float* p = dst.data();
+        if (lstm) {
+          for (int d = 0; d < nd; ++d) {
+            c.tensor(4 * H, P.din, p); p += (size_t)4 * H * P.din;
+            c.tensor(4 * H, H, p);     p += (size_t)4 * H * H;
+            c.tensor(4 * H, 0, p);     p += 4 * H;
+            for (int g = 0; g < 3; ++g) { c.tensor(H, 0, p); p += H; }
+          }
+        } else {
+          c.tensor(P.dout, P.din, p);
+          c.tensor(P.dout, 0, p + (size_t)P.dout * P.din);
+        }
+      };
       while (c.peek() == '<') {
         const std::string t = c.token();
         if (t == "<LearnRateCoef>") P.coef = c.basic<float>();
         else if (t == "<MaxGrad>") P.max_grad = c.basic<float>();
-        else if (t == "<BiLstmAccus>" || t == "<LstmAccus>" || t == "<AffineAccus>")
-          throw Error(EESEN_ERR_INVALID, "model carries Adagrad/RMSProp accumulators (" + t + "); only the SGD rule is implemented");
-        else {
+        else if (t == "<BiLstmAccus>" || t == "<LstmAccus>" || t == "<AffineAccus>") {
+          // Adagrad / RMSProp accumulators precede the weights (bilstm-layer.h:376-395, lstm-layer.h:118-128,
+          // affine-trans-layer.h:99-106)
+          read_tensors(P.accu);
+          break;
+        } else {
           bool known = false;
           for (int k = 0; k < 9; ++k)
             if (t == kDropoutTokens[k]) {
@@ -175,23 +198,7 @@ void Net::read(const std::string& path) {
           if (!known) c.fail("unexpected token " + t);
         }
       }
-      if (lstm) {
-        const int nd = P.kind == EESEN_LAYER_BILSTM_PARALLEL ? 2 : 1;
-        if (P.dout % nd) c.fail("odd <CellDim> for a BiLstm layer");
-        const int H = P.dout / nd;
-        P.flat.resize((size_t)nd * ((size_t)4 * H * P.din + (size_t)4 * H * H + 7 * H));
-        float* p = P.flat.data();
-        for (int d = 0; d < nd; ++d) {
-          c.tensor(4 * H, P.din, p); p += (size_t)4 * H * P.din;
-          c.tensor(4 * H, H, p);     p += (size_t)4 * H * H;
-          c.tensor(4 * H, 0, p);     p += 4 * H;
-          for (int g = 0; g < 3; ++g) { c.tensor(H, 0, p); p += H; }
-        }
-      } else {
-        P.flat.resize((size_t)P.dout * P.din + P.dout);
-        c.tensor(P.dout, P.din, P.flat.data());
-        c.tensor(P.dout, 0, P.flat.data() + (size_t)P.dout * P.din);
-      }
+      read_tensors(P.flat);
     }
     parsed.push_back(std::move(P));
   }
@@ -203,6 +210,16 @@ void Net::read(const std::string& path) {
   for (float v : all)  // Net::Check, net.cc:459-468
     if (!std::isfinite(v)) throw Error(EESEN_ERR_INVALID, "model holds NaN/Inf parameters");
   set_params(all.data(), (long)all.size());
+  bool any_accu = false;
+  for (const ParsedLayer& P : parsed) any_accu = any_accu || !P.accu.empty();
+  if (any_accu) {
+    std::vector<float> acc;
+    for (const ParsedLayer& P : parsed) {
+      if (!P.accu.empty()) acc.insert(acc.end(), P.accu.begin(), P.accu.end());
+      else acc.insert(acc.end(), P.flat.size(), 0.f);
+    }
+    set_accu(acc.data(), (long)acc.size());
+  }
   lr = 0.f;  // net.cc:294
 }
 
@@ -250,7 +267,13 @@ void Net::write(const std::string& path, bool binary) {
   if (binary) { os.put('\0'); os.put('B'); }
   put_token(os, "<Nnet>");
   if (!binary) os << "\n";
+  std::vector<float> acc;
+  if (accu_init) {  // adaBuffersInitialized (bilstm-layer.h:457-476): the accumulators travel with the model
+    acc.resize(all.size());
+    get_flat(accu, acc.data(), (long)acc.size());
+  }
   const float* p = all.data();
+  const float* pa = acc.empty() ? nullptr : acc.data();
   for (const Layer& L : layers) {
     const char* marker = L.kind == EESEN_LAYER_BILSTM_PARALLEL ? "<BiLstmParallel>"
                          : L.kind == EESEN_LAYER_LSTM_PARALLEL ? "<LstmParallel>"
@@ -273,18 +296,27 @@ void Net::write(const std::string& path, bool binary) {
         if (kDropoutIsFloat[k]) put_float(os, binary, 0.f);
         else put_bool(os, binary, false);
       }
-    if (L.is_lstm()) {
-      const int H = L.H;
-      for (int d = 0; d < L.ndir; ++d) {
-        put_tensor(os, binary, p, 4 * H, L.din); p += (size_t)4 * H * L.din;
-        put_tensor(os, binary, p, 4 * H, H);     p += (size_t)4 * H * H;
-        put_tensor(os, binary, p, 4 * H, 0);     p += 4 * H;
-        for (int g = 0; g < 3; ++g) { put_tensor(os, binary, p, H, 0); p += H; }
+    auto write_tensors = [&](const float*& q) {
+      if (L.is_lstm()) {
+        const int H = L.H;
+        for (int d = 0; d < L.ndir; ++d) {
+          put_tensor(os, binary, q, 4 * H, L.din); q += (size_t)4 * H * L.din;
+          put_tensor(os, binary, q, 4 * H, H);     q += (size_t)4 * H * H;
+          put_tensor(os, binary, q, 4 * H, 0);     q += 4 * H;
+          for (int g = 0; g < 3; ++g) { put_tensor(os, binary, q, H, 0); q += H; }
+        }
+      } else {
+        put_tensor(os, binary, q, L.dout, L.din); q += (size_t)L.dout * L.din;
+        put_tensor(os, binary, q, L.dout, 0);     q += L.dout;
       }
-    } else {
-      put_tensor(os, binary, p, L.dout, L.din); p += (size_t)L.dout * L.din;
-      put_tensor(os, binary, p, L.dout, 0);     p += L.dout;
+    };
+    if (pa) {
+      // NB: the reference's uni-directional Lstm::WriteData writes the WEIGHTS under <LstmAccus> (lstm-layer.h:153-163, a
+      // bug); this writer stores the real accumulators there, which is what its own ReadData expects.
+      put_token(os, L.kind == EESEN_LAYER_BILSTM_PARALLEL ? "<BiLstmAccus>" : L.kind == EESEN_LAYER_LSTM_PARALLEL ? "<LstmAccus>" : "<AffineAccus>");
+      write_tensors(pa);
     }
+    write_tensors(p);
   }
   put_token(os, "</Nnet>");
   if (!binary) os << "\n";

@@ -38,6 +38,29 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ par
   }
 }
 
+// Adagrad / RMSProp (TrainableLayer::AdagradAccuUpdate / RMSPropAccuUpdate / AdagradScaleCompute,
+// /root/reference/src/net/trainable-layer.h:65-114, applied as in bilstm-layer.h:885-955, affine-trans-layer.h:196-218):
+//   corr = mmt*corr + fresh; clip;  accu = accu + corr^2 (Adagrad)  |  rho*accu + (1-rho)*corr^2 (RMSProp);
+//   param -= lr * corr / sqrt(accu + eps)      (_sqrt_elements cuda-kernels.cu:607-615, _invert_elements :597)
+// The reference runs 5 elementwise launches per tensor (60 per BiLSTM layer); here one launch per layer.
+__global__ __launch_bounds__(256) void adaptive_update_kernel(float* __restrict__ param, float* __restrict__ corr,
+                                                              const float* __restrict__ fresh, float* __restrict__ accu,
+                                                              long n, float mmt, float lr, float max_grad, float eps,
+                                                              float rho, float one_minus_rho, int rmsprop) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float c = mmt * corr[i] + fresh[i];
+    if (max_grad > 0.f) c = fminf(fmaxf(c, -max_grad), max_grad);
+    const float g2 = c * c;
+    float a = accu[i];
+    a = rmsprop ? (rho * a + one_minus_rho * g2) : (a + g2);
+    const float scale = 1.0f / sqrtf(a + eps);
+    corr[i] = c;
+    accu[i] = a;
+    param[i] += -lr * scale * c;
+  }
+}
+
 // 32x32 LDS-tiled transpose, coalesced on both sides
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, int rows, int cols,
                                                           float* __restrict__ dst) {
@@ -74,6 +97,15 @@ void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, l
   const int blocks = (int)std::min<long>(cdivl(n / 4 + 1, 256), 2048);
   hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad);
   check_launch("sgd_update");
+}
+
+void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop) {
+  if (n <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(n, 256), 4096);
+  hipLaunchKernelGGL(adaptive_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, accu, n, mmt, lr, max_grad, eps,
+                     rho, one_minus_rho, rmsprop ? 1 : 0);
+  check_launch("adaptive_update");
 }
 
 void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst) {

@@ -32,6 +32,10 @@ _DROPOUT_TOKENS = [  # bilstm-layer.h:331-373, in this fixed order; (token, kind
 ]
 
 
+_ACCU_TOKEN = {"BiLstmParallel": "<BiLstmAccus>", "BiLstm": "<BiLstmAccus>", "LstmParallel": "<LstmAccus>", "Lstm": "<LstmAccus>",
+               "AffineTransform": "<AffineAccus>"}
+
+
 def is_lstm(t: str) -> bool:
     return t in LSTM_TYPES
 
@@ -106,6 +110,10 @@ def write_nnet(path: str, layers: List[dict], binary: bool = False, write_dropou
                             f.write(tok.encode() + b" ")
                             if kind == "f": _wf(f, 0.0)
                             else: f.write(b"F")
+                    if L.get("accu") is not None:
+                        f.write(_ACCU_TOKEN[t].encode() + b" ")
+                        for a in L["accu"]:
+                            _write_tensor_bin(f, a)
                     for p in L["params"]:
                         _write_tensor_bin(f, p)
             f.write(b"</Nnet> ")
@@ -120,6 +128,10 @@ def write_nnet(path: str, layers: List[dict], binary: bool = False, write_dropou
                 if t.startswith("BiLstm") and write_dropout_tokens:
                     for tok, kind in _DROPOUT_TOKENS:
                         f.write(tok + (" 0 " if kind == "f" else " F "))
+                if L.get("accu") is not None:
+                    f.write(_ACCU_TOKEN[t] + " ")
+                    for a in L["accu"]:
+                        _write_tensor_text(f, a)
                 for p in L["params"]:
                     _write_tensor_text(f, p)
         f.write("</Nnet> \n")
@@ -226,8 +238,12 @@ def read_nnet(path: str) -> List[dict]:
                         v = r.bool() if binary else (r.token() == "T")
                     if v:
                         raise ValueError(f"dropout option {tk} is set; dropout variants are out of scope")
+                elif tk in ("<BiLstmAccus>", "<LstmAccus>", "<AffineAccus>"):
+                    # Adagrad / RMSProp accumulators precede the weights (bilstm-layer.h:376-395, affine-trans-layer.h:99-106)
+                    L["accu"] = [r.tensor(sh) for sh in shapes]
+                    break
                 else:
-                    raise ValueError(f"unsupported token {tk} in layer {t} (Adagrad/RMSProp accumulators are not handled here)")
+                    raise ValueError(f"unsupported token {tk} in layer {t}")
             for sh in shapes:
                 L["params"].append(r.tensor(sh))
         layers.append(L)

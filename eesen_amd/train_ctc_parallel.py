@@ -37,6 +37,8 @@ def build_parser() -> argparse.ArgumentParser:
     # NetTrainOptions (src/net/train-opts.h:45-51)
     ap.add_argument("--learn-rate", type=float, default=0.008)
     ap.add_argument("--momentum", type=float, default=0.0)
+    ap.add_argument("--adagrad-epsilon", type=float, default=1e-6)
+    ap.add_argument("--rms-prop-rho", type=float, default=0.9)
     # train-ctc-parallel.cc:48-80
     ap.add_argument("--binary", type=_bool, default=True, help="Write model in binary mode")
     ap.add_argument("--cross-validate", type=_bool, default=False, help="Perform cross-validation (no backpropagation)")
@@ -74,8 +76,6 @@ def main(argv=None) -> int:
         if o.num_jobs != 1 and world == 1:
             raise EesenError(-1, "--num-jobs > 1: file-based model averaging is replaced by the RCCL gradient all-reduce; "
                                  "launch one process per GPU with `python -m torch.distributed.run --nproc-per-node N`")
-        if o.opt_algorithm != "SGD":
-            raise EesenError(-1, f"--opt-algorithm={o.opt_algorithm}: only SGD is implemented on this path")
         if o.sequence_out_file:
             raise EesenError(-1, "--sequence-out-file is not supported")
         dist = None
@@ -88,6 +88,7 @@ def main(argv=None) -> int:
 
         net = Net(dev).Read(model_filename)
         net.SetTrainOptions(o.learn_rate, o.momentum)
+        net.SetUpdateAlgorithm(o.opt_algorithm, o.adagrad_epsilon, o.rms_prop_rho)   # net.SetUpdateAlgorithm(opt), :114
         if dist is not None and not o.cross_validate:
             from eesen_amd.parallel import GradAllReducer
             net.grad_hook = GradAllReducer(net)

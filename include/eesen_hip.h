@@ -59,8 +59,8 @@ int eesen_net_add_layer(eesen_net_t* net, int kind, int in_dim, int out_dim,
 /* Allocates parameters (zero) + optimiser state; must follow the last add_layer. */
 int eesen_net_finalize(eesen_net_t* net);
 /* Net::Read (src/net/net.cc:279-309): parse a Kaldi-stream <Nnet> file (text or \0B binary), build
- * the layers and upload the weights.  Fails (EESEN_ERR_INVALID) on non-zero dropout options, Adagrad
- * / RMSProp accumulators or layer kinds outside the list above.  Resets learn_rate to 0 as the
+ * the layers and upload the weights (and the Adagrad/RMSProp accumulators when the file carries them).  Fails
+ * (EESEN_ERR_INVALID) on non-zero dropout options or layer kinds outside the list above.  Resets learn_rate to 0 as the
  * reference does (net.cc:294). */
 int eesen_net_read(eesen_net_t* net, const char* path);
 /* Net::Write (src/net/net.cc:325-334), same byte format as the reference for these layer kinds. */
@@ -79,6 +79,14 @@ int eesen_net_set_params(eesen_net_t* net, const float* host_flat, long n);
 
 /* ---- Net: training options (src/net/train-opts.h:29-62, net.h:147-161) ------------------------- */
 int eesen_net_set_train_options(eesen_net_t* net, float learn_rate, float momentum);
+/* Net::SetUpdateAlgorithm (src/net/net.cc:481-497): "SGD" (default), "Adagrad", "RMSProp" (trainable-layer.h:65-114). */
+int eesen_net_set_update_algorithm(eesen_net_t* net, const char* name);
+/* NetTrainOptions::adagrad_epsilon (1e-6) and rmsprop_rho (0.9) (train-opts.h:33-42). */
+int eesen_net_set_adaptive_options(eesen_net_t* net, float adagrad_epsilon, float rmsprop_rho);
+/* The squared-gradient accumulators (*_corr_accu, bilstm-layer.h:1098-1124) in Net::GetParams order; they are what
+ * <BiLstmAccus>/<LstmAccus>/<AffineAccus> carry in a model file. Zero until an adaptive rule ran or a file held them. */
+int eesen_net_get_accumulators(eesen_net_t* net, float* host_flat, long n);
+int eesen_net_set_accumulators(eesen_net_t* net, const float* host_flat, long n);
 /* Net::SetSeqLengths (net.h:157): frame count of each of the S parallel sequences. host pointer. */
 int eesen_net_set_seq_lengths(eesen_net_t* net, const int* lens, int S);
 

@@ -41,6 +41,10 @@ class OracleNet:
                                     params=[np.array(p, dtype=self.dt, order="C") for p in L["params"]]))
         for L in self.layers:
             L["corr"] = [np.zeros_like(p) for p in L["params"]]     # zeroed at Read (bilstm-layer.h:405-410)
+        self.rule = "SGD"          # Net::SetUpdateAlgorithm (net.cc:481-497)
+        self.ada_eps, self.rms_rho = 1e-6, 0.9
+        for L in self.layers:
+            L["accu"] = [np.zeros_like(p) for p in L["params"]]
         self.learn_rate = 0.0      # Net::Read resets it (net.cc:294)
         self.momentum = 0.0
         self.lens = None
@@ -124,10 +128,23 @@ class OracleNet:
             d = in_diff
         return d
 
+    def set_update_algorithm(self, rule: str, adagrad_epsilon: float = 1e-6, rmsprop_rho: float = 0.9):
+        assert rule in ("SGD", "Adagrad", "RMSProp")
+        self.rule, self.ada_eps, self.rms_rho = rule, adagrad_epsilon, rmsprop_rho
+
+    def get_accu(self) -> np.ndarray:
+        return np.concatenate([a.ravel() for L in self.layers for a in L["accu"]])
+
     def update_layer(self, li: int):
         L = self.layers[li]
-        for p, c in zip(L["params"], L["corr"]):
-            self.lib.orc_sgd_update(C.c_long(p.size), _p(p), _p(c), self.real(self.learn_rate * L["coef"]), self.real(L["max_grad"]))
+        for p, c, a in zip(L["params"], L["corr"], L["accu"]):
+            if self.rule == "SGD":
+                self.lib.orc_sgd_update(C.c_long(p.size), _p(p), _p(c), self.real(self.learn_rate * L["coef"]), self.real(L["max_grad"]))
+            else:
+                rho = np.float32(self.rms_rho)
+                self.lib.orc_adaptive_update(C.c_long(p.size), _p(p), _p(c), _p(a), self.real(self.learn_rate), self.real(L["max_grad"]),
+                                             self.real(self.ada_eps), self.real(rho), self.real(np.float32(1.0) - rho),
+                                             int(self.rule == "RMSProp"))
 
     def fresh_grads_flat(self) -> np.ndarray:
         return np.concatenate([g.ravel() for f in self.fresh if f for g in f])

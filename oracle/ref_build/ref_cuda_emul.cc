@@ -139,4 +139,23 @@ void ref_cuda_tanh(float* y, const float* x, int rows, int cols) {
   emulate_launch(Gr, Bl, [&] { cudaF_tanh(Gr, Bl, y, x, d, cols); });
 }
 
+// Adagrad / RMSProp update of one tensor exactly as TrainableLayer + BiLstm::Update compose it on the GPU
+// (src/net/trainable-layer.h:65-114, src/net/bilstm-layer.h:885-955), through the reference's own elementwise kernel
+// launchers (cuda-kernels.cu: _mul_elements, _scale, _add_mat, _sqrt_elements, _invert_elements, _add_mat_mat_elements).
+// The CPU build of the reference cannot run these rules at all (CuMatrixBase::AddMatMatElements exit(-101),
+// cuda-matrix.cc:657-661).  corr already holds momentum*corr + gradient, clipped.  rmsprop != 0 selects RMSProp.
+void ref_cuda_adaptive_update(float* param, const float* corr, float* accu, int rows, int cols, float lr, float eps,
+                              float rho, float one_minus_rho, int rmsprop) {
+  MatrixDim d = {rows, cols, cols};
+  dim3 Bl(CU2DBLOCK, CU2DBLOCK), Gr(n_blocks(cols, CU2DBLOCK), n_blocks(rows, CU2DBLOCK));
+  std::vector<float> tmp(corr, corr + (size_t)rows * cols);                                     // grad_tmp.CopyFromMat(grad)
+  emulate_launch(Gr, Bl, [&] { cudaF_mul_elements(Gr, Bl, tmp.data(), corr, d, cols); });        // grad_tmp.MulElements(grad)
+  if (rmsprop) emulate_launch(Gr, Bl, [&] { cudaF_scale(Gr, Bl, accu, rho, d); });               // accu.Scale(rho)
+  emulate_launch(Gr, Bl, [&] { cudaF_add_mat(Gr, Bl, rmsprop ? one_minus_rho : 1.0f, tmp.data(), accu, d, cols, 0); });
+  std::vector<float> scale(accu, accu + (size_t)rows * cols);                                    // accu_scale.CopyFromMat(accu)
+  emulate_launch(Gr, Bl, [&] { cudaF_sqrt_elements(Gr, Bl, scale.data(), eps, d); });             // ApplySqrt(epsilon)
+  emulate_launch(Gr, Bl, [&] { cudaF_invert_elements(Gr, Bl, scale.data(), d); });                // InvertElements
+  emulate_launch(Gr, Bl, [&] { cudaF_add_mat_mat_elements(Gr, Bl, param, scale.data(), corr, d, cols, cols, -lr, 1.0f); });
+}
+
 }  // extern "C"

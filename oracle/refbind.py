@@ -138,3 +138,15 @@ def cuda_activation(name: str, x: np.ndarray) -> np.ndarray:
     y = np.empty_like(x)
     getattr(lib, f"ref_cuda_{name}")(_p(y), _p(x), 1, x.shape[1])
     return y.ravel()
+
+
+def cuda_adaptive_update(param: np.ndarray, corr: np.ndarray, accu: np.ndarray, lr: float, eps: float, rho: float, rmsprop: bool):
+    """The reference's Adagrad / RMSProp tensor update through its own elementwise CUDA kernel bodies (in place on
+    param and accu; corr must already hold the clipped momentum-folded gradient)."""
+    lib = _load()
+    assert param.dtype == np.float32 and accu.dtype == np.float32 and param.flags.c_contiguous and accu.flags.c_contiguous
+    corr = np.ascontiguousarray(corr, np.float32)
+    rows, cols = (param.shape if param.ndim == 2 else (1, param.size))
+    r = np.float32(rho)
+    lib.ref_cuda_adaptive_update(_p(param), _p(corr), _p(accu), rows, cols, C.c_float(lr), C.c_float(eps), C.c_float(r),
+                                 C.c_float(np.float32(1.0) - r), int(rmsprop))

@@ -69,5 +69,7 @@ def test_cli_error_contract(gpu, tmp_path):
     r = _run(["scp:" + scp, "ark:" + lab, str(tmp_path / "missing.nnet"), str(tmp_path / "o")])
     assert r.returncode == 255 and "cannot open model file" in r.stderr
     m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(**cfg), binary=False)
-    r = _run(["--opt-algorithm=Adagrad", "scp:" + scp, "ark:" + lab, m_in, str(tmp_path / "o")])
-    assert r.returncode == 255
+    r = _run(["--opt-algorithm=Adam", "scp:" + scp, "ark:" + lab, m_in, str(tmp_path / "o")])
+    assert r.returncode == 255 and "unknown optimization algorithm" in r.stderr
+    r = _run(["--opt-algorithm=Adagrad", "--learn-rate=0.01", "scp:" + scp, "ark:" + lab, m_in, str(tmp_path / "o")])
+    assert r.returncode == 0 and any("accu" in L for L in nnet_io.read_nnet(str(tmp_path / "o")))

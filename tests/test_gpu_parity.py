@@ -247,3 +247,33 @@ def test_persistent_recurrence_matches_step_kernels(gpu, cfg_name, over, monkeyp
             assert np.array_equal(o[2], res[mode][0][0][2]) and np.array_equal(o[3], res[mode][0][0][3])   # deterministic
             assert rel_err(o[2], ref[2]) < 5e-6 and rel_err(o[3], ref[3]) < 5e-6     # in_diff, gradients
     assert rel_err(res["1"][1], res["0"][1]) < 1e-6
+
+
+@pytest.mark.parametrize("rule", ["Adagrad", "RMSProp"])
+def test_adaptive_update_rules(gpu, rule, tmp_path):
+    """--opt-algorithm Adagrad / RMSProp (trainable-layer.h:65-114): three steps against the oracle, then the
+    accumulators through a model file (<BiLstmAccus> / <AffineAccus>) and back."""
+    from eesen_amd.api import Net, Ctc
+    from oracle import net as onet
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(max_grad=0.05, learn_rate_coef=0.5, **cfg)    # coef must NOT enter the adaptive rules
+    batch = synth.make_batch(**cfg)
+    net = Net.from_layers(layers); net.SetTrainOptions(0.002, 0.9); net.SetUpdateAlgorithm(rule, 1e-6, 0.9)
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(0.002, 0.9); ora.set_update_algorithm(rule, 1e-6, 0.9)
+    ctc = Ctc()
+    for step in range(3):
+        net.SetSeqLengths(batch.lens)
+        diff = ctc.EvalParallel(batch.lens, net.Propagate(batch.feats), batch.labels)
+        net.Backpropagate(diff)
+        onet.train_step(ora, batch, "f32")
+        assert rel_err(net.GetParams(), ora.get_params()) < TOL, f"step {step}"
+        # squares double the relative error, and a normalised step moves noise-level gradient entries by O(lr): looser bar
+        assert rel_err(net.GetAccumulators(), ora.get_accu()) < 2e-3, f"step {step}"
+    path = str(tmp_path / "ada.nnet")
+    net.Write(path, binary=True)
+    back = nnet_io.read_nnet(path)
+    assert all(("accu" in L) == bool(L["params"]) for L in back)
+    net2 = Net().Read(path)
+    assert np.array_equal(net2.GetAccumulators(), net.GetAccumulators()) and np.array_equal(net2.GetParams(), net.GetParams())
+    with pytest.raises(Exception):
+        net.SetUpdateAlgorithm("Adam")

@@ -41,3 +41,21 @@ def test_headerless_layer_data_is_accepted(tmp_path):
     p = str(tmp_path / "m.nnet")
     nnet_io.write_nnet(p, layers, binary=False, write_dropout_tokens=False)
     assert np.array_equal(nnet_io.flatten_params(nnet_io.read_nnet(p)), nnet_io.flatten_params(layers))
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_accumulators_roundtrip(tmp_path, binary):
+    """<BiLstmAccus> / <AffineAccus> precede the weights (bilstm-layer.h:376-395, affine-trans-layer.h:99-106)."""
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(**cfg)
+    rng = np.random.default_rng(1)
+    for L in layers:
+        if L["params"]:
+            L["accu"] = [rng.random(p.shape).astype(np.float32) for p in L["params"]]
+    p = str(tmp_path / "m.nnet")
+    nnet_io.write_nnet(p, layers, binary=binary)
+    back = nnet_io.read_nnet(p)
+    for a, b in zip(back, layers):
+        assert np.array_equal(nnet_io.flatten_params([a]), nnet_io.flatten_params([b]))
+        if b["params"]:
+            assert all(np.array_equal(x, y) for x, y in zip(a["accu"], b["accu"]))

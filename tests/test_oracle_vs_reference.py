@@ -70,3 +70,22 @@ def test_model_file_written_by_reference_is_read_back(tmp_path):
     ours = str(tmp_path / "ours.nnet")
     nnet_io.write_nnet(ours, layers, binary=True)
     assert open(ours, "rb").read() == open(str(tmp_path / "ref_1.nnet"), "rb").read()
+
+
+@pytest.mark.parametrize("rmsprop", [False, True])
+def test_adaptive_update_restatement_equals_reference_kernels(rmsprop):
+    """Adagrad / RMSProp exist only as CUDA code in the reference; its elementwise kernel bodies, run on the CPU shim in
+    the order TrainableLayer composes them, must equal oracle/eesen_oracle.c:orc_adaptive_update bit for bit."""
+    import ctypes as C
+    from oracle import cbind
+    lib = cbind.load("f32")
+    rng = np.random.default_rng(7)
+    p = rng.standard_normal((9, 6)).astype(np.float32); c = (3 * rng.standard_normal((9, 6))).astype(np.float32)
+    a = rng.random((9, 6)).astype(np.float32)
+    p2, a2, c2 = p.copy(), a.copy(), c.copy()
+    for _ in range(3):
+        refbind.cuda_adaptive_update(p, c, a, 0.01, 1e-6, 0.9, rmsprop)
+        rho = np.float32(0.9)
+        lib.orc_adaptive_update(C.c_long(p2.size), p2.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p), a2.ctypes.data_as(C.c_void_p),
+                                C.c_float(0.01), C.c_float(0.0), C.c_float(1e-6), C.c_float(rho), C.c_float(np.float32(1) - rho), int(rmsprop))
+    assert np.array_equal(p, p2) and np.array_equal(a, a2)
