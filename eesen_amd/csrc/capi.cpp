@@ -235,6 +235,22 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
   });
 }
 
+int eesen_op_log_sub_prior(int device, void* stream, float* m_dev, int rows, int cols, int ld, int apply_log,
+                           const float* log_priors_host, float prior_scale) {
+  return guard([&] {
+    REQ_PTR(m_dev);
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DevBuf<float> pri;
+    if (log_priors_host) {
+      pri.reserve(cols);
+      EESEN_HIP_CHECK(hipMemcpyAsync(pri.p, log_priors_host, sizeof(float) * cols, hipMemcpyHostToDevice, st));
+    }
+    log_sub_prior(st, m_dev, ld, rows, cols, apply_log != 0, log_priors_host ? pri.p : nullptr, prior_scale);
+    EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
 int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                         float* C, int ldc, int iters, float* avg_ms) {
   return guard([&] {

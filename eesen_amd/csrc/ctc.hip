@@ -264,6 +264,20 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
   for (int k = lane; k < K; k += 64) drow[k] = ek[k] - yr[k] * rsum;                       // :164-168
 }
 
+// m = (apply_log ? log(m) : m) - prior_scale * log_prior[col]   (net-output-extract.cc:103-112: ApplyLog, then
+// ClassPrior::SubtractOnLogpost = AddVecToRows(-prior_scale, log_priors), class-prior.cc:80-91)
+__global__ __launch_bounds__(256) void log_sub_prior_kernel(float* __restrict__ m, int ld, int rows, int K, int apply_log,
+                                                            const float* __restrict__ log_prior, float prior_scale) {
+  const size_t total = (size_t)rows * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / K, k = i % K;
+    float v = m[r * ld + k];
+    if (apply_log) v = logf(v);
+    if (log_prior) v += -prior_scale * log_prior[k];
+    m[r * ld + k] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ m, int ld, int rows, int K,
                                                          int* __restrict__ ids) {
   const int lane = threadIdx.x & 63;
@@ -328,6 +342,14 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
   hipLaunchKernelGGL(ctc_error_diff_kernel, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens,
                      cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
   check_launch("ctc_error_diff");
+}
+
+void log_sub_prior(hipStream_t st, float* m, int ld, int rows, int K, bool apply_log, const float* log_prior, float prior_scale) {
+  if (rows <= 0) return;
+  const size_t total = (size_t)rows * K;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(log_sub_prior_kernel, dim3(blocks), dim3(256), 0, st, m, ld, rows, K, apply_log ? 1 : 0, log_prior, prior_scale);
+  check_launch("log_sub_prior");
 }
 
 void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* ids) {

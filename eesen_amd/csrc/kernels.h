@@ -66,6 +66,8 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
                     const int* cls_off, const int* cls_pos, const float* alpha, const float* beta, const float* pzx,
                     float* diff, int ldd);
+// in place: m = (apply_log ? log m : m) - prior_scale * log_prior[col]; log_prior may be null (net-output-extract.cc:103-112)
+void log_sub_prior(hipStream_t st, float* m, int ld, int rows, int K, bool apply_log, const float* log_prior, float prior_scale);
 // ids[r] = argmax_k m[r][k], first maximum wins (CuMatrixBase::FindRowMaxId, cuda-matrix.cc:1038-1095)
 void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* ids);
 

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""net-output-extract on MI355X: forward pass for decoding (/root/reference/src/netbin/net-output-extract.cc).
+
+Usage: python -m eesen_amd.net_output_extract [options] <model-in> <feature-rspecifier> <feature-wspecifier>
+e.g.:  python -m eesen_amd.net_output_extract --class-frame-counts=label.counts --apply-log=true net ark:feats.ark ark:out.ark
+
+Per utterance: Net::Feedforward (net.cc:110-132) -> optional ApplyLog -> optional ClassPrior::SubtractOnLogpost
+(class-prior.cc:30-91), written as a float-matrix table.  The reference converts <BiLstmParallel> to the single-sequence
+<BiLstm> on read (layer.cc:164-170); here the same kernels run with S = 1 (or --num-sequence utterances padded together,
+which changes nothing on valid frames because padding is masked in both directions).
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+import numpy as np
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def class_log_priors(counts_path: str, prior_cutoff: float = 1e-10, blank_scale: float = 1.0) -> np.ndarray:
+    """ClassPrior::ClassPrior (class-prior.cc:30-77): counts -> floor -> blank scaling -> normalise -> log, with
+    FLT_MAX/2 added for classes below the cutoff so that they get zero likelihood."""
+    txt = open(counts_path).read().replace("[", " ").replace("]", " ")
+    pri = np.array(txt.split(), dtype=np.float64)
+    mask = np.zeros(pri.size, np.float32)
+    low = pri < prior_cutoff
+    pri[low] = prior_cutoff
+    mask[low] = FLT_MAX / 2
+    if blank_scale != 1.0:
+        pri[0] *= blank_scale
+    pri = np.log(pri / pri.sum())
+    return pri.astype(np.float32) + mask
+
+
+def _bool(v: str) -> bool:
+    return v.lower() in ("true", "t", "1", "yes")
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="net-output-extract")
+    ap.add_argument("--class-frame-counts", default="")
+    ap.add_argument("--prior-scale", type=float, default=1.0)
+    ap.add_argument("--prior-cutoff", type=float, default=1e-10)
+    ap.add_argument("--blank-scale", type=float, default=1.0)
+    ap.add_argument("--apply-log", type=_bool, default=False)
+    ap.add_argument("--use-gpu", default="yes")
+    ap.add_argument("--num-sequence", type=int, default=1, help="utterances propagated together (extension; 1 = the reference)")
+    ap.add_argument("--frame-limit", type=float, default=1e5)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("args", nargs="*")
+    o = ap.parse_args(argv)
+    if len(o.args) != 3:
+        ap.print_usage(sys.stderr)
+        return 1
+    model_filename, feature_rspecifier, feature_wspecifier = o.args
+    try:
+        import ctypes as C
+        from eesen_amd import kaldi_io, _lib
+        from eesen_amd.api import Net, CuMatrix
+        from eesen_amd.batching import interleave
+        kind, out_path, text = kaldi_io._parse_specifier(feature_wspecifier)
+        if kind != "ark":
+            raise kaldi_io.KaldiIOError("only ark: output is supported")
+        net = Net(o.device).Read(model_filename)
+        log_pri = class_log_priors(o.class_frame_counts, o.prior_cutoff, o.blank_scale) if o.class_frame_counts else None
+        K = net.OutputDim()
+        if log_pri is not None and log_pri.size != K:
+            raise kaldi_io.KaldiIOError(f"Dimensionality mismatch, class_frame_counts {log_pri.size} class_output_llk {K}")
+        t0 = time.time()
+        num_done = tot_t = 0
+        results = []
+
+        def flush(group):
+            nonlocal num_done, tot_t
+            feats, lens, T = interleave([m for _, m in group], net.InputDim())
+            net.SetSeqLengths(lens)
+            out = net.Propagate(feats)
+            if o.apply_log or log_pri is not None:
+                _lib.check(_lib.load().eesen_op_log_sub_prior(o.device, None, C.c_void_p(out.ptr), out.rows, out.cols, out.stride, int(o.apply_log),
+                                                              log_pri.ctypes.data_as(C.c_void_p) if log_pri is not None else None, o.prior_scale))
+            host = out.numpy().reshape(T, len(group), K)
+            for s, (key, m) in enumerate(group):
+                results.append((key, np.ascontiguousarray(host[: m.shape[0], s, :])))
+                num_done += 1; tot_t += m.shape[0]
+
+        group, max_len = [], 0
+        for key, mat in kaldi_io.read_mat_table(feature_rspecifier):
+            if group and (len(group) == o.num_sequence or max(max_len, mat.shape[0]) * (len(group) + 1) > o.frame_limit):
+                flush(group); group, max_len = [], 0
+            group.append((key, mat)); max_len = max(max_len, mat.shape[0])
+        if group:
+            flush(group)
+        kaldi_io.write_mat_ark(out_path, results, text=text)
+        el = max(time.time() - t0, 1e-9)
+        print(f"LOG (net-output-extract:main()) Done {num_done} files in {el / 60:g}min, (fps {tot_t / el:g})", file=sys.stderr)
+        return 0 if num_done else 255
+    except Exception as e:
+        print(f"ERROR (net-output-extract:main()) {e}", file=sys.stderr)
+        return 255
+
+
+if __name__ == "__main__":
+    sys.exit(main())

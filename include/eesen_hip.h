@@ -170,6 +170,12 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
                   const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                   const float* bias);
 
+/* Post-processing of net-output-extract (src/netbin/net-output-extract.cc:103-112) on a device matrix, in place:
+ * CuMatrixBase::ApplyLog when apply_log != 0, then ClassPrior::SubtractOnLogpost (src/net/class-prior.cc:80-91)
+ * m[r][k] -= prior_scale * log_priors[k] when log_priors_host (cols floats) is not NULL.  Synchronises. */
+int eesen_op_log_sub_prior(int device, void* stream, float* m_dev, int rows, int cols, int ld, int apply_log,
+                           const float* log_priors_host, float prior_scale);
+
 /* Average milliseconds (HIP events) of `iters` back-to-back launches of the same GEMM (beta = 0, no bias);
  * microbenchmark entry point used by scripts/gemm_bench.py. */
 int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda,

@@ -73,3 +73,34 @@ def test_cli_error_contract(gpu, tmp_path):
     assert r.returncode == 255 and "unknown optimization algorithm" in r.stderr
     r = _run(["--opt-algorithm=Adagrad", "--learn-rate=0.01", "scp:" + scp, "ark:" + lab, m_in, str(tmp_path / "o")])
     assert r.returncode == 0 and any("accu" in L for L in nnet_io.read_nnet(str(tmp_path / "o")))
+
+
+def test_net_output_extract(gpu, tmp_path):
+    """net-output-extract (forward for decoding): log-posteriors minus scaled log-priors, per utterance, against the oracle
+    at S = 1; batching several utterances must not change a single bit on valid frames."""
+    from oracle import net as onet
+    from eesen_amd.net_output_extract import class_log_priors
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(**cfg)
+    feats, labs, scp, lab = _dataset(tmp_path, n=6, D=cfg["D"], K=cfg["K"])
+    model = str(tmp_path / "final.nnet"); nnet_io.write_nnet(model, layers, binary=True)
+    counts = str(tmp_path / "label.counts")
+    open(counts, "w").write("[ 1200 30 0 45.5 8 19 77 ]\n")            # one class below the cutoff
+    out1, out4 = str(tmp_path / "o1.ark"), str(tmp_path / "o4.ark")
+    base = [sys.executable, "-m", "eesen_amd.net_output_extract", "--class-frame-counts=" + counts, "--apply-log=true", "--prior-scale=0.8",
+            "--blank-scale=0.5"]
+    r = subprocess.run(base + [model, "scp:" + scp, "ark:" + out1], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "Done 6 files" in r.stderr, r.stderr[-2000:]
+    r = subprocess.run(base + ["--num-sequence=4", model, "scp:" + scp, "ark:" + out4], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got1 = dict(kaldi_io.read_mat_table("ark:" + out1)); got4 = dict(kaldi_io.read_mat_table("ark:" + out4))
+    pri = class_log_priors(counts, 1e-10, 0.5)
+    ora = onet.OracleNet(layers, "f32")
+    for key, m in feats:
+        ora.set_seq_lengths([m.shape[0]])
+        want = np.log(ora.propagate(m)) - np.float32(0.8) * pri[None, :]
+        assert got1[key].shape == want.shape
+        ok = pri < 1e30                                               # the floored class carries -0.8 * FLT_MAX/2 on both sides
+        assert rel_err(got1[key][:, ok], want[:, ok]) < 1e-4
+        assert np.all(got1[key][:, ~ok] < -1e37)
+        assert np.array_equal(got1[key], got4[key])
