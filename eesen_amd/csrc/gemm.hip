@@ -40,6 +40,7 @@ struct GemmParams {
   int splits;   // grid.y
   int k_chunk;  // K elements per split (multiple of BK)
   int tiles_n;
+  GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
 
 // Load one [rows x BK] operand tile (rows = BM or BN) from HBM into registers: NLD float4 per thread.
@@ -107,12 +108,46 @@ __device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const 
   }
 }
 
-template <bool A_KC, bool B_KC, bool GUARD>
+template <bool A_KC, bool B_KC, bool GUARD, bool GATED = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][BM + LDP], float (*Bs)[BK][BN + LDP]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
-  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  int tm = tile / p.tiles_n;
+  if (GATED) {  // middle-out over time: row tiles in the order in which a bidirectional layer completes their frames
+    const int tiles_m = (p.M + BM - 1) / BM, mid = tiles_m / 2;
+    // i = 0, 1, 2, 3, ... -> mid, mid-1, mid+1, mid-2, ...; when one side runs out the other side continues
+    const int i = tm, lo_cnt = mid, hi_cnt = tiles_m - mid;   // tiles below mid / at-or-above mid
+    const int pairs = min(lo_cnt, hi_cnt);
+    if (i < 2 * pairs) tm = (i & 1) ? mid - (i + 1) / 2 : mid + i / 2;
+    else tm = hi_cnt > lo_cnt ? mid + (i - pairs) : mid - 1 - (i - pairs);
+  }
+  const int m0 = tm * BM, n0 = (tile % p.tiles_n) * BN;
+  if (GATED) {
+    __shared__ int s_go;
+    const GemmGate& g = p.gate;
+    const int t_lo = m0 / g.S, t_hi = min(p.M - 1, m0 + BM - 1) / g.S;
+    if (wave == 0) {
+      const int groups = g.ndir * g.nz;
+      const bool mine = lane < groups * kShards;
+      const int grp = lane / kShards, shard = lane % kShards, dir = grp / g.nz;
+      const unsigned need = mine ? (unsigned)((g.nblk - shard + kShards - 1) / kShards) * (unsigned)(dir == 0 ? t_hi + 1 : g.T - t_lo) : 0u;
+      const unsigned* c = g.cnt + (size_t)grp * kShards * kShardStride + shard * kShardStride;
+      bool go = false;
+      for (int spins = 0; spins < g.spin_limit; ++spins) {
+        bool ok = true;
+        if (mine) ok = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+        if (__all(ok)) { go = true; break; }
+        if ((spins & 1023) == 1023 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(64);  // readiness changes once per recurrence step (~5 us): poll sparsely
+        __builtin_amdgcn_s_sleep(64);
+      }
+      if (!go && lane == 0) __hip_atomic_store(g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) s_go = go ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_go) return;
+  }
   const int split = blockIdx.y;
   const int kbeg = split * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
@@ -204,6 +239,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmParams p) {
   gemm_body<A_KC, B_KC, GUARD>(p, As, Bs);
 }
 
+// The gated variant (see kernels.h): k-contiguous operands, unguarded tiles only (host checks the shape).
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LDP];
+  gemm_body<true, true, false, true>(p, As, Bs);
+}
+
 // C = alpha * sum_s ws[s] + beta * C + bias
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
                                                             float alpha, float beta, float* __restrict__ C, int ldc,
@@ -231,6 +273,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.alpha = alpha; p.beta = beta;
+  p.gate = GemmGate{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
   p.tiles_n = tiles_n;
   const long tiles = (long)tiles_m * tiles_n;
@@ -270,6 +313,24 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
                        C, ldc, bias);
     check_launch("splitk_reduce");
   }
+}
+
+void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                       int ldc, const float* bias, const GemmGate& gate) {
+  EESEN_REQUIRE((M % BM) == 0 && (N % BN) == 0 && (K % BK) == 0, EESEN_ERR_INVALID, "gated GEMM needs whole tiles");
+  EESEN_REQUIRE(gate.ndir * gate.nz * kShards <= 64, EESEN_ERR_INVALID, "gated GEMM: too many counter groups");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = 1.f; p.beta = 0.f;
+  p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN;
+  p.gate = gate;
+  // Occupancy cap: waiting tiles SPIN, so they must never keep the producing (cooperative) kernel's workgroups from
+  // becoming resident.  26 KB of unused dynamic LDS on top of the 33 KB static makes at most two of these workgroups
+  // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
+  // next to 2 x 112) whatever the dispatch order.
+  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 26 * 1024, st, p);
+  check_launch("gemm_f32_mfma_gated");
 }
 
 }  // namespace eesen

@@ -15,6 +15,24 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
               size_t ws_floats);
 
+// Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
+// shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.
+constexpr int kShards = 8, kShardStride = 32;  // words
+
+// "Gated" input->gates GEMM: C = A * B^T + bias where the rows of A are the time-major output [T*S x K] of an LSTM layer
+// whose persistent forward kernel is STILL RUNNING on another stream.  A tile of rows waits until the arrival counters
+// say that both directions have passed its frames (forward direction: steps >= t_hi + 1, backward: steps >= T - t_lo);
+// tiles are visited middle-out in time, which is the order in which a bidirectional layer completes frames.
+struct GemmGate {
+  const unsigned* cnt;  // counters of the producing kernel
+  unsigned* err;        // raised when the bounded spin gives up
+  int ndir, nz, nblk;   // counter groups (ndir x nz) and workgroups per group
+  int T, S;
+  int spin_limit;
+};
+void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                       int ldc, const float* bias, const GemmGate& gate);
+
 // ---------------------------------------------------------------------------------------- lstm.hip
 struct LstmLayerDev {
   // geometry
@@ -38,7 +56,7 @@ void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float*
 // cnt: >= ndir * ceil(S/16) zero-initialisable counters, err: one word raised when a bounded spin gives up.
 // Return false (nothing launched) when the shape does not fit the resident-workgroup budget: use the step kernels then.
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
-                         unsigned long long* trace = nullptr);
+                         unsigned long long* trace = nullptr, hipEvent_t after_reset = nullptr);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

@@ -64,7 +64,6 @@ __device__ __forceinline__ void ld8_plain(const float* __restrict__ row, int k, 
 // Arrival counters are sharded 8 ways (shard = blockIdx.x & 7, one 128-byte line each) so that the increments of a
 // step do not serialise on one address.  Lanes 0-7 of wave 0 each poll one shard until it reaches its own target
 // (workgroups in that shard x steps).  Returns false (and raises *err) when the bound is hit or a peer gave up.
-constexpr int kShards = 8, kShardStride = 32;  // words
 __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
                                               int lane) {
   const unsigned mine = lane < kShards ? ((nblk - lane + kShards - 1) / kShards) * step : 0u;
@@ -93,6 +92,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
                                                                       int spin_limit, unsigned long long* trace) {
   __shared__ __attribute__((aligned(16))) float red[NW][32][20];
   __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win issue arbitration against co-resident GEMM waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       cprev = c;
     }
     EESEN_STAMP(3);
-    if (step + 1 < T) {
+    {  // published after EVERY step: the last one is what a gated GEMM of the next layer waits for
       if (tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
       __syncthreads();                                                 // (also fences `red` for the next step)
       EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok)  // next step's gate pre-activations: issued AFTER the publish so the drain above never waits for HBM
+      if (e_ok && step + 1 < T)  // next step's gate pre-activations: issued AFTER the publish so the drain never waits for HBM
         gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
     }
   }
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
                                                                       unsigned* err, int spin_limit, unsigned long long* trace) {
   __shared__ float red[NW][16][17];
   __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
@@ -332,12 +333,13 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
-                         unsigned long long* trace) {
+                         unsigned long long* trace, hipEvent_t after_reset) {
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
   dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
   if (need > 4 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+  if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
 #define EESEN_FP(CPW)                                                                   \
   do {                                                                                   \
     if (!fits(lstm_fwd_persistent_kernel<CPW>, grid, NW * 64)) return false;             \

@@ -118,6 +118,12 @@ Net::Net(int dev, void* stream) : device(dev) {
   }
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_rec, hipEventDisableTiming));
   for (auto& e : ev_grad) EESEN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_reset, hipEventDisableTiming));
+  EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_done, hipEventDisableTiming));
+  // measured on MI355X (cfg2): hiding the next layer's input GEMM under the forward recurrence is bit-identical but a net
+  // loss (74.7 vs 73.0 ms/step: the forward hand-off chain slows from 4.9 to 7 us/step under the GEMM's memory traffic,
+  // more than the 7 ms of GEMM it hides; wave priority does not help), so it is opt-in
+  gate_fwd = getenv("EESEN_GATE_FWD") && atoi(getenv("EESEN_GATE_FWD")) != 0;
   if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
   // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on MI355X, cfg2: with the
   // one-launch-per-step recurrence it is neutral (105.1 vs 104.9 ms/step: the step kernels slow down by what the
@@ -155,6 +161,8 @@ Net::~Net() {
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
   if (ev_rec) (void)hipEventDestroy(ev_rec);
   for (auto& e : ev_grad) if (e) (void)hipEventDestroy(e);
+  if (ev_gate_reset) (void)hipEventDestroy(ev_gate_reset);
+  if (ev_gate_done) (void)hipEventDestroy(ev_gate_done);
   if (own_stream) (void)hipStreamDestroy(st);
 }
 
@@ -337,6 +345,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
                                    rows, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   const float* x = input.p;
   int ldx = D4;
+  bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   for (Layer& L : layers) {
     if (L.is_lstm()) {
       const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
@@ -351,16 +360,41 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
       EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
       // all gate pre-activations of both directions in one GEMM: G = x * Wx^T + bias  (:109-110, :163-164)
-      { const int ti_ = timer.begin(st, 0);
-      gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
-               params.p + L.p_off + L.off_bias, nullptr, 0);
-      timer.end(st, ti_); }
+      if (g_gated) {  // already computed on the side stream, gated on the previous layer's progress (see below)
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
+        g_gated = false;
+      } else {
+        const int ti_ = timer.begin(st, 0);
+        gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
+                 params.p + L.p_off + L.off_bias, nullptr, 0);
+        timer.end(st, ti_);
+      }
+      // The NEXT LSTM layer's input GEMM can run on the side stream WHILE this layer's persistent kernel is running:
+      // its row tiles wait on the kernel's arrival counters and are visited middle-out in time (gemm_f32_nt_gated).
+      Layer* nxt = (&L - layers.data()) + 1 < (long)layers.size() ? &layers[(&L - layers.data()) + 1] : nullptr;
+      const int nz = cdiv(S, 32);
+      const bool plan_gate = persistent && overlap && gate_fwd && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
+                             (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
-      if (!(persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p)))
+      const bool pers = persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p,
+                                                          plan_gate ? ev_gate_reset : nullptr);
+      if (!pers)
         for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
       check_launch("lstm_fwd");
-      timer.end(st, ti_); }
+      timer.end(st, ti_);
+      if (pers && plan_gate) {
+        const int ldG2 = nxt->ndir * 4 * nxt->H;
+        nxt->G.reserve((size_t)rows * ldG2);
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+        const int tj_ = timer.begin(st2, 0);
+        GemmGate gate{ctl.p, ctl.p + kCtlWords - 1, nd, nz, H / 4, T, S, spin_limit};
+        gemm_f32_nt_gated(st2, rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
+                          nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate);
+        timer.end(st2, tj_);
+        EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
+        g_gated = true;
+      } }
       x = L.Y.p + (size_t)S * ldY;
       ldx = ldY;
     } else if (L.kind == EESEN_LAYER_AFFINE) {

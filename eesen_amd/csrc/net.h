@@ -72,6 +72,8 @@ struct Net {
   hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;
+  hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated input GEMM of the next layer (forward)
+  bool gate_fwd = true;
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
   int spin_limit = 400000;
