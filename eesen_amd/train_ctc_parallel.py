@@ -31,6 +31,32 @@ def log(msg: str, level: str = "LOG"):
     print(f"{level} (train-ctc-parallel:main():eesen_amd/train_ctc_parallel.py) {msg}", file=sys.stderr, flush=True)
 
 
+def _prefetch(it, depth: int = 2):
+    """Reads and assembles the next minibatches on a host thread while the GPU works on the current one (the reference
+    reads, pads and uploads synchronously between steps, train-ctc-parallel.cc:149-198)."""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    END = object()
+
+    def run():
+        try:
+            for x in it:
+                q.put(x)
+            q.put(END)
+        except BaseException as e:   # surface reader errors in the consumer
+            q.put(e)
+
+    threading.Thread(target=run, daemon=True).start()
+    while True:
+        x = q.get()
+        if x is END:
+            return
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+
+
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="train-ctc-parallel", add_help=True,
                                  description="Perform one iteration of CTC training by SGD; multiple utterances are processed in parallel.")
@@ -100,7 +126,7 @@ def main(argv=None) -> int:
         t0 = time.time()
         num_done, total_frames, seq_since_report = 0, 0, 0
         obj_prog = err_prog = ref_prog = 0.0
-        batches = assemble(kaldi_io.read_mat_table(feature_rspecifier), targets, o.num_sequence, o.frame_limit, feat_dim, stats)
+        batches = _prefetch(assemble(kaldi_io.read_mat_table(feature_rspecifier), targets, o.num_sequence, o.frame_limit, feat_dim, stats))
         diff = None
         while True:
             mb = next(batches, None)

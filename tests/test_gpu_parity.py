@@ -277,3 +277,22 @@ def test_adaptive_update_rules(gpu, rule, tmp_path):
     assert np.array_equal(net2.GetAccumulators(), net.GetAccumulators()) and np.array_equal(net2.GetParams(), net.GetParams())
     with pytest.raises(Exception):
         net.SetUpdateAlgorithm("Adam")
+
+
+def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch):
+    """A hand-off that cannot complete (here: a spin bound of zero polls) must surface as EesenError at the next
+    synchronisation point, never as a hang or as silently wrong numbers; the per-step fallback then still works."""
+    from eesen_amd.api import Net, EesenError
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    monkeypatch.setenv("EESEN_SPIN_LIMIT", "0")
+    net = Net.from_layers(layers)
+    net.SetSeqLengths(batch.lens)
+    with pytest.raises(EesenError, match="persistent recurrence kernel gave up"):
+        net.Propagate(batch.feats)
+        net.Synchronize()
+    monkeypatch.setenv("EESEN_PERSISTENT", "0")
+    monkeypatch.delenv("EESEN_SPIN_LIMIT")
+    ok = Net.from_layers(layers); ok.SetSeqLengths(batch.lens)
+    out = ok.Propagate(batch.feats).numpy()
+    assert np.all(np.isfinite(out))
