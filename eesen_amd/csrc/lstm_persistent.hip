@@ -29,8 +29,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NW = 8;
 constexpr int kSc1 = 16;  // cache-policy bit of the raw-buffer builtins: sc1 = write-through store / L1-bypassing load
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + expf(2.f * x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the ~40-instruction libm expf and IEEE division: the cell update is on the
+// per-step critical path; the error (~2e-7 relative) is three orders below the parity bar
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 // ------------------------------------------------------------------------------------------------
 // backward: grid (ceil(H/16), ndir, ceil(S/16)), 512 threads -- the decomposition of lstm_bwd_step_kernel
 // ------------------------------------------------------------------------------------------------
-template <int CPW>
+template <int CPW, int ST>  // ST = sequences per workgroup (16, or 8: half-filled MFMA rows but half the DG_next fetch per CU)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
                                                                       unsigned* err, int spin_limit, unsigned long long* trace) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
-  const int u0 = blockIdx.x * 16, dir = blockIdx.y, s0 = blockIdx.z * 16;
+  const int u0 = blockIdx.x * 16, dir = blockIdx.y, s0 = blockIdx.z * ST;
   unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
   const unsigned nblk = gridDim.x;
 
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   }
   const int es = tid >> 4, eu = tid & 15;
   const int s_e = s0 + es, u_e = u0 + eu;
-  const bool e_ok = tid < 256 && s_e < S && u_e < H;
+  const bool e_ok = tid < ST * 16 && s_e < S && u_e < H;
   float p_i = 0.f, p_f = 0.f, p_o = 0.f;
   int len = 0;
   if (e_ok) {
@@ -263,8 +265,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave + c * NW) * 32 + kq * 8;
-        ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, sa < S, a[c]);
+        ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
       }
+#ifdef EESEN_TRACE_FETCH  // experiment: make the fetch visible in the timeline (serialises fetch and MFMA in every workgroup)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      EESEN_STAMP(1);
+#endif
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     }
     EESEN_STAMP(3);
     if (step + 1 < T) {
-      if (tid < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -356,19 +363,30 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
                          unsigned* err, int spin_limit, unsigned long long* trace) {
   const int nch = (4 * L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
-  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16)), block(NW * 64);
+  // Sequences per workgroup: 16 fills the MFMA rows; 8 wastes half of them but halves the 128 KB of DG_next each workgroup
+  // must fetch per step, which is what bounds the step (measured: 3.75 us of fetch at ~34 GB/s per CU vs 1.8 us of MFMA).
+  // Take 8 whenever 16 would leave half of the chip's CUs without a workgroup.
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  static const int force_st = getenv("EESEN_BWD_SEQ_TILE") ? atoi(getenv("EESEN_BWD_SEQ_TILE")) : 0;
+  const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
+  const int stile = force_st ? force_st : (2 * blocks16 <= ncu && L.S > 8 ? 8 : 16);
+  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, stile)), block(NW * 64);
   if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
   if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
-#define EESEN_BP(CPW)                                                                              \
-  do {                                                                                              \
-    if (!fits(lstm_bwd_persistent_kernel<CPW>, grid, NW * 64)) return false;                        \
-    coop_launch(st, lstm_bwd_persistent_kernel<CPW>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit, trace); \
+#define EESEN_BP2(CPW, STV)                                                                                       \
+  do {                                                                                                            \
+    if (!fits(lstm_bwd_persistent_kernel<CPW, STV>, grid, NW * 64)) return false;                                 \
+    coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit, trace); \
   } while (0)
+#define EESEN_BP(CPW) do { if (stile == 8) EESEN_BP2(CPW, 8); else EESEN_BP2(CPW, 16); } while (0)
   if (need <= 1) EESEN_BP(1);
   else if (need <= 2) EESEN_BP(2);
   else if (need <= 4) EESEN_BP(4);
   else EESEN_BP(8);
+#undef EESEN_BP2
 #undef EESEN_BP
   return true;
 }
