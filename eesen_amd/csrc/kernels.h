@@ -57,6 +57,8 @@ void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float*
 // Return false (nothing launched) when the shape does not fit the resident-workgroup budget: use the step kernels then.
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace = nullptr, hipEvent_t after_reset = nullptr);
+// counter geometry of the forward persistent kernel (for gated consumers): workgroups per group, sequence tiles
+void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

@@ -87,32 +87,39 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
     trace[step * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ------------------------------------------------------------------------------------------------
-// forward: grid (H/4, ndir, ceil(S/32)), 512 threads -- the decomposition of lstm_fwd_step_kernel
+// forward: workgroup = (4*NT hidden units) x (16*MT sequences) x 1 direction, 512 threads, MT*NT = 2.
+//   <MT=2, NT=1>: grid (H/4, ndir, ceil(S/32)) -- the decomposition of lstm_fwd_step_kernel
+//   <MT=1, NT=2>: grid (H/8, ndir, ceil(S/16)) -- same workgroup count at S = 32, same MFMA count, but each workgroup
+//                 fetches m_{t-1} of 16 sequences instead of 32: the per-CU fetch (~34 GB/s per CU for data that just
+//                 crossed the fabric) is what bounds the step, so halving it is worth the second 16-row slice of W_m
+//                 in registers.
 // ------------------------------------------------------------------------------------------------
-template <int CPW>
+template <int CPW, int MT, int NT>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
                                                                       int spin_limit, unsigned long long* trace) {
-  __shared__ __attribute__((aligned(16))) float red[NW][32][20];
+  constexpr int ST = 16 * MT, UB = 4 * NT, RW = 16 * NT + 4;  // sequences, units per workgroup; padded LDS row
+  __shared__ __attribute__((aligned(16))) float red[NW][ST][RW];
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win issue arbitration against co-resident GEMM waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
-  const int u0 = blockIdx.x * 4, dir = blockIdx.y, s0 = blockIdx.z * 32;
+  const int u0 = blockIdx.x * UB, dir = blockIdx.y, s0 = blockIdx.z * ST;
   unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
   const unsigned nblk = gridDim.x;
 
   const int li = lane & 15, kq = lane >> 4;
-  // this wave's part of the workgroup's 16 gate rows of W_m: resident in registers for the whole layer pass
-  float b[CPW][8];
-  {
-    const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + li) * H;
+  // this wave's part of the workgroup's 16*NT gate rows of W_m: resident in registers for the whole layer pass
+  float b[NT][CPW][8];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, b[c]);
+  for (int n = 0; n < NT; ++n) {
+    const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + n * 16 + li) * H;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, b[n][c]);
   }
-  const int es = tid >> 2, eu = tid & 3;
+  const int es = tid / UB, eu = tid % UB;
   const int s_e = s0 + es;
-  const bool e_ok = tid < 128 && s_e < S;
+  const bool e_ok = tid < ST * UB && s_e < S;
   float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;  // c_{t-1} of this thread's (sequence, unit) never leaves the register
   int len = 0;
   if (e_ok) {
@@ -120,7 +127,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
     len = L.lens[s_e];
   }
-  const int sa0 = s0 + li, sa1 = s0 + 16 + li;
   const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
@@ -128,7 +134,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
       if (wave == 0) {
@@ -139,26 +149,32 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       if (!s_go) return;
       EESEN_STAMP(1);
       const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y + (size_t)(tp + 1) * S * ldY + dir * H);
-      float a0[CPW][8], a1[CPW][8];
+      float a[MT][CPW][8];
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave + c * NW) * 32 + kq * 8;
-        ld8_sc1(rY, (unsigned)(((size_t)sa0 * ldY + k) * 4), k, H, sa0 < S, a0[c]);
-        ld8_sc1(rY, (unsigned)(((size_t)sa1 * ldY + k) * 4), k, H, sa1 < S, a1[c]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int sa = s0 + m * 16 + li;
+          ld8_sc1(rY, (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[m][c]);
+        }
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c][j], b[c][j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c][j], b[c][j], acc1, 0, 0, 0);
-        }
-    }
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[wave][4 * kq + r][li] = acc0[r];
-      red[wave][16 + 4 * kq + r][li] = acc1[r];
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][c][j], b[n][c][j], acc[m][n], 0, 0, 0);
     }
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m * 16 + 4 * kq + r][n * 16 + li] = acc[m][n][r];
     __syncthreads();
     EESEN_STAMP(2);
     if (e_ok) {
@@ -339,22 +355,41 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 }  // namespace
 
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
+static bool fwd_tile16(const LstmLayerDev& L) {
+  // 16 sequences x 8 units per workgroup when the shape allows it (half the m_{t-1} fetch per CU), else 32 x 4
+  static const int force_tile = getenv("EESEN_FWD_SEQ_TILE") ? atoi(getenv("EESEN_FWD_SEQ_TILE")) : 0;
+  const int need = ((L.H + 31) / 32 + NW - 1) / NW;
+  return force_tile ? force_tile == 16 : (L.H % 8 == 0 && L.S > 16 && need <= 2);
+}
+
+void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz) {
+  const bool t16 = fwd_tile16(L);
+  *nblk = t16 ? L.H / 8 : L.H / 4;
+  *nz = cdiv(L.S, t16 ? 16 : 32);
+}
+
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace, hipEvent_t after_reset) {
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
-  dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
-  if (need > 4 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  const bool t16 = fwd_tile16(L);
+  dim3 grid(t16 ? L.H / 8 : L.H / 4, L.ndir, cdiv(L.S, t16 ? 16 : 32)), block(NW * 64);
+  if (need > 4 || (t16 && need > 2) || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
   if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
-#define EESEN_FP(CPW)                                                                   \
-  do {                                                                                   \
-    if (!fits(lstm_fwd_persistent_kernel<CPW>, grid, NW * 64)) return false;             \
-    coop_launch(st, lstm_fwd_persistent_kernel<CPW>, grid, block, L, cnt, err, spin_limit, trace); \
+#define EESEN_FP(CPW, MT, NT)                                                                          \
+  do {                                                                                                  \
+    if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, NW * 64)) return false;                    \
+    coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, block, L, cnt, err, spin_limit, trace); \
   } while (0)
-  if (need <= 1) EESEN_FP(1);
-  else if (need <= 2) EESEN_FP(2);
-  else EESEN_FP(4);
+  if (t16) {
+    if (need <= 1) EESEN_FP(1, 1, 2);
+    else EESEN_FP(2, 1, 2);
+  } else {
+    if (need <= 1) EESEN_FP(1, 2, 1);
+    else if (need <= 2) EESEN_FP(2, 2, 1);
+    else EESEN_FP(4, 2, 1);
+  }
 #undef EESEN_FP
   return true;
 }

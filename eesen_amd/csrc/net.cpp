@@ -372,7 +372,8 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       // The NEXT LSTM layer's input GEMM can run on the side stream WHILE this layer's persistent kernel is running:
       // its row tiles wait on the kernel's arrival counters and are visited middle-out in time (gemm_f32_nt_gated).
       Layer* nxt = (&L - layers.data()) + 1 < (long)layers.size() ? &layers[(&L - layers.data()) + 1] : nullptr;
-      const int nz = cdiv(S, 32);
+      int gate_nblk = 0, nz = 1;
+      lstm_fwd_persistent_geometry(lstm_view(*this, L), &gate_nblk, &nz);
       const bool plan_gate = persistent && overlap && gate_fwd && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
@@ -388,7 +389,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
         nxt->G.reserve((size_t)rows * ldG2);
         EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
         const int tj_ = timer.begin(st2, 0);
-        GemmGate gate{ctl.p, ctl.p + kCtlWords - 1, nd, nz, H / 4, T, S, spin_limit};
+        GemmGate gate{ctl.p, ctl.p + kCtlWords - 1, nd, nz, gate_nblk, T, S, spin_limit};
         gemm_f32_nt_gated(st2, rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
                           nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate);
         timer.end(st2, tj_);
