@@ -204,8 +204,17 @@ def main():
             k["avg_us"] = 1e6 * k["total_s"] / k["launches"]
             k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12
         dom = max(kern, key=lambda n: kern[n]["total_s"])
+        # HBM traffic per launch of the dominant kernel, from the committed PMC pass (rocprofv3 --pmc cannot run inside this
+        # process); only quoted when the workload is the one the counters were collected on
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt["config"] == {"config": args.config, "T": T, "S": S} and not (args.H or args.layers):
+                traffic = pt["bytes_per_launch"].get(dom)
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
                     "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                    "flops_per_frame": fpf},
