@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace
 
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
-              const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats) {
+              const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats,
+              int extra_lds_bytes) {
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
@@ -297,8 +298,8 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   const bool guard = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % BK) != 0 || !(a_kc && b_kc);
 #define EESEN_GEMM_LAUNCH(AK, BKC)                                                                        \
   do {                                                                                                    \
-    if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, 0, st, p);          \
-    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, 0, st, p);               \
+    if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
   if (a_kc && b_kc) EESEN_GEMM_LAUNCH(true, true);
   else if (a_kc && !b_kc) EESEN_GEMM_LAUNCH(true, false);

@@ -13,7 +13,7 @@ namespace eesen {
 // CuMatrixBase::AddMatMat (/root/reference/src/gpucompute/cuda-matrix.cc:604-639).
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
-              size_t ws_floats);
+              size_t ws_floats, int extra_lds_bytes = 0);  // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
 
 // Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
 // shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.

@@ -512,15 +512,20 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // Everything that only feeds the parameter gradients leaves the critical path: it runs on the side stream,
       // under the next layer's (latency-bound, mostly idle-chip) recurrence.
       hipStream_t sg = overlap ? st2 : st;
+      // 48 KB of unused dynamic LDS = at most ONE side-stream GEMM workgroup per CU, so that the next layer's cooperative
+      // recurrence kernel (one 512-thread workgroup on EVERY CU) never waits for long-running GEMM tiles to retire
+      // (measured, cfg2: 64.0 ms/step uncapped, 64.1 at two per CU, 62.0 at one per CU)
+      static const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : 48) * 1024;
+      const int side_lds = overlap ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
-      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, ws2.cap);
+      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, ws2.cap, side_lds);
       // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
       for (int dir = 0; dir < nd; ++dir)
         gemm_f32(sg, false, false, 4 * H, H, rows, 1.f, DGl + (size_t)dir * 4 * H, ldG,
                  L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
-                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, ws2.cap);
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, ws2.cap, side_lds);
       lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, ws2.cap);
       timer.end(sg, ti_); }
       if (overlap) {
