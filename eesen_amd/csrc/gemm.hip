@@ -330,7 +330,8 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // becoming resident.  26 KB of unused dynamic LDS on top of the 33 KB static makes at most two of these workgroups
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
-  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3((unsigned)((M / BM) * (N / BN))), dim3(256), 26 * 1024, st, p);
+  static const int gate_lds = (getenv("EESEN_GATE_LDS_KB") ? atoi(getenv("EESEN_GATE_LDS_KB")) : 26) * 1024;
+  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3((unsigned)((M / BM) * (N / BN))), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");
 }
 

@@ -120,10 +120,11 @@ Net::Net(int dev, void* stream) : device(dev) {
   for (auto& e : ev_grad) EESEN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_reset, hipEventDisableTiming));
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_done, hipEventDisableTiming));
-  // measured on MI355X (cfg2): hiding the next layer's input GEMM under the forward recurrence is bit-identical but a net
-  // loss (74.7 vs 73.0 ms/step: the forward hand-off chain slows from 4.9 to 7 us/step under the GEMM's memory traffic,
-  // more than the 7 ms of GEMM it hides; wave priority does not help), so it is opt-in
-  gate_fwd = getenv("EESEN_GATE_FWD") && atoi(getenv("EESEN_GATE_FWD")) != 0;
+  // The next layer's input GEMM runs UNDER this layer's forward recurrence, gated tile by tile on the recurrence's
+  // arrival counters (gemm_f32_nt_gated).  Measured on MI355X (cfg2), bit-identical results: with the 32x4 forward tiles
+  // it lost (74.7 vs 73.0 ms/step: the hand-off chain slowed more than the 7 ms of GEMM it hid; wave priority did not
+  // help); with the 16x8 tiles and capped side-stream occupancy it wins: 62.0 -> 60.0 ms/step.
+  gate_fwd = !(getenv("EESEN_GATE_FWD") && atoi(getenv("EESEN_GATE_FWD")) == 0);
   if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
   // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on MI355X, cfg2: with the
   // one-launch-per-step recurrence it is neutral (105.1 vs 104.9 ms/step: the step kernels slow down by what the
