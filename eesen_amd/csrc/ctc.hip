@@ -39,6 +39,19 @@ __device__ __forceinline__ float LogAPlusB(float a, float b) {
   return AddAB(b, logf(1.f + ExpA(SubAB(a, b))));
 }
 
+// The same helper on the hardware transcendental units (v_exp_f32 / v_log_f32, ~1 ulp) for the lattice sweep, whose T-step
+// dependency chain is made of exactly these two operations (8 exp + 8 log per lane and step at PL = 4).  Their error
+// (< 4e-7 absolute on log(1 + e^d) in (0, ln 2]) is below the fp32 rounding of the alpha values it is added to.
+// Branch-free form: with the FINITE sentinel -1e30 plain fp32 arithmetic already reproduces every special case of
+// AddAB / SubAB / ExpA above -- x + (-1e30) == -1e30 exactly for |x| < 1e22 (ulp(1e30) = 7.6e22), exp(-1e30 - m) == 0,
+// and logadd(-1e30, -1e30) = -1e30 + ln 2 == -1e30 -- so max + log(1 + exp(min - max)) equals LogAPlusB on every input
+// the lattice can produce (log-probabilities are <= 0, so the exp never overflows), in 6 instructions instead of ~40.
+__device__ __forceinline__ float LogAPlusB_fast(float a, float b) {
+  const float m = fmaxf(a, b), n = fminf(a, b);
+  return m + __logf(1.f + __expf(n - m));
+}
+__device__ __forceinline__ float AddAB_fast(float a, float b) { return a + b; }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
     return;
   }
   float* out = (is_beta ? beta : alpha) + (size_t)s * T * Lpad + j0;
-  float cur[PL], pn[PL];
+  float cur[PL];
 
   if (!is_beta) {
     // row 0 (:1391-1393)
@@ -128,41 +141,57 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       cur[i] = (cls[i] >= 0 && j < 2) ? lp[cls[i]] : kLogZero;
     }
     store_row<PL>(out, cur);
-    if (len > 1) {
-      const float* l1 = logp + (size_t)(1 * S + s) * ld;
+    // The gathers of the log-probabilities run DEPTH steps ahead of their use (a ring of DEPTH register sets): one step
+    // of look-ahead leaves the chain bound by the HBM latency of the gather (measured 1.66 us per step).
+    constexpr int DEPTH = 4;
+    float P[DEPTH][PL];
 #pragma unroll
-      for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? l1[cls[i]] : 0.f;
+    for (int u = 0; u < DEPTH; ++u) {
+      const int t = 1 + u;
+      const float* lr = logp + (size_t)((t < len ? t : 0) * S + s) * ld;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) P[u][i] = (t < len && cls[i] >= 0) ? lr[cls[i]] : 0.f;
     }
-    for (int t = 1; t < len; ++t) {
-      float p[PL];
+    for (int base = 1; base < len; base += DEPTH) {
+      float Q[DEPTH][PL];
 #pragma unroll
-      for (int i = 0; i < PL; ++i) p[i] = pn[i];
-      if (t + 1 < len) {  // gather for the next step now; it is consumed one iteration later
-        const float* ln = logp + (size_t)((t + 1) * S + s) * ld;
+      for (int u = 0; u < DEPTH; ++u) {  // gathers for steps base+DEPTH .. base+2*DEPTH-1
+        const int t = base + DEPTH + u;
+        const float* lr = logp + (size_t)((t < len ? t : 0) * S + s) * ld;
 #pragma unroll
-        for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? ln[cls[i]] : 0.f;
-      }
-      const float pm1 = __shfl_up(cur[PL - 1], 1);
-      const float pm2 = PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2);
-      float nxt[PL];
-#pragma unroll
-      for (int i = 0; i < PL; ++i) {
-        const int j = j0 + i;
-        const float a0 = cur[i];
-        const float a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : pm1;
-        const float a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? pm1 : pm2);
-        float v;
-        if (cls[i] < 0) v = kLogZero;                                          // :1380-1383
-        else if (j > 1) {
-          const float tmp = LogAPlusB(a1, a0);                                  // :1397 / :1399
-          v = three[i] ? AddAB(p[i], LogAPlusB(a2, tmp)) : AddAB(p[i], tmp);    // :1400 / :1397
-        } else if (j == 1) v = AddAB(p[i], LogAPlusB(a1, a0));                 // :1403
-        else v = AddAB(p[i], a0);                                              // :1405
-        nxt[i] = v;
+        for (int i = 0; i < PL; ++i) Q[u][i] = (t < len && cls[i] >= 0) ? lr[cls[i]] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
-      store_row<PL>(out + (size_t)t * Lpad, cur);
+      for (int u = 0; u < DEPTH; ++u) {
+        const int t = base + u;
+        if (t < len) {
+          const float pm1 = __shfl_up(cur[PL - 1], 1);
+          const float pm2 = PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2);
+          float nxt[PL];
+#pragma unroll
+          for (int i = 0; i < PL; ++i) {
+            const int j = j0 + i;
+            const float a0 = cur[i];
+            const float a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : pm1;
+            const float a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? pm1 : pm2);
+            float v;
+            if (cls[i] < 0) v = kLogZero;                                                  // :1380-1383
+            else if (j > 1) {
+              const float tmp = LogAPlusB_fast(a1, a0);                                     // :1397 / :1399
+              v = three[i] ? AddAB_fast(P[u][i], LogAPlusB_fast(a2, tmp)) : AddAB_fast(P[u][i], tmp); // :1400 / :1397
+            } else if (j == 1) v = AddAB_fast(P[u][i], LogAPlusB_fast(a1, a0));                 // :1403
+            else v = AddAB_fast(P[u][i], a0);                                                   // :1405
+            nxt[i] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
+          store_row<PL>(out + (size_t)t * Lpad, cur);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+        for (int i = 0; i < PL; ++i) P[u][i] = Q[u][i];
     }
     // ln p(z|x) = logadd(alpha[T_s-1][L'_s-1], alpha[T_s-1][L'_s-2])  (ctc-loss.cc:147-153)
 #pragma unroll
@@ -181,41 +210,55 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       cur[i] = (cls[i] >= 0 && j > ll - 3) ? lp[cls[i]] : kLogZero;
     }
     store_row<PL>(out + (size_t)(len - 1) * Lpad, cur);
-    if (len > 1) {
-      const float* l1 = logp + (size_t)((len - 2) * S + s) * ld;
+    constexpr int DEPTH = 4;
+    float P[DEPTH][PL];
 #pragma unroll
-      for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? l1[cls[i]] : 0.f;
+    for (int u = 0; u < DEPTH; ++u) {
+      const int t = len - 2 - u;
+      const float* lr = logp + (size_t)((t >= 0 ? t : 0) * S + s) * ld;
+#pragma unroll
+      for (int i = 0; i < PL; ++i) P[u][i] = (t >= 0 && cls[i] >= 0) ? lr[cls[i]] : 0.f;
     }
-    for (int t = len - 2; t >= 0; --t) {
-      float p[PL];
+    for (int base = len - 2; base >= 0; base -= DEPTH) {
+      float Q[DEPTH][PL];
 #pragma unroll
-      for (int i = 0; i < PL; ++i) p[i] = pn[i];
-      if (t > 0) {
-        const float* ln = logp + (size_t)((t - 1) * S + s) * ld;
+      for (int u = 0; u < DEPTH; ++u) {
+        const int t = base - DEPTH - u;
+        const float* lr = logp + (size_t)((t >= 0 ? t : 0) * S + s) * ld;
 #pragma unroll
-        for (int i = 0; i < PL; ++i) pn[i] = cls[i] >= 0 ? ln[cls[i]] : 0.f;
-      }
-      const float nm1 = __shfl_down(cur[0], 1);
-      const float nm2 = PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2);
-      float nxt[PL];
-#pragma unroll
-      for (int i = 0; i < PL; ++i) {
-        const int j = j0 + i;
-        const float b0 = cur[i];
-        const float b1 = i + 1 < PL ? cur[i + 1 < PL ? i + 1 : 0] : nm1;
-        const float b2 = i + 2 < PL ? cur[i + 2 < PL ? i + 2 : 0] : (i + 2 == PL ? nm1 : nm2);
-        float v;
-        if (cls[i] < 0) v = kLogZero;                                          // :1495-1498
-        else if (j < ll - 2) {
-          const float tmp = LogAPlusB(b1, b0);                                  // :1533 / :1535
-          v = three[i] ? AddAB(p[i], LogAPlusB(b2, tmp)) : AddAB(p[i], tmp);    // :1536 / :1533
-        } else if (j == ll - 2) v = AddAB(p[i], LogAPlusB(b1, b0));            // :1539
-        else v = AddAB(p[i], b0);                                              // :1541
-        nxt[i] = v;
+        for (int i = 0; i < PL; ++i) Q[u][i] = (t >= 0 && cls[i] >= 0) ? lr[cls[i]] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
-      store_row<PL>(out + (size_t)t * Lpad, cur);
+      for (int u = 0; u < DEPTH; ++u) {
+        const int t = base - u;
+        if (t >= 0) {
+          const float nm1 = __shfl_down(cur[0], 1);
+          const float nm2 = PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2);
+          float nxt[PL];
+#pragma unroll
+          for (int i = 0; i < PL; ++i) {
+            const int j = j0 + i;
+            const float b0 = cur[i];
+            const float b1 = i + 1 < PL ? cur[i + 1 < PL ? i + 1 : 0] : nm1;
+            const float b2 = i + 2 < PL ? cur[i + 2 < PL ? i + 2 : 0] : (i + 2 == PL ? nm1 : nm2);
+            float v;
+            if (cls[i] < 0) v = kLogZero;                                                  // :1495-1498
+            else if (j < ll - 2) {
+              const float tmp = LogAPlusB_fast(b1, b0);                                     // :1533 / :1535
+              v = three[i] ? AddAB_fast(P[u][i], LogAPlusB_fast(b2, tmp)) : AddAB_fast(P[u][i], tmp); // :1536 / :1533
+            } else if (j == ll - 2) v = AddAB_fast(P[u][i], LogAPlusB_fast(b1, b0));            // :1539
+            else v = AddAB_fast(P[u][i], b0);                                                   // :1541
+            nxt[i] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
+          store_row<PL>(out + (size_t)t * Lpad, cur);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+        for (int i = 0; i < PL; ++i) P[u][i] = Q[u][i];
     }
   }
 }
