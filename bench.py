@@ -155,6 +155,28 @@ def main():
             torch.cuda.synchronize()
         net.Synchronize()
 
+    # One probing step first: if the cooperative (persistent) recurrence kernels cannot run on this box (the library then
+    # raises instead of hanging), fall back to the one-launch-per-step kernels -- on EVERY rank, so all ranks time the same code.
+    ok = 1.0
+    try:
+        step()
+        net.Synchronize()
+    except Exception as e:   # noqa: BLE001
+        print(f"bench: persistent path failed on rank {rank} ({e}); falling back to per-step kernels", file=sys.stderr)
+        ok = 0.0
+    if dist is not None:
+        import torch
+        t_ok = torch.tensor([ok], device=f"cuda:{local}")
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        ok = float(t_ok.item())
+    if ok == 0.0:
+        os.environ["EESEN_PERSISTENT"] = "0"
+        net = Net.from_layers(layers, device=dev)
+        net.SetTrainOptions(4e-5, 0.9)
+        net.SetProfiling(True)
+        if world > 1:
+            from eesen_amd.parallel import GradAllReducer
+            net.grad_hook = GradAllReducer(net)
     for _ in range(args.warmup):
         step()
     barrier()
