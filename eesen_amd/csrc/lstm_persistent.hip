@@ -12,14 +12,16 @@
 //             ONE lane bumps the (direction, sequence-tile) arrival counter with a relaxed agent-scope atomic;
 //   consumer: ONE lane polls that counter (relaxed, agent scope, s_sleep between polls, BOUNDED spin) -> workgroup
 //             barrier -> every wave reads the payload with sc1 loads (served from L2 / memory, never from a stale L1).
-// Every step writes row blocks that no one has read before in this launch, so no cache can hold a stale copy.
+// Every step writes row blocks that no one has read before in this launch, so no cache can hold a stale copy -- PROVIDED
+// a step's row block starts on a 128-byte line (the launchers check it and fall back otherwise): an unaligned block
+// shares its first line with the previous block, which caches it one step early.
 // A workgroup can run at most one step ahead of the slowest one of its (direction, sequence-tile) group, and step t
 // writes row block t while laggards still read row block t-1, so there is no write-after-read hazard.
 // All workgroups must be co-resident: the host launches cooperatively after an occupancy check with margin and
 // otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an error word instead of hanging.
 //
-// Arithmetic is identical to lstm.hip (same MFMA order, same LDS reduction order, same cell equations), so results
-// are bit-identical to the per-step path; tests assert exactly that.
+// Arithmetic is identical to lstm.hip (same MFMA order, same LDS reduction order, same cell equations): the forward pass
+// is bit-identical to the per-step path, the backward pass up to FMA contraction; tests assert exactly that.
 #include "kernels.h"
 
 namespace eesen {
@@ -375,6 +377,11 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
   const bool t16 = fwd_tile16(L);
   dim3 grid(t16 ? L.H / 8 : L.H / 4, L.ndir, cdiv(L.S, t16 ? 16 : 32)), block(NW * 64);
   if (need > 4 || (t16 && need > 2) || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
+  // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
+  // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
+  // and is read back stale one step later (seen at S = 17, H = 20).  Such shapes use the per-step kernels.
+  if (((size_t)L.S * L.ndir * L.H * sizeof(float)) % 128 != 0) return false;
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
   if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
 #define EESEN_FP(CPW, MT, NT)                                                                          \
@@ -410,6 +417,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, stile)), block(NW * 64);
   if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
   if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets
+  if (((size_t)L.S * L.ndir * 4 * L.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \

@@ -296,3 +296,19 @@ def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch):
     ok = Net.from_layers(layers); ok.SetSeqLengths(batch.lens)
     out = ok.Propagate(batch.feats).numpy()
     assert np.all(np.isfinite(out))
+
+
+@pytest.mark.parametrize("over", [dict(S=1, T=37), dict(S=2, T=2), dict(S=17, T=9, H=20), dict(S=33, T=5, H=36, layers=1),
+                                  dict(S=6, T=40, min_frac=0.2)])
+def test_odd_shapes_and_single_sequence(gpu, over):
+    """Single-sequence training (the reference's `train-ctc` is this path at S = 1), partially filled sequence / unit tiles,
+    very short T and heavily ragged lengths, against the oracle."""
+    cfg = dict(synth.config("small_bi")); cfg.update(over)
+    layers, batch, res = _run_both("small_bi", lr=1.0, mmt=0.0, max_grad=0.0, **over)
+    r = res[0]; o = r["o"]
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(r["net_out"][vm], o["net_out"][vm]) < TOL
+    assert rel_err(r["pzx"], o["pzx"]) < TOL
+    assert rel_err(r["diff"], o["diff"]) < TOL
+    assert rel_err(r["in_diff"], o["in_diff"]) < TOL
+    assert rel_err(r["grads"], r["ora_grads"]) < TOL
