@@ -106,7 +106,14 @@ def main():
     ap.add_argument("--H", type=int, default=0, help="override cells per direction (debug)")
     ap.add_argument("--S", type=int, default=0, help="override utterances per GPU (debug)")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (torch first, RCCL process group, gradient all-reduce) even with one rank (debug)")
     args = ap.parse_args()
+    # stdout carries exactly ONE JSON line: everything else that C libraries print there (RCCL prints its version banner on
+    # stdout, buffered until exit) is rerouted to stderr by swapping the file descriptors for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -115,10 +122,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        if args.force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from eesen_amd.api import Net, Ctc, CuMatrix
@@ -130,11 +139,11 @@ def main():
             cfg[k] = getattr(args, k)
     layers = synth.make_model(max_grad=50.0, **cfg)                 # recipe settings: model_topo.py:90, run_ctc_phn.sh:84-85
     batch = synth.make_batch(**{**cfg, "seed": 777 + rank})         # every rank its own shard of the global batch
-    dev = local if world > 1 else 0
+    dev = local if dist is not None else 0
     net = Net.from_layers(layers, device=dev)
     net.SetTrainOptions(4e-5, 0.9)
     ctc = Ctc(device=dev)
-    if world > 1:
+    if dist is not None:
         from eesen_amd.parallel import GradAllReducer
         net.grad_hook = GradAllReducer(net)
     feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # inputs resident in HBM before the timed region
@@ -174,7 +183,7 @@ def main():
         net = Net.from_layers(layers, device=dev)
         net.SetTrainOptions(4e-5, 0.9)
         net.SetProfiling(True)
-        if world > 1:
+        if dist is not None:
             from eesen_amd.parallel import GradAllReducer
             net.grad_hook = GradAllReducer(net)
     for _ in range(args.warmup):
@@ -266,7 +275,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
