@@ -312,3 +312,26 @@ def test_odd_shapes_and_single_sequence(gpu, over):
     assert rel_err(r["diff"], o["diff"]) < TOL
     assert rel_err(r["in_diff"], o["in_diff"]) < TOL
     assert rel_err(r["grads"], r["ora_grads"]) < TOL
+
+
+def test_ctc_edge_cases(gpu):
+    """Infeasible alignment (fewer frames than the labels need: ln p ~ -1e30 in the reference), a
+    one-label utterance, and the expanded-label limit."""
+    from eesen_amd.api import CuMatrix, Ctc, EesenError
+    from oracle import net as onet
+    rng = np.random.default_rng(1)
+    S, T, K = 3, 6, 5
+    lens = np.array([3, 6, 6], np.int32)
+    labels = [np.array([2, 2, 2], np.int32),        # needs 5 frames (blanks between repeats), has 3: infeasible
+              np.array([1], np.int32), np.array([3, 4, 1], np.int32)]
+    x = rng.standard_normal((T * S, K)).astype(np.float32)
+    p = np.exp(x - x.max(1, keepdims=True)); p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+    ids = np.concatenate(labels); off = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    want = onet.ctc_eval_parallel(p, T, S, lens, ids, off, "f32")
+    ctc = Ctc()
+    diff = ctc.EvalParallel(lens, CuMatrix.from_numpy(p), labels).numpy()
+    assert ctc.pzx[0] < -1e29 and want["pzx"][0] < -1e29
+    assert rel_err(ctc.pzx[1:], want["pzx"][1:]) < 1e-6
+    assert np.all(np.isfinite(diff)) and rel_err(diff, want["diff"]) < TOL
+    with pytest.raises(EesenError, match="above 1024"):
+        ctc.EvalParallel([1300], CuMatrix(1300, K), [np.ones(600, np.int32)])
