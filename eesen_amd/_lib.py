@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "lib", "libeesen_hip.so")
+# EESEN_HIP_LIBRARY: developer override used by scripts/build_variant.py to A/B kernel build flags on the GPU box
+LIB_PATH = os.environ.get("EESEN_HIP_LIBRARY") or os.path.join(_DIR, "lib", "libeesen_hip.so")
 
 OK = 0
 LAYER_AFFINE, LAYER_SOFTMAX, LAYER_LSTM_PARALLEL, LAYER_BILSTM_PARALLEL = 1, 2, 3, 4

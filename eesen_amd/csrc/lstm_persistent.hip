@@ -46,14 +46,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 // launch, so neither the CU's L1 nor the XCD's L2 can hold an older copy, (ii) the producers' sc1 stores write through
 // and drop the line from their L2, and (iii) no load is issued before the arrival counters say every producer has
 // drained its stores -- and they let the 16 workgroups of an XCD share one fabric fetch through the L2.
+// Polling wave and back-off.  Wave 0 also prefetches the next step's epilogue operands from HBM right after the publish;
+// vmcnt is in-order, so its first poll completes only when those arrive -- a natural back-off.  Measured: polling from a
+// wave without that delay (EESEN_POLL_WAVE=7) is SLOWER (backward 16.8 -> 19.8 ms): eager polls of 256 workgroups crowd
+// the counter lines and delay the increments they are waiting for.
+#ifndef EESEN_POLL_WAVE
+#define EESEN_POLL_WAVE 0
+#endif
+#ifndef EESEN_POLL_SLEEP
+#define EESEN_POLL_SLEEP 1
+#endif
 #ifndef EESEN_SC1_LOADS
 #define EESEN_SC1_LOADS 0
 #endif
+// Branch-free on purpose: a lane that has nothing to read points its offset past the descriptor's num_records and the
+// buffer unit returns zeros.  With predicated loads (`if (ok) load`) the compiler cannot count outstanding loads and puts
+// one `s_waitcnt vmcnt(0)` in front of the whole MFMA chain, which serialised operand fetch (~1.9 us per backward step)
+// and MFMA (~1.7 us); straight-line loads get per-chunk `vmcnt(n)` waits and the two overlap.
 __device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int k, int kmax, bool ok, float (&v)[8]) {
-  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
   constexpr int pol = EESEN_SC1_LOADS ? kSc1 : 0;
-  if (ok && k < kmax) a = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, pol);
-  if (ok && k + 4 < kmax) b = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, pol);
+  constexpr unsigned kOob = 0x80000000u;  // >= num_records (0x7fffffff): reads as zero
+  const unsigned oa = (ok && k < kmax) ? byte_off : kOob;
+  const unsigned ob = (ok && k + 4 < kmax) ? byte_off + 16 : kOob;
+  const f32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, oa, 0, pol);
+  const f32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, ob, 0, pol);
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
@@ -65,7 +81,22 @@ __device__ __forceinline__ void ld8_plain(const float* __restrict__ row, int k, 
   v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-// Arrival counters are sharded 8 ways (shard = blockIdx.x & 7, one 128-byte line each) so that the increments of a
+// Workgroup -> (unit group, direction, sequence group).  The grid is 1-D; with `xcd` set the (direction, sequence group)
+// pair varies FASTEST, so that -- with the dispatcher's observed block b -> XCD b % 8 placement -- all workgroups that
+// exchange rows with each other (same direction, same sequence group) sit behind the same L2 when there are 8 such
+// groups (2 directions x 4 sequence tiles at S = 32 backward), or behind two L2s when there are 4 (forward): each
+// L2 then pulls only its own group's rows through the fabric instead of every group's.  Pure speed hint: the hand-off
+// protocol does not depend on the placement.
+struct Role {
+  int nblk, ndir, nz, xcd;
+  int census;  // 1: take the XCD census and use the L2-local hand-off when every group sits behind one L2
+  __device__ __forceinline__ int combo(int b) const { return xcd ? b % (ndir * nz) : b / nblk; }
+  __device__ __forceinline__ int unit_group(int b) const { return xcd ? b / (ndir * nz) : b % nblk; }
+  __device__ __forceinline__ int dir(int b) const { return combo(b) % ndir; }
+  __device__ __forceinline__ int seq_group(int b) const { return combo(b) / ndir; }
+};
+
+// Arrival counters are sharded 8 ways (shard = unit group & 7, one 128-byte line each) so that the increments of a
 // step do not serialise on one address.  Lanes 0-7 of wave 0 each poll one shard until it reaches its own target
 // (workgroups in that shard x steps).  Returns false (and raises *err) when the bound is hit or a peer gave up.
 __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
@@ -77,15 +108,35 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
     if (__all(ok)) return true;
     if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
 #ifndef EESEN_POLL_NOSLEEP
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
 #endif
   }
   if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
 }
 
+// XCD census.  When the (direction, sequence-tile) groups number exactly 8 and the role map is XCD-aware, group g is
+// MEANT to run on XCD g -- then all of a group's hand-offs can stay inside that XCD's L2 (the coherence point of its 32
+// CUs): plain stores that keep the line in L2, L2-executed counter increments, no trip through the fabric.  Placement is
+// not a contract, so it is CHECKED, per launch: every workgroup reads HW_REG_XCC_ID, votes with an agent-scope atomic,
+// waits (bounded) for all votes, and the L2-local protocol is used only if EVERY workgroup sits where the map assumes;
+// otherwise all of them use the placement-independent write-through protocol.  Returns 1 (local), 0 (global), -1 (error).
+__device__ __forceinline__ int xcd_census(unsigned* word, unsigned nwg, unsigned* err, int spin_limit) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
+  const unsigned good = xcc == (blockIdx.x & 7u) ? 1u : 0u;
+  __hip_atomic_fetch_add(word, 1u + (good << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int spins = 0; spins < spin_limit; ++spins) {
+    const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v & 0xffffu) == nwg) return (v >> 16) == nwg ? 1 : 0;
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return -1;
+}
+
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
-#define EESEN_STAMP(i) do { if (trace && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && step < 128) \
+#define EESEN_STAMP(i) do { if (trace && tid == 0 && blockIdx.x == 0 && step < 127) \
     trace[step * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -98,7 +149,7 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
 // ------------------------------------------------------------------------------------------------
 template <int CPW, int MT, int NT>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
-                                                                      int spin_limit, unsigned long long* trace) {
+                                                                      int spin_limit, unsigned long long* trace, Role R) {
   constexpr int ST = 16 * MT, UB = 4 * NT, RW = 16 * NT + 4;  // sequences, units per workgroup; padded LDS row
   __shared__ __attribute__((aligned(16))) float red[NW][ST][RW];
   __shared__ int s_go;
@@ -106,9 +157,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
-  const int u0 = blockIdx.x * UB, dir = blockIdx.y, s0 = blockIdx.z * ST;
-  unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
-  const unsigned nblk = gridDim.x;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int u0 = bx * UB, s0 = bz * ST;
+  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
+  const unsigned nblk = R.nblk;
 
   const int li = lane & 15, kq = lane >> 4;
   // this wave's part of the workgroup's 16*NT gate rows of W_m: resident in registers for the whole layer pass
@@ -143,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
-      if (wave == 0) {
+      if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
         if (lane == 0) s_go = go ? 1 : 0;
       }
@@ -161,6 +213,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
           ld8_sc1(rY, (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[m][c]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA (else they are issued lazily, 2 at a time)
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
@@ -205,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       if (tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
       __syncthreads();                                                 // (also fences `red` for the next step)
       EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok && step + 1 < T)  // next step's gate pre-activations: issued AFTER the publish so the drain never waits for HBM
         gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
     }
@@ -218,16 +271,26 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 template <int CPW, int ST>  // ST = sequences per workgroup (16, or 8: half-filled MFMA rows but half the DG_next fetch per CU)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
-                                                                      unsigned* err, int spin_limit, unsigned long long* trace) {
+                                                                      unsigned* err, int spin_limit, unsigned long long* trace,
+                                                                      Role R) {
   __shared__ float red[NW][16][17];
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
-  const int u0 = blockIdx.x * 16, dir = blockIdx.y, s0 = blockIdx.z * ST;
-  unsigned* my_cnt = cnt + (size_t)(dir * gridDim.z + blockIdx.z) * kShards * kShardStride;
-  const unsigned nblk = gridDim.x;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int u0 = bx * 16, s0 = bz * ST;
+  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
+  const unsigned nblk = R.nblk;
+
+  // L2-local hand-off (see xcd_census): decided once per launch, identically by every workgroup
+  if (tid == 0) s_go = R.census ? xcd_census(cnt + (size_t)R.ndir * R.nz * kShards * kShardStride, gridDim.x, err, spin_limit) : 0;
+  __syncthreads();
+  const int local = s_go;
+  if (local < 0) return;
+  if (trace && tid == 0 && blockIdx.x == 0) trace[639] = (unsigned long long)local;
+  __syncthreads();
 
   const int li = lane & 15, kq = lane >> 4;
   const int sa = s0 + li, ub = u0 + li;
@@ -271,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     EESEN_STAMP(0);
     if (step > 0) {
-      if (wave == 0) {
+      if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
         if (lane == 0) s_go = go ? 1 : 0;
       }
@@ -285,6 +348,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         const int k = (wave + c * NW) * 32 + kq * 8;
         ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
       }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
 #ifdef EESEN_TRACE_FETCH  // experiment: make the fetch visible in the timeline (serialises fetch and MFMA in every workgroup)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -317,7 +381,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       float carry = dc * f;
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
-      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4), 0, kSc1);
+      const unsigned ooff = (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4);
+      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
+      else __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
     EESEN_STAMP(3);
@@ -325,7 +391,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (blockIdx.x & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        unsigned* c = my_cnt + (bx & (kShards - 1)) * kShardStride;
+        if (local) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // executes in the XCD's L2
+        else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (e_ok) {  // next step's operands, issued after the publish
         const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
         gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
@@ -356,6 +426,16 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 
 }  // namespace
 
+static int xcd_map() {
+  static const int v = getenv("EESEN_XCD_MAP") ? atoi(getenv("EESEN_XCD_MAP")) : 1;
+  return v;
+}
+
+static int l2_local() {
+  static const int v = getenv("EESEN_L2_LOCAL") ? atoi(getenv("EESEN_L2_LOCAL")) : 1;
+  return v;
+}
+
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
 static bool fwd_tile16(const LstmLayerDev& L) {
   // 16 sequences x 8 units per workgroup when the shape allows it (half the m_{t-1} fetch per CU), else 32 x 4
@@ -376,6 +456,8 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
   const int need = (nch + NW - 1) / NW;
   const bool t16 = fwd_tile16(L);
   dim3 grid(t16 ? L.H / 8 : L.H / 4, L.ndir, cdiv(L.S, t16 ? 16 : 32)), block(NW * 64);
+  const dim3 grid1(grid.x * grid.y * grid.z);
+  const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
   if (need > 4 || (t16 && need > 2) || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
   // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
   // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
@@ -387,7 +469,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
 #define EESEN_FP(CPW, MT, NT)                                                                          \
   do {                                                                                                  \
     if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, NW * 64)) return false;                    \
-    coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, block, L, cnt, err, spin_limit, trace); \
+    coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT>, grid1, block, L, cnt, err, spin_limit, trace, role); \
   } while (0)
   if (t16) {
     if (need <= 1) EESEN_FP(1, 1, 2);
@@ -415,14 +497,17 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
   const int stile = force_st ? force_st : (2 * blocks16 <= ncu && L.S > 8 ? 8 : 16);
   dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, stile)), block(NW * 64);
-  if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  const dim3 grid1(grid.x * grid.y * grid.z);
+  const int ngroups = (int)(grid.y * grid.z);
+  const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
+  if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
   if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets
   if (((size_t)L.S * L.ndir * 4 * L.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
-  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \
     if (!fits(lstm_bwd_persistent_kernel<CPW, STV>, grid, NW * 64)) return false;                                 \
-    coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV>, grid, block, L, dY, lddy, DG, cnt, err, spin_limit, trace); \
+    coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
   } while (0)
 #define EESEN_BP(CPW) do { if (stile == 8) EESEN_BP2(CPW, 8); else EESEN_BP2(CPW, 16); } while (0)
   if (need <= 1) EESEN_BP(1);

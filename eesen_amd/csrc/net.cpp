@@ -157,6 +157,7 @@ Net::~Net() {
         }
         if (n) fprintf(stderr, "EESEN_TRACE %s: wait %.0f | A-load+MFMA+reduce %.0f | epilogue %.0f | drain+barrier %.0f | publish->next %.0f ticks/step (%d steps)\n",
                        pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
+        if (pass) fprintf(stderr, "EESEN_TRACE bwd hand-off: %s\n", h[640 + 639] ? "L2-local (XCD census passed)" : "write-through");
       }
   }
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
