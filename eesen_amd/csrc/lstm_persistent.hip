@@ -56,6 +56,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 #ifndef EESEN_POLL_SLEEP
 #define EESEN_POLL_SLEEP 1
 #endif
+#ifndef EESEN_BWD_FULL_LINES
+#define EESEN_BWD_FULL_LINES 1
+#endif
 #ifndef EESEN_SC1_LOADS
 #define EESEN_SC1_LOADS 0
 #endif
@@ -69,9 +72,16 @@ __device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
   const unsigned oa = (ok && k < kmax) ? byte_off : kOob;
   const unsigned ob = (ok && k + 4 < kmax) ? byte_off + 16 : kOob;
   const f32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, oa, 0, pol);
+#ifdef EESEN_EXP_HALF_LOADS  // timing experiment only (wrong numbers): one request per line instead of two
+  const f32x4 b = a; (void)ob;
+#else
   const f32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, ob, 0, pol);
+#endif
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ float ror8(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xf, 0xf, true));
 }
 __device__ __forceinline__ void ld8_plain(const float* __restrict__ row, int k, int kmax, bool ok, float (&v)[8]) {
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -298,7 +308,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   {
     const float* Br = L.WmT + ((size_t)dir * H + ub) * K4;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, K4, ub < H, b[c]);
+    for (int c = 0; c < CPW; ++c) {
+      const int k0 = (wave + c * NW) * 32;
+      if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {  // k order of the full-line operand fetch below: j < 4 -> k0 + 4kq + j, j >= 4 -> k0 + 16 + 4kq + (j - 4)
+        float lo[8], hi[8];
+        ld8_plain(Br, k0 + kq * 4, K4, ub < H, lo);       // only lo[0..3] / hi[0..3] are used
+        ld8_plain(Br, k0 + 16 + kq * 4, K4, ub < H, hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[c][j] = lo[j]; b[c][4 + j] = hi[j]; }
+      } else {
+        ld8_plain(Br, k0 + kq * 8, K4, ub < H, b[c]);
+      }
+    }
   }
   const int es = tid >> 4, eu = tid & 15;
   const int s_e = s0 + es, u_e = u0 + eu;
@@ -342,25 +363,53 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       if (!s_go) return;
       EESEN_STAMP(1);
       const size_t arow = ((size_t)(tn * S + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row
-      float a[CPW][8];
+      if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
+        // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
+        // load: lane (li, kq) reads 16 bytes of sequence li & 7 at segment (li >> 3) * 4 + kq of the 128-byte chunk -- one
+        // request per line and ONE load instruction per chunk instead of two half-empty ones that each touch every line (the
+        // second request of a line occupies the L1 miss queue like the first; measured -740 ticks per step).  The upper
+        // half of the chunk reaches rows 0-7 through a rotate-by-8 DPP move inside each 16-lane row; rows 8-15 of the
+        // product are garbage that nobody reads.
+        const unsigned arow8 = (unsigned)(((size_t)(tn * S + s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
+        const bool rok = s0 + (li & 7) < S;
+        const int seg = (li >> 3) * 4 + kq;
+        f32x4 a4[CPW];
 #pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        const int k = (wave + c * NW) * 32 + kq * 8;
-        ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
-#ifdef EESEN_TRACE_FETCH  // experiment: make the fetch visible in the timeline (serialises fetch and MFMA in every workgroup)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      EESEN_STAMP(1);
-#endif
-#pragma unroll
-      for (int c = 0; c < CPW; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
+        for (int c = 0; c < CPW; ++c) {
+          const int k = (wave + c * NW) * 32 + seg * 4;
+          a4[c] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow8 + (unsigned)k * 4u : 0x80000000u, 0,
+                                                        EESEN_SC1_LOADS ? kSc1 : 0);
         }
+        __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          // row_ror:8 = lane i of a 16-lane row receives lane (i + 8) % 16
+          const float hi[4] = {ror8(a4[c][0]), ror8(a4[c][1]), ror8(a4[c][2]), ror8(a4[c][3])};
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][0], b[c][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][1], b[c][1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][2], b[c][2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[c][3], b[c][3], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[0], b[c][4], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[1], b[c][5], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[2], b[c][6], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[3], b[c][7], acc1, 0, 0, 0);
+        }
+      } else {
+        float a[CPW][8];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const int k = (wave + c * NW) * 32 + kq * 8;
+          ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
+          }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
