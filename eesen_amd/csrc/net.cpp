@@ -514,10 +514,12 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // Everything that only feeds the parameter gradients leaves the critical path: it runs on the side stream,
       // under the next layer's (latency-bound, mostly idle-chip) recurrence.
       hipStream_t sg = overlap ? st2 : st;
-      // 48 KB of unused dynamic LDS = at most ONE side-stream GEMM workgroup per CU, so that the next layer's cooperative
-      // recurrence kernel (one 512-thread workgroup on EVERY CU) never waits for long-running GEMM tiles to retire
-      // (measured, cfg2: 64.0 ms/step uncapped, 64.1 at two per CU, 62.0 at one per CU)
-      static const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : 48) * 1024;
+      // Unused dynamic LDS caps the side-stream GEMM's occupancy, so that the next layer's cooperative recurrence kernel (one
+      // 512-thread workgroup on EVERY CU) never waits for long-running GEMM tiles to retire.  32 KB = two GEMM workgroups per
+      // CU.  Measured on cfg2 (3 runs of 20 steps each, same box): uncapped 58.0, 48 KB (one per CU) 55.3, 32 KB 54.7 ms/step --
+      // with one per CU the side stream itself became the critical path (12 ms of gradient GEMMs per layer against 9 ms of
+      // recurrence + input-gradient GEMM); before the recurrence kernels overlapped fetch and MFMA the ranking was the reverse.
+      static const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : 32) * 1024;
       const int side_lds = overlap ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);
