@@ -60,6 +60,11 @@ SIGNATURES = {
     "eesen_ctc_stats": (_i, [_vp, _pd, _pl, _pl, _pl, _pl]),
     "eesen_ctc_get_alpha_beta": (_i, [_vp, _vp, _vp, _pi]),
     "eesen_ctc_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_feeder_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
+    "eesen_feeder_destroy": (_i, [_vp]),
+    "eesen_feeder_submit": (_i, [_vp, C.POINTER(_vp), _pi, _pi, _i, _i, _pi]),
+    "eesen_feeder_acquire": (_i, [_vp, _i, C.POINTER(_vp), _pi, _pi, _pi]),
+    "eesen_feeder_release": (_i, [_vp, _i]),
     "eesen_dev_alloc": (_i, [_i, _l, C.POINTER(_vp)]),
     "eesen_dev_free": (_i, [_i, _vp]),
     "eesen_dev_copy": (_i, [_i, _vp, _vp, _l, _i]),

@@ -7,6 +7,7 @@ Same names, argument meaning and error behaviour as the classes `train-ctc-paral
          Propagate, Backpropagate                      (/root/reference/src/net/net.h:48-161)
   Ctc  : EvalParallel, ErrorRateMSeq, Report, NumErrorTokens, NumRefTokens
                                                        (/root/reference/src/net/ctc-loss.h:40-63)
+  Feeder : device-side minibatch assembly (train-ctc-parallel.cc:186-195), double-buffered
   CuMatrix : a [rows x cols] fp32 device matrix with a stride, the stand-in for CuMatrix<BaseFloat>
                                                        (/root/reference/src/gpucompute/cuda-matrix.h)
 
@@ -320,6 +321,58 @@ class Ctc:
         out = np.zeros(3, np.float32)
         check(self.lib.eesen_ctc_get_phase_times(self.h, _np_ptr(out)))
         return dict(zip(["log", "alpha_beta", "error_diff"], out.tolist()))
+
+
+class Feeder:
+    """Device-side minibatch assembly, double-buffered (include/eesen_hip.h `eesen_feeder_*`; replaces the host padding +
+    interleave + blocking copy of /root/reference/src/netbin/train-ctc-parallel.cc:186-195).
+
+        slot = feeder.submit(mats)          # S host matrices [T_s x D]; returns at once, copy + interleave run async
+        feats = feeder.acquire(slot)        # CuMatrix view [T*S x D], row t*S + s; the compute stream waits on-device
+        out = net.Propagate(feats); feeder.release(slot)
+    """
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, slots: int = 2):
+        self.lib = _lib.load()
+        self.device = device
+        self.h = C.c_void_p()
+        check(self.lib.eesen_feeder_create(device, C.c_void_p(stream) if stream else None, slots, C.byref(self.h)))
+        self._dims = {}
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            try:
+                self.lib.eesen_feeder_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    def submit(self, mats: Sequence[np.ndarray]) -> int:
+        if not len(mats):
+            raise EesenError(-1, "empty minibatch")
+        mats = [m if (m.dtype == np.float32 and m.ndim == 2 and m.strides[1] == 4 and m.strides[0] % 4 == 0 and m.strides[0] >= 4 * m.shape[1])
+                else np.ascontiguousarray(m, np.float32) for m in mats]
+        D = mats[0].shape[1]
+        for m in mats:
+            if m.ndim != 2 or m.shape[1] != D:
+                raise EesenError(-1, f"feature dimension {m.shape[1] if m.ndim == 2 else m.shape} does not match {D}")
+        S = len(mats)
+        ptrs = (C.c_void_p * S)(*[m.ctypes.data for m in mats])
+        frames = np.array([m.shape[0] for m in mats], np.int32)
+        strides = np.array([m.strides[0] // 4 for m in mats], np.int32)
+        slot = C.c_int()
+        check(self.lib.eesen_feeder_submit(self.h, ptrs, frames.ctypes.data_as(C.POINTER(C.c_int)), strides.ctypes.data_as(C.POINTER(C.c_int)),
+                                           S, D, C.byref(slot)))
+        self._dims[slot.value] = D
+        return slot.value
+
+    def acquire(self, slot: int) -> CuMatrix:
+        p, T, S, ld = C.c_void_p(), C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.eesen_feeder_acquire(self.h, slot, C.byref(p), C.byref(T), C.byref(S), C.byref(ld)))
+        return CuMatrix.view(p.value, T.value * S.value, self._dims[slot], ld.value, self.device, keepalive=self)
+
+    def release(self, slot: int):
+        check(self.lib.eesen_feeder_release(self.h, slot))
 
 
 def train_step(net: Net, ctc: Ctc, batch, error_rate: bool = False) -> dict:

@@ -13,11 +13,13 @@ import numpy as np
 @dataclass
 class Minibatch:
     feats: np.ndarray            # [T*S x D] float32, time-major interleaved, zero beyond each utterance's length
+                                 # (None when assembled with interleaved=False: the device Feeder builds it from `mats`)
     lens: np.ndarray             # frame_num_utt, int32 [S]
     labels: List[np.ndarray]     # S int32 label vectors
     keys: List[str]
     T: int
     S: int
+    mats: List[np.ndarray] = None    # the S utterance matrices [T_s x D] (kept only with interleaved=False)
 
 
 @dataclass
@@ -41,7 +43,7 @@ def interleave(mats: List[np.ndarray], feat_dim: int) -> Tuple[np.ndarray, np.nd
 
 
 def assemble(features: Iterable[Tuple[str, np.ndarray]], targets: Dict[str, np.ndarray], num_sequence: int, frame_limit: float,
-             feat_dim: int, stats: AssemblyStats = None) -> Iterator[Minibatch]:
+             feat_dim: int, stats: AssemblyStats = None, interleaved: bool = True) -> Iterator[Minibatch]:
     """The while(1) loop of train-ctc-parallel.cc:144-183.  An utterance that does not fit the current group
     (new_max_len * (n + 1) > frame_limit) opens the next group (:170-172, the reader is not advanced); a full group
     (n == num_sequence) advances the reader and closes (:179-182)."""
@@ -78,9 +80,15 @@ def assemble(features: Iterable[Tuple[str, np.ndarray]], targets: Dict[str, np.n
             pending = None
             if len(mats) == num_sequence:
                 break
-        if mats:
+        if mats and interleaved:
             feats, lens, T = interleave(mats, feat_dim)
             yield Minibatch(feats=feats, lens=lens, labels=labs, keys=keys, T=T, S=len(mats))
+        elif mats:  # padding + interleave happen on the device (eesen_amd.api.Feeder)
+            for m in mats:
+                if m.shape[1] != feat_dim:
+                    raise ValueError(f"feature dimension {m.shape[1]} does not match the net's InputDim {feat_dim}")
+            lens = np.array([m.shape[0] for m in mats], np.int32)
+            yield Minibatch(feats=None, lens=lens, labels=labs, keys=keys, T=int(lens.max()), S=len(mats), mats=mats)
         elif not done and pending is not None:
             # a single utterance within frame_limit always fits an empty group, so this cannot loop
             raise RuntimeError("batch assembly made no progress")

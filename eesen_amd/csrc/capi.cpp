@@ -2,6 +2,7 @@
 // exceptions into a status code and a thread-local message; no exception leaves the library.
 #include <cstring>
 
+#include "guard.h"
 #include "net.h"
 
 using namespace eesen;
@@ -9,31 +10,16 @@ using namespace eesen;
 struct eesen_net : public Net { using Net::Net; };
 struct eesen_ctc : public Ctc { using Ctc::Ctc; };
 
-namespace {
-thread_local std::string g_err;
-
-template <class F>
-int guard(F f) {
-  try {
-    f();
-    return EESEN_OK;
-  } catch (const Error& e) {
-    g_err = e.what();
-    return e.code;
-  } catch (const std::exception& e) {
-    g_err = e.what();
-    return EESEN_ERR_INVALID;
-  } catch (...) {
-    g_err = "unknown failure";
-    return EESEN_ERR_INVALID;
-  }
+namespace eesen {
+std::string& last_error_slot() {
+  thread_local std::string g_err;
+  return g_err;
 }
-#define REQ_PTR(p) EESEN_REQUIRE((p) != nullptr, EESEN_ERR_INVALID, "null pointer argument")
-}  // namespace
+}  // namespace eesen
 
 extern "C" {
 
-const char* eesen_last_error(void) { return g_err.c_str(); }
+const char* eesen_last_error(void) { return last_error_slot().c_str(); }
 const char* eesen_version(void) { return "eesen_hip 0.1.0 (gfx950)"; }
 
 int eesen_device_count(int* count) {

@@ -93,7 +93,7 @@ def main(argv=None) -> int:
     target_model_filename = None if o.cross_validate else o.args[3]
     try:
         from eesen_amd import kaldi_io
-        from eesen_amd.api import Net, Ctc, CuMatrix, EesenError
+        from eesen_amd.api import Net, Ctc, CuMatrix, EesenError, Feeder
         from eesen_amd.batching import assemble, AssemblyStats
 
         world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,10 +126,20 @@ def main(argv=None) -> int:
         t0 = time.time()
         num_done, total_frames, seq_since_report = 0, 0, 0
         obj_prog = err_prog = ref_prog = 0.0
-        batches = _prefetch(assemble(kaldi_io.read_mat_table(feature_rspecifier), targets, o.num_sequence, o.frame_limit, feat_dim, stats))
+        # the reader thread parses the archives; padding + interleave + H2D of batch n+1 run on the device feeder's own
+        # stream while batch n trains (the reference pads on the host and copies synchronously, train-ctc-parallel.cc:186-198)
+        batches = _prefetch(assemble(kaldi_io.read_mat_table(feature_rspecifier), targets, o.num_sequence, o.frame_limit, feat_dim, stats,
+                                     interleaved=False))
+        feeder = Feeder(dev, slots=2)
+
+        def stage():
+            b = next(batches, None)
+            return (b, feeder.submit(b.mats)) if b is not None else (None, -1)
+
         diff = None
+        staged = stage()
         while True:
-            mb = next(batches, None)
+            mb, slot = staged
             if dist is not None:     # ranks may hold different numbers of minibatches: keep stepping until all are done
                 import torch
                 flag = torch.tensor([1.0 if mb is not None else 0.0], device=f"cuda:{local}")
@@ -140,13 +150,15 @@ def main(argv=None) -> int:
                 break
             if mb is not None:
                 net.SetSeqLengths(mb.lens)
-                net_out = net.Propagate(mb.feats)
+                net_out = net.Propagate(feeder.acquire(slot))
+                feeder.release(slot)
                 if diff is None or diff.rows != net_out.rows:
                     diff = CuMatrix(net_out.rows, net_out.cols, dev, zero=False)
                 ctc.EvalParallel(mb.lens, net_out, mb.labels, diff)
                 ne, nr = ctc.ErrorRateMSeq(mb.lens, net_out, mb.labels)
                 if not o.cross_validate:
                     net.Backpropagate(diff)
+                staged = stage()                     # next batch: staged while the GPU runs this one's backward pass
                 num_done += mb.S
                 total_frames += mb.T * mb.S          # padded frames, as the reference counts them (:215)
                 obj_prog += float(ctc.pzx.sum()); err_prog += ne; ref_prog += nr; seq_since_report += mb.S
@@ -162,6 +174,7 @@ def main(argv=None) -> int:
                 grad_tensor(net).zero_()
                 net.grad_hook(net)
                 net.Update()
+                staged = stage()
         for w in stats.warnings:
             log(w, "WARNING")
         net.Synchronize()

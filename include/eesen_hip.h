@@ -157,6 +157,25 @@ int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_ho
 /* seconds of the last EvalParallel's device work (HIP events): out[0]=log, [1]=alpha/beta sweep, [2]=error+jacobian */
 int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3);
 
+/* ---- minibatch assembly on the device (row a1) ---------------------------------------------------
+ * Replaces the host-side padding + interleave + blocking H2D of src/netbin/train-ctc-parallel.cc:186-195: the S utterance
+ * matrices are packed back to back into a pinned staging slot (no padding crosses PCIe), copied on the feeder's own
+ * stream, and a kernel writes the zero-padded time-major matrix (row t*S + s, leading dimension ld = D rounded up to 4)
+ * in HBM.  `slots` staging slots rotate: submit() of batch n+1 overlaps the training step of batch n.
+ *   submit : host pointers utts[s] -> [frames[s] x D] row-major, row stride strides[s] floats (strides == NULL: D).
+ *            Asynchronous; blocks only if the slot being reused is still in flight / not yet released.
+ *   acquire: makes `compute_stream` wait (on the device) for the slot; returns the assembled device matrix.  The
+ *            pointer stays valid until the slot is submitted again.
+ *   release: call after the last consumer of the slot has been ENQUEUED on compute_stream (eesen_net_propagate copies
+ *            its input, so right after it). */
+typedef struct eesen_feeder eesen_feeder_t;
+int eesen_feeder_create(int device, void* compute_stream, int slots, eesen_feeder_t** out);
+int eesen_feeder_destroy(eesen_feeder_t* f);
+int eesen_feeder_submit(eesen_feeder_t* f, const float* const* utts, const int* frames, const int* strides, int S, int D,
+                        int* slot);
+int eesen_feeder_acquire(eesen_feeder_t* f, int slot, float** feats_dev, int* T, int* S, int* ld);
+int eesen_feeder_release(eesen_feeder_t* f, int slot);
+
 /* ---- raw device helpers for hosts that own no GPU allocator --------------------------------- */
 int eesen_dev_alloc(int device, long bytes, void** dev_ptr);
 int eesen_dev_free(int device, void* dev_ptr);
