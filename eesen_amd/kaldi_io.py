@@ -8,8 +8,12 @@ Host-side data loading for the CLI mirror (eesen_amd/train_ctc_parallel.py); for
   * int32 vector (BasicVectorHolder, src/util/kaldi-holder-inl.h:190-260): binary = sized int32 count, then every
     element as a sized int32; text = `1 2 3\\n`;
   * script files: `key path[:byte_offset]` per line, the offset pointing at the object (src/util/kaldi-table.h).
-Supported specifiers: `ark:path`, `ark,t:path`, `scp:path`, and `ark:-` for stdin.  Compressed matrices (`CM`), pipes
-and double-precision matrices are outside the hot path and raise.
+  * compressed float matrix (`copy-feats --compress=true`, src/cpucompute/compressed-matrix.cc:437-470): token `CM `
+    (one byte per element, per-column 16-bit percentile header) or `CM2 ` (uint16 per element) + GlobalHeader without its
+    format field {float min_value, float range, int32 rows, int32 cols}; decoded here with the reference's own fp32/fp64
+    expression order (`Uint16ToFloat` :244-250, `CharToFloat` :363-373) -- bit-exact against its CopyToMat (tests).
+Supported specifiers: `ark:path`, `ark,t:path`, `scp:path`, and `ark:-` for stdin.  Pipes and double-precision matrices
+are outside the hot path and raise.
 """
 from __future__ import annotations
 
@@ -61,12 +65,51 @@ def _read_sized_int(f: BinaryIO) -> int:
     return struct.unpack("<i", b[1:])[0]
 
 
+def _u16_to_float(min_value: np.float32, rng: np.float32, v: np.ndarray) -> np.ndarray:
+    """CompressedMatrix::Uint16ToFloat (compressed-matrix.cc:244-250): min + range * (1/65535)f * value, all in fp32, left to right."""
+    return (np.float32(min_value) + (np.float32(rng) * np.float32(1.52590218966964e-05)) * v.astype(np.float32)).astype(np.float32)
+
+
+def _read_compressed(f: BinaryIO, fmt: int) -> np.ndarray:
+    """CompressedMatrix::Read + CopyToMat (compressed-matrix.cc:437-470, 485-520)."""
+    hdr = f.read(16)
+    if len(hdr) != 16:
+        raise KaldiIOError("truncated compressed-matrix header")
+    min_value, rng = np.frombuffer(hdr, "<f4", 2)
+    rows, cols = (int(x) for x in np.frombuffer(hdr, "<i4", 2, 8))
+    if cols == 0:
+        return np.zeros((0, 0), np.float32)
+    if fmt == 2:
+        buf = f.read(2 * rows * cols)
+        if len(buf) != 2 * rows * cols:
+            raise KaldiIOError("truncated compressed matrix")
+        return _u16_to_float(min_value, rng, np.frombuffer(buf, "<u2").reshape(rows, cols))
+    buf = f.read(cols * (8 + rows))
+    if len(buf) != cols * (8 + rows):
+        raise KaldiIOError("truncated compressed matrix")
+    pc = _u16_to_float(min_value, rng, np.frombuffer(buf, "<u2", 4 * cols).reshape(cols, 4))   # percentiles 0, 25, 75, 100 per column
+    v = np.frombuffer(buf, np.uint8, rows * cols, 8 * cols).reshape(cols, rows)                # column-major bytes
+    p0, p25, p75, p100 = (pc[:, i:i + 1] for i in range(4))
+    vf = v.astype(np.float32)
+
+    def seg(lo, hi, x, scale):      # float diff * float value -> fp32; * double constant and + lo in fp64; rounded once to fp32
+        return (lo.astype(np.float64) + ((hi - lo).astype(np.float32) * x).astype(np.float32).astype(np.float64) * scale).astype(np.float32)
+
+    out = np.where(v <= 64, seg(p0, p25, vf, 1 / 64.0),
+                   np.where(v <= 192, seg(p25, p75, vf - np.float32(64), 1 / 128.0), seg(p75, p100, vf - np.float32(192), 1 / 63.0)))
+    return np.ascontiguousarray(out.T, np.float32)
+
+
 def _read_matrix(f: BinaryIO) -> np.ndarray:
     hdr = f.read(2)
     if hdr == b"\x00B":
         tok = f.read(3)
-        if tok == b"CM " or tok[:2] == b"CM":
-            raise KaldiIOError("compressed matrices (CM) are not supported; run copy-feats --compress=false")
+        if tok == b"CM ":
+            return _read_compressed(f, 1)
+        if tok == b"CM2":
+            if f.read(1) != b" ":
+                raise KaldiIOError("malformed CM2 token")
+            return _read_compressed(f, 2)
         if tok == b"DM ":
             raise KaldiIOError("double-precision matrices are not supported (the path is BaseFloat = float)")
         if tok != b"FM ":

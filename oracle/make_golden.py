@@ -13,6 +13,7 @@ src/net/Makefile:10), so these outputs of the reference code are the pin.
 from __future__ import annotations
 
 import os
+import sys
 import tempfile
 
 import numpy as np
@@ -55,9 +56,33 @@ def make_case(name: str, spec: dict) -> dict:
                 in_diff=in_diff, params_after=after, errors=np.array([ne, nr], np.int64))
 
 
+def compressed_feature_case():
+    """A compressed feature archive written by the reference's own CompressedMatrixWriter (`CM` for > 8 rows, `CM2` below,
+    /root/reference/src/cpucompute/compressed-matrix.cc:41-110) plus what its CopyToMat decodes: pins eesen_amd.kaldi_io."""
+    import ctypes as C
+    lib = refbind._load()
+    rng = np.random.default_rng(11)
+    mats = [(f"utt{i}", (rng.standard_normal((r, 6)) * (1 + i)).astype(np.float32) + np.float32(i)) for i, r in enumerate([23, 5, 9, 8, 1, 40])]
+    mats.append(("const", np.full((12, 6), 2.5, np.float32)))          # zero range: the header's percentile spacing rules kick in
+    n = len(mats)
+    keys = (C.c_char_p * n)(*[k.encode() for k, _ in mats])
+    ptrs = (C.c_void_p * n)(*[m.ctypes.data for _, m in mats])
+    rows = (C.c_int * n)(*[m.shape[0] for _, m in mats])
+    decoded = np.zeros((sum(m.shape[0] for _, m in mats), 6), np.float32)
+    path = os.path.join(OUT, "compressed_feats.ark")
+    lib.ref_write_compressed_feats.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    assert lib.ref_write_compressed_feats(("ark:" + path).encode(), n, keys, ptrs, rows, 6, decoded.ctypes.data_as(C.c_void_p)) == 0
+    np.savez_compressed(os.path.join(OUT, "compressed_feats.npz"), decoded=decoded, rows=np.array([m.shape[0] for _, m in mats], np.int32),
+                        keys=np.array([k for k, _ in mats]), original=np.concatenate([m for _, m in mats]))
+    print("compressed_feats", decoded.shape, os.path.getsize(path), "bytes")
+
+
 def main():
     assert refbind.build_if_possible(), "oracle/_ref could not be built (needs /root/reference)"
     os.makedirs(OUT, exist_ok=True)
+    compressed_feature_case()
+    if "--compressed-only" in sys.argv:
+        return
     for name, spec in CASES.items():
         d = make_case(name, spec)
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **d)

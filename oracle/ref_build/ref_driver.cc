@@ -21,6 +21,7 @@
 #include "net/ctc-loss.h"
 #include "net/train-opts.h"
 #include "cpucompute/matrix.h"
+#include "cpucompute/compressed-matrix.h"
 #include "gpucompute/cuda-matrix.h"
 #include "util/kaldi-table.h"
 #include "util/kaldi-holder.h"
@@ -220,6 +221,27 @@ int ref_read_feats_summary(const char* rspecifier, int* n_utts, long* total_rows
   }
   *n_utts = n; *total_rows = rows; *checksum = cs;
   if (keys_out && keys_cap > 0) { strncpy(keys_out, keys.c_str(), keys_cap - 1); keys_out[keys_cap - 1] = 0; }
+  return 0;
+  REF_CATCH(-1)
+}
+
+// Compressed feature archives (what `copy-feats --compress=true` writes): the reference's CompressedMatrix does the lossy
+// encoding AND tells us what its own CopyToMat decodes, so our reader can be pinned bit-exactly against it.
+// `decoded` [sum rows x cols] receives the reference's decompression of every matrix, back to back.
+int ref_write_compressed_feats(const char* wspecifier, int n, const char** keys, const float** mats, const int* rows, int cols,
+                               float* decoded) {
+  REF_TRY
+  CompressedMatrixWriter w(wspecifier);
+  size_t o = 0;
+  for (int i = 0; i < n; i++) {
+    Matrix<BaseFloat> m(rows[i], cols, kUndefined);
+    for (int r = 0; r < rows[i]; r++) memcpy(m.RowData(r), mats[i] + (size_t)r * cols, sizeof(float) * cols);
+    CompressedMatrix cm(m);
+    w.Write(keys[i], cm);
+    Matrix<BaseFloat> back(rows[i], cols, kUndefined);
+    cm.CopyToMat(&back);
+    for (int r = 0; r < rows[i]; r++, o += cols) memcpy(decoded + o, back.RowData(r), sizeof(float) * cols);
+  }
   return 0;
   REF_CATCH(-1)
 }

@@ -108,3 +108,39 @@ def test_every_utterance_lands_in_exactly_one_group():
         mbs = list(assemble(iter(feats), labs, ns, fl, 5))
         assert [k for mb in mbs for k in mb.keys] == [k for k, _ in feats]
         assert all(mb.S <= ns and mb.T * mb.S <= fl for mb in mbs)
+
+
+def test_compressed_feature_archive_golden():
+    """`CM` / `CM2` archives (copy-feats --compress=true): the fixture was written by the reference's CompressedMatrixWriter and
+    carries the reference's own CopyToMat output (oracle/make_golden.py compressed_feature_case); our reader must decode the
+    same bits."""
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    ref = np.load(os.path.join(g, "compressed_feats.npz"))
+    got = list(kaldi_io.read_mat_table("ark:" + os.path.join(g, "compressed_feats.ark")))
+    assert [k for k, _ in got] == list(ref["keys"])
+    o = 0
+    for (_, m), r in zip(got, ref["rows"]):
+        assert m.dtype == np.float32 and m.shape == (r, 6)
+        assert np.array_equal(m, ref["decoded"][o:o + r])
+        # lossy but close: one byte per element over the column's range
+        orig = ref["original"][o:o + r]
+        assert np.abs(m - orig).max() <= 0.02 * max(1e-3, float(np.ptp(orig)))
+        o += r
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+def test_compressed_feature_archive_against_reference(tmp_path):
+    lib = refbind._load()
+    rng = np.random.default_rng(21)
+    mats = [(f"k{i}", (rng.standard_normal((r, 40)) * 3).astype(np.float32)) for i, r in enumerate([300, 7, 64, 2])]
+    n = len(mats)
+    keys = (C.c_char_p * n)(*[k.encode() for k, _ in mats])
+    ptrs = (C.c_void_p * n)(*[m.ctypes.data for _, m in mats])
+    rows = (C.c_int * n)(*[m.shape[0] for _, m in mats])
+    decoded = np.zeros((sum(m.shape[0] for _, m in mats), 40), np.float32)
+    path = str(tmp_path / "c.ark")
+    lib.ref_write_compressed_feats.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    assert lib.ref_write_compressed_feats(("ark:" + path).encode(), n, keys, ptrs, rows, 40, decoded.ctypes.data_as(C.c_void_p)) == 0
+    got = np.concatenate([m for _, m in kaldi_io.read_mat_table("ark:" + path)])
+    assert np.array_equal(got, decoded)
