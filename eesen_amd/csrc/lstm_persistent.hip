@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     }
     EESEN_STAMP(3);
     {  // published after EVERY step: the last one is what a gated GEMM of the next layer waits for
-      if (tid < 128) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+      if (tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (ST * UB is a multiple of 64)
       __syncthreads();                                                 // (also fences `red` for the next step)
       EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
     }
   }
-  const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);  // DG is at most rows * ldG * 4 bytes < 2 GB (checked on the host)
+  // buffer resources are re-based on the time step's row block every step, so the 32-bit offsets only span one block
+  // (S * ldG * 4 bytes, checked on the host) whatever T is
 
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
-      const size_t arow = ((size_t)(tn * S + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row
+      const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG + (size_t)tn * S * ldG);
+      const size_t arow = ((size_t)sa * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row in block tn
       if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
         // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
         // load: lane (li, kq) reads 16 bytes of sequence li & 7 at segment (li >> 3) * 4 + kq of the 128-byte chunk -- one
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         // second request of a line occupies the L1 miss queue like the first; measured -740 ticks per step).  The upper
         // half of the chunk reaches rows 0-7 through a rotate-by-8 DPP move inside each 16-lane row; rows 8-15 of the
         // product are garbage that nobody reads.
-        const unsigned arow8 = (unsigned)(((size_t)(tn * S + s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
+        const unsigned arow8 = (unsigned)(((size_t)(s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
         const bool rok = s0 + (li & 7) < S;
         const int seg = (li >> 3) * 4 + kq;
         f32x4 a4[CPW];
@@ -395,20 +397,26 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[3], b[c][7], acc1, 0, 0, 0);
         }
       } else {
-        float a[CPW][8];
+        // at most 8 chunks (64 registers) of operands in flight: K = 4H = 4096 (H = 1024) takes two rounds
+        constexpr int CH = CPW > 8 ? 8 : CPW;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-          const int k = (wave + c * NW) * 32 + kq * 8;
-          ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+        for (int h = 0; h < CPW; h += CH) {
+          float a[CH][8];
 #pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
+          for (int c = 0; c < CH; ++c) {
+            const int k = (wave + (h + c) * NW) * 32 + kq * 8;
+            ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
           }
+          __builtin_amdgcn_sched_barrier(0);  // all loads of the round in flight BEFORE its first MFMA
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[h + c][j], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[h + c][j + 1], acc1, 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 #pragma unroll
@@ -430,9 +438,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       float carry = dc * f;
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
-      const unsigned ooff = (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4);
-      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
-      else __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
+      const __amdgpu_buffer_rsrc_t rOut = make_rsrc(DG + (size_t)t * S * ldG);
+      const unsigned ooff = (unsigned)(((size_t)s_e * ldG + gcol) * 4);
+      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rOut, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
+      else __builtin_amdgcn_raw_buffer_store_b128(out, rOut, ooff, 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
     EESEN_STAMP(3);
@@ -486,28 +495,42 @@ static int l2_local() {
 }
 
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
-static bool fwd_tile16(const LstmLayerDev& L) {
-  // 16 sequences x 8 units per workgroup when the shape allows it (half the m_{t-1} fetch per CU), else 32 x 4
+// Forward tile (sequences x hidden units per workgroup), chosen so that every CU gets ONE workgroup where the shape allows:
+//   32 x 4  <MT=2, NT=1>: the decomposition of lstm_fwd_step_kernel (any H)
+//   16 x 8  <MT=1, NT=2>: half the m_{t-1} fetch per CU; 256 workgroups at H = 512, S = 32
+//   16 x 16 <MT=1, NT=4>: for wide layers (H = 1024: 16 x 8 would need 512 co-resident workgroups); 64 gate rows of W_m
+//                         (256 KB at H = 1024) live in the registers of one workgroup
+struct FwdTile { int mt, nt; };
+static FwdTile fwd_tile(const LstmLayerDev& L) {
   static const int force_tile = getenv("EESEN_FWD_SEQ_TILE") ? atoi(getenv("EESEN_FWD_SEQ_TILE")) : 0;
   const int need = ((L.H + 31) / 32 + NW - 1) / NW;
-  return force_tile ? force_tile == 16 : (L.H % 8 == 0 && L.S > 16 && need <= 2);
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (force_tile == 32) return {2, 1};
+  const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || force_tile == 16);
+  if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > ncu)) return {1, 4};
+  if (t16_ok && need <= 2) return {1, 2};
+  return {2, 1};
 }
 
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz) {
-  const bool t16 = fwd_tile16(L);
-  *nblk = t16 ? L.H / 8 : L.H / 4;
-  *nz = cdiv(L.S, t16 ? 16 : 32);
+  const FwdTile ft = fwd_tile(L);
+  *nblk = L.H / (4 * ft.nt);
+  *nz = cdiv(L.S, 16 * ft.mt);
 }
 
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace, hipEvent_t after_reset) {
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
-  const bool t16 = fwd_tile16(L);
-  dim3 grid(t16 ? L.H / 8 : L.H / 4, L.ndir, cdiv(L.S, t16 ? 16 : 32)), block(NW * 64);
+  const FwdTile ft = fwd_tile(L);
+  dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.S, 16 * ft.mt)), block(NW * 64);
   const dim3 grid1(grid.x * grid.y * grid.z);
   const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
-  if (need > 4 || (t16 && need > 2) || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+  if (need > 4 || (ft.nt == 2 && need > 2) || L.H % (4 * ft.nt) != 0 || L.T < 2 ||
+      (size_t)grid.y * grid.z * kShards * kShardStride > 8192)
+    return false;
   // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
   // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
   // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
@@ -520,7 +543,11 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
     if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, NW * 64)) return false;                    \
     coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT>, grid1, block, L, cnt, err, spin_limit, trace, role); \
   } while (0)
-  if (t16) {
+  if (ft.nt == 4) {
+    if (need <= 1) EESEN_FP(1, 1, 4);
+    else if (need <= 2) EESEN_FP(2, 1, 4);
+    else EESEN_FP(4, 1, 4);
+  } else if (ft.nt == 2) {
     if (need <= 1) EESEN_FP(1, 1, 2);
     else EESEN_FP(2, 1, 2);
   } else {
@@ -549,8 +576,8 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   const dim3 grid1(grid.x * grid.y * grid.z);
   const int ngroups = (int)(grid.y * grid.z);
   const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
-  if (need > 8 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
-  if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets
+  if (need > 16 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
+  if ((size_t)L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 30)) return false;  // 32-bit buffer offsets within one time step's row block
   if (((size_t)L.S * L.ndir * 4 * L.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
@@ -562,7 +589,8 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   if (need <= 1) EESEN_BP(1);
   else if (need <= 2) EESEN_BP(2);
   else if (need <= 4) EESEN_BP(4);
-  else EESEN_BP(8);
+  else if (need <= 8) EESEN_BP(8);
+  else EESEN_BP(16);
 #undef EESEN_BP2
 #undef EESEN_BP
   return true;
