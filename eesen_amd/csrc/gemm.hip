@@ -246,6 +246,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
   gemm_body<true, true, false, true>(p, As, Bs);
 }
 
+// Interference probes (EESEN_GEMM_SYNTH=1|2|3, side-stream launches only; results are garbage, timing experiments only):
+// a stand-in with the GEMM's grid, occupancy and pacing that exercises ONE resource -- 1: the matrix pipe (32 MFMAs per
+// k-tile on registers, no memory), 2: the global-load path (the GEMM's tile loads, then sleeps for the MFMA time),
+// 3: LDS (the GEMM's LDS stores + reads, then sleeps).  Used to find what a co-running GEMM takes from the recurrence.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_synth_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LDP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int tile = blockIdx.x, m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int kbeg = blockIdx.y * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk), nk = (kend - kbeg + BK - 1) / BK;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float keep = 0.f;
+  float4 ra[NLD], rb[NLD];
+  for (int i = 0; i < NLD; ++i) ra[i] = rb[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const float a0 = (float)lane, b0 = (float)kk;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[1][1], 0, 0, 0);
+      }
+    } else if (MODE == 2) {
+      load_tile<false, true>(p.A, p.lda, p.M, m0, kbeg + kt * BK, kend, tid, ra);
+      load_tile<false, true>(p.B, p.ldb, p.N, n0, kbeg + kt * BK, kend, tid, rb);
+      for (int i = 0; i < NLD; ++i) keep += ra[i].x + rb[i].w;
+      __builtin_amdgcn_s_sleep(32);  // ~2048 cycles: the k-tile's MFMA time
+    } else {
+      store_tile<false>(As[kt & 1], tid, ra);
+      store_tile<false>(Bs[kt & 1], tid, rb);
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) keep += As[kt & 1][kk][lane] + As[kt & 1][kk][64 + lane] + Bs[kt & 1][kk][lane] + Bs[kt & 1][kk][64 + lane];
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+  if (keep == 12345.678f) p.C[0] = keep;  // never true: keeps the work alive
+}
+
 // C = alpha * sum_s ws[s] + beta * C + bias
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N,
                                                             float alpha, float beta, float* __restrict__ C, int ldc,
@@ -301,7 +345,12 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
-  if (a_kc && b_kc) EESEN_GEMM_LAUNCH(true, true);
+  static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
+  if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
+    if (synth == 1) hipLaunchKernelGGL(gemm_synth_kernel<1>, grid, block, extra_lds_bytes, st, p);
+    else if (synth == 2) hipLaunchKernelGGL(gemm_synth_kernel<2>, grid, block, extra_lds_bytes, st, p);
+    else hipLaunchKernelGGL(gemm_synth_kernel<3>, grid, block, extra_lds_bytes, st, p);
+  } else if (a_kc && b_kc) EESEN_GEMM_LAUNCH(true, true);
   else if (a_kc && !b_kc) EESEN_GEMM_LAUNCH(true, false);
   else if (!a_kc && b_kc) EESEN_GEMM_LAUNCH(false, true);
   else EESEN_GEMM_LAUNCH(false, false);
