@@ -30,6 +30,16 @@ _DROPOUT_TOKENS = [  # bilstm-layer.h:331-373, in this fixed order; (token, kind
     ("<RecurrentTimeStepDropout>", "b"), ("<RecurrentSequenceDropout>", "b"), ("<RNNDrop>", "b"),
     ("<NoMemLossDropout>", "b"), ("<RecurrentDropoutFactor>", "f"), ("<TwiddleForward>", "b"),
 ]
+# keys of a layer's optional "dropout" dict, in token order (all default to 0 / False)
+DROPOUT_KEYS = ["forward", "fw_step", "fw_seq", "rec_step", "rec_seq", "rnndrop", "nml", "recurrent", "twiddle"]
+
+
+def dropout_values(L: dict) -> list:
+    d = L.get("dropout") or {}
+    unknown = set(d) - set(DROPOUT_KEYS)
+    if unknown:
+        raise ValueError(f"unknown dropout option(s) {sorted(unknown)}")
+    return [float(d.get(k, 0.0)) if kind == "f" else bool(d.get(k, False)) for k, (_, kind) in zip(DROPOUT_KEYS, _DROPOUT_TOKENS)]
 
 
 _ACCU_TOKEN = {"BiLstmParallel": "<BiLstmAccus>", "BiLstm": "<BiLstmAccus>", "LstmParallel": "<LstmAccus>", "Lstm": "<LstmAccus>",
@@ -106,10 +116,10 @@ def write_nnet(path: str, layers: List[dict], binary: bool = False, write_dropou
                     f.write(b"<LearnRateCoef> "); _wf(f, L.get("learn_rate_coef", 1.0))
                     f.write(b"<MaxGrad> "); _wf(f, L.get("max_grad", 0.0))
                     if t.startswith("BiLstm") and write_dropout_tokens:
-                        for tok, kind in _DROPOUT_TOKENS:
+                        for (tok, kind), v in zip(_DROPOUT_TOKENS, dropout_values(L)):
                             f.write(tok.encode() + b" ")
-                            if kind == "f": _wf(f, 0.0)
-                            else: f.write(b"F")
+                            if kind == "f": _wf(f, v)
+                            else: f.write(b"T" if v else b"F")
                     if L.get("accu") is not None:
                         f.write(_ACCU_TOKEN[t].encode() + b" ")
                         for a in L["accu"]:
@@ -126,8 +136,8 @@ def write_nnet(path: str, layers: List[dict], binary: bool = False, write_dropou
             if param_shapes(t, L["input_dim"], L["output_dim"]):
                 f.write(f"<LearnRateCoef> {_fmt(L.get('learn_rate_coef', 1.0))} <MaxGrad> {_fmt(L.get('max_grad', 0.0))} ")
                 if t.startswith("BiLstm") and write_dropout_tokens:
-                    for tok, kind in _DROPOUT_TOKENS:
-                        f.write(tok + (" 0 " if kind == "f" else " F "))
+                    for (tok, kind), v in zip(_DROPOUT_TOKENS, dropout_values(L)):
+                        f.write(tok + (f" {_fmt(v)} " if kind == "f" else (" T " if v else " F ")))
                 if L.get("accu") is not None:
                     f.write(_ACCU_TOKEN[t] + " ")
                     for a in L["accu"]:
@@ -237,7 +247,7 @@ def read_nnet(path: str) -> List[dict]:
                     else:
                         v = r.bool() if binary else (r.token() == "T")
                     if v:
-                        raise ValueError(f"dropout option {tk} is set; dropout variants are out of scope")
+                        L.setdefault("dropout", {})[DROPOUT_KEYS[[t for t, _ in _DROPOUT_TOKENS].index(tk)]] = v
                 elif tk in ("<BiLstmAccus>", "<LstmAccus>", "<AffineAccus>"):
                     # Adagrad / RMSProp accumulators precede the weights (bilstm-layer.h:376-395, affine-trans-layer.h:99-106)
                     L["accu"] = [r.tensor(sh) for sh in shapes]

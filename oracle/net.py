@@ -38,6 +38,7 @@ class OracleNet:
         for L in layers:
             self.layers.append(dict(type=L["type"], din=L["input_dim"], dout=L["output_dim"],
                                     coef=float(L.get("learn_rate_coef", 1.0)), max_grad=float(L.get("max_grad", 0.0)),
+                                    dropout=dict(L.get("dropout") or {}),
                                     params=[np.array(p, dtype=self.dt, order="C") for p in L["params"]]))
         for L in self.layers:
             L["corr"] = [np.zeros_like(p) for p in L["params"]]     # zeroed at Read (bilstm-layer.h:405-410)
@@ -49,6 +50,30 @@ class OracleNet:
         self.momentum = 0.0
         self.lens = None
         self.bufs = None
+        self.in_train = True       # BiLstm::in_train defaults to true (bilstm-layer.h:38)
+        self.masks = {}            # layer index -> dict(fwd=[T*S x 2H], rec_fw/rec_bw=[(T+2)*S or S x H], twiddle_apply_forward)
+
+    # -- dropout ---------------------------------------------------------------
+    def set_mode(self, train: bool):
+        """Net::SetTrainMode / SetTestMode (net.cc:396-412)."""
+        self.in_train = bool(train)
+
+    def set_dropout_masks(self, layer: int, fwd=None, rec_fw=None, rec_bw=None, twiddle_apply_forward: bool = False):
+        """The masks the reference would draw from its host RNG (bilstm-parallel-layer.h:46-94) are INPUTS here."""
+        cv = lambda a: None if a is None or not np.size(a) else np.ascontiguousarray(a, self.dt)
+        self.masks[layer] = dict(fwd=cv(fwd), rec_fw=cv(rec_fw), rec_bw=cv(rec_bw), twiddle_apply_forward=bool(twiddle_apply_forward))
+
+    def _dropout_plan(self, li: int):
+        """(drop_mode, forward_dropout?) for layer li in the current mode: bilstm-parallel-layer.h:385-390."""
+        o = self.layers[li]["dropout"]
+        if not o or not self.in_train:
+            return 0, False
+        tw = bool(o.get("twiddle", False))
+        coin = self.masks.get(li, {}).get("twiddle_apply_forward", False)
+        rec = (o.get("rnndrop", False) or o.get("nml", False)) and (not tw or not coin)
+        fwd = o.get("forward", 0.0) > 0.0 and (not tw or coin)
+        mode = 0 if not rec else (2 if o.get("rnndrop", False) else 1)
+        return mode, bool(fwd)
 
     # -- reference API mirror -------------------------------------------------------------------
     def set_train_options(self, learn_rate: float, momentum: float):
@@ -67,20 +92,28 @@ class OracleNet:
         S = len(self.lens); rows = feats.shape[0]; T = rows // S
         x = np.ascontiguousarray(feats, self.dt)
         self.acts = [x]; self.state = []
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             t = L["type"]
             if t in ("BiLstmParallel", "LstmParallel"):
                 ndir = 2 if t == "BiLstmParallel" else 1
                 H = L["dout"] // ndir
                 out = np.zeros((rows, L["dout"]), self.dt)
                 bufs = []
+                mode, fwd_drop = self._dropout_plan(li)
+                mk = self.masks.get(li, {})
+                step = bool(L["dropout"].get("rec_step", False))
                 for d in range(ndir):
                     Wx, Wm, b, pi, pf, po = L["params"][6 * d: 6 * d + 6]
                     buf = np.empty(((T + 2) * S, 7 * H), self.dt)
+                    rm = (mk.get("rec_bw") if d else mk.get("rec_fw")) if mode else None
+                    assert not mode or (rm is not None and rm.shape == (((T + 2) * S if step else S), H)), "recurrent dropout needs its masks"
                     self.lib.orc_lstm_dir_forward(T, S, L["din"], H, d, _p(self.lens), _p(x), _p(Wx), _p(Wm), _p(b),
-                                                  _p(pi), _p(pf), _p(po), _p(buf))
+                                                  _p(pi), _p(pf), _p(po), _p(buf), _p(rm), int(step), mode)
                     out[:, d * H:(d + 1) * H] = buf[S:(T + 1) * S, 6 * H:7 * H]   # bilstm-parallel-layer.h:409-419
                     bufs.append(buf)
+                if fwd_drop:                                                        # :414-417
+                    assert mk.get("fwd") is not None and mk["fwd"].shape == out.shape, "forward dropout needs its mask"
+                    out = out * mk["fwd"]
                 self.state.append(bufs)
             elif t == "AffineTransform":
                 out = np.empty((rows, L["dout"]), self.dt)
@@ -108,13 +141,19 @@ class OracleNet:
             if t in ("BiLstmParallel", "LstmParallel"):
                 ndir = 2 if t == "BiLstmParallel" else 1
                 H = L["dout"] // ndir
+                mode, fwd_drop = self._dropout_plan(li)
+                mk = self.masks.get(li, {})
+                step = bool(L["dropout"].get("rec_step", False))
+                if fwd_drop:
+                    d = np.ascontiguousarray(d * mk["fwd"])                          # out_diff_drop, :892-896
                 for dd in range(ndir):
                     Wx, Wm, b, pi, pf, po = L["params"][6 * dd: 6 * dd + 6]
                     cWx, cWm, cb, cpi, cpf, cpo = L["corr"][6 * dd: 6 * dd + 6]
                     dbuf = np.empty(((T + 2) * S, 7 * H), self.dt)
+                    rm = (mk.get("rec_bw") if dd else mk.get("rec_fw")) if mode else None
                     self.lib.orc_lstm_dir_backward(T, S, L["din"], H, dd, _p(x), _p(self.state[li][dd]), _p(d), L["dout"], dd * H,
                                                    _p(Wx), _p(Wm), _p(pi), _p(pf), _p(po), _p(dbuf), _p(in_diff), dd, mmt,
-                                                   _p(cWx), _p(cWm), _p(cb), _p(cpi), _p(cpf), _p(cpo))
+                                                   _p(cWx), _p(cWm), _p(cb), _p(cpi), _p(cpf), _p(cpo), _p(rm), int(step), mode)
             elif t == "AffineTransform":
                 self.lib.orc_affine_backward(rows, L["din"], L["dout"], _p(d), _p(L["params"][0]), _p(in_diff))
                 # gradients are computed inside Update in the reference (affine-trans-layer.h:182-183)

@@ -19,6 +19,8 @@
 
 #include "net/net.h"
 #include "net/ctc-loss.h"
+#include "net/bilstm-layer.h"
+#include "net/bilstm-parallel-layer.h"
 #include "net/train-opts.h"
 #include "cpucompute/matrix.h"
 #include "cpucompute/compressed-matrix.h"
@@ -181,6 +183,46 @@ int ref_ctc_error_rate_mseq(void* p, const float* net_out, int T, int S, int K, 
   h->ctc.ErrorRateMSeq(lens, cout, labels, out_file);
   *num_err = h->ctc.NumErrorTokens() - e0;
   *num_ref = h->ctc.NumRefTokens() - r0;
+  return 0;
+  REF_CATCH(-1)
+}
+
+// ---- dropout: the reference draws its masks from the host RNG inside PropagateFnc
+// (bilstm-parallel-layer.h:46-94); they are protected members of BiLstm (bilstm-layer.h:1054-1062), read here through
+// member pointers formed in a derived class (no change to the reference, no access-specifier macros) so that the SAME masks
+// can be fed to the restatement and to the HIP library.
+namespace {
+struct MaskPeek : public BiLstm {
+  static CuMatrix<BaseFloat> BiLstm::*fwd() { return &MaskPeek::forward_drop_mask_; }
+  static CuMatrix<BaseFloat> BiLstm::*rec_fw() { return &MaskPeek::recurrent_drop_mask_fw_; }
+  static CuMatrix<BaseFloat> BiLstm::*rec_bw() { return &MaskPeek::recurrent_drop_mask_bw_; }
+  static bool BiLstm::*twiddle_apply() { return &MaskPeek::twiddle_apply_forward; }
+};
+}  // namespace
+
+int ref_net_set_mode(void* p, int train) {
+  REF_TRY
+  if (train) static_cast<RefNet*>(p)->net.SetTrainMode();
+  else static_cast<RefNet*>(p)->net.SetTestMode();
+  return 0;
+  REF_CATCH(-1)
+}
+
+// Masks of BiLstm(Parallel) layer `layer` as left behind by the last Propagate.  dims = {fwd rows, fwd cols, rec rows, rec cols
+// (per direction), twiddle_apply_forward}; a buffer may be NULL to query the dims only.  Returns -2 if the layer is no BiLstm.
+int ref_net_get_dropout_masks(void* p, int layer, float* fwd, float* rec_fw, float* rec_bw, int* dims) {
+  REF_TRY
+  Net& net = static_cast<RefNet*>(p)->net;
+  BiLstm* l = dynamic_cast<BiLstm*>(&net.GetLayer(layer));
+  if (!l) return -2;
+  const CuMatrix<BaseFloat>& f = l->*MaskPeek::fwd();
+  const CuMatrix<BaseFloat>& rf = l->*MaskPeek::rec_fw();
+  const CuMatrix<BaseFloat>& rb = l->*MaskPeek::rec_bw();
+  dims[0] = f.NumRows(); dims[1] = f.NumCols(); dims[2] = rf.NumRows(); dims[3] = rf.NumCols();
+  dims[4] = (l->*MaskPeek::twiddle_apply()) ? 1 : 0;
+  if (fwd && f.NumRows()) FromCu(f, fwd);
+  if (rec_fw && rf.NumRows()) FromCu(rf, rec_fw);
+  if (rec_bw && rb.NumRows()) FromCu(rb, rec_bw);
   return 0;
   REF_CATCH(-1)
 }

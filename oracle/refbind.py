@@ -106,6 +106,24 @@ class RefNet:
     def write(self, path: str, binary: bool):
         self._ck(self.lib.ref_net_write(self.h, path.encode(), int(binary)))
 
+    def set_mode(self, train: bool):
+        """Net::SetTrainMode / SetTestMode (net.cc:396-412)."""
+        self._ck(self.lib.ref_net_set_mode(self.h, int(bool(train))))
+
+    def dropout_masks(self, layer: int) -> dict:
+        """The masks the reference drew in its last Propagate for BiLstm(Parallel) layer `layer` (bilstm-parallel-layer.h:46-94):
+        fwd [T*S x 2H] (empty if unused), rec_fw / rec_bw [rows x H] with rows = (T+2)*S (step) or S (sequence), and the
+        twiddle coin.  Values are 0 or 1/(1-p)."""
+        dims = (C.c_int * 5)()
+        rc = self.lib.ref_net_get_dropout_masks(self.h, layer, None, None, None, dims)
+        if rc == -2:
+            return {}
+        self._ck(rc)
+        fwd = np.zeros((dims[0], dims[1]), np.float32); rf = np.zeros((dims[2], dims[3]), np.float32); rb = np.zeros_like(rf)
+        self._ck(self.lib.ref_net_get_dropout_masks(self.h, layer, _p(fwd) if fwd.size else None, _p(rf) if rf.size else None,
+                                                    _p(rb) if rb.size else None, dims))
+        return dict(fwd=fwd, rec_fw=rf, rec_bw=rb, twiddle_apply_forward=bool(dims[4]))
+
     def error_rate_mseq(self, net_out, T, S, lens, label_ids, label_off):
         net_out = np.ascontiguousarray(net_out, np.float32)
         lens = np.ascontiguousarray(lens, np.int32)

@@ -9,7 +9,7 @@ import pytest
 
 from eesen_amd import nnet_io, synth
 from oracle import net as onet, refbind
-from tests.util import rel_err
+from tests.util import rel_err, valid_mask
 
 pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref/libeesen_ref.so not built (needs /root/reference)")
 
@@ -89,3 +89,54 @@ def test_adaptive_update_restatement_equals_reference_kernels(rmsprop):
         lib.orc_adaptive_update(C.c_long(p2.size), p2.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p), a2.ctypes.data_as(C.c_void_p),
                                 C.c_float(0.01), C.c_float(0.0), C.c_float(1e-6), C.c_float(rho), C.c_float(np.float32(1) - rho), int(rmsprop))
     assert np.array_equal(p, p2) and np.array_equal(a, a2)
+
+
+DROPOUT_CASES = {
+    "fwd_step": [dict(forward=0.3, fw_step=True), dict(forward=0.2, fw_step=True)],
+    "fwd_seq": [dict(forward=0.3, fw_seq=True), {}],
+    "rnndrop_step": [dict(recurrent=0.25, rec_step=True, rnndrop=True)] * 2,
+    "nml_step": [dict(recurrent=0.3, rec_step=True, nml=True), {}],
+    "rnndrop_seq": [dict(recurrent=0.25, rec_seq=True, rnndrop=True), dict(recurrent=0.4, rec_seq=True, rnndrop=True)],
+    "nml_seq": [{}, dict(recurrent=0.3, rec_seq=True, nml=True)],
+    "both": [dict(forward=0.2, fw_step=True, recurrent=0.25, rec_step=True, rnndrop=True),
+             dict(forward=0.1, fw_seq=True, recurrent=0.2, rec_seq=True, nml=True)],
+    "twiddle": [dict(forward=0.2, fw_step=True, recurrent=0.25, rec_step=True, rnndrop=True, twiddle=True)] * 2,
+}
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", sorted(DROPOUT_CASES))
+def test_dropout_restatement_matches_the_reference(tmp_path, name):
+    """the reference's dropout variants (bilstm-parallel-layer.h:46-94, 209-377, 604-879) run on the CPU with
+    masks from its host RNG; the masks are read back (oracle/ref_build/ref_driver.cc MaskPeek) and fed to the C restatement,
+    which must then reproduce net_out, in_diff and the lr = 1 parameter update."""
+    from eesen_amd import nnet_io
+    from oracle.net import OracleNet, ctc_eval_parallel
+    cfg = synth.config("small_bi"); cfg.update(T=25, S=5, H=24)
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    for L, d in zip([l for l in layers if l["type"].startswith("BiLstm")], DROPOUT_CASES[name]):
+        if d:
+            L["dropout"] = d
+    path = str(tmp_path / "m.txt")
+    nnet_io.write_nnet(path, layers, binary=False)
+    ref = refbind.RefNet(path); ref.set_train_options(1.0, 0.0); ref.set_seq_lengths(batch.lens)
+    back = nnet_io.read_nnet(path)
+    assert [l.get("dropout") for l in back] == [l.get("dropout") for l in layers]       # options survive our reader
+    orc = OracleNet(back); orc.set_train_options(1.0, 0.0); orc.set_seq_lengths(batch.lens)
+    out_r = ref.propagate(batch.feats)
+    drew = False
+    for li, L in enumerate(layers):
+        if L["type"].startswith("BiLstm"):
+            m = ref.dropout_masks(li)
+            drew |= bool(m["fwd"].size or m["rec_fw"].size)
+            orc.set_dropout_masks(li, **m)
+    assert drew
+    out_o = orc.propagate(batch.feats)
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(out_o[vm], out_r[vm]) < 1e-5
+    ctc = ctc_eval_parallel(out_o, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+    ind_r = ref.backpropagate(ctc["diff"], True); ind_o = orc.backpropagate(ctc["diff"], True)
+    assert rel_err(ind_o, ind_r) < 1e-5 and rel_err(orc.get_params(), ref.get_params()) < 1e-5
+    # test mode: no dropout at all (masks are pre-scaled so inference needs none, :75-76)
+    ref.set_mode(False); orc.set_mode(False)
+    assert rel_err(orc.propagate(batch.feats)[vm], ref.propagate(batch.feats)[vm]) < 1e-5
