@@ -60,6 +60,12 @@ SIGNATURES = {
     "eesen_ctc_stats": (_i, [_vp, _pd, _pl, _pl, _pl, _pl]),
     "eesen_ctc_get_alpha_beta": (_i, [_vp, _vp, _vp, _pi]),
     "eesen_ctc_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_net_set_train_mode": (_i, [_vp, _i]),
+    "eesen_net_set_dropout_seed": (_i, [_vp, C.c_ulonglong]),
+    "eesen_net_set_layer_dropout": (_i, [_vp, _i, _pf]),
+    "eesen_net_get_layer_dropout": (_i, [_vp, _i, _pf]),
+    "eesen_net_set_dropout_masks": (_i, [_vp, _i, _vp, _l, _vp, _i, _l, _i]),
+    "eesen_net_get_dropout_masks": (_i, [_vp, _i, _vp, _vp, _pi]),
     "eesen_feeder_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
     "eesen_feeder_destroy": (_i, [_vp]),
     "eesen_feeder_submit": (_i, [_vp, C.POINTER(_vp), _pi, _pi, _i, _i, _pi]),

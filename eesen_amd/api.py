@@ -128,7 +128,53 @@ class Net:
         flat = [np.asarray(p, np.float32).ravel() for L in layers for p in L["params"]]
         if flat:
             net.SetParams(np.concatenate(flat))
+        for i, L in enumerate(layers):
+            if L.get("dropout"):
+                net.SetLayerDropout(i, L["dropout"])
         return net
+
+    # ---- dropout (bilstm-parallel-layer.h:46-94) ------------------------------------------------
+    def SetTrainMode(self):
+        """Net::SetTrainMode (net.cc:405-412): dropout layers draw and apply their masks (the default)."""
+        check(self.lib.eesen_net_set_train_mode(self.h, 1))
+
+    def SetTestMode(self):
+        """Net::SetTestMode (net.cc:396-403): no dropout."""
+        check(self.lib.eesen_net_set_train_mode(self.h, 0))
+
+    def SetLayerDropout(self, layer: int, opts: dict):
+        """opts: keys of eesen_amd.nnet_io.DROPOUT_KEYS (forward, fw_step, fw_seq, rec_step, rec_seq, rnndrop, nml, recurrent, twiddle)."""
+        from .nnet_io import dropout_values
+        v = np.array([float(x) for x in dropout_values({"dropout": opts})], np.float32)
+        check(self.lib.eesen_net_set_layer_dropout(self.h, layer, v.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def GetLayerDropout(self, layer: int) -> dict:
+        from .nnet_io import DROPOUT_KEYS
+        v = np.zeros(9, np.float32)
+        check(self.lib.eesen_net_get_layer_dropout(self.h, layer, v.ctypes.data_as(C.POINTER(C.c_float))))
+        return {k: (float(x) if k in ("forward", "recurrent") else bool(x)) for k, x in zip(DROPOUT_KEYS, v) if x}
+
+    def SetDropoutSeed(self, seed: int):
+        check(self.lib.eesen_net_set_dropout_seed(self.h, C.c_ulonglong(seed)))
+
+    def SetDropoutMasks(self, layer: int, fwd=None, rec=None, twiddle_coin: int = -1):
+        """Masks for the NEXT Propagate (parity tests): fwd [T*S x 2H]; rec [(T+2)*S x 2H] or [S x 2H] (fw columns, then bw)."""
+        f = None if fwd is None else np.ascontiguousarray(fwd, np.float32)
+        r = None if rec is None else np.ascontiguousarray(rec, np.float32)
+        check(self.lib.eesen_net_set_dropout_masks(self.h, layer, _np_ptr(f) if f is not None else None, 0 if f is None else f.size,
+                                                   _np_ptr(r) if r is not None else None, 0 if r is None else r.shape[0],
+                                                   0 if r is None else r.size, int(twiddle_coin)))
+
+    def GetDropoutMasks(self, layer: int, T: int, S: int) -> dict:
+        """What the last Propagate applied to `layer`: dict(fwd [T*S x 2H] | None, rec [(T+2)*S x 2H] | None, mode, coin)."""
+        info = (C.c_int * 4)()
+        check(self.lib.eesen_net_get_dropout_masks(self.h, layer, None, None, info))
+        w = info[3]
+        fwd = np.zeros((T * S, w), np.float32) if info[0] else None
+        rec = np.zeros(((T + 2) * S, w), np.float32) if info[1] else None
+        check(self.lib.eesen_net_get_dropout_masks(self.h, layer, _np_ptr(fwd) if fwd is not None else None,
+                                                   _np_ptr(rec) if rec is not None else None, info))
+        return dict(fwd=fwd, rec=rec, mode=int(info[1]), coin=bool(info[2]))
 
     def layers(self) -> List[dict]:
         n = C.c_int()
@@ -139,6 +185,9 @@ class Net:
             check(self.lib.eesen_net_layer_info(self.h, i, C.byref(k), C.byref(di), C.byref(do), C.byref(cf), C.byref(mg)))
             out.append(dict(type=_lib.NAME_OF[k.value], input_dim=di.value, output_dim=do.value,
                             learn_rate_coef=cf.value, max_grad=mg.value))
+            dr = self.GetLayerDropout(i)
+            if dr:
+                out[-1]["dropout"] = dr
         return out
 
     def InputDim(self) -> int:

@@ -43,6 +43,25 @@ int eesen_net_destroy(eesen_net_t* net) {
 int eesen_net_add_layer(eesen_net_t* net, int kind, int in_dim, int out_dim, float coef, float max_grad) {
   return guard([&] { REQ_PTR(net); net->add_layer(kind, in_dim, out_dim, coef, max_grad); });
 }
+int eesen_net_set_train_mode(eesen_net_t* net, int train) {
+  return guard([&] { REQ_PTR(net); net->set_train_mode(train != 0); });
+}
+int eesen_net_set_dropout_seed(eesen_net_t* net, unsigned long long seed) {
+  return guard([&] { REQ_PTR(net); net->drop_seed = seed; net->drop_counter = 0; });
+}
+int eesen_net_set_layer_dropout(eesen_net_t* net, int layer, const float* nine) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(nine); net->set_layer_dropout(layer, nine); });
+}
+int eesen_net_get_layer_dropout(eesen_net_t* net, int layer, float* nine) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(nine); net->get_layer_dropout(layer, nine); });
+}
+int eesen_net_set_dropout_masks(eesen_net_t* net, int layer, const float* fwd_mask_host, long fwd_floats,
+                                const float* rec_mask_host, int rec_rows, long rec_floats, int twiddle_coin) {
+  return guard([&] { REQ_PTR(net); net->set_dropout_masks(layer, fwd_mask_host, fwd_floats, rec_mask_host, rec_rows, rec_floats, twiddle_coin); });
+}
+int eesen_net_get_dropout_masks(eesen_net_t* net, int layer, float* fwd_mask_host, float* rec_mask_host, int* info4) {
+  return guard([&] { REQ_PTR(net); net->get_dropout_masks(layer, fwd_mask_host, rec_mask_host, info4); });
+}
 int eesen_net_finalize(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->finalize(); });
 }

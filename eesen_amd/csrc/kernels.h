@@ -46,7 +46,17 @@ struct LstmLayerDev {
   const float* WmT;  // [ndir][H x 4H]   transpose of the above
   const float* peep; // [ndir][3][H]     p_i, p_f, p_o
   const int* lens;   // [S]
+  // recurrent dropout (bilstm-parallel-layer.h:209-377): mask of 0 / 1/(1-p), [(T+2)*S x ndir*H], indexed like C;
+  // drop_mode 0 none, 1 no-memory-loss (mask multiplies g*i), 2 RNNDrop (mask multiplies the whole new cell)
+  const float* rmask = nullptr;
+  int drop_mode = 0;
 };
+// EESEN_NO_DROPOUT (build flag, A/B only): compiles the recurrent-dropout branches out of the recurrence kernels
+#ifdef EESEN_NO_DROPOUT
+#define EESEN_DROP_MODE(L) 0
+#else
+#define EESEN_DROP_MODE(L) ((L).drop_mode)
+#endif
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
 // One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.
@@ -58,6 +68,12 @@ void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float*
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace = nullptr, hipEvent_t after_reset = nullptr);
 // counter geometry of the forward persistent kernel (for gated consumers): workgroups per group, sequence tiles
+// out[r][c] = (u(r,c) > p) ? 1/(1-p) : 0 with u ~ U[0,1) from a counter-based hash of (seed, element) -- the mask recipe of
+// bilstm-parallel-layer.h:54-61 (SetRandUniform / SetRandUniformCol, Add(-p), ApplyHeaviside, Scale(1/(1-p))); per_column
+// draws one value per column and repeats it down the rows (SetRandUniformCol, cpucompute/matrix.cc:952-965).
+void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float p, unsigned long long seed, bool per_column);
+// out[r][c] = a[r][c] * m[r][c]   (MulElements, :416 / :895)
+void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int ldm, float* out, int ldo, long rows, int cols);
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);

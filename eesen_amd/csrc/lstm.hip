@@ -120,6 +120,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
   float i = sigmoidf_(pre.y + p_i * cprev);
   float f = sigmoidf_(pre.z + p_f * cprev);
   float c = g * i + cprev * f;
+  if (EESEN_DROP_MODE(L)) {  // recurrent dropout (:266-272): the mask multiplies g*i (no-memory-loss) or the whole new cell (RNNDrop)
+    const float mk = L.rmask[(size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu];
+    c = EESEN_DROP_MODE(L) == 1 ? mk * (g * i) + cprev * f : mk * (g * i + cprev * f);
+  }
   float h = tanhf_(c);
   float o = sigmoidf_(pre.w + p_o * c);
   float m = h * o;
@@ -221,10 +225,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
   const float dh = (1.f - h * h) * (dm * o);
   float dob = o * (1.f - o) * (dm * h);
   float dc = dh + dcf + dgn.y * p_i + dgn.z * p_f + dob * p_o;
-  float df = f * (1.f - f) * (dc * c_p);
-  float di = i * (1.f - i) * (dc * g);
-  float dg = (1.f - g * g) * (dc * i);
-  float carry = dc * f;  // what the next step adds as d_c,next * f_next (:482)
+  // recurrent dropout (:700-725): d_i, d_g see d_c times the mask; with RNNDrop so do d_f and the carry to the next step
+  float dcm = dc, dcx = dc;
+  if (EESEN_DROP_MODE(L)) {
+    dcm = dc * L.rmask[cofs];
+    if (EESEN_DROP_MODE(L) == 2) dcx = dcm;
+  }
+  float df = f * (1.f - f) * (dcx * c_p);
+  float di = i * (1.f - i) * (dcm * g);
+  float dg = (1.f - g * g) * (dcm * i);
+  float carry = dcx * f;  // what the next step adds as d_c,next * f_next (:482 / :701,:706)
   if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
   *reinterpret_cast<float4*>(DG + gofs) = make_float4(dg, di, df, dob);
   DCF[(size_t)s_e * ldY + dir * H + u_e] = carry;

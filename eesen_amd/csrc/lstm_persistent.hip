@@ -157,7 +157,7 @@ __device__ __forceinline__ int xcd_census(unsigned* word, unsigned nwg, unsigned
 //                 crossed the fabric) is what bounds the step, so halving it is worth the second 16-row slice of W_m
 //                 in registers.
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int MT, int NT>
+template <int CPW, int MT, int NT, bool DROP>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
                                                                       int spin_limit, unsigned long long* trace, Role R) {
   constexpr int ST = 16 * MT, UB = 4 * NT, RW = 16 * NT + 4;  // sequences, units per workgroup; padded LDS row
@@ -253,6 +253,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       float i = sigmoidf_(pre.y + p_i * cprev);
       float f = sigmoidf_(pre.z + p_f * cprev);
       float c = g * i + cprev * f;
+      if (DROP) {  // recurrent dropout (a separate instantiation: the plain kernel carries no trace of it): see lstm_fwd_step_kernel
+        const float mk = L.rmask[(size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu];
+        c = L.drop_mode == 1 ? mk * (g * i) + cprev * f : mk * (g * i + cprev * f);
+      }
       float h = tanhf_(c);
       float o = sigmoidf_(pre.w + p_o * c);
       float m = h * o;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 // ------------------------------------------------------------------------------------------------
 // backward: grid (ceil(H/16), ndir, ceil(S/16)), 512 threads -- the decomposition of lstm_bwd_step_kernel
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int ST>  // ST = sequences per workgroup (16, or 8: half-filled MFMA rows but half the DG_next fetch per CU)
+template <int CPW, int ST, bool DROP>  // ST = sequences per workgroup (16, or 8: half-filled MFMA rows but half the DG_next fetch per CU)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
                                                                       unsigned* err, int spin_limit, unsigned long long* trace,
@@ -432,10 +436,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       const float dh = (1.f - h * h) * (dm * o);
       float dob = o * (1.f - o) * (dm * h);
       float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
-      float df = f * (1.f - f) * (dc * c_p);
-      float di = i * (1.f - i) * (dc * g);
-      float dg = (1.f - g * g) * (dc * i);
-      float carry = dc * f;
+      float dcm = dc, dcx = dc;  // recurrent dropout: see lstm_bwd_step_kernel
+      if (DROP) {
+        dcm = dc * L.rmask[(size_t)((t + 1) * S + s_e) * ldY + ycol];
+        if (L.drop_mode == 2) dcx = dcm;
+      }
+      float df = f * (1.f - f) * (dcx * c_p);
+      float di = i * (1.f - i) * (dcm * g);
+      float dg = (1.f - g * g) * (dcm * i);
+      float carry = dcx * f;
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
       const __amdgpu_buffer_rsrc_t rOut = make_rsrc(DG + (size_t)t * S * ldG);
@@ -540,8 +549,13 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
   if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
 #define EESEN_FP(CPW, MT, NT)                                                                          \
   do {                                                                                                  \
-    if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT>, grid, NW * 64)) return false;                    \
-    coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT>, grid1, block, L, cnt, err, spin_limit, trace, role); \
+    if (L.drop_mode) {                                                                                  \
+      if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid, NW * 64)) return false;            \
+      coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
+    } else {                                                                                            \
+      if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid, NW * 64)) return false;           \
+      coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid1, block, L, cnt, err, spin_limit, trace, role); \
+    }                                                                                                   \
   } while (0)
   if (ft.nt == 4) {
     if (need <= 1) EESEN_FP(1, 1, 4);
@@ -582,8 +596,13 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \
-    if (!fits(lstm_bwd_persistent_kernel<CPW, STV>, grid, NW * 64)) return false;                                 \
-    coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+    if (L.drop_mode) {                                                                                            \
+      if (!fits(lstm_bwd_persistent_kernel<CPW, STV, true>, grid, NW * 64)) return false;                         \
+      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+    } else {                                                                                                      \
+      if (!fits(lstm_bwd_persistent_kernel<CPW, STV, false>, grid, NW * 64)) return false;                        \
+      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+    }                                                                                                             \
   } while (0)
 #define EESEN_BP(CPW) do { if (stile == 8) EESEN_BP2(CPW, 8); else EESEN_BP2(CPW, 16); } while (0)
   if (need <= 1) EESEN_BP(1);

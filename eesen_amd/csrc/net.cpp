@@ -326,7 +326,103 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.WmT = L.WmT.p;
   d.peep = net.params.p + L.p_off + L.off_peep;
   d.lens = net.lens_d.p;
+  d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
+  d.drop_mode = L.cur_drop_mode;
   return d;
+}
+
+// ---- dropout (bilstm-parallel-layer.h:46-94, 385-390) --------------------------------------------------------------------
+void Net::set_layer_dropout(int layer, const float* nine) {
+  EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size(), EESEN_ERR_INVALID, "layer index out of range");
+  Layer& L = layers[layer];
+  bool any = false;
+  for (int k = 0; k < 9; ++k) any |= nine[k] != 0.f;
+  EESEN_REQUIRE(!any || L.kind == EESEN_LAYER_BILSTM_PARALLEL, EESEN_ERR_INVALID, "dropout options exist on BiLstm layers only");
+  EESEN_REQUIRE(nine[0] >= 0.f && nine[0] < 1.f && nine[7] >= 0.f && nine[7] < 1.f, EESEN_ERR_INVALID, "dropout factor outside [0, 1)");
+  for (int k = 0; k < 9; ++k) L.drop[k] = (k == 0 || k == 7) ? nine[k] : (nine[k] != 0.f ? 1.f : 0.f);
+}
+
+void Net::get_layer_dropout(int layer, float* nine) const {
+  EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size(), EESEN_ERR_INVALID, "layer index out of range");
+  for (int k = 0; k < 9; ++k) nine[k] = layers[layer].drop[k];
+}
+
+void Net::set_dropout_masks(int layer, const float* fwd, long fwd_n, const float* rec, int rec_rows, long rec_n, int coin) {
+  EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size() && layers[layer].is_lstm(), EESEN_ERR_INVALID, "not an LSTM layer");
+  Layer& L = layers[layer];
+  L.inj_fmask.assign(fwd, fwd + (fwd ? fwd_n : 0));
+  L.inj_rmask.assign(rec, rec + (rec ? rec_n : 0));
+  L.inj_rmask_rows = rec ? rec_rows : 0;
+  L.inj_coin = coin;
+}
+
+void Net::get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* info4) {
+  EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size() && layers[layer].is_lstm(), EESEN_ERR_INVALID, "not an LSTM layer");
+  EESEN_REQUIRE(propagated, EESEN_ERR_STATE, "no Propagate yet");
+  Layer& L = layers[layer];
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  sync();
+  const size_t ldY = (size_t)L.ndir * L.H;
+  if (fwd_host && L.cur_fwd_drop)
+    EESEN_HIP_CHECK(hipMemcpy(fwd_host, L.fmask.p, (size_t)rows * ldY * sizeof(float), hipMemcpyDeviceToHost));
+  if (rec_host && L.cur_drop_mode)
+    EESEN_HIP_CHECK(hipMemcpy(rec_host, L.rmask.p, (size_t)(T + 2) * S * ldY * sizeof(float), hipMemcpyDeviceToHost));
+  if (info4) { info4[0] = L.cur_fwd_drop; info4[1] = L.cur_drop_mode; info4[2] = L.cur_twiddle_coin; info4[3] = (int)ldY; }
+}
+
+// Decides what this Propagate applies to layer L and puts the masks in HBM: injected ones if the caller supplied them
+// (one-shot), otherwise drawn on the device from (drop_seed, draw counter).
+static void prepare_dropout(Net& net, Layer& L) {
+  L.cur_fwd_drop = false; L.cur_drop_mode = 0; L.cur_twiddle_coin = false;
+  const bool want = net.in_train && L.has_dropout();
+  if (!want) { L.inj_fmask.clear(); L.inj_rmask.clear(); L.inj_rmask_rows = 0; L.inj_coin = -1; return; }
+  const float fwd_p = L.drop[0], rec_p = L.drop[7];
+  const bool fw_seq = L.drop[2] != 0.f, rec_step = L.drop[3] != 0.f, rec_seq = L.drop[4] != 0.f;
+  const bool rnndrop = L.drop[5] != 0.f, nml = L.drop[6] != 0.f, twiddle = L.drop[8] != 0.f;
+  const int T = net.T, S = net.S, ldY = L.ndir * L.H;
+  bool coin = false;
+  if (twiddle) {  // :385-387: one fair coin per Propagate decides between forward and recurrent dropout
+    if (L.inj_coin >= 0) coin = L.inj_coin != 0;
+    else {
+      unsigned long long z = net.drop_seed + (++net.drop_counter) * 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      coin = (z >> 63) != 0;
+    }
+  }
+  L.cur_twiddle_coin = coin;
+  const bool rec = (rnndrop || nml) && (!twiddle || !coin);   // :389
+  const bool fwd = fwd_p > 0.f && (!twiddle || coin);         // :390
+  if (rec) {
+    EESEN_REQUIRE(rec_step != rec_seq, EESEN_ERR_INVALID,
+                  "recurrent dropout needs exactly one of RecurrentTimeStepDropout / RecurrentSequenceDropout (bilstm-layer.h:102-113)");
+    EESEN_REQUIRE(!(rnndrop && nml), EESEN_ERR_INVALID, "RNNDrop and NoMemLossDropout are mutually exclusive");
+    const long mrows = (long)(T + 2) * S;
+    L.rmask.reserve((size_t)mrows * ldY);
+    if (!L.inj_rmask.empty()) {  // [(T+2)*S x ndir*H] as is, or [S x ndir*H] (sequence mask) repeated for every time step
+      EESEN_REQUIRE((L.inj_rmask_rows == mrows || L.inj_rmask_rows == S) && (long)L.inj_rmask.size() == (long)L.inj_rmask_rows * ldY,
+                    EESEN_ERR_INVALID, "injected recurrent mask has the wrong shape");
+      const size_t chunk = (size_t)L.inj_rmask_rows * ldY;
+      for (long r0 = 0; r0 < mrows; r0 += L.inj_rmask_rows)
+        EESEN_HIP_CHECK(hipMemcpyAsync(L.rmask.p + (size_t)r0 * ldY, L.inj_rmask.data(), chunk * sizeof(float), hipMemcpyHostToDevice, net.st));
+      EESEN_HIP_CHECK(hipStreamSynchronize(net.st));  // the host vector is released below
+    } else {
+      dropout_mask(net.st, L.rmask.p, mrows, ldY, ldY, rec_p, net.drop_seed + (++net.drop_counter) * 0x632BE59BD9B4E019ull, rec_seq);
+    }
+    L.cur_drop_mode = rnndrop ? 2 : 1;
+  }
+  if (fwd) {
+    L.fmask.reserve((size_t)net.rows * ldY);
+    L.Yd.reserve((size_t)net.rows * ldY);
+    if (!L.inj_fmask.empty()) {
+      EESEN_REQUIRE((long)L.inj_fmask.size() == (long)net.rows * ldY, EESEN_ERR_INVALID, "injected forward mask has the wrong shape");
+      EESEN_HIP_CHECK(hipMemcpyAsync(L.fmask.p, L.inj_fmask.data(), L.inj_fmask.size() * sizeof(float), hipMemcpyHostToDevice, net.st));
+      EESEN_HIP_CHECK(hipStreamSynchronize(net.st));
+    } else {
+      dropout_mask(net.st, L.fmask.p, net.rows, ldY, ldY, fwd_p, net.drop_seed + (++net.drop_counter) * 0x632BE59BD9B4E019ull, fw_seq);
+    }
+    L.cur_fwd_drop = true;
+  }
+  L.inj_fmask.clear(); L.inj_rmask.clear(); L.inj_rmask_rows = 0; L.inj_coin = -1;
 }
 
 void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
@@ -361,6 +457,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p, 0, blk, st));
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
       EESEN_HIP_CHECK(hipMemsetAsync(L.Y.p + (size_t)(T + 1) * S * ldY, 0, blk, st));
+      prepare_dropout(*this, L);
       // all gate pre-activations of both directions in one GEMM: G = x * Wx^T + bias  (:109-110, :163-164)
       if (g_gated) {  // already computed on the side stream, gated on the previous layer's progress (see below)
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
@@ -376,7 +473,8 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       Layer* nxt = (&L - layers.data()) + 1 < (long)layers.size() ? &layers[(&L - layers.data()) + 1] : nullptr;
       int gate_nblk = 0, nz = 1;
       lstm_fwd_persistent_geometry(lstm_view(*this, L), &gate_nblk, &nz);
-      const bool plan_gate = persistent && overlap && gate_fwd && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
+      // (with forward dropout the next layer reads the MASKED output, which exists only after the recurrence: no gating)
+      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
@@ -398,7 +496,9 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
         g_gated = true;
       } }
-      x = L.Y.p + (size_t)S * ldY;
+      if (L.cur_fwd_drop)  // :414-417: the layer's output, not its recurrent state, is masked
+        mul_elements(st, L.Y.p + (size_t)S * ldY, ldY, L.fmask.p, ldY, L.Yd.p, ldY, rows, ldY);
+      x = L.output(S);
       ldx = ldY;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       const int ldo = pad4(L.dout);
@@ -469,7 +569,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     if (li == 0) { x = input.p; ldx = pad4(L.din); }
     else {
       const Layer& Pv = layers[li - 1];
-      if (Pv.is_lstm()) { ldx = Pv.ndir * Pv.H; x = Pv.Y.p + (size_t)S * ldx; }
+      if (Pv.is_lstm()) { ldx = Pv.ndir * Pv.H; x = Pv.output(S); }
       else { ldx = pad4(Pv.dout); x = Pv.out.p; }
     }
     const bool want_in = li > 0 || in_diff != nullptr;
@@ -491,6 +591,8 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
       const LstmLayerDev v = lstm_view(*this, L);
+      EESEN_REQUIRE(in_train || !L.has_dropout(), EESEN_ERR_STATE, "Can't backpropagate a dropout layer in test mode (bilstm-parallel-layer.h:425)");
+      if (L.cur_fwd_drop) mul_elements(st, d, ld_d, L.fmask.p, ldY, d, ld_d, rows, ldY);  // out_diff_drop, :892-896
       // Gate-gradient buffers alternate between LSTM layers: while this layer's weight-gradient GEMMs (side stream)
       // still read DGb[slot], the next-lower layer's recurrence (main stream) already fills the other one.
       float* DGl = DGb[dg_slot].p;

@@ -22,6 +22,23 @@ struct Layer {
   // AffineTransform
   size_t off_w = 0, off_b = 0;
   DevBuf<float> out;  // affine / softmax output [rows x pad4(dout)]
+  // Dropout options of BiLstm(Parallel) in model-file token order (bilstm-layer.h:331-373): ForwardDropoutFactor,
+  // ForwardTimeStepDropout, ForwardSequenceDropout, RecurrentTimeStepDropout, RecurrentSequenceDropout, RNNDrop,
+  // NoMemLossDropout, RecurrentDropoutFactor, TwiddleForward (booleans stored as 0 / 1)
+  float drop[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool has_dropout() const { return drop[0] > 0.f || drop[5] != 0.f || drop[6] != 0.f; }
+  DevBuf<float> fmask;  // forward-dropout mask [T*S x ndir*H] of the current minibatch
+  DevBuf<float> rmask;  // recurrent-dropout mask [(T+2)*S x ndir*H], indexed like C
+  DevBuf<float> Yd;     // layer output after forward dropout [T*S x ndir*H]
+  // what the last Propagate applied (Backpropagate must use the same, :888-889)
+  bool cur_fwd_drop = false;
+  int cur_drop_mode = 0;   // 0 none, 1 no-memory-loss, 2 RNNDrop
+  bool cur_twiddle_coin = false;
+  // one-shot injected masks (tests pin the kernels against the oracle with IDENTICAL masks): host copies until Propagate
+  std::vector<float> inj_fmask, inj_rmask;
+  int inj_rmask_rows = 0, inj_coin = -1;
+  // the activation the next layer (and this layer's consumers) read
+  const float* output(int S) const { return cur_fwd_drop ? Yd.p : Y.p + (size_t)S * ndir * H; }
   bool is_lstm() const { return kind == EESEN_LAYER_LSTM_PARALLEL || kind == EESEN_LAYER_BILSTM_PARALLEL; }
   bool trainable() const { return kind != EESEN_LAYER_SOFTMAX; }
   long file_params() const;
@@ -79,6 +96,14 @@ struct Net {
   int spin_limit = 400000;
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error();
+  // dropout
+  bool in_train = true;                       // BiLstm::in_train (bilstm-layer.h:38), Net::SetTrainMode / SetTestMode
+  unsigned long long drop_seed = 777, drop_counter = 0;   // masks are a pure function of (seed, draw counter, element)
+  void set_train_mode(bool train) { in_train = train; }
+  void set_layer_dropout(int layer, const float* nine);
+  void get_layer_dropout(int layer, float* nine) const;
+  void set_dropout_masks(int layer, const float* fwd, long fwd_n, const float* rec, int rec_rows, long rec_n, int coin);
+  void get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* info4);
   size_t ws_floats = 0;
   PhaseTimer timer;
 

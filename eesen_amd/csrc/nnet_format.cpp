@@ -114,6 +114,7 @@ struct ParsedLayer {
   float coef = 1.f, max_grad = 0.f;
   std::vector<float> flat;  // Net::GetParams order
   std::vector<float> accu;  // same order; empty unless the file carries <...Accus>
+  float drop[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // dropout options, token order (Layer::drop)
 };
 
 int marker_kind(const std::string& m) {
@@ -192,8 +193,9 @@ void Net::read(const std::string& path) {
           for (int k = 0; k < 9; ++k)
             if (t == kDropoutTokens[k]) {
               known = true;
-              const bool set = kDropoutIsFloat[k] ? (c.basic<float>() != 0.f) : c.boolean();
-              if (set) throw Error(EESEN_ERR_INVALID, "dropout option " + t + " is set; dropout variants are out of scope of this path");
+              P.drop[k] = kDropoutIsFloat[k] ? c.basic<float>() : (c.boolean() ? 1.f : 0.f);
+              if (P.kind != EESEN_LAYER_BILSTM_PARALLEL && P.drop[k] != 0.f)   // only BiLstm reads these tokens (lstm-layer.h has none)
+                throw Error(EESEN_ERR_INVALID, "dropout option " + t + " on a layer that is not a BiLstm");
             }
           if (!known) c.fail("unexpected token " + t);
         }
@@ -203,7 +205,10 @@ void Net::read(const std::string& path) {
     parsed.push_back(std::move(P));
   }
   if (parsed.empty()) throw Error(EESEN_ERR_IO, "model file " + path + " holds no layers");
-  for (const ParsedLayer& P : parsed) add_layer(P.kind, P.din, P.dout, P.coef, P.max_grad);
+  for (const ParsedLayer& P : parsed) {
+    add_layer(P.kind, P.din, P.dout, P.coef, P.max_grad);
+    for (int k = 0; k < 9; ++k) layers.back().drop[k] = P.drop[k];
+  }
   finalize();
   std::vector<float> all;
   for (const ParsedLayer& P : parsed) all.insert(all.end(), P.flat.begin(), P.flat.end());
@@ -293,8 +298,8 @@ void Net::write(const std::string& path, bool binary) {
     if (L.kind == EESEN_LAYER_BILSTM_PARALLEL)  // bilstm-layer.h:435-455; the uni-LSTM writes none (lstm-layer.h:147-151)
       for (int k = 0; k < 9; ++k) {
         put_token(os, kDropoutTokens[k]);
-        if (kDropoutIsFloat[k]) put_float(os, binary, 0.f);
-        else put_bool(os, binary, false);
+        if (kDropoutIsFloat[k]) put_float(os, binary, L.drop[k]);
+        else put_bool(os, binary, L.drop[k] != 0.f);
       }
     auto write_tensors = [&](const float*& q) {
       if (L.is_lstm()) {

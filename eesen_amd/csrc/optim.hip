@@ -121,4 +121,48 @@ void copy2d(hipStream_t st, const float* src, int lds, float* dst, int ldd, int 
   check_launch("copy2d");
 }
 
+
+namespace {
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0, 1)
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long rows, int cols, int ld, float p, float scale,
+                                                           unsigned long long seed, int per_column) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float u = hash_uniform(seed, per_column ? (unsigned long long)c : (unsigned long long)i);
+    out[r * ld + c] = (u - p > 0.f) ? scale : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void mul_elements_kernel(const float* __restrict__ a, int lda, const float* __restrict__ m, int ldm,
+                                                           float* __restrict__ out, int ldo, long rows, int cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    out[r * ldo + c] = a[r * lda + c] * m[r * ldm + c];
+  }
+}
+}  // namespace
+
+void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float p, unsigned long long seed, bool per_column) {
+  if (rows <= 0 || cols <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(rows * cols, 256), 256L * 16);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, st, out, rows, cols, ld, p, 1.0f / (1.0f - p), seed, per_column ? 1 : 0);
+  check_launch("dropout_mask");
+}
+
+void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int ldm, float* out, int ldo, long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(rows * cols, 256), 256L * 16);
+  hipLaunchKernelGGL(mul_elements_kernel, dim3(blocks), dim3(256), 0, st, a, lda, m, ldm, out, ldo, rows, cols);
+  check_launch("mul_elements");
+}
+
 }  // namespace eesen

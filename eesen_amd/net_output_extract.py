@@ -65,6 +65,7 @@ def main(argv=None) -> int:
         if kind != "ark":
             raise kaldi_io.KaldiIOError("only ark: output is supported")
         net = Net(o.device).Read(model_filename)
+        net.SetTestMode()                                  # net-output-extract.cc:76
         log_pri = class_log_priors(o.class_frame_counts, o.prior_cutoff, o.blank_scale) if o.class_frame_counts else None
         K = net.OutputDim()
         if log_pri is not None and log_pri.size != K:

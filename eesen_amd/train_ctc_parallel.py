@@ -115,6 +115,12 @@ def main(argv=None) -> int:
         net = Net(dev).Read(model_filename)
         net.SetTrainOptions(o.learn_rate, o.momentum)
         net.SetUpdateAlgorithm(o.opt_algorithm, o.adagrad_epsilon, o.rms_prop_rho)   # net.SetUpdateAlgorithm(opt), :114
+        if o.cross_validate:                                                          # :116-119: dropout layers draw masks only in training
+            net.SetTestMode()
+        else:
+            net.SetTrainMode()
+            if dist is not None:      # every rank its own masks
+                net.SetDropoutSeed(777 + rank)
         if dist is not None and not o.cross_validate:
             from eesen_amd.parallel import GradAllReducer
             net.grad_hook = GradAllReducer(net)

@@ -157,6 +157,26 @@ int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_ho
 /* seconds of the last EvalParallel's device work (HIP events): out[0]=log, [1]=alpha/beta sweep, [2]=error+jacobian */
 int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3);
 
+/* ---- dropout variants of BiLstm(Parallel) (src/net/bilstm-parallel-layer.h:46-94,209-377,604-879) ------
+ * Options travel in the model file (nine tokens, src/net/bilstm-layer.h:331-373) and through set/get_layer_dropout, in token
+ * order: {ForwardDropoutFactor, ForwardTimeStepDropout, ForwardSequenceDropout, RecurrentTimeStepDropout,
+ * RecurrentSequenceDropout, RNNDrop, NoMemLossDropout, RecurrentDropoutFactor, TwiddleForward} (booleans as 0 / 1).
+ * Net::SetTrainMode / SetTestMode (src/net/net.cc:396-412): dropout is applied in train mode only (the default).
+ * Masks (values 0 or 1/(1-p)) are drawn on the device from (seed, draw counter, element) -- the reference draws them with the
+ * host RNG and copies them over (:50-62).  For parity tests the masks of the NEXT eesen_net_propagate can be supplied:
+ *   fwd_mask  [T*S x 2H] or NULL;  rec_mask [rec_rows x 2H] with rec_rows = (T+2)*S (time-step masks, row t*S+s as in the
+ *   reference's buffers) or S (sequence masks), columns = forward-direction H then backward-direction H, or NULL;
+ *   twiddle_coin: 0 / 1 = value of the TwiddleForward coin, -1 = draw it. */
+int eesen_net_set_train_mode(eesen_net_t* net, int train);
+int eesen_net_set_dropout_seed(eesen_net_t* net, unsigned long long seed);
+int eesen_net_set_layer_dropout(eesen_net_t* net, int layer, const float* nine);
+int eesen_net_get_layer_dropout(eesen_net_t* net, int layer, float* nine);
+int eesen_net_set_dropout_masks(eesen_net_t* net, int layer, const float* fwd_mask_host, long fwd_floats,
+                                const float* rec_mask_host, int rec_rows, long rec_floats, int twiddle_coin);
+/* masks used by the LAST propagate: fwd_mask_host [T*S x 2H], rec_mask_host [(T+2)*S x 2H] (either may be NULL);
+ * info4 = {forward dropout applied, recurrent mode (0 none, 1 no-memory-loss, 2 RNNDrop), twiddle coin, 2H}. */
+int eesen_net_get_dropout_masks(eesen_net_t* net, int layer, float* fwd_mask_host, float* rec_mask_host, int* info4);
+
 /* ---- minibatch assembly on the device (row a1) ---------------------------------------------------
  * Replaces the host-side padding + interleave + blocking H2D of src/netbin/train-ctc-parallel.cc:186-195: the S utterance
  * matrices are packed back to back into a pinned staging slot (no padding crosses PCIe), copied on the feeder's own

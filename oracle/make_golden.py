@@ -28,14 +28,25 @@ CASES = {
     "small_bi": dict(cfg="small_bi"),
     "proj_bi": dict(cfg="tiny_bi", layers=3, proj=12, H=12, T=20, S=4),
     "ragged_bi": dict(cfg="tiny_bi", T=30, S=5, min_frac=0.3, K=5, repeat_frac=0.5),
+    # dropout variants: the reference draws the masks from its host RNG; they are stored with the outputs
+    "dropout_bi": dict(cfg="tiny_bi", T=20, S=4, H=16, min_frac=0.5,
+                       dropout=[dict(forward=0.25, fw_step=True, recurrent=0.25, rec_step=True, rnndrop=True),
+                                dict(forward=0.2, fw_seq=True, recurrent=0.3, rec_seq=True, nml=True)]),
+    "dropout_twiddle": dict(cfg="tiny_bi", T=16, S=3, H=8,
+                            dropout=[dict(forward=0.3, fw_step=True, recurrent=0.3, rec_step=True, nml=True, twiddle=True),
+                                     dict(forward=0.3, fw_step=True, recurrent=0.3, rec_seq=True, rnndrop=True, twiddle=True)]),
 }
 
 
 def make_case(name: str, spec: dict) -> dict:
     spec = dict(spec)
+    drops = spec.pop("dropout", None)
     cfg = synth.config(spec.pop("cfg"))
     cfg.update(spec)
     layers = synth.make_model(**cfg)
+    if drops:
+        for L, d in zip([l for l in layers if l["type"].startswith("BiLstm")], drops):
+            L["dropout"] = d
     batch = synth.make_batch(**cfg)
     path = tempfile.mktemp(suffix=".nnet")
     nnet_io.write_nnet(path, layers, binary=False)     # text, so the reference parses exactly these values
@@ -46,6 +57,15 @@ def make_case(name: str, spec: dict) -> dict:
     ref.set_train_options(1.0, 0.0)
     ref.set_seq_lengths(batch.lens)
     net_out = ref.propagate(batch.feats)
+    extra = {}
+    if drops:
+        extra["dropout"] = np.array(repr(drops))
+        for li, L in enumerate(layers):
+            if L.get("dropout"):
+                m = ref.dropout_masks(li)
+                extra[f"m{li}_fwd"] = m["fwd"]
+                extra[f"m{li}_rec"] = np.hstack([m["rec_fw"], m["rec_bw"]])     # fw columns, then bw
+                extra[f"m{li}_coin"] = np.array(int(m["twiddle_apply_forward"]))
     ctc = refbind.cuda_ctc_eval_parallel(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
     ne, nr = ref.error_rate_mseq(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
     in_diff = ref.backpropagate(ctc["diff"], True)
@@ -53,7 +73,7 @@ def make_case(name: str, spec: dict) -> dict:
     meta = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str))}
     return dict(meta=np.array(repr(meta)), feats=batch.feats, lens=batch.lens, label_ids=batch.label_ids, label_off=batch.label_off,
                 params=before, net_out=net_out, alpha=ctc["alpha"], beta=ctc["beta"], pzx=ctc["pzx"], diff=ctc["diff"],
-                in_diff=in_diff, params_after=after, errors=np.array([ne, nr], np.int64))
+                in_diff=in_diff, params_after=after, errors=np.array([ne, nr], np.int64), **extra)
 
 
 def compressed_feature_case():

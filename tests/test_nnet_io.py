@@ -27,11 +27,19 @@ def test_param_count_matches_reference_formula():
     assert n == 21211182
 
 
-def test_dropout_is_refused(tmp_path):
+@pytest.mark.parametrize("binary", [False, True])
+def test_dropout_options_roundtrip(tmp_path, binary):
+    """The nine dropout tokens of BiLstm (bilstm-layer.h:331-373, :435-455) survive write -> read with their values."""
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(**cfg)
+    layers[0]["dropout"] = dict(forward=0.25, fw_step=True, recurrent=0.125, rec_seq=True, nml=True, twiddle=True)
+    layers[1]["dropout"] = dict(recurrent=0.5, rec_step=True, rnndrop=True)
     p = str(tmp_path / "d.nnet")
-    open(p, "w").write("<Nnet>\n<BiLstmParallel> <InputDim> 2 <CellDim> 8\n<LearnRateCoef> 1 <MaxGrad> 0 <ForwardDropoutFactor> 0.2 <ForwardTimeStepDropout> T ")
-    with pytest.raises(ValueError, match="dropout"):
-        nnet_io.read_nnet(p)
+    nnet_io.write_nnet(p, layers, binary=binary)
+    back = nnet_io.read_nnet(p)
+    assert back[0]["dropout"] == layers[0]["dropout"] and back[1]["dropout"] == layers[1]["dropout"]
+    assert "dropout" not in back[2]
+    assert np.array_equal(nnet_io.flatten_params(back), nnet_io.flatten_params(layers))
 
 
 def test_headerless_layer_data_is_accepted(tmp_path):

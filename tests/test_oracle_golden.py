@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import net as onet
-from tests.util import GOLDEN, load_golden, rel_err, valid_mask
+from tests.util import GOLDEN, GOLDEN_DROPOUT, golden_masks, load_golden, rel_err, valid_mask
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -47,3 +47,20 @@ def test_padded_rows_of_diff_are_zero():
     cfg, layers, batch, g = load_golden("ragged_bi")
     assert np.all(g["diff"][~valid_mask(batch.lens, batch.T, batch.S)] == 0)
     assert np.all(g["in_diff"][~valid_mask(batch.lens, batch.T, batch.S)] == 0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_DROPOUT)
+def test_oracle_matches_reference_dropout_outputs(name):
+    """Dropout fixtures: outputs of the reference run with the masks its host RNG drew (stored alongside)."""
+    cfg, layers, batch, g = load_golden(name)
+    ora = onet.OracleNet(layers, "f32")
+    ora.set_train_options(1.0, 0.0)
+    H = cfg["H"]
+    for li, fwd, rec, coin in golden_masks(layers, g):
+        ora.set_dropout_masks(li, fwd=fwd, rec_fw=None if rec is None else rec[:, :H], rec_bw=None if rec is None else rec[:, H:],
+                              twiddle_apply_forward=bool(coin))
+    o = onet.train_step(ora, batch, "f32")
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(o["net_out"][vm], g["net_out"][vm]) < 2e-6
+    assert rel_err(o["in_diff"], g["in_diff"]) < 2e-5
+    assert rel_err(ora.get_params(), g["params_after"]) < 2e-5

@@ -46,6 +46,9 @@ def load_golden(name):
         for k, p in enumerate(L["params"]):
             L["params"][k] = flat[i:i + p.size].reshape(p.shape).astype(np.float32); i += p.size
     assert i == flat.size
+    if "dropout" in g:      # options + the masks the reference drew (oracle/make_golden.py)
+        for L, d in zip([l for l in layers if l["type"].startswith("BiLstm")], ast.literal_eval(str(g["dropout"]))):
+            L["dropout"] = d
     off = g["label_off"]
     labels = [g["label_ids"][off[s]:off[s + 1]].astype(np.int32) for s in range(len(off) - 1)]
     S = len(g["lens"])
@@ -54,3 +57,14 @@ def load_golden(name):
 
 
 GOLDEN = ["tiny_bi", "small_uni", "small_bi", "proj_bi", "ragged_bi"]
+GOLDEN_DROPOUT = ["dropout_bi", "dropout_twiddle"]
+
+
+def golden_masks(layers, g):
+    """[(layer index, fwd | None, rec | None, coin)] of a dropout fixture."""
+    out = []
+    for li, L in enumerate(layers):
+        if L.get("dropout"):
+            fwd, rec = g[f"m{li}_fwd"], g[f"m{li}_rec"]
+            out.append((li, fwd if fwd.size else None, rec if rec.size else None, int(g[f"m{li}_coin"])))
+    return out
