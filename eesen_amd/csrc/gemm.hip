@@ -347,6 +347,8 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   } while (0)
   static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
   if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "eesen_hip: EESEN_GEMM_SYNTH=%d -- weight gradients are NOT computed (timing probe)\n", synth); warned = true; }
     if (synth == 1) hipLaunchKernelGGL(gemm_synth_kernel<1>, grid, block, extra_lds_bytes, st, p);
     else if (synth == 2) hipLaunchKernelGGL(gemm_synth_kernel<2>, grid, block, extra_lds_bytes, st, p);
     else hipLaunchKernelGGL(gemm_synth_kernel<3>, grid, block, extra_lds_bytes, st, p);

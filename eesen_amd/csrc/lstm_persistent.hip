@@ -72,11 +72,7 @@ __device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_
   const unsigned oa = (ok && k < kmax) ? byte_off : kOob;
   const unsigned ob = (ok && k + 4 < kmax) ? byte_off + 16 : kOob;
   const f32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, oa, 0, pol);
-#ifdef EESEN_EXP_HALF_LOADS  // timing experiment only (wrong numbers): one request per line instead of two
-  const f32x4 b = a; (void)ob;
-#else
   const f32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, ob, 0, pol);
-#endif
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
   v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
@@ -493,14 +489,14 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 
 }  // namespace
 
-static int xcd_map() {
-  static const int v = getenv("EESEN_XCD_MAP") ? atoi(getenv("EESEN_XCD_MAP")) : 1;
-  return v;
+static int xcd_map() {  // read per launch (a few ns): tests flip these between nets of one process
+  const char* e = getenv("EESEN_XCD_MAP");
+  return e ? atoi(e) : 1;
 }
 
-static int l2_local() {
-  static const int v = getenv("EESEN_L2_LOCAL") ? atoi(getenv("EESEN_L2_LOCAL")) : 0;  // measured neutral (55.1 vs 55.0 ms/step): opt-in
-  return v;
+static int l2_local() {  // measured neutral (55.1 vs 55.0 ms/step): opt-in
+  const char* e = getenv("EESEN_L2_LOCAL");
+  return e ? atoi(e) : 0;
 }
 
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag

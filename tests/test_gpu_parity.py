@@ -280,6 +280,31 @@ def test_adaptive_update_rules(gpu, rule, tmp_path):
         net.SetUpdateAlgorithm("Adam")
 
 
+def test_l2_local_handoff_option(gpu, monkeypatch):
+    """EESEN_L2_LOCAL=1 (opt-in): the backward hand-off stays inside the XCD's L2 when the in-kernel HW_REG_XCC_ID census
+    confirms the placement, and falls back to the write-through protocol otherwise -- either way the numbers are those of
+    the default path, run after run."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config("cfg2"); cfg.update(T=40, layers=2)      # S = 32, bidirectional, 8-sequence tiles: 8 groups = 8 XCDs
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EESEN_L2_LOCAL", mode)
+        net = Net.from_layers(layers); ctc = Ctc()
+        runs = []
+        for _ in range(4):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            idf = CuMatrix(batch.T * batch.S, cfg["D"])
+            net.BackpropagateNoUpdate(diff, idf)
+            runs.append((idf.numpy(), net.GetGrads()))
+        res[mode] = runs
+    for mode in ("0", "1"):
+        for r in res[mode]:
+            assert np.array_equal(r[0], res["0"][0][0]) and np.array_equal(r[1], res["0"][0][1])
+
+
 def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch):
     """A hand-off that cannot complete (here: a spin bound of zero polls) must surface as EesenError at the next
     synchronisation point, never as a hang or as silently wrong numbers; the per-step fallback then still works."""
