@@ -53,6 +53,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 #ifndef EESEN_POLL_WAVE
 #define EESEN_POLL_WAVE 0
 #endif
+#ifndef EESEN_POLL_DELAY
+#define EESEN_POLL_DELAY 0
+#endif
 #ifndef EESEN_POLL_SLEEP
 #define EESEN_POLL_SLEEP 1
 #endif
@@ -108,6 +111,9 @@ struct Role {
 __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
                                               int lane) {
   const unsigned mine = lane < kShards ? ((nblk - lane + kShards - 1) / kShards) * step : 0u;
+#if EESEN_POLL_DELAY > 0
+  __builtin_amdgcn_s_sleep(EESEN_POLL_DELAY);  // nobody can have arrived yet: the peers are still in their own step
+#endif
   for (int spins = 0; spins < spin_limit; ++spins) {
     bool ok = true;
     if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
