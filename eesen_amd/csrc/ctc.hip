@@ -103,27 +103,37 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
 }
 
 // ---- alpha / beta sweeps: grid (S, 2), one wavefront each -------------------------------------------
-template <int PL>
-__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, int ld, int T, int S,
-                                                            const int* __restrict__ labx, const int* __restrict__ lens,
-                                                            const int* __restrict__ lablens, float* __restrict__ alpha,
-                                                            float* __restrict__ beta, float* __restrict__ pzx) {
+template <int PL, bool is_beta>
+__device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld, int T, int S, const int* __restrict__ labx,
+                                          const int* __restrict__ lens, const int* __restrict__ lablens,
+                                          float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ pzx,
+                                          float* last) {
   constexpr int Lpad = 64 * PL;
-  __shared__ float last[Lpad];
   const int s = blockIdx.x, lane = threadIdx.x;
-  const bool is_beta = blockIdx.y == 1;
   const int len = lens[s], ll = lablens[s];
   const int* lab = labx + (size_t)s * Lpad;
   const int j0 = lane * PL;
 
-  int cls[PL];
-  bool three[PL];
+  // Everything per-position that does not change over time is decided once: the class to gather (0 for the -1 padding: a
+  // valid address whose value is never used), and which neighbours take part.  A neighbour that does not take part enters
+  // the log-add as the sentinel -1e30, for which LogAPlusB_fast is the exact identity (see above), so ONE straight-line
+  // expression covers the reference's four cases (:1380-1405 / :1495-1541) -- no divergent branches on the T-step chain and
+  // no branches around the gathers (which would also stop hipcc from counting them in flight).
+  int gi[PL];
+  bool valid[PL], use1[PL], use2[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int j = j0 + i;
-    cls[i] = lab[j];
-    if (!is_beta) three[i] = cls[i] >= 0 && j > 1 && (j & 1) && lab[j - 2] != cls[i];                 // :1396
-    else three[i] = cls[i] >= 0 && j < ll - 2 && (j & 1) && lab[j + 2] != cls[i];                      // :1532
+    const int c = lab[j];
+    valid[i] = c >= 0;
+    gi[i] = c >= 0 ? c : 0;
+    if (!is_beta) {
+      use1[i] = valid[i] && j >= 1;                                              // :1397-1403: alpha[j-1]
+      use2[i] = valid[i] && j > 1 && (j & 1) && lab[j - 2] != c;                // :1396
+    } else {
+      use1[i] = valid[i] && j <= ll - 2;                                         // :1533-1539: beta[j+1]
+      use2[i] = valid[i] && j < ll - 2 && (j & 1) && lab[j + 2] != c;           // :1532
+    }
   }
   if (len <= 0) {
     if (!is_beta && lane == 0) pzx[s] = kLogZero;
@@ -131,68 +141,74 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
   }
   float* out = (is_beta ? beta : alpha) + (size_t)s * T * Lpad + j0;
   float cur[PL];
-
-  if (!is_beta) {
-    // row 0 (:1391-1393)
-    const float* lp = logp + (size_t)s * ld;
+  // The gathers of the log-probabilities run DEPTH steps ahead of their use (a ring of DEPTH register sets): one step
+  // of look-ahead leaves the chain bound by the HBM latency of the gather (measured 1.66 us per step).
+  constexpr int DEPTH = 4;
+  const int t_first = is_beta ? len - 1 : 0, dt = is_beta ? -1 : 1;   // sweep direction
+  auto row = [&](int k) {  // log-prob row of the k-th step of this sweep (clamped to a valid frame past the end)
+    const int t = t_first + dt * k;
+    return logp + (size_t)((k < len ? t : t_first) * S + s) * ld;
+  };
+  {  // first row (:1391-1393 / :1527-1529)
+    const float* lp = row(0);
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       const int j = j0 + i;
-      cur[i] = (cls[i] >= 0 && j < 2) ? lp[cls[i]] : kLogZero;
+      const bool on = valid[i] && (is_beta ? j > ll - 3 : j < 2);
+      const float v = lp[gi[i]];
+      cur[i] = on ? v : kLogZero;
     }
-    store_row<PL>(out, cur);
-    // The gathers of the log-probabilities run DEPTH steps ahead of their use (a ring of DEPTH register sets): one step
-    // of look-ahead leaves the chain bound by the HBM latency of the gather (measured 1.66 us per step).
-    constexpr int DEPTH = 4;
-    float P[DEPTH][PL];
+    store_row<PL>(out + (size_t)t_first * Lpad, cur);
+  }
+  float P[DEPTH][PL];
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    const float* lr = row(1 + u);
+#pragma unroll
+    for (int i = 0; i < PL; ++i) P[u][i] = lr[gi[i]];
+  }
+  for (int base = 1; base < len; base += DEPTH) {
+    float Q[DEPTH][PL];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {  // gathers for steps base+DEPTH .. base+2*DEPTH-1
+      const float* lr = row(base + DEPTH + u);
+#pragma unroll
+      for (int i = 0; i < PL; ++i) Q[u][i] = lr[gi[i]];
+    }
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) {
-      const int t = 1 + u;
-      const float* lr = logp + (size_t)((t < len ? t : 0) * S + s) * ld;
+      const int k = base + u;
+      if (k < len) {  // wave-uniform
+        // the two neighbours beyond this lane's chunk: alpha looks down (j-1, j-2), beta up (j+1, j+2)
+        const float e1 = is_beta ? __shfl_down(cur[0], 1) : __shfl_up(cur[PL - 1], 1);
+        const float e2 = is_beta ? (PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2))
+                                 : (PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2));
+        float nxt[PL];
 #pragma unroll
-      for (int i = 0; i < PL; ++i) P[u][i] = (t < len && cls[i] >= 0) ? lr[cls[i]] : 0.f;
-    }
-    for (int base = 1; base < len; base += DEPTH) {
-      float Q[DEPTH][PL];
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {  // gathers for steps base+DEPTH .. base+2*DEPTH-1
-        const int t = base + DEPTH + u;
-        const float* lr = logp + (size_t)((t < len ? t : 0) * S + s) * ld;
-#pragma unroll
-        for (int i = 0; i < PL; ++i) Q[u][i] = (t < len && cls[i] >= 0) ? lr[cls[i]] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        const int t = base + u;
-        if (t < len) {
-          const float pm1 = __shfl_up(cur[PL - 1], 1);
-          const float pm2 = PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2);
-          float nxt[PL];
-#pragma unroll
-          for (int i = 0; i < PL; ++i) {
-            const int j = j0 + i;
-            const float a0 = cur[i];
-            const float a1 = i >= 1 ? cur[i >= 1 ? i - 1 : 0] : pm1;
-            const float a2 = i >= 2 ? cur[i >= 2 ? i - 2 : 0] : (i == 1 ? pm1 : pm2);
-            float v;
-            if (cls[i] < 0) v = kLogZero;                                                  // :1380-1383
-            else if (j > 1) {
-              const float tmp = LogAPlusB_fast(a1, a0);                                     // :1397 / :1399
-              v = three[i] ? AddAB_fast(P[u][i], LogAPlusB_fast(a2, tmp)) : AddAB_fast(P[u][i], tmp); // :1400 / :1397
-            } else if (j == 1) v = AddAB_fast(P[u][i], LogAPlusB_fast(a1, a0));                 // :1403
-            else v = AddAB_fast(P[u][i], a0);                                                   // :1405
-            nxt[i] = v;
-          }
-#pragma unroll
-          for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
-          store_row<PL>(out + (size_t)t * Lpad, cur);
+        for (int i = 0; i < PL; ++i) {
+          const int i1 = is_beta ? i + 1 : i - 1, i2 = is_beta ? i + 2 : i - 2;
+          const bool in1 = i1 >= 0 && i1 < PL, in2 = i2 >= 0 && i2 < PL;
+          float n1 = in1 ? cur[in1 ? i1 : 0] : e1;
+          // the second neighbour is either in this lane, or the neighbour lane's edge (e1) / next-to-edge (e2) element
+          float n2 = in2 ? cur[in2 ? i2 : 0] : ((is_beta ? i2 == PL : i2 == -1) ? e1 : e2);
+          n1 = use1[i] ? n1 : kLogZero;
+          n2 = use2[i] ? n2 : kLogZero;
+          float acc = LogAPlusB_fast(n1, cur[i]);                               // :1397,:1399,:1403 / :1533,:1535,:1539
+          if (PL % 2 != 0 || (i & 1)) acc = LogAPlusB_fast(n2, acc);           // :1400 / :1536 (odd positions only: labels)
+          const float v = AddAB_fast(P[u][i], acc);                             // :1397-1405 / :1533-1541
+          nxt[i] = valid[i] ? v : kLogZero;                                      // :1380-1383 / :1495-1498
         }
+#pragma unroll
+        for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
+        store_row<PL>(out + (size_t)(t_first + dt * k) * Lpad, cur);
       }
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u)
-#pragma unroll
-        for (int i = 0; i < PL; ++i) P[u][i] = Q[u][i];
     }
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+      for (int i = 0; i < PL; ++i) P[u][i] = Q[u][i];
+  }
+  if (!is_beta) {
     // ln p(z|x) = logadd(alpha[T_s-1][L'_s-1], alpha[T_s-1][L'_s-2])  (ctc-loss.cc:147-153)
 #pragma unroll
     for (int i = 0; i < PL; ++i) last[j0 + i] = cur[i];
@@ -201,66 +217,18 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
       const float tmp1 = last[ll - 1], tmp2 = ll >= 2 ? last[ll - 2] : kLogZero;
       pzx[s] = tmp1 + logf(1.f + ExpA(tmp2 - tmp1));
     }
-  } else {
-    // row T_s - 1 (:1527-1529)
-    const float* lp = logp + (size_t)((len - 1) * S + s) * ld;
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int j = j0 + i;
-      cur[i] = (cls[i] >= 0 && j > ll - 3) ? lp[cls[i]] : kLogZero;
-    }
-    store_row<PL>(out + (size_t)(len - 1) * Lpad, cur);
-    constexpr int DEPTH = 4;
-    float P[DEPTH][PL];
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-      const int t = len - 2 - u;
-      const float* lr = logp + (size_t)((t >= 0 ? t : 0) * S + s) * ld;
-#pragma unroll
-      for (int i = 0; i < PL; ++i) P[u][i] = (t >= 0 && cls[i] >= 0) ? lr[cls[i]] : 0.f;
-    }
-    for (int base = len - 2; base >= 0; base -= DEPTH) {
-      float Q[DEPTH][PL];
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        const int t = base - DEPTH - u;
-        const float* lr = logp + (size_t)((t >= 0 ? t : 0) * S + s) * ld;
-#pragma unroll
-        for (int i = 0; i < PL; ++i) Q[u][i] = (t >= 0 && cls[i] >= 0) ? lr[cls[i]] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        const int t = base - u;
-        if (t >= 0) {
-          const float nm1 = __shfl_down(cur[0], 1);
-          const float nm2 = PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2);
-          float nxt[PL];
-#pragma unroll
-          for (int i = 0; i < PL; ++i) {
-            const int j = j0 + i;
-            const float b0 = cur[i];
-            const float b1 = i + 1 < PL ? cur[i + 1 < PL ? i + 1 : 0] : nm1;
-            const float b2 = i + 2 < PL ? cur[i + 2 < PL ? i + 2 : 0] : (i + 2 == PL ? nm1 : nm2);
-            float v;
-            if (cls[i] < 0) v = kLogZero;                                                  // :1495-1498
-            else if (j < ll - 2) {
-              const float tmp = LogAPlusB_fast(b1, b0);                                     // :1533 / :1535
-              v = three[i] ? AddAB_fast(P[u][i], LogAPlusB_fast(b2, tmp)) : AddAB_fast(P[u][i], tmp); // :1536 / :1533
-            } else if (j == ll - 2) v = AddAB_fast(P[u][i], LogAPlusB_fast(b1, b0));            // :1539
-            else v = AddAB_fast(P[u][i], b0);                                                   // :1541
-            nxt[i] = v;
-          }
-#pragma unroll
-          for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
-          store_row<PL>(out + (size_t)t * Lpad, cur);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u)
-#pragma unroll
-        for (int i = 0; i < PL; ++i) P[u][i] = Q[u][i];
-    }
   }
+}
+
+template <int PL>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, int ld, int T, int S,
+                                                            const int* __restrict__ labx, const int* __restrict__ lens,
+                                                            const int* __restrict__ lablens, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, float* __restrict__ pzx) {
+  __shared__ float last[64 * PL];
+  // the sweep direction is a template parameter so that every register-array index in the step is a compile-time constant
+  if (blockIdx.y == 1) ctc_sweep<PL, true>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last);
+  else ctc_sweep<PL, false>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last);
 }
 
 // ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per frame -----
