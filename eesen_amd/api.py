@@ -283,8 +283,9 @@ class Net:
     def Synchronize(self):
         check(self.lib.eesen_net_synchronize(self.h))
 
-    def SetProfiling(self, on: bool):
-        check(self.lib.eesen_net_set_profiling(self.h, int(on)))
+    def SetProfiling(self, on, accumulate: bool = False):
+        """HIP-event phase timers: per step (read after every step), or accumulated over several steps until PhaseTimes()."""
+        check(self.lib.eesen_net_set_profiling(self.h, 2 if (on and accumulate) else int(bool(on))))
 
     def PhaseTimes(self) -> dict:
         out = np.zeros(6, np.float32)

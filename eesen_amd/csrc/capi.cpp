@@ -162,7 +162,7 @@ int eesen_net_synchronize(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->sync(); });
 }
 int eesen_net_set_profiling(eesen_net_t* net, int on) {
-  return guard([&] { REQ_PTR(net); net->timer.enable(on != 0); });
+  return guard([&] { REQ_PTR(net); net->timer.enable(on != 0); net->timer.set_accumulate(on == 2); });
 }
 int eesen_net_get_phase_times(eesen_net_t* net, float* out6) {
   return guard([&] { REQ_PTR(net); REQ_PTR(out6); net->timer.collect(out6, 6); });

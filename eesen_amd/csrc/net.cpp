@@ -49,6 +49,7 @@ void PhaseTimer::collect(float* out, int nphase) {
     EESEN_HIP_CHECK(hipEventElapsedTime(&ms, spans_[i].a, spans_[i].b));
     if (spans_[i].phase >= 0 && spans_[i].phase < nphase) out[spans_[i].phase] += ms * 1e-3f;
   }
+  if (accumulate_) used_ = 0;
 }
 
 // ------------------------------------------------------------------------------------------ Layer

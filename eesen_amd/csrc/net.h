@@ -49,7 +49,10 @@ class PhaseTimer {
   ~PhaseTimer();
   void enable(bool on) { on_ = on; }
   bool enabled() const { return on_; }
-  void reset() { used_ = 0; }
+  // accumulate: spans pile up over several steps and are summed (and cleared) by one collect() -- no host
+  // synchronisation per step is needed to time a multi-step region
+  void set_accumulate(bool a) { accumulate_ = a; used_ = 0; }
+  void reset() { if (!accumulate_) used_ = 0; }
   int begin(hipStream_t st, int phase);  // returns a span index (-1 when disabled)
   void end(hipStream_t st, int idx);
   void collect(float* out, int nphase);  // seconds per phase; synchronises on the recorded events
@@ -57,7 +60,7 @@ class PhaseTimer {
   struct Span { hipEvent_t a, b; int phase; };
   std::vector<Span> spans_;
   size_t used_ = 0;
-  bool on_ = false;
+  bool on_ = false, accumulate_ = false;
 };
 
 struct Net {

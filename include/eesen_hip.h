@@ -124,7 +124,8 @@ int eesen_net_update(eesen_net_t* net);
 int eesen_net_synchronize(eesen_net_t* net);
 /* Seconds spent (HIP events on the handle's stream) in the phases of the last step, for bench.py:
  * out[0]=input GEMMs, [1]=recurrence fwd, [2]=affine+softmax, [3]=recurrence bwd, [4]=gradient GEMMs
- * and reductions, [5]=update.  Enabled by eesen_net_set_profiling(net, 1). */
+ * and reductions, [5]=update.  Enabled by eesen_net_set_profiling(net, 1); with 2 the timers ACCUMULATE over all steps
+ * since the last eesen_net_get_phase_times, so a multi-step region needs no host synchronisation per step. */
 int eesen_net_set_profiling(eesen_net_t* net, int on);
 int eesen_net_get_phase_times(eesen_net_t* net, float* out6);
 
