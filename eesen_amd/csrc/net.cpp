@@ -161,6 +161,10 @@ Net::~Net() {
         if (pass) fprintf(stderr, "EESEN_TRACE bwd hand-off: %s\n", h[640 + 639] ? "L2-local (XCD census passed)" : "write-through");
       }
   }
+  if (lens_pin) (void)hipHostFree(lens_pin);
+  if (err_pin) (void)hipHostFree(err_pin);
+  if (lens_ev) (void)hipEventDestroy(lens_ev);
+  if (err_ev) (void)hipEventDestroy(err_ev);
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
   if (ev_rec) (void)hipEventDestroy(ev_rec);
   for (auto& e : ev_grad) if (e) (void)hipEventDestroy(e);
@@ -184,6 +188,24 @@ void Net::check_device_error() {
     throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
                                "resident?); rerun with EESEN_PERSISTENT=0");
   }
+}
+
+void Net::arm_device_error_poll() {
+  if (!ctl.p) return;
+  if (!err_pin) {
+    EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_pin), sizeof(unsigned), hipHostMallocDefault));
+    *err_pin = 0;
+    EESEN_HIP_CHECK(hipEventCreateWithFlags(&err_ev, hipEventDisableTiming));
+  }
+  EESEN_HIP_CHECK(hipMemcpyAsync(err_pin, ctl.p + kCtlWords - 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipEventRecord(err_ev, st));
+  err_armed = true;
+}
+
+void Net::poll_device_error() {
+  if (!err_armed || hipEventQuery(err_ev) != hipSuccess) return;  // not there yet: the next poll or sync() will see it
+  err_armed = false;
+  if (*err_pin) check_device_error();  // re-reads, resets and throws
 }
 
 void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
@@ -312,9 +334,21 @@ void Net::set_seq_lengths(const int* l, int s) {
   EESEN_HIP_CHECK(hipSetDevice(device));
   lens.assign(l, l + s);
   for (int v : lens) EESEN_REQUIRE(v >= 0, EESEN_ERR_INVALID, "negative sequence length");
+  poll_device_error();
   lens_d.reserve(s);
-  sync();  // the previous step may still read the old lengths
-  EESEN_HIP_CHECK(hipMemcpy(lens_d.p, lens.data(), s * sizeof(int), hipMemcpyHostToDevice));
+  // Stream-ordered upload: kernels of the previous step that still read the old lengths are ahead of this copy on the
+  // stream (the side stream was joined at the end of Backpropagate), so nothing has to be drained.
+  if ((size_t)s > lens_pin_cap) {
+    if (lens_pin) { EESEN_HIP_CHECK(hipStreamSynchronize(st)); EESEN_HIP_CHECK(hipHostFree(lens_pin)); }
+    lens_pin = nullptr;
+    lens_pin_cap = std::max<size_t>(64, (size_t)s * 2);
+    EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&lens_pin), lens_pin_cap * sizeof(int), hipHostMallocDefault));
+  }
+  if (!lens_ev) EESEN_HIP_CHECK(hipEventCreateWithFlags(&lens_ev, hipEventDisableTiming));
+  else EESEN_HIP_CHECK(hipEventSynchronize(lens_ev));  // the previous upload has left the staging buffer
+  std::copy(lens.begin(), lens.end(), lens_pin);
+  EESEN_HIP_CHECK(hipMemcpyAsync(lens_d.p, lens_pin, s * sizeof(int), hipMemcpyHostToDevice, st));
+  EESEN_HIP_CHECK(hipEventRecord(lens_ev, st));
   S = s;
   propagated = false;
 }
@@ -524,6 +558,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
   out_cols = layers.back().dout;
   out_ld = ldx;
   propagated = true;
+  if (persistent) arm_device_error_poll();
 }
 
 void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi) {
@@ -668,6 +703,7 @@ void Net::update() {
     }
   refresh_derived();
   timer.end(st, ti_); }
+  if (persistent) arm_device_error_poll();
 }
 
 }  // namespace eesen

@@ -99,6 +99,16 @@ struct Net {
   int spin_limit = 400000;
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error();
+  // set_seq_lengths does not drain the stream: the lengths go through a pinned staging word-array (the previous copy has
+  // long completed; waiting for it bounds the host's run-ahead to one step), and the persistent kernels' error word is
+  // polled through an asynchronous copy enqueued behind every Propagate / Update (full check in sync()).
+  int* lens_pin = nullptr;
+  size_t lens_pin_cap = 0;
+  hipEvent_t lens_ev = nullptr, err_ev = nullptr;
+  unsigned* err_pin = nullptr;
+  bool err_armed = false;
+  void poll_device_error();      // non-blocking
+  void arm_device_error_poll();  // enqueue the copy of the error word
   // dropout
   bool in_train = true;                       // BiLstm::in_train (bilstm-layer.h:38), Net::SetTrainMode / SetTestMode
   unsigned long long drop_seed = 777, drop_counter = 0;   // masks are a pure function of (seed, draw counter, element)
