@@ -74,7 +74,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
 void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float p, unsigned long long seed, bool per_column);
 // out[r][c] = a[r][c] * m[r][c]   (MulElements, :416 / :895)
 void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int ldm, float* out, int ldo, long rows, int cols);
-void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz);
+void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg = nullptr);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

@@ -525,10 +525,11 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   return {2, 1};
 }
 
-void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz) {
+void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg) {
   const FwdTile ft = fwd_tile(L);
   *nblk = L.H / (4 * ft.nt);
   *nz = cdiv(L.S, 16 * ft.mt);
+  if (units_per_wg) *units_per_wg = 4 * ft.nt;
 }
 
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,

@@ -506,10 +506,12 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       // The NEXT LSTM layer's input GEMM can run on the side stream WHILE this layer's persistent kernel is running:
       // its row tiles wait on the kernel's arrival counters and are visited middle-out in time (gemm_f32_nt_gated).
       Layer* nxt = (&L - layers.data()) + 1 < (long)layers.size() ? &layers[(&L - layers.data()) + 1] : nullptr;
-      int gate_nblk = 0, nz = 1;
-      lstm_fwd_persistent_geometry(lstm_view(*this, L), &gate_nblk, &nz);
+      int gate_nblk = 0, nz = 1, gate_units = 0;
+      lstm_fwd_persistent_geometry(lstm_view(*this, L), &gate_nblk, &nz, &gate_units);
       // (with forward dropout the next layer reads the MASKED output, which exists only after the recurrence: no gating)
-      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
+      // (the 16-unit tile of wide layers fills the register file -- 2 x 206 VGPRs per SIMD -- so spinning GEMM workgroups
+      // could keep its cooperative kernel from becoming resident: no gating there)
+      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
