@@ -353,8 +353,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
     }
   }
-  // buffer resources are re-based on the time step's row block every step, so the 32-bit offsets only span one block
-  // (S * ldG * 4 bytes, checked on the host) whatever T is
+  // ONE loop-invariant buffer resource over all of DG (at most 2 GB, checked on the host).  Re-basing it on the time step's
+  // row block every step (to lift the 2 GB limit) was measured: +0.27 us per step, 1 ms per cfg2 minibatch -- not worth it.
+  const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
 
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
-      const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG + (size_t)tn * S * ldG);
-      const size_t arow = ((size_t)sa * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row in block tn
+      const int tnb = tn * S;
+      const size_t arow = ((size_t)(tnb + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row in block tn
       if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
         // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
         // load: lane (li, kq) reads 16 bytes of sequence li & 7 at segment (li >> 3) * 4 + kq of the 128-byte chunk -- one
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         // second request of a line occupies the L1 miss queue like the first; measured -740 ticks per step).  The upper
         // half of the chunk reaches rows 0-7 through a rotate-by-8 DPP move inside each 16-lane row; rows 8-15 of the
         // product are garbage that nobody reads.
-        const unsigned arow8 = (unsigned)(((size_t)(s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
+        const unsigned arow8 = (unsigned)(((size_t)(tnb + s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
         const bool rok = s0 + (li & 7) < S;
         const int seg = (li >> 3) * 4 + kq;
         f32x4 a4[CPW];
@@ -449,10 +450,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       float carry = dcx * f;
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
-      const __amdgpu_buffer_rsrc_t rOut = make_rsrc(DG + (size_t)t * S * ldG);
-      const unsigned ooff = (unsigned)(((size_t)s_e * ldG + gcol) * 4);
-      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rOut, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
-      else __builtin_amdgcn_raw_buffer_store_b128(out, rOut, ooff, 0, kSc1);
+      const unsigned ooff = (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4);
+      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
+      else __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
     EESEN_STAMP(3);
@@ -594,7 +594,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   const int ngroups = (int)(grid.y * grid.z);
   const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
   if (need > 16 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
-  if ((size_t)L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 30)) return false;  // 32-bit buffer offsets within one time step's row block
+  if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of DG
   if (((size_t)L.S * L.ndir * 4 * L.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
