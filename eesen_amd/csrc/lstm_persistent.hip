@@ -197,6 +197,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
 
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y);  // loop-invariant (re-basing it every step costs ~0.25 us per step)
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
-      const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y + (size_t)(tp + 1) * S * ldY + dir * H);
+      const unsigned ybase = (unsigned)(((size_t)(tp + 1) * S * ldY + dir * H) * 4);  // < 2 GB, checked on the host
       float a[MT][CPW][8];
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int sa = s0 + m * 16 + li;
-          ld8_sc1(rY, (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[m][c]);
+          ld8_sc1(rY, ybase + (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[m][c]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA (else they are issued lazily, 2 at a time)
@@ -548,6 +549,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
   // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
   // and is read back stale one step later (seen at S = 17, H = 20).  Such shapes use the per-step kernels.
   if (((size_t)L.S * L.ndir * L.H * sizeof(float)) % 128 != 0) return false;
+  if ((size_t)(L.T + 2) * L.S * L.ndir * L.H * sizeof(float) >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of Y
   EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
   if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
 #define EESEN_FP(CPW, MT, NT)                                                                          \
