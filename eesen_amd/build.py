@@ -19,6 +19,10 @@ HEADERS = ["common.h", "guard.h", "kernels.h", "net.h", os.path.join("..", "..",
 FLAGS = (["-DEESEN_POLL_NOSLEEP"] if os.environ.get("EESEN_BUILD_NOSLEEP") else []) + (os.environ.get("EESEN_BUILD_DEFS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+BINDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin")
+TOOLS = {"train-ctc-parallel": "train_ctc_parallel.cc"}
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -61,6 +65,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(warn, file=sys.stderr)
     if jobs or force or _stale(LIB, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    # host-only C++ tools over the C-ABI (no HIP in these sources): the reference's trainer binary, natively
+    os.makedirs(BINDIR, exist_ok=True)
+    cxx = shutil.which("g++") or "g++"
+    for name, src in TOOLS.items():
+        exe = os.path.join(BINDIR, name)
+        srcp = os.path.join(CSRC, "tools", src)
+        if force or _stale(exe, [srcp, LIB, os.path.join(CSRC, "..", "..", "include", "eesen_hip.h")]):
+            run([cxx, "-O2", "-std=c++17", "-Wall", srcp, "-o", exe, "-L" + LIBDIR, "-leesen_hip", "-Wl,-rpath," + LIBDIR,
+                 "-Wl,-rpath,$ORIGIN/../lib", "-Wl,--allow-shlib-undefined"])
     return LIB
 
 

@@ -1,0 +1,413 @@
+// train_ctc_parallel.cc -- the reference's trainer binary (src/netbin/train-ctc-parallel.cc) over the C-ABI of include/eesen_hip.h.
+//
+// Host C++ only: no HIP headers, no torch, no Python.  Same options, positional arguments, stderr protocol and exit codes
+// as the reference binary; one GPU (multi-GPU is one process per GPU with an all-reduce of eesen_net_grad_buffer(), see
+// eesen_amd/train_ctc_parallel.py for the torch.distributed launcher that does it).  What differs from the reference's
+// loop (:144-215) is only where the work happens: minibatch padding + interleave + upload run on the device feeder's own
+// stream under the previous step (eesen_feeder_*), and Propagate / CTC / Backpropagate are the HIP path.
+//
+// Tables: `ark:file`, `ark,t:file`, `scp:file` for the features (float matrices: binary FM, text, compressed CM / CM2 --
+// src/cpucompute/matrix.cc:968-994, compressed-matrix.cc:437-520) and the labels (int32 vectors, binary or text --
+// src/util/kaldi-holder-inl.h:190-260).
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/eesen_hip.h"
+
+namespace {
+
+void ck(int rc) {  // KALDI_ERR: message + std::runtime_error (src/base/kaldi-error.cc:168-182)
+  if (rc != EESEN_OK) throw std::runtime_error(eesen_last_error());
+}
+void log_line(const char* level, const std::string& msg) {
+  std::cerr << level << " (train-ctc-parallel:main():eesen_amd/csrc/tools/train_ctc_parallel.cc) " << msg << std::endl;
+}
+std::string fmt_g(double v) {  // what operator<< prints for a float/double by default
+  std::ostringstream o;
+  o << v;
+  return o.str();
+}
+
+// ---------------------------------------------------------------------------------------------------- Kaldi tables
+struct Mat {
+  std::vector<float> v;
+  int rows = 0, cols = 0;
+};
+
+void need(std::istream& is, const char* what) {
+  if (!is) throw std::runtime_error(std::string("table read error: ") + what);
+}
+int32_t read_sized_int(std::istream& is) {  // io-funcs-inl.h:32-41: size byte 4 + little-endian payload
+  char sz = 0;
+  is.get(sz);
+  int32_t v = 0;
+  is.read(reinterpret_cast<char*>(&v), 4);
+  if (!is || sz != 4) throw std::runtime_error("bad binary int32 in table");
+  return v;
+}
+std::string read_key(std::istream& is) {  // bytes up to the first space; "" at EOF; leading newlines skipped (text mode)
+  std::string k;
+  char c;
+  while (is.get(c)) {
+    if (c == ' ' || c == '\t') { if (!k.empty()) return k; continue; }
+    if ((c == '\n' || c == '\r') && k.empty()) continue;
+    k.push_back(c);
+  }
+  return k;
+}
+float u16_to_float(float min_value, float range, uint16_t v) {  // compressed-matrix.cc:244-250
+  return min_value + range * 1.52590218966964e-05F * v;
+}
+float char_to_float(float p0, float p25, float p75, float p100, unsigned char value) {  // compressed-matrix.cc:363-373
+  if (value <= 64) return p0 + (p25 - p0) * value * (1 / 64.0);
+  if (value <= 192) return p25 + (p75 - p25) * (value - 64) * (1 / 128.0);
+  return p75 + (p100 - p75) * (value - 192) * (1 / 63.0);
+}
+Mat read_compressed(std::istream& is, int format) {  // compressed-matrix.cc:437-470 + CopyToMat :485-520
+  struct { float min_value, range; int32_t num_rows, num_cols; } h;
+  is.read(reinterpret_cast<char*>(&h), sizeof(h));
+  need(is, "compressed-matrix header");
+  Mat m;
+  m.rows = h.num_rows; m.cols = h.num_cols;
+  if (h.num_cols == 0) { m.rows = 0; return m; }
+  m.v.resize((size_t)m.rows * m.cols);
+  if (format == 2) {
+    std::vector<uint16_t> d((size_t)m.rows * m.cols);
+    is.read(reinterpret_cast<char*>(d.data()), d.size() * 2);
+    need(is, "CM2 data");
+    for (size_t i = 0; i < d.size(); ++i) m.v[i] = u16_to_float(h.min_value, h.range, d[i]);
+    return m;
+  }
+  std::vector<uint16_t> pc((size_t)4 * m.cols);
+  is.read(reinterpret_cast<char*>(pc.data()), pc.size() * 2);
+  std::vector<unsigned char> bytes((size_t)m.rows * m.cols);
+  is.read(reinterpret_cast<char*>(bytes.data()), bytes.size());
+  need(is, "CM data");
+  for (int c = 0; c < m.cols; ++c) {
+    const float p0 = u16_to_float(h.min_value, h.range, pc[4 * c]), p25 = u16_to_float(h.min_value, h.range, pc[4 * c + 1]),
+                p75 = u16_to_float(h.min_value, h.range, pc[4 * c + 2]), p100 = u16_to_float(h.min_value, h.range, pc[4 * c + 3]);
+    for (int r = 0; r < m.rows; ++r) m.v[(size_t)r * m.cols + c] = char_to_float(p0, p25, p75, p100, bytes[(size_t)c * m.rows + r]);
+  }
+  return m;
+}
+Mat read_matrix(std::istream& is) {
+  Mat m;
+  if (is.peek() == '\0') {  // binary: \0B then a token
+    is.get(); is.get();
+    std::string tok;
+    is >> tok;
+    is.get();  // the space after the token
+    if (tok == "CM") return read_compressed(is, 1);
+    if (tok == "CM2") return read_compressed(is, 2);
+    if (tok == "DM") throw std::runtime_error("double-precision matrices are not supported (the path is BaseFloat = float)");
+    if (tok != "FM") throw std::runtime_error("expected FM / CM / CM2, got " + tok);
+    m.rows = read_sized_int(is); m.cols = read_sized_int(is);
+    m.v.resize((size_t)m.rows * m.cols);
+    is.read(reinterpret_cast<char*>(m.v.data()), m.v.size() * 4);
+    need(is, "matrix data");
+    return m;
+  }
+  // text: " [" rows separated by newlines "]"
+  char c;
+  do { need(is.get(c), "text matrix"); } while (c != '[');
+  std::string body;
+  std::getline(is, body, ']');
+  std::istringstream rows(body);
+  std::string line;
+  while (std::getline(rows, line)) {
+    std::istringstream ls(line);
+    float f;
+    int n = 0;
+    while (ls >> f) { m.v.push_back(f); ++n; }
+    if (n) { if (m.cols && n != m.cols) throw std::runtime_error("ragged text matrix"); m.cols = n; ++m.rows; }
+  }
+  std::getline(is, line);  // rest of the closing line
+  return m;
+}
+std::vector<int32_t> read_int_vector(std::istream& is) {
+  std::vector<int32_t> v;
+  if (is.peek() == '\0') {
+    is.get(); is.get();
+    const int32_t n = read_sized_int(is);
+    v.resize(n);
+    for (int32_t i = 0; i < n; ++i) v[i] = read_sized_int(is);
+    return v;
+  }
+  std::string line;
+  std::getline(is, line);
+  std::istringstream ls(line);
+  int32_t x;
+  while (ls >> x) v.push_back(x);
+  return v;
+}
+struct Spec { std::string kind, path; };
+Spec parse_spec(const std::string& s) {
+  const size_t c = s.find(':');
+  if (c == std::string::npos) throw std::runtime_error("bad table specifier '" + s + "' (expected ark:... or scp:...)");
+  Spec sp{s.substr(0, s.find_first_of(",:")), s.substr(c + 1)};
+  if (sp.kind != "ark" && sp.kind != "scp") throw std::runtime_error("unsupported table kind in '" + s + "'");
+  if (!sp.path.empty() && (sp.path.back() == '|' || sp.path.front() == '|')) throw std::runtime_error("pipes in table specifiers are not supported");
+  return sp;
+}
+// SequentialBaseFloatMatrixReader (train-ctc-parallel.cc:124)
+class FeatureReader {
+ public:
+  explicit FeatureReader(const std::string& rspecifier) : sp_(parse_spec(rspecifier)) {
+    f_.open(sp_.path, std::ios::binary);
+    if (!f_) throw std::runtime_error("cannot open " + sp_.path);
+    Next();
+  }
+  bool Done() const { return done_; }
+  const std::string& Key() const { return key_; }
+  Mat& Value() { return val_; }
+  void Next() {
+    if (sp_.kind == "ark") {
+      key_ = read_key(f_);
+      if (key_.empty()) { done_ = true; return; }
+      val_ = read_matrix(f_);
+      return;
+    }
+    std::string line;
+    while (std::getline(f_, line)) {
+      std::istringstream ls(line);
+      std::string loc;
+      if (!(ls >> key_ >> loc)) continue;
+      std::streamoff off = 0;
+      const size_t c = loc.rfind(':');
+      if (c != std::string::npos && c + 1 < loc.size() && loc.find_first_not_of("0123456789", c + 1) == std::string::npos) {
+        off = std::stoll(loc.substr(c + 1));
+        loc = loc.substr(0, c);
+      }
+      std::ifstream a(loc, std::ios::binary);
+      if (!a) throw std::runtime_error("cannot open " + loc);
+      a.seekg(off);
+      val_ = read_matrix(a);
+      return;
+    }
+    done_ = true;
+  }
+ private:
+  Spec sp_;
+  std::ifstream f_;
+  std::string key_;
+  Mat val_;
+  bool done_ = false;
+};
+// RandomAccessInt32VectorReader (train-ctc-parallel.cc:125): the whole table in memory
+std::map<std::string, std::vector<int32_t>> read_targets(const std::string& rspecifier) {
+  const Spec sp = parse_spec(rspecifier);
+  if (sp.kind != "ark") throw std::runtime_error("labels: only ark: tables are supported");
+  std::ifstream f(sp.path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + sp.path);
+  std::map<std::string, std::vector<int32_t>> t;
+  for (;;) {
+    const std::string k = read_key(f);
+    if (k.empty()) break;
+    t[k] = read_int_vector(f);
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------------- options
+struct Options {  // train-ctc-parallel.cc:45-80, NetTrainOptions train-opts.h:29-62
+  float learn_rate = 0.008f, momentum = 0.f, adagrad_epsilon = 1e-6f, rms_prop_rho = 0.9f;
+  bool binary = true, cross_validate = false;
+  int num_sequence = 5, report_step = 100, num_jobs = 1, job_id = 1, utts_per_avg = 500, verbose = 0, device = 0;
+  double frame_limit = 100000;
+  std::string opt_algorithm = "SGD", sequence_out_file;
+  std::vector<std::string> args;
+};
+bool parse_bool(const std::string& v) {
+  if (v == "true" || v == "True" || v == "T" || v == "1" || v.empty()) return true;
+  if (v == "false" || v == "False" || v == "F" || v == "0") return false;
+  throw std::runtime_error("bad boolean option value '" + v + "'");
+}
+Options parse_options(int argc, char** argv) {
+  Options o;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a.rfind("--", 0) != 0) { o.args.push_back(a); continue; }
+    const size_t eq = a.find('=');
+    const std::string k = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+    const std::string v = eq == std::string::npos ? "" : a.substr(eq + 1);
+    if (k == "learn-rate") o.learn_rate = std::stof(v);
+    else if (k == "momentum") o.momentum = std::stof(v);
+    else if (k == "adagrad-epsilon") o.adagrad_epsilon = std::stof(v);
+    else if (k == "rms-prop-rho") o.rms_prop_rho = std::stof(v);
+    else if (k == "binary") o.binary = parse_bool(v);
+    else if (k == "cross-validate") o.cross_validate = parse_bool(v);
+    else if (k == "sequence-out-file") o.sequence_out_file = v;
+    else if (k == "num-sequence") o.num_sequence = std::stoi(v);
+    else if (k == "frame-limit") o.frame_limit = std::stod(v);
+    else if (k == "report-step") o.report_step = std::stoi(v);
+    else if (k == "num-jobs") o.num_jobs = std::stoi(v);
+    else if (k == "job-id") o.job_id = std::stoi(v);
+    else if (k == "utts-per-avg") o.utts_per_avg = std::stoi(v);
+    else if (k == "opt-algorithm") o.opt_algorithm = v;
+    else if (k == "verbose") o.verbose = std::stoi(v);
+    else if (k == "device") o.device = std::stoi(v);
+    else throw std::runtime_error("unknown option --" + k);
+  }
+  return o;
+}
+
+struct Minibatch {
+  std::vector<Mat> mats;
+  std::vector<std::vector<int32_t>> labels;
+  std::vector<int> frames;
+  int T = 0;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    const Options o = parse_options(argc, argv);
+    if ((int)o.args.size() != 4 - (o.cross_validate ? 1 : 0)) {  // :82-85
+      std::cerr << "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n";
+      return 1;
+    }
+    if (o.num_jobs != 1) throw std::runtime_error("--num-jobs > 1: file-based model averaging is replaced by one process per GPU with a gradient all-reduce (python -m torch.distributed.run -m eesen_amd.train_ctc_parallel)");
+    if (!o.sequence_out_file.empty()) throw std::runtime_error("--sequence-out-file is not supported");
+    const std::string feature_rspecifier = o.args[0], targets_rspecifier = o.args[1], model_filename = o.args[2];
+    const std::string target_model_filename = o.cross_validate ? "" : o.args[3];
+
+    eesen_net_t* net = nullptr;
+    eesen_ctc_t* ctc = nullptr;
+    eesen_feeder_t* feeder = nullptr;
+    ck(eesen_net_create(o.device, nullptr, &net));
+    ck(eesen_net_read(net, model_filename.c_str()));                                   // :111
+    ck(eesen_net_set_train_options(net, o.learn_rate, o.momentum));                    // :112-113
+    ck(eesen_net_set_adaptive_options(net, o.adagrad_epsilon, o.rms_prop_rho));
+    ck(eesen_net_set_update_algorithm(net, o.opt_algorithm.c_str()));                  // :114
+    ck(eesen_net_set_train_mode(net, o.cross_validate ? 0 : 1));                       // :116-119
+    ck(eesen_ctc_create(o.device, nullptr, &ctc));
+    ck(eesen_feeder_create(o.device, nullptr, 2, &feeder));
+    int feat_dim = 0, K = 0;
+    ck(eesen_net_input_dim(net, &feat_dim));
+    ck(eesen_net_output_dim(net, &K));
+
+    FeatureReader feature_reader(feature_rspecifier);
+    const std::map<std::string, std::vector<int32_t>> targets_reader = read_targets(targets_rspecifier);
+    log_line("LOG", std::string(o.cross_validate ? "CROSS-VALIDATION" : "TRAINING") + " STARTED");   // :133
+    const auto t0 = std::chrono::steady_clock::now();
+    long num_done = 0, num_no_tgt_mat = 0, num_other_error = 0;
+    double total_frames = 0;
+    std::vector<std::string> warnings;
+
+    // the while(1) loop of :144-183: greedy groups of up to num_sequence utterances within frame_limit padded frames
+    auto next_batch = [&](Minibatch* mb) -> bool {
+      mb->mats.clear(); mb->labels.clear(); mb->frames.clear(); mb->T = 0;
+      int max_frame_num = 0;
+      for (; !feature_reader.Done(); feature_reader.Next()) {
+        const std::string utt = feature_reader.Key();
+        auto tg = targets_reader.find(utt);
+        if (tg == targets_reader.end()) {                                               // :152-156
+          warnings.push_back(utt + ", missing targets");
+          ++num_no_tgt_mat;
+          continue;
+        }
+        Mat& mat = feature_reader.Value();
+        if (mat.rows > o.frame_limit) {                                                 // :161-164
+          warnings.push_back(utt + ", has too many frames; ignoring: " + std::to_string(mat.rows) + " > " + fmt_g(o.frame_limit));
+          continue;
+        }
+        if (mat.cols != feat_dim) throw std::runtime_error("feature dimension " + std::to_string(mat.cols) + " does not match the net's InputDim " + std::to_string(feat_dim));
+        const int new_max = std::max(max_frame_num, mat.rows);
+        if ((double)new_max * (mb->mats.size() + 1) > o.frame_limit) break;             // :170-172: opens the next group, reader not advanced
+        max_frame_num = new_max;
+        mb->frames.push_back(mat.rows);
+        mb->labels.push_back(tg->second);
+        mb->mats.push_back(std::move(mat));
+        if ((int)mb->mats.size() == o.num_sequence) { feature_reader.Next(); break; }   // :179-182
+      }
+      mb->T = max_frame_num;
+      return !mb->mats.empty();
+    };
+    auto stage = [&](const Minibatch& mb) -> int {  // padding + interleave + upload on the feeder's stream (replaces :186-195)
+      std::vector<const float*> ptr(mb.mats.size());
+      for (size_t s = 0; s < mb.mats.size(); ++s) ptr[s] = mb.mats[s].v.data();
+      int slot = -1;
+      ck(eesen_feeder_submit(feeder, ptr.data(), mb.frames.data(), nullptr, (int)mb.mats.size(), feat_dim, &slot));
+      return slot;
+    };
+
+    Minibatch cur, nxt;
+    bool have = next_batch(&cur);
+    int slot = have ? stage(cur) : -1;
+    float* diff = nullptr;
+    long diff_cap = 0;
+    double obj_prog = 0, err_prog = 0, ref_prog = 0;
+    long seq_since_report = 0;
+    while (have) {
+      const int S = (int)cur.mats.size();
+      float* feats = nullptr;
+      int T = 0, S2 = 0, ld = 0;
+      ck(eesen_feeder_acquire(feeder, slot, &feats, &T, &S2, &ld));
+      ck(eesen_net_set_seq_lengths(net, cur.frames.data(), S));                        // :195
+      const float* net_out = nullptr;
+      int out_cols = 0, out_ld = 0;
+      ck(eesen_net_propagate(net, feats, T * S, ld, /*in_is_device*/ 1, &net_out, &out_cols, &out_ld));   // :198
+      ck(eesen_feeder_release(feeder, slot));
+      std::vector<int> ids, off(1, 0);
+      for (const auto& l : cur.labels) { ids.insert(ids.end(), l.begin(), l.end()); off.push_back((int)ids.size()); }
+      if ((long)T * S * out_ld > diff_cap) {
+        if (diff) ck(eesen_dev_free(o.device, diff));
+        diff_cap = (long)T * S * out_ld;
+        ck(eesen_dev_alloc(o.device, diff_cap * 4, reinterpret_cast<void**>(&diff)));
+      }
+      std::vector<float> pzx(S);
+      ck(eesen_ctc_eval_parallel(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), diff, out_ld, pzx.data()));  // :199
+      int ne = 0, nr = 0;
+      ck(eesen_ctc_error_rate_mseq(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), &ne, &nr));             // :202
+      if (!o.cross_validate) {                                                          // :206-208
+        ck(eesen_net_backpropagate(net, diff, out_ld, nullptr, 0));
+        ck(eesen_net_update(net));
+      }
+      have = next_batch(&nxt);                     // next batch: read and staged while the GPU runs this one's backward pass
+      slot = have ? stage(nxt) : -1;
+      num_done += S;
+      total_frames += (double)T * S;                                                    // padded frames, as the reference counts them (:215)
+      for (float p : pzx) obj_prog += p;
+      err_prog += ne; ref_prog += nr; seq_since_report += S;
+      if (o.verbose >= 1 && seq_since_report >= o.report_step) {                        // ctc-loss.cc:180-192
+        double obj; long seqs, frames, e, r;
+        ck(eesen_ctc_stats(ctc, &obj, &seqs, &frames, &e, &r));
+        log_line("VLOG[1]", "After " + std::to_string(seqs) + " sequences (" + fmt_g(frames / (100.0 * 3600)) + "Hr): Obj(log[Pzx]) = " +
+                                fmt_g(obj_prog / seq_since_report) + "   TokenAcc = " + fmt_g(100.0 * (1.0 - err_prog / std::max(ref_prog, 1.0))) + "%");
+        obj_prog = err_prog = ref_prog = 0; seq_since_report = 0;
+      }
+      std::swap(cur, nxt);
+    }
+    for (const auto& w : warnings) log_line("WARNING", w);
+    ck(eesen_net_synchronize(net));
+    if (!o.cross_validate) ck(eesen_net_write(net, target_model_filename.c_str(), o.binary ? 1 : 0));   // :244-246
+    const double el = std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    log_line("LOG", "Done " + std::to_string(num_done) + " files, " + std::to_string(num_no_tgt_mat) + " with no targets, " +
+                        std::to_string(num_other_error) + " with other errors. [" + (o.cross_validate ? "CROSS-VALIDATION" : "TRAINING") + ", " +
+                        fmt_g(el / 60) + " min, fps" + fmt_g(total_frames / el) + "]");              // :247-252
+    double obj; long seqs, frames, e, r;
+    ck(eesen_ctc_stats(ctc, &obj, &seqs, &frames, &e, &r));
+    log_line("LOG", "\nTOKEN_ACCURACY >> " + fmt_g(100.0 * (1.0 - (double)e / (double)r)) + "% <<");     // ctc-loss.cc:300-304
+    if (diff) eesen_dev_free(o.device, diff);
+    eesen_feeder_destroy(feeder);
+    eesen_ctc_destroy(ctc);
+    eesen_net_destroy(net);
+    return 0;
+  } catch (const std::exception& e) {  // :260-263
+    std::cerr << e.what() << std::endl;
+    return 255;
+  }
+}

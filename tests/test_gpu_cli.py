@@ -104,3 +104,46 @@ def test_net_output_extract(gpu, tmp_path):
         assert rel_err(got1[key][:, ok], want[:, ok]) < 1e-4
         assert np.all(got1[key][:, ~ok] < -1e37)
         assert np.array_equal(got1[key], got4[key])
+
+
+def test_native_trainer_binary_equals_python_mirror(gpu, tmp_path):
+    """eesen_amd/bin/train-ctc-parallel (host C++ over the C-ABI, its own Kaldi table readers) against the Python mirror on the
+    same archives: the same library calls in the same order, so the written models are byte-identical and the report lines
+    agree; text, scp and compressed inputs included."""
+    exe = os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")
+    assert os.path.exists(exe), "run python -m eesen_amd.build"
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    layers[0]["dropout"] = dict(forward=0.2, fw_step=True)          # device-drawn masks are a function of (seed, counter): equal too
+    feats, labs, scp, lab = _dataset(tmp_path, D=cfg["D"], K=cfg["K"])
+    m_in = str(tmp_path / "nnet.init")
+    nnet_io.write_nnet(m_in, layers, binary=True)
+    ark_t, lab_t = str(tmp_path / "feats_t.ark"), str(tmp_path / "labels_t.ark")
+    kaldi_io.write_mat_ark(ark_t, feats, text=True)
+    kaldi_io.write_vec_int_ark(lab_t, labs.items(), text=True)
+    opts = ["--learn-rate=0.01", "--momentum=0.9", "--num-sequence=4", "--frame-limit=90", "--report-step=4", "--verbose=1"]
+    for fspec, lspec in (("scp:" + scp, "ark:" + lab), ("ark:" + str(tmp_path / "feats.ark"), "ark:" + lab), ("ark,t:" + ark_t, "ark,t:" + lab_t)):
+        o_py, o_cc = str(tmp_path / "py.nnet"), str(tmp_path / "cc.nnet")
+        r1 = _run(opts + [fspec, lspec, m_in, o_py])
+        r2 = subprocess.run([exe] + opts + [fspec, lspec, m_in, o_cc], capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
+        assert open(o_py, "rb").read() == open(o_cc, "rb").read()
+        acc = [re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r.stderr).group(1) for r in (r1, r2)]
+        assert acc[0] == acc[1]
+        assert "TRAINING STARTED" in r2.stderr and re.search(r"Done 14 files, 0 with no targets, 0 with other errors", r2.stderr)
+        assert "Obj(log[Pzx])" in r2.stderr
+    # the compressed archive of the reference's writer (tests/golden/compressed_feats.ark): cross-validation over it runs
+    g = os.path.join(ROOT, "tests", "golden")
+    ref = np.load(os.path.join(g, "compressed_feats.npz"))
+    labs6 = {str(k): np.arange(1, 1 + max(1, int(r) // 6), dtype=np.int32) % 5 + 1 for k, r in zip(ref["keys"], ref["rows"])}
+    lab6 = str(tmp_path / "lab6.ark"); kaldi_io.write_vec_int_ark(lab6, labs6.items())
+    cfg6 = dict(cfg); cfg6.update(D=6)
+    m6 = str(tmp_path / "m6.nnet"); nnet_io.write_nnet(m6, synth.make_model(**cfg6), binary=True)
+    cv = ["--cross-validate=true", "--num-sequence=3", "ark:" + os.path.join(g, "compressed_feats.ark"), "ark:" + lab6, m6]
+    r1 = _run(cv); r2 = subprocess.run([exe] + cv, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
+    assert re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r1.stderr).group(1) == re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r2.stderr).group(1)
+    # error contract: usage -> 1, failures -> message on stderr + 255 (train-ctc-parallel.cc:81-84, 260-263)
+    assert subprocess.run([exe, "scp:" + scp], capture_output=True).returncode == 1
+    r = subprocess.run([exe, "scp:" + scp, "ark:" + lab, str(tmp_path / "missing"), str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode == 255 and "cannot open model file" in r.stderr
