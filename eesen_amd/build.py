@@ -20,7 +20,7 @@ FLAGS = (["-DEESEN_POLL_NOSLEEP"] if os.environ.get("EESEN_BUILD_NOSLEEP") else 
 
 
 BINDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin")
-TOOLS = {"train-ctc-parallel": "train_ctc_parallel.cc"}
+TOOLS = {"train-ctc-parallel": "train_ctc_parallel.cc", "net-output-extract": "net_output_extract.cc"}
 
 
 def hipcc() -> str:
@@ -71,7 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for name, src in TOOLS.items():
         exe = os.path.join(BINDIR, name)
         srcp = os.path.join(CSRC, "tools", src)
-        if force or _stale(exe, [srcp, LIB, os.path.join(CSRC, "..", "..", "include", "eesen_hip.h")]):
+        if force or _stale(exe, [srcp, LIB, os.path.join(CSRC, "tools", "kaldi_tables.h"), os.path.join(CSRC, "..", "..", "include", "eesen_hip.h")]):
             run([cxx, "-O2", "-std=c++17", "-Wall", srcp, "-o", exe, "-L" + LIBDIR, "-leesen_hip", "-Wl,-rpath," + LIBDIR,
                  "-Wl,-rpath,$ORIGIN/../lib", "-Wl,--allow-shlib-undefined"])
     return LIB

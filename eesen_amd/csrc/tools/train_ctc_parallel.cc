@@ -25,8 +25,10 @@
 #include <vector>
 
 #include "../../../include/eesen_hip.h"
+#include "kaldi_tables.h"
 
 namespace {
+using namespace ktab;
 
 void ck(int rc) {  // KALDI_ERR: message + std::runtime_error (src/base/kaldi-error.cc:168-182)
   if (rc != EESEN_OK) throw std::runtime_error(eesen_last_error());
@@ -38,186 +40,6 @@ std::string fmt_g(double v) {  // what operator<< prints for a float/double by d
   std::ostringstream o;
   o << v;
   return o.str();
-}
-
-// ---------------------------------------------------------------------------------------------------- Kaldi tables
-struct Mat {
-  std::vector<float> v;
-  int rows = 0, cols = 0;
-};
-
-void need(std::istream& is, const char* what) {
-  if (!is) throw std::runtime_error(std::string("table read error: ") + what);
-}
-int32_t read_sized_int(std::istream& is) {  // io-funcs-inl.h:32-41: size byte 4 + little-endian payload
-  char sz = 0;
-  is.get(sz);
-  int32_t v = 0;
-  is.read(reinterpret_cast<char*>(&v), 4);
-  if (!is || sz != 4) throw std::runtime_error("bad binary int32 in table");
-  return v;
-}
-std::string read_key(std::istream& is) {  // bytes up to the first space; "" at EOF; leading newlines skipped (text mode)
-  std::string k;
-  char c;
-  while (is.get(c)) {
-    if (c == ' ' || c == '\t') { if (!k.empty()) return k; continue; }
-    if ((c == '\n' || c == '\r') && k.empty()) continue;
-    k.push_back(c);
-  }
-  return k;
-}
-float u16_to_float(float min_value, float range, uint16_t v) {  // compressed-matrix.cc:244-250
-  return min_value + range * 1.52590218966964e-05F * v;
-}
-float char_to_float(float p0, float p25, float p75, float p100, unsigned char value) {  // compressed-matrix.cc:363-373
-  if (value <= 64) return p0 + (p25 - p0) * value * (1 / 64.0);
-  if (value <= 192) return p25 + (p75 - p25) * (value - 64) * (1 / 128.0);
-  return p75 + (p100 - p75) * (value - 192) * (1 / 63.0);
-}
-Mat read_compressed(std::istream& is, int format) {  // compressed-matrix.cc:437-470 + CopyToMat :485-520
-  struct { float min_value, range; int32_t num_rows, num_cols; } h;
-  is.read(reinterpret_cast<char*>(&h), sizeof(h));
-  need(is, "compressed-matrix header");
-  Mat m;
-  m.rows = h.num_rows; m.cols = h.num_cols;
-  if (h.num_cols == 0) { m.rows = 0; return m; }
-  m.v.resize((size_t)m.rows * m.cols);
-  if (format == 2) {
-    std::vector<uint16_t> d((size_t)m.rows * m.cols);
-    is.read(reinterpret_cast<char*>(d.data()), d.size() * 2);
-    need(is, "CM2 data");
-    for (size_t i = 0; i < d.size(); ++i) m.v[i] = u16_to_float(h.min_value, h.range, d[i]);
-    return m;
-  }
-  std::vector<uint16_t> pc((size_t)4 * m.cols);
-  is.read(reinterpret_cast<char*>(pc.data()), pc.size() * 2);
-  std::vector<unsigned char> bytes((size_t)m.rows * m.cols);
-  is.read(reinterpret_cast<char*>(bytes.data()), bytes.size());
-  need(is, "CM data");
-  for (int c = 0; c < m.cols; ++c) {
-    const float p0 = u16_to_float(h.min_value, h.range, pc[4 * c]), p25 = u16_to_float(h.min_value, h.range, pc[4 * c + 1]),
-                p75 = u16_to_float(h.min_value, h.range, pc[4 * c + 2]), p100 = u16_to_float(h.min_value, h.range, pc[4 * c + 3]);
-    for (int r = 0; r < m.rows; ++r) m.v[(size_t)r * m.cols + c] = char_to_float(p0, p25, p75, p100, bytes[(size_t)c * m.rows + r]);
-  }
-  return m;
-}
-Mat read_matrix(std::istream& is) {
-  Mat m;
-  if (is.peek() == '\0') {  // binary: \0B then a token
-    is.get(); is.get();
-    std::string tok;
-    is >> tok;
-    is.get();  // the space after the token
-    if (tok == "CM") return read_compressed(is, 1);
-    if (tok == "CM2") return read_compressed(is, 2);
-    if (tok == "DM") throw std::runtime_error("double-precision matrices are not supported (the path is BaseFloat = float)");
-    if (tok != "FM") throw std::runtime_error("expected FM / CM / CM2, got " + tok);
-    m.rows = read_sized_int(is); m.cols = read_sized_int(is);
-    m.v.resize((size_t)m.rows * m.cols);
-    is.read(reinterpret_cast<char*>(m.v.data()), m.v.size() * 4);
-    need(is, "matrix data");
-    return m;
-  }
-  // text: " [" rows separated by newlines "]"
-  char c;
-  do { need(is.get(c), "text matrix"); } while (c != '[');
-  std::string body;
-  std::getline(is, body, ']');
-  std::istringstream rows(body);
-  std::string line;
-  while (std::getline(rows, line)) {
-    std::istringstream ls(line);
-    float f;
-    int n = 0;
-    while (ls >> f) { m.v.push_back(f); ++n; }
-    if (n) { if (m.cols && n != m.cols) throw std::runtime_error("ragged text matrix"); m.cols = n; ++m.rows; }
-  }
-  std::getline(is, line);  // rest of the closing line
-  return m;
-}
-std::vector<int32_t> read_int_vector(std::istream& is) {
-  std::vector<int32_t> v;
-  if (is.peek() == '\0') {
-    is.get(); is.get();
-    const int32_t n = read_sized_int(is);
-    v.resize(n);
-    for (int32_t i = 0; i < n; ++i) v[i] = read_sized_int(is);
-    return v;
-  }
-  std::string line;
-  std::getline(is, line);
-  std::istringstream ls(line);
-  int32_t x;
-  while (ls >> x) v.push_back(x);
-  return v;
-}
-struct Spec { std::string kind, path; };
-Spec parse_spec(const std::string& s) {
-  const size_t c = s.find(':');
-  if (c == std::string::npos) throw std::runtime_error("bad table specifier '" + s + "' (expected ark:... or scp:...)");
-  Spec sp{s.substr(0, s.find_first_of(",:")), s.substr(c + 1)};
-  if (sp.kind != "ark" && sp.kind != "scp") throw std::runtime_error("unsupported table kind in '" + s + "'");
-  if (!sp.path.empty() && (sp.path.back() == '|' || sp.path.front() == '|')) throw std::runtime_error("pipes in table specifiers are not supported");
-  return sp;
-}
-// SequentialBaseFloatMatrixReader (train-ctc-parallel.cc:124)
-class FeatureReader {
- public:
-  explicit FeatureReader(const std::string& rspecifier) : sp_(parse_spec(rspecifier)) {
-    f_.open(sp_.path, std::ios::binary);
-    if (!f_) throw std::runtime_error("cannot open " + sp_.path);
-    Next();
-  }
-  bool Done() const { return done_; }
-  const std::string& Key() const { return key_; }
-  Mat& Value() { return val_; }
-  void Next() {
-    if (sp_.kind == "ark") {
-      key_ = read_key(f_);
-      if (key_.empty()) { done_ = true; return; }
-      val_ = read_matrix(f_);
-      return;
-    }
-    std::string line;
-    while (std::getline(f_, line)) {
-      std::istringstream ls(line);
-      std::string loc;
-      if (!(ls >> key_ >> loc)) continue;
-      std::streamoff off = 0;
-      const size_t c = loc.rfind(':');
-      if (c != std::string::npos && c + 1 < loc.size() && loc.find_first_not_of("0123456789", c + 1) == std::string::npos) {
-        off = std::stoll(loc.substr(c + 1));
-        loc = loc.substr(0, c);
-      }
-      std::ifstream a(loc, std::ios::binary);
-      if (!a) throw std::runtime_error("cannot open " + loc);
-      a.seekg(off);
-      val_ = read_matrix(a);
-      return;
-    }
-    done_ = true;
-  }
- private:
-  Spec sp_;
-  std::ifstream f_;
-  std::string key_;
-  Mat val_;
-  bool done_ = false;
-};
-// RandomAccessInt32VectorReader (train-ctc-parallel.cc:125): the whole table in memory
-std::map<std::string, std::vector<int32_t>> read_targets(const std::string& rspecifier) {
-  const Spec sp = parse_spec(rspecifier);
-  if (sp.kind != "ark") throw std::runtime_error("labels: only ark: tables are supported");
-  std::ifstream f(sp.path, std::ios::binary);
-  if (!f) throw std::runtime_error("cannot open " + sp.path);
-  std::map<std::string, std::vector<int32_t>> t;
-  for (;;) {
-    const std::string k = read_key(f);
-    if (k.empty()) break;
-    t[k] = read_int_vector(f);
-  }
-  return t;
 }
 
 // ---------------------------------------------------------------------------------------------------- options

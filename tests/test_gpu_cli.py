@@ -147,3 +147,29 @@ def test_native_trainer_binary_equals_python_mirror(gpu, tmp_path):
     assert subprocess.run([exe, "scp:" + scp], capture_output=True).returncode == 1
     r = subprocess.run([exe, "scp:" + scp, "ark:" + lab, str(tmp_path / "missing"), str(tmp_path / "o")], capture_output=True, text=True)
     assert r.returncode == 255 and "cannot open model file" in r.stderr
+
+
+def test_native_net_output_extract_equals_python_mirror(gpu, tmp_path):
+    exe = os.path.join(ROOT, "eesen_amd", "bin", "net-output-extract")
+    assert os.path.exists(exe), "run python -m eesen_amd.build"
+    cfg = synth.config("tiny_bi")
+    feats, labs, scp, lab = _dataset(tmp_path, n=6, D=cfg["D"], K=cfg["K"])
+    model = str(tmp_path / "final.nnet"); nnet_io.write_nnet(model, synth.make_model(**cfg), binary=True)
+    counts = str(tmp_path / "label.counts")
+    open(counts, "w").write("[ 1200 30 0 45.5 8 19 77 ]\n")
+    for extra in ([], ["--num-sequence=4"], ["--class-frame-counts=" + counts, "--apply-log=true", "--prior-scale=0.8", "--blank-scale=0.5"]):
+        o_py, o_cc = str(tmp_path / "py.ark"), str(tmp_path / "cc.ark")
+        r1 = subprocess.run([sys.executable, "-m", "eesen_amd.net_output_extract"] + extra + [model, "scp:" + scp, "ark:" + o_py],
+                            capture_output=True, text=True, cwd=ROOT, timeout=600)
+        r2 = subprocess.run([exe] + extra + [model, "scp:" + scp, "ark:" + o_cc], capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
+        assert "Done 6 files" in r2.stderr
+        assert open(o_py, "rb").read() == open(o_cc, "rb").read()
+    # text output parses back to the same values
+    o_t = str(tmp_path / "cc_t.ark")
+    assert subprocess.run([exe, model, "scp:" + scp, "ark,t:" + o_t], capture_output=True).returncode == 0
+    a = dict(kaldi_io.read_mat_table("ark:" + o_cc)); b = dict(kaldi_io.read_mat_table("ark,t:" + o_t))
+    r3 = subprocess.run([exe, model, "scp:" + scp, "ark:" + o_cc], capture_output=True)
+    a = dict(kaldi_io.read_mat_table("ark:" + o_cc))
+    assert r3.returncode == 0 and all(np.array_equal(a[k], b[k]) for k in a)
+    assert subprocess.run([exe, model], capture_output=True).returncode == 1
