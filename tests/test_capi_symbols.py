@@ -53,3 +53,16 @@ def test_product_package_does_not_import_the_oracle():
                 s = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
                 assert "liboracle" not in s and "libeesen_ref" not in s, f
+
+
+def test_native_tools_are_built_and_load():
+    """The host-C++ tools over the C-ABI (eesen_amd/csrc/tools) link against the library alone and answer a usage error with exit
+    code 1 before touching a GPU (train-ctc-parallel.cc:81-84)."""
+    import subprocess
+    from eesen_amd import build
+    build.build()
+    for name in build.TOOLS:
+        exe = os.path.join(build.BINDIR, name)
+        assert os.path.exists(exe)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "Usage: " + name in r.stderr, r.stderr
