@@ -9,9 +9,13 @@
 //
 // Cross-workgroup hand-off per step (the placement-independent recipe of the CDNA4 guide, section 6 G16, form R1):
 //   producer: payload with write-through (sc1) stores -> every storing wave drains vmcnt -> workgroup barrier ->
-//             ONE lane bumps the (direction, sequence-tile) arrival counter with a relaxed agent-scope atomic;
-//   consumer: ONE lane polls that counter (relaxed, agent scope, s_sleep between polls, BOUNDED spin) -> workgroup
-//             barrier -> every wave reads the payload with sc1 loads (served from L2 / memory, never from a stale L1).
+//             one lane bumps its shard of the (direction, sequence-tile) group's arrival counters (8 shards on separate
+//             128-byte lines, relaxed agent-scope atomic);
+//   consumer: 8 lanes of wave 0 poll the 8 shards (relaxed, agent scope, s_sleep between polls, BOUNDED spin) ->
+//             workgroup barrier -> every wave reads the payload with plain loads of lines nobody has read before (see below;
+//             EESEN_SC1_LOADS=1 builds the L1-bypassing variant, measured slower).
+// Workgroup roles are laid out so that, with the observed block -> XCD round-robin, the workgroups of one group share an L2
+// (struct Role); that only changes how much crosses the fabric, never correctness.
 // Every step writes row blocks that no one has read before in this launch, so no cache can hold a stale copy -- PROVIDED
 // a step's row block starts on a 128-byte line (the launchers check it and fall back otherwise): an unaligned block
 // shares its first line with the previous block, which caches it one step early.
@@ -20,8 +24,9 @@
 // All workgroups must be co-resident: the host launches cooperatively after an occupancy check with margin and
 // otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an error word instead of hanging.
 //
-// Arithmetic is identical to lstm.hip (same MFMA order, same LDS reduction order, same cell equations): the forward pass
-// is bit-identical to the per-step path, the backward pass up to FMA contraction; tests assert exactly that.
+// Arithmetic is that of lstm.hip (same cell equations, K split over the 8 waves the same way): the forward pass is
+// bit-identical to the per-step path; the backward pass differs in the last bits (FMA contraction, and the full-line operand
+// fetch consumes each 32-float chunk as two 16-float halves); tests assert exactly that.
 #include "kernels.h"
 
 namespace eesen {
