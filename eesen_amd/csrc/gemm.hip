@@ -21,6 +21,9 @@
 namespace eesen {
 namespace {
 
+#ifndef EESEN_GEMM_PRIO
+#define EESEN_GEMM_PRIO 0
+#endif
 #ifndef EESEN_GEMM_BK
 #define EESEN_GEMM_BK 16  // measured on MI355X: BK=32 is -8 % on the k-contiguous shapes (97 vs 107 TF), +3 % on the tall-K transposed ones
 #endif
@@ -180,6 +183,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
     // keep the prefetch ABOVE the MFMA block: without the guards' branches hipcc sinks these loads to just before the
     // LDS stores, which serialises HBM latency with the matrix pipe (measured: 93 -> 66 TF on the tall-K shapes)
     __builtin_amdgcn_sched_barrier(0);
+#if EESEN_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(EESEN_GEMM_PRIO);
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int kr = 2 * kk + lk;
@@ -192,6 +198,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+#if EESEN_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (kt + 1 < nk) {
       store_tile<A_KC>(As[cur ^ 1], tid, ra);
       store_tile<B_KC>(Bs[cur ^ 1], tid, rb);
