@@ -58,7 +58,7 @@ def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
     from eesen_amd import nnet_io
     ncores = os.cpu_count() or 1
     sc = dict(cfg)
-    sc["T"] = 96  # 32 utterances x 96 frames = 3072 padded frames of the same 4x512 BiLSTM
+    sc["T"] = 250  # 32 utterances x 250 frames = 8000 padded frames of the same 4x512 BiLSTM: ~20 s over the three thread settings
     layers = synth.make_model(max_grad=50.0, **sc)
     batch = synth.make_batch(**sc)
     frames = batch.T * batch.S
