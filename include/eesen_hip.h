@@ -49,7 +49,10 @@ int eesen_device_count(int* count);
 /* ---- Net: construction, model I/O ------------------------------------------------------------ */
 /* New empty net on `device`.  `stream` is a hipStream_t to enqueue on (e.g. the caller framework's
  * current stream) or NULL for the device's default stream.  A Net and the Ctc it feeds must share a
- * stream (the reference has one implicit stream for everything). */
+ * stream (the reference has one implicit stream for everything).  A handle is not thread-safe, and the recurrence
+ * kernels are cooperative launches that want every CU of the device: two Nets on the same device must not run
+ * Propagate / Backpropagate CONCURRENTLY on different streams (each would hold half the CUs and wait for the rest until
+ * its spin bound raises EESEN_ERR_HIP); on one stream, or one after the other, any number of handles coexist. */
 int eesen_net_create(int device, void* stream, eesen_net_t** out);
 int eesen_net_destroy(eesen_net_t* net);
 /* Net::AppendLayer (src/net/net.cc:197-205) with the layer header of src/net/layer.cc:138-222:
