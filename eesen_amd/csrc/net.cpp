@@ -265,6 +265,12 @@ void Net::finalize() {
     EESEN_HIP_CHECK(hipMemsetAsync(corr.p, 0, P * sizeof(float), st));
     EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, P * sizeof(float), st));
   }
+  // Side-stream gradient GEMMs pay only while the backward recurrence leaves register room for a GEMM workgroup next to
+  // it; the 16x16 tile of wide layers (H > 512: 256 VGPRs x 2 waves per SIMD) does not, and a GEMM that started before the
+  // cooperative launch then only delays it (measured on cfg4: 141 ms overlapped, 138 ms not).  EESEN_OVERLAP overrides.
+  if (!getenv("EESEN_OVERLAP"))
+    for (const Layer& L : layers)
+      if (L.is_lstm() && L.H > 512) overlap = false;
   finalized = true;
   refresh_derived();
   sync();
