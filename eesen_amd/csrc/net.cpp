@@ -485,6 +485,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
   const float* x = input.p;
   int ldx = D4;
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
+  int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
   for (Layer& L : layers) {
     if (L.is_lstm()) {
       const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
@@ -501,6 +502,12 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       prepare_dropout(*this, L);
       // all gate pre-activations of both directions in one GEMM: G = x * Wx^T + bias  (:109-110, :163-164)
       if (g_gated) {  // already computed on the side stream, gated on the previous layer's progress (see below)
+        if (gated_rows < rows) {  // the last, partial row tile (T*S not a multiple of 128): its frames are the last to complete anyway
+          const int ti_ = timer.begin(st, 0);
+          gemm_f32(st, true, true, rows - gated_rows, ldG, L.din, 1.f, x + (size_t)gated_rows * ldx, ldx, params.p + L.p_off + L.off_wx,
+                   pad4(L.din), 0.f, L.G.p + (size_t)gated_rows * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0);
+          timer.end(st, ti_);
+        }
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
         g_gated = false;
       } else {
@@ -517,7 +524,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       // (with forward dropout the next layer reads the MASKED output, which exists only after the recurrence: no gating)
       // (the 16-unit tile of wide layers fills the register file -- 2 x 206 VGPRs per SIMD -- so spinning GEMM workgroups
       // could keep its cooperative kernel from becoming resident: no gating there)
-      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows % 128 == 0 &&
+      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows >= 128 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
@@ -533,7 +540,8 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
         EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
         const int tj_ = timer.begin(st2, 0);
         GemmGate gate{ctl.p, ctl.p + kCtlWords - 1, nd, nz, gate_nblk, T, S, spin_limit};
-        gemm_f32_nt_gated(st2, rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
+        gated_rows = rows / 128 * 128;
+        gemm_f32_nt_gated(st2, gated_rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
                           nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate);
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
