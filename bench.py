@@ -2,11 +2,14 @@
 """bench.py -- CTC training frames/sec of the MI355X path on BASELINE.json's configuration.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...), or on its own: without
+  WORLD_SIZE in the environment `bench.py --gpus N` starts its N ranks itself (one process per GPU) and still prints
+  exactly one JSON line.
 
 A "step" is one pass of train-ctc-parallel's inner loop (/root/reference/src/netbin/train-ctc-parallel.cc:195-207)
-over one synthetic utterance mini-batch per GPU: SetSeqLengths -> Propagate -> Ctc::EvalParallel ->
-Backpropagate (+ gradient all-reduce when N > 1) -> Update.  Workload at N = 1 = BASELINE.json configs[1]:
+over one synthetic utterance mini-batch per GPU: SetSeqLengths -> Propagate -> Ctc::EvalParallel -> Ctc::ErrorRateMSeq ->
+Backpropagate (+ per-layer RCCL gradient all-reduce when N > 1, issued by the library under the backward pass) -> Update.  Workload at N = 1 = BASELINE.json configs[1]:
 4 x BiLSTM (512 cells/direction), 40-d input, 46 classes, 32 utterances, T_max = 1000, fp32.
 Weak scaling: every rank runs its own 32-utterance shard (global batch 32 N = configs[2] at N = 8).
 `value` = padded frames/s of the whole job (the reference's own fps counts padded frames,
@@ -107,8 +110,13 @@ def main():
     ap.add_argument("--S", type=int, default=0, help="override utterances per GPU (debug)")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the multi-GPU code path (torch first, RCCL process group, gradient all-reduce) even with one rank (debug)")
+                    help="take the multi-GPU code path (RCCL communicator, per-layer gradient all-reduce) even with one rank (debug)")
+    ap.add_argument("--comm", choices=["native", "bulk", "torch"], default="native",
+                    help="gradient exchange: native = the library's RCCL communicator, one bucket per layer overlapped with the backward "
+                         "pass (default); bulk = the same communicator, one all-reduce after the backward pass; torch = torch.distributed")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     # stdout carries exactly ONE JSON line: everything else that C libraries print there (RCCL prints its version banner on
     # stdout, buffered until exit) is rerouted to stderr by swapping the file descriptors for the duration of the run
     sys.stdout.flush()
@@ -118,11 +126,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
+    multi = world > 1 or args.force_dist
     dist = None
-    if world > 1 or args.force_dist:
+    if multi and args.comm == "torch":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -130,8 +136,19 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from eesen_amd.api import Net, Ctc, CuMatrix
+    from eesen_amd.api import Net, Ctc, CuMatrix, Comm
     from eesen_amd import _lib
+    comm = Comm.from_env(device=local) if (multi and dist is None) else None   # the library's own RCCL communicator: no torch in the process
+
+    def all_reduce(values, op=Comm.SUM):
+        """Host scalars over the ranks (sum / max), whatever the transport."""
+        if comm is not None:
+            return comm.allreduce(values, op)
+        if dist is not None:
+            t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == Comm.MAX else dist.ReduceOp.SUM)
+            return t.tolist()
+        return list(values)
 
     cfg = synth.config(args.config)
     for k in ("T", "H", "S", "layers"):
@@ -139,30 +156,39 @@ def main():
             cfg[k] = getattr(args, k)
     layers = synth.make_model(max_grad=50.0, **cfg)                 # recipe settings: model_topo.py:90, run_ctc_phn.sh:84-85
     batch = synth.make_batch(**{**cfg, "seed": 777 + rank})         # every rank its own shard of the global batch
-    dev = local if dist is not None else 0
-    net = Net.from_layers(layers, device=dev)
-    net.SetTrainOptions(4e-5, 0.9)
+    dev = local if multi else 0
+
+    def make_net():
+        n = Net.from_layers(layers, device=dev)
+        n.SetTrainOptions(4e-5, 0.9)
+        n.SetProfiling(True)
+        if comm is not None and args.comm == "native":
+            n.SetComm(comm)                                   # per-layer buckets, overlapped with the backward pass
+        elif comm is not None:
+            n.grad_hook = lambda nn: nn.AllReduceGrads(comm)  # one bulk all-reduce between backprop and update
+        elif dist is not None:
+            from eesen_amd.parallel import GradAllReducer
+            n.grad_hook = GradAllReducer(n)
+        return n
+
+    net = make_net()
     ctc = Ctc(device=dev)
-    if dist is not None:
-        from eesen_amd.parallel import GradAllReducer
-        net.grad_hook = GradAllReducer(net)
     feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # inputs resident in HBM before the timed region
     diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
-    net.SetProfiling(True)
 
-    def step():
+    def step():   # the reference trainer's loop body, train-ctc-parallel.cc:195-207
         net.SetSeqLengths(batch.lens)
         out = net.Propagate(feats_dev)
-        ctc.EvalParallel(batch.lens, out, batch.labels, diff)
+        ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)   # like the reference's call: accumulates the objective
+        ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)        # :202: greedy decode + edit distance, every minibatch
         net.Backpropagate(diff)
         return out
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
         net.Synchronize()
+        if multi:
+            all_reduce([0.0])                                  # every rank has drained its own work
+        _lib.check(_lib.load().eesen_device_synchronize(dev))  # = torch.cuda.synchronize() on this rank's GPU
 
     # One probing step first: if the cooperative (persistent) recurrence kernels cannot run on this box (the library then
     # raises instead of hanging), fall back to the one-launch-per-step kernels -- on EVERY rank, so all ranks time the same code.
@@ -173,19 +199,11 @@ def main():
     except Exception as e:   # noqa: BLE001
         print(f"bench: persistent path failed on rank {rank} ({e}); falling back to per-step kernels", file=sys.stderr)
         ok = 0.0
-    if dist is not None:
-        import torch
-        t_ok = torch.tensor([ok], device=f"cuda:{local}")
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        ok = float(t_ok.item())
+    if multi:
+        ok = 1.0 - all_reduce([1.0 - ok], Comm.MAX)[0]        # any rank failed -> every rank falls back
     if ok == 0.0:
         os.environ["EESEN_PERSISTENT"] = "0"
-        net = Net.from_layers(layers, device=dev)
-        net.SetTrainOptions(4e-5, 0.9)
-        net.SetProfiling(True)
-        if dist is not None:
-            from eesen_amd.parallel import GradAllReducer
-            net.grad_hook = GradAllReducer(net)
+        net = make_net()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -193,25 +211,19 @@ def main():
     # accumulates their spans and they are read once, after the closing barrier -- no host synchronisation inside the region
     # beyond what a training step does itself (the CTC returns ln p to the host every step).
     net.SetProfiling(True, accumulate=True)
-    phases = {}
-    ctc_ph = {}
+    ctc.SetProfiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for k, v in ctc.PhaseTimes().items():      # events of a call that has already synchronised: no wait
-            ctc_ph[k] = ctc_ph.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
     phases = net.PhaseTimes()
+    ctc_ph = ctc.PhaseTimes()
+    ctc.SetProfiling(False)
     net.SetProfiling(True)
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        fr = torch.tensor([float(batch.T * batch.S), float(batch.real_frames)], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
-        padded, real = fr.tolist()
+    if multi:
+        dt = all_reduce([dt], Comm.MAX)[0]                                       # the slowest rank's clock
+        padded, real = all_reduce([float(batch.T * batch.S), float(batch.real_frames)])
     else:
         padded, real = float(batch.T * batch.S), float(batch.real_frames)
 
@@ -230,7 +242,8 @@ def main():
             net.SetSeqLengths(batch.lens)
             out = net.Propagate(feeder.acquire(slot))
             feeder.release(slot)
-            ctc.EvalParallel(batch.lens, out, batch.labels, diff)
+            ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
+            ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)
             net.Backpropagate(diff)
             slot = feeder.submit(mats)      # next batch: staged while this one's backward pass runs
         net.Synchronize()
@@ -313,6 +326,10 @@ def main():
             "config": {"workload": f"{args.config}: {nl}x{H} {'Bi' if nd == 2 else ''}LSTM + affine + softmax + CTC, D={cfg['D']}, K={cfg['K']}, "
                                    f"S={S} utterances/GPU, T_max={T}, SGD lr=4e-5 momentum=0.9 max_grad=50",
                        "global_batch_utterances": S * world, "parallelism": f"dp{world}",
+                       "gradient_exchange": (None if not multi else
+                                             {"native": "RCCL all-reduce(sum, fp32) per layer bucket on a communication stream, issued by libeesen_hip.so as each layer's weight-gradient kernels are enqueued",
+                                              "bulk": "one RCCL all-reduce of the whole gradient buffer after the backward pass (libeesen_hip.so)",
+                                              "torch": "one torch.distributed all-reduce of the whole gradient buffer"}[args.comm]),
                        "real_frames_per_s": real * K / dt, "padded_frames_per_step": padded, "real_frames_per_step": real,
                        "pcie_inclusive_frames_per_s": pcie_fps},
             "phase_ms_per_step": {k: 1e3 * v / K for k, v in {**phases, **{'ctc_' + a: b for a, b in ctc_ph.items()}}.items()},
@@ -324,9 +341,30 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if multi:
+        all_reduce([0.0])
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`bench.py --gpus N` outside any launcher: start the N ranks (one process per GPU, same argv), hand rank 0's stdout --
+    the one JSON line -- through, return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s0:
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 if __name__ == "__main__":

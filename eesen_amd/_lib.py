@@ -53,12 +53,25 @@ SIGNATURES = {
     "eesen_net_synchronize": (_i, [_vp]),
     "eesen_net_set_profiling": (_i, [_vp, _i]),
     "eesen_net_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_device_synchronize": (_i, [_i]),
+    "eesen_comm_get_unique_id": (_i, [_vp]),
+    "eesen_comm_exchange": (_i, [C.c_char_p, _i, _i, _i, _vp, _i, _i]),
+    "eesen_comm_create": (_i, [_i, _vp, _i, _i, C.POINTER(_vp)]),
+    "eesen_comm_create_tcp": (_i, [_i, C.c_char_p, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "eesen_comm_destroy": (_i, [_vp]),
+    "eesen_comm_info": (_i, [_vp, _pi, _pi]),
+    "eesen_comm_allreduce_host": (_i, [_vp, _pd, _i, _i]),
+    "eesen_net_set_comm": (_i, [_vp, _vp]),
+    "eesen_net_allreduce_grads": (_i, [_vp, _vp]),
+    "eesen_net_backpropagate_zero": (_i, [_vp]),
+    "eesen_net_bucket_order": (_i, [_vp, _pi, _i, _pi]),
     "eesen_ctc_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "eesen_ctc_destroy": (_i, [_vp]),
     "eesen_ctc_eval_parallel": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "eesen_ctc_error_rate_mseq": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _pi, _pi]),
     "eesen_ctc_stats": (_i, [_vp, _pd, _pl, _pl, _pl, _pl]),
     "eesen_ctc_get_alpha_beta": (_i, [_vp, _vp, _vp, _pi]),
+    "eesen_ctc_set_profiling": (_i, [_vp, _i]),
     "eesen_ctc_get_phase_times": (_i, [_vp, _vp]),
     "eesen_net_set_train_mode": (_i, [_vp, _i]),
     "eesen_net_set_dropout_seed": (_i, [_vp, C.c_ulonglong]),

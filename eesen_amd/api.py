@@ -88,6 +88,47 @@ class CuMatrix:
             self.ptr = None
 
 
+class Comm:
+    """One rank of the data-parallel job: an RCCL communicator owned by libeesen_hip.so (include/eesen_hip.h
+    `eesen_comm_*`), the replacement of the reference's file-based comm_avg_weights / comm_touch_done
+    (/root/reference/src/net/communicator.h:39-170).  No torch involved: rank 0 hands the RCCL unique id to the other
+    ranks over a plain TCP connection on MASTER_ADDR : (EESEN_COMM_PORT | MASTER_PORT + 17)."""
+
+    SUM, MAX = 0, 1
+
+    def __init__(self, device: int, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29517, timeout_s: int = 120):
+        self.lib = _lib.load()
+        self.device, self.rank, self.world = device, rank, world
+        self.h = C.c_void_p()
+        check(self.lib.eesen_comm_create_tcp(device, addr.encode(), int(port), rank, world, int(timeout_s), C.byref(self.h)))
+
+    @classmethod
+    def from_env(cls, device: Optional[int] = None, timeout_s: int = 120) -> "Comm":
+        """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or bench.py's own launcher) export them."""
+        import os
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+        port = int(os.environ.get("EESEN_COMM_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29500")) + 17
+        return cls(dev, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, timeout_s)
+
+    def __del__(self):
+        if getattr(self, "h", None) and self.h:
+            try:
+                self.lib.eesen_comm_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    def allreduce(self, values: Sequence[float], op: int = 0) -> List[float]:
+        """Sum (or max) of up to 64 host scalars over the ranks; blocks (also serves as a barrier)."""
+        a = (C.c_double * len(values))(*[float(v) for v in values])
+        check(self.lib.eesen_comm_allreduce_host(self.h, a, len(values), int(op)))
+        return list(a)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+
 class Net:
     """eesen::Net for BiLstmParallel / LstmParallel / AffineTransform / Softmax stacks."""
 
@@ -274,6 +315,26 @@ class Net:
             self.grad_hook(self)
         self.Update()
 
+    def SetComm(self, comm: Optional[Comm]):
+        """Attach the data-parallel communicator: Backpropagate then all-reduces every layer's fresh gradients (one bucket per
+        layer, on the communicator's stream, under the lower layers' backward pass) and Update waits bucket by bucket."""
+        check(self.lib.eesen_net_set_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
+
+    def AllReduceGrads(self, comm: Comm):
+        """The bulk form: one all-reduce of the whole gradient buffer, between BackpropagateNoUpdate and Update."""
+        check(self.lib.eesen_net_allreduce_grads(self.h, comm.h))
+
+    def BackpropagateZero(self):
+        """This rank has no minibatch this step (others do): zero gradient through the same collectives; then Update()."""
+        check(self.lib.eesen_net_backpropagate_zero(self.h))
+
+    def BucketOrder(self) -> List[int]:
+        buf = (C.c_int * 64)()
+        n = C.c_int()
+        check(self.lib.eesen_net_bucket_order(self.h, buf, 64, C.byref(n)))
+        return list(buf[: n.value])
+
     def grad_buffer(self):
         """(device pointer, float count) of the contiguous fresh-gradient buffer (all-reduce payload)."""
         p, n = C.c_void_p(), C.c_long()
@@ -319,26 +380,32 @@ class Ctc:
         return np.ascontiguousarray(ids, np.int32), off
 
     def EvalParallel(self, frame_num_utt: Sequence[int], net_out: CuMatrix, label: Sequence[Sequence[int]],
-                     diff: Optional[CuMatrix] = None) -> CuMatrix:
-        """Ctc::EvalParallel (ctc-loss.cc:101-194). Returns diff (allocated when not given); self.pzx = ln p per sequence."""
+                     diff: Optional[CuMatrix] = None, want_pzx: bool = True) -> CuMatrix:
+        """Ctc::EvalParallel (ctc-loss.cc:101-194). Returns diff (allocated when not given); self.pzx = ln p per sequence.
+        want_pzx=False: nothing waits for the device -- ln p joins the objective sum (stats()) when it has arrived, as the
+        reference's own call returns nothing but `diff` and only accumulates obj_progress_ (:171-177); self.pzx is None then."""
         fn = np.ascontiguousarray(frame_num_utt, np.int32)
         ids, off = self._csr(label)
         if diff is None:
             diff = CuMatrix(net_out.rows, net_out.cols, self.device, zero=False)
-        pzx = np.empty(fn.size, np.float32)
+        pzx = np.empty(fn.size, np.float32) if want_pzx else None
         check(self.lib.eesen_ctc_eval_parallel(self.h, _np_ptr(fn), fn.size, C.c_void_p(net_out.ptr), net_out.rows, net_out.cols,
                                                net_out.stride, _np_ptr(ids), _np_ptr(off), C.c_void_p(diff.ptr), diff.stride,
-                                               _np_ptr(pzx)))
+                                               _np_ptr(pzx) if want_pzx else None))
         self.pzx = pzx
         return diff
 
-    def ErrorRateMSeq(self, frame_num_utt: Sequence[int], net_out: CuMatrix, label: Sequence[Sequence[int]]):
+    def ErrorRateMSeq(self, frame_num_utt: Sequence[int], net_out: CuMatrix, label: Sequence[Sequence[int]], deferred: bool = False):
+        """Ctc::ErrorRateMSeq (ctc-loss.cc:235-298): accumulates the error / reference token counts.  Returns this call's
+        (errors, refs); with deferred=True only the argmax and the copy of the ids are enqueued and the host part (collapse +
+        edit distance) runs at the next call / stats(), under the device's backward pass -- the reference's call returns void."""
         fn = np.ascontiguousarray(frame_num_utt, np.int32)
         ids, off = self._csr(label)
         ne, nr = C.c_int(), C.c_int()
         check(self.lib.eesen_ctc_error_rate_mseq(self.h, _np_ptr(fn), fn.size, C.c_void_p(net_out.ptr), net_out.rows, net_out.cols,
-                                                 net_out.stride, _np_ptr(ids), _np_ptr(off), C.byref(ne), C.byref(nr)))
-        return ne.value, nr.value
+                                                 net_out.stride, _np_ptr(ids), _np_ptr(off), None if deferred else C.byref(ne),
+                                                 None if deferred else C.byref(nr)))
+        return None if deferred else (ne.value, nr.value)
 
     def stats(self) -> dict:
         o, s, f, e, r = C.c_double(), C.c_long(), C.c_long(), C.c_long(), C.c_long()
@@ -366,6 +433,10 @@ class Ctc:
         b = np.empty((rows, L.value), np.float32)
         check(self.lib.eesen_ctc_get_alpha_beta(self.h, _np_ptr(a), _np_ptr(b), C.byref(L)))
         return a, b
+
+    def SetProfiling(self, accumulate: bool):
+        """accumulate=True: PhaseTimes() returns the sums over all EvalParallel calls since the last read (no per-call sync)."""
+        check(self.lib.eesen_ctc_set_profiling(self.h, 2 if accumulate else 0))
 
     def PhaseTimes(self) -> dict:
         out = np.zeros(3, np.float32)

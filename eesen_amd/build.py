@@ -14,8 +14,8 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_DIR, "csrc")
 LIBDIR = os.path.join(_DIR, "lib")
 LIB = os.path.join(LIBDIR, "libeesen_hip.so")
-SOURCES = ["gemm.hip", "lstm.hip", "lstm_persistent.hip", "ctc.hip", "optim.hip", "feeder.hip", "net.cpp", "ctc_host.cpp", "nnet_format.cpp", "capi.cpp"]
-HEADERS = ["common.h", "guard.h", "kernels.h", "net.h", os.path.join("..", "..", "include", "eesen_hip.h")]
+SOURCES = ["gemm.hip", "lstm.hip", "lstm_persistent.hip", "ctc.hip", "optim.hip", "feeder.hip", "net.cpp", "ctc_host.cpp", "nnet_format.cpp", "capi.cpp", "comm.cpp"]
+HEADERS = ["common.h", "guard.h", "kernels.h", "net.h", "handles.h", os.path.join("..", "..", "include", "eesen_hip.h")]
 FLAGS = (["-DEESEN_POLL_NOSLEEP"] if os.environ.get("EESEN_BUILD_NOSLEEP") else []) + (os.environ.get("EESEN_BUILD_DEFS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if verbose and warn:
                 print(warn, file=sys.stderr)
     if jobs or force or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     # host-only C++ tools over the C-ABI (no HIP in these sources): the reference's trainer binary, natively
     os.makedirs(BINDIR, exist_ok=True)
     cxx = shutil.which("g++") or "g++"

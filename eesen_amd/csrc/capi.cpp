@@ -7,8 +7,7 @@
 
 using namespace eesen;
 
-struct eesen_net : public Net { using Net::Net; };
-struct eesen_ctc : public Ctc { using Ctc::Ctc; };
+#include "handles.h"
 
 namespace eesen {
 std::string& last_error_slot() {
@@ -28,6 +27,13 @@ int eesen_device_count(int* count) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
     *count = n;
+  });
+}
+
+int eesen_device_synchronize(int device) {
+  return guard([&] {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    EESEN_HIP_CHECK(hipDeviceSynchronize());
   });
 }
 
@@ -192,6 +198,7 @@ int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S,
 int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* frames, long* err_tokens, long* ref_tokens) {
   return guard([&] {
     REQ_PTR(ctc);
+    ctc->flush();  // deferred results of earlier calls
     if (obj_sum) *obj_sum = ctc->obj_sum;
     if (sequences) *sequences = ctc->sequences;
     if (frames) *frames = ctc->frames;
@@ -201,6 +208,9 @@ int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* fr
 }
 int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_host, int* Lprime) {
   return guard([&] { REQ_PTR(ctc); ctc->get_alpha_beta(alpha_host, beta_host, Lprime); });
+}
+int eesen_ctc_set_profiling(eesen_ctc_t* ctc, int mode) {
+  return guard([&] { REQ_PTR(ctc); ctc->timer.enable(mode == 2); ctc->timer.set_accumulate(mode == 2); });
 }
 int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3) {
   return guard([&] { REQ_PTR(ctc); REQ_PTR(out3); ctc->phase_times(out3); });

@@ -1,0 +1,346 @@
+// comm.cpp -- the data-parallel exchange of the hot path: one process per GPU, RCCL over xGMI.
+//
+// Replaces the reference's multi-job mode, which is asynchronous MODEL AVERAGING THROUGH FILES
+// (/root/reference/src/net/communicator.h:39-119: every --utts-per-avg utterances each job writes nnet.avgK.jobJ, job 1
+// polls with usleep, sums, rescales and writes nnet.avgK, the others re-read it; :121-170 merge the error counts through
+// "done" files).  Here the FRESH gradients (sums over frames, bilstm-parallel-layer.h:504-510) are summed over the ranks
+// every minibatch, per layer, as soon as that layer's weight-gradient GEMMs have finished -- the point where the reference
+// calls Update on the layer (/root/reference/src/net/net.cc:98-104) -- on a separate stream, under the lower layers'
+// backward pass; momentum, clipping and the update then run identically on every rank (N ranks x S
+// utterances == one process with --num-sequence = N*S).  The scalar statistics travel through the same communicator.
+//
+// RCCL is loaded with dlopen on first use: a single-GPU process never maps it, and the library keeps loading on boxes
+// without it.  Rendezvous of the 128-byte ncclUniqueId is a plain TCP hand-out by rank 0 (no MPI, no torch).
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include <rccl/rccl.h>
+
+#include "guard.h"
+#include "handles.h"
+#include "net.h"
+
+namespace eesen {
+
+namespace {
+
+struct RcclApi {
+  void* dl = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.dl) return api;
+  const char* names[] = {getenv("EESEN_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    api.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (api.dl) break;
+  }
+  if (!api.dl) throw Error(EESEN_ERR_HIP, std::string("RCCL is not loadable (librccl.so.1): ") + (dlerror() ? dlerror() : "not found"));
+  auto sym = [&](const char* s) {
+    void* p = dlsym(api.dl, s);
+    if (!p) throw Error(EESEN_ERR_HIP, std::string("RCCL symbol missing: ") + s);
+    return p;
+  };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  return api;
+}
+
+#define EESEN_NCCL_CHECK(expr)                                                                                   \
+  do {                                                                                                            \
+    ncclResult_t r_ = (expr);                                                                                     \
+    if (r_ != ncclSuccess)                                                                                        \
+      throw ::eesen::Error(EESEN_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_) + " (" + __FILE__ + \
+                                              ":" + std::to_string(__LINE__) + ")");                              \
+  } while (0)
+
+// ---- TCP hand-out of the unique id --------------------------------------------------------------------------------
+void send_all(int fd, const char* p, size_t n) {
+  while (n) {
+    const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+    if (k <= 0) throw Error(EESEN_ERR_IO, std::string("rendezvous send failed: ") + strerror(errno));
+    p += k; n -= (size_t)k;
+  }
+}
+void recv_all(int fd, char* p, size_t n) {
+  while (n) {
+    const ssize_t k = ::recv(fd, p, n, 0);
+    if (k <= 0) throw Error(EESEN_ERR_IO, std::string("rendezvous receive failed: ") + (k == 0 ? "peer closed" : strerror(errno)));
+    p += k; n -= (size_t)k;
+  }
+}
+struct Fd {
+  int fd = -1;
+  ~Fd() { if (fd >= 0) ::close(fd); }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// Rank 0 listens on addr:port and hands `buf` (n bytes) to the world-1 ranks that connect and announce their rank;
+// every other rank connects (retrying until rank 0 is up) and receives into `buf`.  Each peer is served exactly once.
+void comm_exchange(const char* addr, int port, int rank, int world, char* buf, int n, int timeout_s) {
+  EESEN_REQUIRE(world >= 1 && rank >= 0 && rank < world, EESEN_ERR_INVALID, "rendezvous: bad rank / world size");
+  EESEN_REQUIRE(port > 0 && port < 65536, EESEN_ERR_INVALID, "rendezvous: bad port");
+  if (world == 1) return;
+  const double deadline = now_s() + timeout_s;
+  const unsigned magic = 0x45534e31u;  // "ESN1"
+  if (rank == 0) {
+    Fd ls;
+    ls.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    EESEN_REQUIRE(ls.fd >= 0, EESEN_ERR_IO, "rendezvous: socket() failed");
+    int one = 1;
+    (void)setsockopt(ls.fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa{};
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0)
+      throw Error(EESEN_ERR_IO, "rendezvous: cannot bind port " + std::to_string(port) + ": " + strerror(errno));
+    EESEN_REQUIRE(::listen(ls.fd, world) == 0, EESEN_ERR_IO, "rendezvous: listen() failed");
+    std::vector<char> served(world, 0);
+    int left = world - 1;
+    while (left > 0) {
+      const double remain = deadline - now_s();
+      if (remain <= 0) throw Error(EESEN_ERR_IO, "rendezvous: timed out waiting for " + std::to_string(left) + " rank(s)");
+      timeval tv{(time_t)remain, (suseconds_t)((remain - (time_t)remain) * 1e6)};
+      fd_set rf;
+      FD_ZERO(&rf);
+      FD_SET(ls.fd, &rf);
+      if (::select(ls.fd + 1, &rf, nullptr, nullptr, &tv) <= 0) continue;
+      Fd c;
+      c.fd = ::accept(ls.fd, nullptr, nullptr);
+      if (c.fd < 0) continue;
+      timeval rt{10, 0};
+      (void)setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));
+      unsigned hello[2] = {0, 0};
+      try {
+        recv_all(c.fd, reinterpret_cast<char*>(hello), sizeof(hello));
+      } catch (const Error&) {
+        continue;  // a stray connection: ignore it
+      }
+      if (hello[0] != magic || hello[1] == 0 || hello[1] >= (unsigned)world || served[hello[1]]) continue;
+      send_all(c.fd, buf, (size_t)n);
+      served[hello[1]] = 1;
+      --left;
+    }
+  } else {
+    addrinfo hints{}, *res = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    const std::string ps = std::to_string(port);
+    if (getaddrinfo(addr && *addr ? addr : "127.0.0.1", ps.c_str(), &hints, &res) != 0 || !res)
+      throw Error(EESEN_ERR_IO, std::string("rendezvous: cannot resolve ") + (addr ? addr : "(null)"));
+    std::string last = "no attempt";
+    for (;;) {
+      Fd c;
+      c.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (c.fd >= 0 && ::connect(c.fd, res->ai_addr, res->ai_addrlen) == 0) {
+        timeval rt{(time_t)std::max(1.0, deadline - now_s()), 0};
+        (void)setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &rt, sizeof(rt));
+        const unsigned hello[2] = {magic, (unsigned)rank};
+        try {
+          send_all(c.fd, reinterpret_cast<const char*>(hello), sizeof(hello));
+          recv_all(c.fd, buf, (size_t)n);
+          freeaddrinfo(res);
+          return;
+        } catch (const Error& e) {
+          last = e.what();
+        }
+      } else {
+        last = strerror(errno);
+      }
+      if (now_s() > deadline) {
+        freeaddrinfo(res);
+        throw Error(EESEN_ERR_IO, "rendezvous: rank " + std::to_string(rank) + " could not reach rank 0 at " + (addr ? addr : "") + ":" + ps + " (" + last + ")");
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+  }
+}
+
+// ---- Comm ---------------------------------------------------------------------------------------------------------
+struct Comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t st = nullptr;  // the exchange runs here, beside the compute stream(s)
+  double* scratch_d = nullptr;
+  double* scratch_h = nullptr;  // pinned
+  static constexpr int kScratch = 64;
+
+  Comm(int dev, const char* id128, int rank_, int world_) : device(dev), rank(rank_), world(world_) {
+    EESEN_REQUIRE(world >= 1 && rank >= 0 && rank < world, EESEN_ERR_INVALID, "communicator: bad rank / world size");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(EESEN_ERR_HIP, "no HIP device available for the communicator");
+    EESEN_REQUIRE(dev >= 0 && dev < n, EESEN_ERR_INVALID, "device index out of range");
+    EESEN_HIP_CHECK(hipSetDevice(dev));
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    EESEN_NCCL_CHECK(rccl().CommInitRank(&comm, world, id, rank));
+    int lo = 0, hi = 0;
+    EESEN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    EESEN_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch_d), kScratch * sizeof(double)));
+    EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&scratch_h), kScratch * sizeof(double), hipHostMallocDefault));
+  }
+  ~Comm() {
+    (void)hipSetDevice(device);
+    if (st) (void)hipStreamSynchronize(st);
+    if (comm) (void)rccl().CommDestroy(comm);
+    if (scratch_d) (void)hipFree(scratch_d);
+    if (scratch_h) (void)hipHostFree(scratch_h);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  // in place, sum, fp32, enqueued on `on`
+  void allreduce_f32(float* buf, size_t n, hipStream_t on) {
+    if (n == 0) return;
+    EESEN_NCCL_CHECK(rccl().AllReduce(buf, buf, n, ncclFloat32, ncclSum, comm, on));
+  }
+  // host scalars: sum (op 0) or max (op 1) over the ranks; blocks until done
+  void allreduce_host(double* v, int n, int op) {
+    EESEN_REQUIRE(n >= 0 && n <= kScratch, EESEN_ERR_INVALID, "at most 64 scalars per call");
+    if (n == 0) return;
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    std::memcpy(scratch_h, v, n * sizeof(double));
+    EESEN_HIP_CHECK(hipMemcpyAsync(scratch_d, scratch_h, n * sizeof(double), hipMemcpyHostToDevice, st));
+    EESEN_NCCL_CHECK(rccl().AllReduce(scratch_d, scratch_d, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, comm, st));
+    EESEN_HIP_CHECK(hipMemcpyAsync(scratch_h, scratch_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    EESEN_HIP_CHECK(hipStreamSynchronize(st));
+    std::memcpy(v, scratch_h, n * sizeof(double));
+  }
+};
+
+// ---- Net side: per-layer buckets -------------------------------------------------------------------------------------
+void Net::set_comm(Comm* c) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(!c || c->device == device, EESEN_ERR_INVALID, "communicator and net live on different devices");
+  wait_buckets_host();
+  comm = c;
+  if (c && ev_ready.size() < layers.size()) {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    const size_t old = ev_ready.size();
+    ev_ready.resize(layers.size(), nullptr);
+    ev_bucket.resize(layers.size(), nullptr);
+    for (size_t i = old; i < layers.size(); ++i) {
+      EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
+      EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_bucket[i], hipEventDisableTiming));
+    }
+  }
+  bucket_pending.assign(layers.size(), 0);
+}
+
+// layer li's fresh gradients are complete once everything enqueued on `producer` so far has run: sum them over the ranks
+// on the communicator's stream; update() makes the compute stream wait for exactly this bucket
+void Net::bucket_allreduce(int li, hipStream_t producer) {
+  if (!comm || !layers[li].p_n) return;
+  bucket_log.push_back(li);
+  EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], producer));
+  EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_ready[li], 0));
+  comm->allreduce_f32(fresh.p + layers[li].p_off, layers[li].p_n, comm->st);
+  EESEN_HIP_CHECK(hipEventRecord(ev_bucket[li], comm->st));
+  bucket_pending[li] = 1;
+}
+
+void Net::wait_buckets_host() {
+  if (!comm) return;
+  bool any = false;
+  for (char p : bucket_pending) any |= p != 0;
+  if (any) EESEN_HIP_CHECK(hipStreamSynchronize(comm->st));
+}
+
+// a rank that has no minibatch this step: zero gradient, same collectives in the same (top-down) order
+void Net::backpropagate_zero() {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, P * sizeof(float), st));
+  bucket_log.clear();
+  for (int li = (int)layers.size() - 1; li >= 0; --li) bucket_allreduce(li, st);
+}
+
+void Net::allreduce_grads(Comm* c) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(c && c->device == device, EESEN_ERR_INVALID, "communicator missing or on another device");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  c->allreduce_f32(fresh.p, P, st);  // ordered on the compute stream: after Backpropagate's kernels, before Update's
+}
+
+}  // namespace eesen
+
+using namespace eesen;
+struct eesen_comm : public Comm { using Comm::Comm; };
+
+extern "C" {
+
+int eesen_comm_get_unique_id(char* id128) {
+  return guard([&] {
+    REQ_PTR(id128);
+    ncclUniqueId id;
+    EESEN_NCCL_CHECK(rccl().GetUniqueId(&id));
+    std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  });
+}
+int eesen_comm_exchange(const char* addr, int port, int rank, int world, char* buf, int nbytes, int timeout_s) {
+  return guard([&] { REQ_PTR(buf); comm_exchange(addr, port, rank, world, buf, nbytes, timeout_s); });
+}
+int eesen_comm_create(int device, const char* id128, int rank, int world, eesen_comm_t** out) {
+  return guard([&] { REQ_PTR(id128); REQ_PTR(out); *out = new eesen_comm(device, id128, rank, world); });
+}
+int eesen_comm_create_tcp(int device, const char* addr, int port, int rank, int world, int timeout_s, eesen_comm_t** out) {
+  return guard([&] {
+    REQ_PTR(out);
+    char id[NCCL_UNIQUE_ID_BYTES] = {0};
+    if (rank == 0) {
+      ncclUniqueId u;
+      EESEN_NCCL_CHECK(rccl().GetUniqueId(&u));
+      std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    }
+    comm_exchange(addr, port, rank, world, id, NCCL_UNIQUE_ID_BYTES, timeout_s);
+    *out = new eesen_comm(device, id, rank, world);
+  });
+}
+int eesen_comm_destroy(eesen_comm_t* comm) {
+  return guard([&] { delete comm; });
+}
+int eesen_comm_info(eesen_comm_t* comm, int* rank, int* world) {
+  return guard([&] { REQ_PTR(comm); if (rank) *rank = comm->rank; if (world) *world = comm->world; });
+}
+int eesen_comm_allreduce_host(eesen_comm_t* comm, double* values, int n, int op) {
+  return guard([&] { REQ_PTR(comm); REQ_PTR(values); comm->allreduce_host(values, n, op); });
+}
+int eesen_net_set_comm(eesen_net_t* net, eesen_comm_t* comm) {
+  return guard([&] { REQ_PTR(net); net->set_comm(comm); });
+}
+int eesen_net_allreduce_grads(eesen_net_t* net, eesen_comm_t* comm) {
+  return guard([&] { REQ_PTR(net); net->allreduce_grads(comm); });
+}
+int eesen_net_backpropagate_zero(eesen_net_t* net) {
+  return guard([&] { REQ_PTR(net); net->backpropagate_zero(); });
+}
+int eesen_net_bucket_order(eesen_net_t* net, int* layers_out, int cap, int* n) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(n);
+    *n = (int)net->bucket_log.size();
+    for (int i = 0; i < *n && i < cap && layers_out; ++i) layers_out[i] = net->bucket_log[i];
+  });
+}
+
+}  // extern "C"

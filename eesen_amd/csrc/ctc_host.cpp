@@ -24,7 +24,43 @@ Ctc::~Ctc() {
   (void)hipStreamSynchronize(st);
   for (auto& x : ev)
     if (x) (void)hipEventDestroy(x);
+  auto drop = [](Pin& pin) {
+    if (pin.p) (void)hipHostFree(pin.p);
+    if (pin.ev) (void)hipEventDestroy(pin.ev);
+  };
+  for (auto& x : stage) drop(x);
+  for (auto& x : ppzx) drop(x.pin);
+  for (auto& x : perr) drop(x.pin);
   if (own_stream) (void)hipStreamDestroy(st);
+}
+
+void* Ctc::pin_reserve(Pin& pin, size_t bytes) {
+  if (!pin.ev) EESEN_HIP_CHECK(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
+  if (pin.busy) { EESEN_HIP_CHECK(hipEventSynchronize(pin.ev)); pin.busy = false; }  // two calls ago: long done
+  if (bytes > pin.cap) {
+    if (pin.p) EESEN_HIP_CHECK(hipHostFree(pin.p));
+    pin.p = nullptr;
+    pin.cap = std::max<size_t>(bytes * 2, 4096);
+    EESEN_HIP_CHECK(hipHostMalloc(&pin.p, pin.cap, hipHostMallocDefault));
+  }
+  return pin.p;
+}
+
+void Ctc::flush_pzx(PendingPzx& q) {
+  if (!q.active) return;
+  EESEN_HIP_CHECK(hipEventSynchronize(q.pin.ev));
+  q.pin.busy = false;
+  const float* pz = static_cast<const float*>(q.pin.p);
+  double sum = 0;
+  for (int s = 0; s < q.S; ++s) sum += pz[s];
+  obj_sum += sum;  // ctc-loss.cc:171-177
+  q.active = false;
+}
+
+void Ctc::flush() {
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  for (unsigned k = 0; k < 2; ++k) flush_pzx(ppzx[(ppzx_idx + k) & 1]);   // oldest first
+  for (unsigned k = 0; k < 2; ++k) flush_err(perr[(perr_idx + k) & 1], nullptr, nullptr);
 }
 
 static void check_batch(const int* frame_num_utt, int S, int rows, int K, const int* label_ids, const int* label_off) {
@@ -86,44 +122,59 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
     int* cp = pos_h + (size_t)s * Lpad;
     for (int j = 0; j < 2 * U + 1; ++j) cp[fill[lx[j]]++] = j;  // ascending j within each class, as the error kernel's loop visits them
   }
+  // Stream-ordered upload through a pinned slot: kernels of the previous call that still read labx are ahead of this copy on
+  // the stream, and the slot written here was last read by the copy of two calls ago -- nothing drains the stream.
+  if (labx.cap < h.size()) EESEN_HIP_CHECK(hipStreamSynchronize(st));  // reallocation frees what queued kernels may still read
   labx.reserve(h.size());
-  EESEN_HIP_CHECK(hipStreamSynchronize(st));  // a previous call may still read the staging buffers
-  EESEN_HIP_CHECK(hipMemcpy(labx.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  Pin& sp = stage[stage_idx++ & 1];
+  int* pinned = static_cast<int*>(pin_reserve(sp, h.size() * sizeof(int)));
+  std::copy(h.begin(), h.end(), pinned);
+  EESEN_HIP_CHECK(hipMemcpyAsync(labx.p, pinned, h.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  EESEN_HIP_CHECK(hipEventRecord(sp.ev, st));
+  sp.busy = true;
   const int* labx_d = labx.p;
   const int* pos_d = labx_d + n_labx;
   const int* off_d = pos_d + n_labx;
   const int* lens_dd = off_d + n_off;
   const int* ll_d = lens_dd + S;
 
+  if (logp.cap < (size_t)rows * K || alpha.cap < (size_t)S * T * Lpad || pzx_d.cap < (size_t)S) EESEN_HIP_CHECK(hipStreamSynchronize(st));
   logp.reserve((size_t)rows * K);
   alpha.reserve((size_t)S * T * Lpad);
   beta.reserve((size_t)S * T * Lpad);
   pzx_d.reserve(S);
 
-  EESEN_HIP_CHECK(hipEventRecord(ev[0], st));
+  const bool acc = timer.enabled();
+  int sp0 = -1, sp1 = -1, sp2 = -1;
+  if (acc) sp0 = timer.begin(st, 0); else EESEN_HIP_CHECK(hipEventRecord(ev[0], st));
   log_rows(st, net_out, ld, logp.p, K, rows, K);                                               // ctc-loss.cc:132-133
-  EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
+  if (acc) { timer.end(st, sp0); sp1 = timer.begin(st, 1); } else EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
   ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p);  // :136-153
-  EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
+  if (acc) { timer.end(st, sp1); sp2 = timer.begin(st, 2); } else EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
   ctc_error_diff(st, net_out, ld, T, S, K, Lpad, lens_dd, off_d, pos_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
-  EESEN_HIP_CHECK(hipEventRecord(ev[3], st));
+  if (acc) timer.end(st, sp2); else EESEN_HIP_CHECK(hipEventRecord(ev[3], st));
 
-  std::vector<float> pz(S);
-  EESEN_HIP_CHECK(hipMemcpyAsync(pz.data(), pzx_d.p, S * sizeof(float), hipMemcpyDeviceToHost, st));
-  EESEN_HIP_CHECK(hipStreamSynchronize(st));
-  double sum = 0;
-  for (int s = 0; s < S; ++s) {
-    sum += pz[s];
-    frames += frame_num_utt[s];
-    if (pzx_host) pzx_host[s] = pz[s];
+  // ln p(z|x) per sequence (ctc-loss.cc:146-153 reads it element by element): back through a pinned slot.  A caller that wants
+  // the values now waits for them; otherwise they join the objective sum when the next call needs the slot or the statistics.
+  PendingPzx& q = ppzx[ppzx_idx++ & 1];
+  flush_pzx(q);
+  float* pz = static_cast<float*>(pin_reserve(q.pin, (size_t)S * sizeof(float)));
+  EESEN_HIP_CHECK(hipMemcpyAsync(pz, pzx_d.p, S * sizeof(float), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipEventRecord(q.pin.ev, st));
+  q.pin.busy = true; q.S = S; q.active = true;
+  if (pzx_host) {
+    flush();  // keeps the accumulation order of the calls
+    for (int s = 0; s < S; ++s) pzx_host[s] = pz[s];
   }
-  obj_sum += sum;  // ctc-loss.cc:171-177
+  for (int s = 0; s < S; ++s) frames += frame_num_utt[s];
   sequences += S;
   last_lens.assign(frame_num_utt, frame_num_utt + S);
   last_T = T; last_S = S; last_Lpad = Lpad; last_Lprime = Lprime;
 }
 
 void Ctc::phase_times(float* out3) {
+  if (timer.enabled()) { timer.collect(out3, 3); return; }   // sums since the last read
+  EESEN_HIP_CHECK(hipEventSynchronize(ev[3]));
   for (int i = 0; i < 3; ++i) {
     float ms = 0.f;
     EESEN_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
@@ -171,35 +222,59 @@ static int levenshtein(const int* ref, int nr, const std::vector<int>& hyp) {
   return prev[nh];
 }
 
-void Ctc::error_rate_mseq(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld,
-                          const int* label_ids, const int* label_off, int* num_err, int* num_ref) {
-  check_batch(frame_num_utt, S, rows, K, label_ids, label_off);
-  EESEN_HIP_CHECK(hipSetDevice(device));
-  ids_d.reserve(rows);
-  row_argmax(st, net_out, ld, rows, K, ids_d.p);  // FindRowMaxId, ctc-loss.cc:238-239
-  std::vector<int> ids(rows);
-  EESEN_HIP_CHECK(hipMemcpyAsync(ids.data(), ids_d.p, rows * sizeof(int), hipMemcpyDeviceToHost, st));
-  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+void Ctc::flush_err(PendingErr& q, int* num_err, int* num_ref) {
+  if (!q.active) return;
+  EESEN_HIP_CHECK(hipEventSynchronize(q.pin.ev));
+  q.pin.busy = false;
+  const int* ids = static_cast<const int*>(q.pin.p);
+  const int S = q.S;
   int err = 0, ref = 0;
   std::vector<int> hyp;
   for (int s = 0; s < S; ++s) {
     hyp.clear();
     int last = -1;
-    for (int f = 0; f < frame_num_utt[s]; ++f) {  // collapse repeats, drop blanks (ctc-loss.cc:252-275)
+    for (int f = 0; f < q.frames[s]; ++f) {  // collapse repeats, drop blanks (ctc-loss.cc:252-275)
       const int id = ids[(size_t)f * S + s];
       if (f == 0 || id != last) {
         if (id != 0) hyp.push_back(id);
       }
       last = id;
     }
-    const int U = label_off[s + 1] - label_off[s];
-    err += levenshtein(label_ids + label_off[s], U, hyp);
+    const int U = q.off[s + 1] - q.off[s];
+    err += levenshtein(q.ids.data() + q.off[s], U, hyp);
     ref += U;
   }
   err_tokens += err;
   ref_tokens += ref;
   if (num_err) *num_err = err;
   if (num_ref) *num_ref = ref;
+  q.active = false;
+}
+
+// With num_err == num_ref == NULL the call only ENQUEUES the argmax and the copy of the ids; collapsing and the edit
+// distances (host work, ctc-loss.cc:252-296) run when the next call needs the slot or the statistics are read -- by then
+// the device is busy with the backward pass, so neither side waits for the other.
+void Ctc::error_rate_mseq(const int* frame_num_utt, int S, const float* net_out, int rows, int K, int ld,
+                          const int* label_ids, const int* label_off, int* num_err, int* num_ref) {
+  check_batch(frame_num_utt, S, rows, K, label_ids, label_off);
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  if (ids_d.cap < (size_t)rows) EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  ids_d.reserve(rows);
+  PendingErr& q = perr[perr_idx++ & 1];
+  flush_err(q, nullptr, nullptr);
+  row_argmax(st, net_out, ld, rows, K, ids_d.p);  // FindRowMaxId, ctc-loss.cc:238-239
+  int* pinned = static_cast<int*>(pin_reserve(q.pin, (size_t)rows * sizeof(int)));
+  EESEN_HIP_CHECK(hipMemcpyAsync(pinned, ids_d.p, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipEventRecord(q.pin.ev, st));
+  q.pin.busy = true; q.S = S; q.active = true;
+  q.frames.assign(frame_num_utt, frame_num_utt + S);
+  q.off.assign(label_off, label_off + S + 1);
+  for (int& o : q.off) o -= label_off[0];
+  q.ids.assign(label_ids + label_off[0], label_ids + label_off[S]);
+  if (num_err || num_ref) {
+    flush_err(perr[perr_idx & 1], nullptr, nullptr);  // the older one first: totals accumulate in call order
+    flush_err(q, num_err, num_ref);
+  }
 }
 
 }  // namespace eesen

@@ -43,8 +43,36 @@ struct GemmParams {
   int splits;   // grid.y
   int k_chunk;  // K elements per split (multiple of BK)
   int tiles_n;
+  int tiles_m;
+  int gm;       // > 0: XCD-aware tile map with row groups of gm tiles (see tile_of); 0: row-major
   GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
+
+// blockIdx.x -> output tile.  The dispatcher places block b on XCD b % 8 (observed; a speed hint only) and every XCD has
+// its own L2, so with a plain row-major map the tiles_n blocks that share one A row-slab are spread over all eight L2s and
+// each of them pulls the slab through the fabric: measured 4.8x the algorithmic bytes on the input->gates GEMM
+// (profiles/r01e_pmc_fetch_write.md).  Here the tile grid is cut into row groups of `gm` tile-rows; group g belongs to XCD
+// g % 8 (so all XCDs work on early rows first -- the gated GEMM visits rows in completion order), and inside a group the
+// blocks of one XCD walk column-major (gm rows down, then the next tile column): the ~64 tiles resident on an XCD at any
+// time form a gm x (64/gm) patch whose A slabs are shared by 64/gm and whose B slabs by gm concurrent tiles.
+// Blocks beyond the ragged edge of the last group (or of the last round of groups) exit at once.
+__device__ __forceinline__ bool tile_of(const GemmParams& p, int& tm, int& tn) {
+  if (p.gm <= 0) {
+    tm = blockIdx.x / p.tiles_n;
+    tn = blockIdx.x % p.tiles_n;
+    return true;
+  }
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int gt = p.gm * p.tiles_n;
+  const int g = (j / gt) * 8 + x, r = j % gt;
+  const int first = g * p.gm;
+  if (first >= p.tiles_m) return false;
+  const int gs = min(p.gm, p.tiles_m - first);
+  if (r >= gs * p.tiles_n) return false;
+  tm = first + r % gs;
+  tn = r / gs;
+  return true;
+}
 
 // Load one [rows x BK] operand tile (rows = BM or BN) from HBM into registers: NLD float4 per thread.
 // KC = true : operand stored [R x K], k contiguous.  float4 f -> (r = f / (BK/4), kq = f % (BK/4))
@@ -115,17 +143,17 @@ template <bool A_KC, bool B_KC, bool GUARD, bool GATED = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][BM + LDP], float (*Bs)[BK][BN + LDP]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x;
-  int tm = tile / p.tiles_n;
+  int tm, tn;
+  if (!tile_of(p, tm, tn)) return;
   if (GATED) {  // middle-out over time: row tiles in the order in which a bidirectional layer completes their frames
-    const int tiles_m = (p.M + BM - 1) / BM, mid = tiles_m / 2;
+    const int tiles_m = p.tiles_m, mid = tiles_m / 2;
     // i = 0, 1, 2, 3, ... -> mid, mid-1, mid+1, mid-2, ...; when one side runs out the other side continues
     const int i = tm, lo_cnt = mid, hi_cnt = tiles_m - mid;   // tiles below mid / at-or-above mid
     const int pairs = min(lo_cnt, hi_cnt);
     if (i < 2 * pairs) tm = (i & 1) ? mid - (i + 1) / 2 : mid + i / 2;
     else tm = hi_cnt > lo_cnt ? mid + (i - pairs) : mid - 1 - (i - pairs);
   }
-  const int m0 = tm * BM, n0 = (tile % p.tiles_n) * BN;
+  const int m0 = tm * BM, n0 = tn * BN;
   if (GATED) {
     __shared__ int s_go;
     const GemmGate& g = p.gate;
@@ -317,12 +345,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
+// Row-group height of the XCD-aware tile map (0 = plain row-major) and the grid it needs.  Groups of 8 tile-rows once
+// every XCD gets at least two of them; fewer rows per group for short grids so that all eight XCDs still get work.
+static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
+  static const int mode = getenv("EESEN_GEMM_XCD") ? atoi(getenv("EESEN_GEMM_XCD")) : 8;  // 0 disables, else the group height
+  if (mode <= 0 || tiles_m < 8) return 0;
+  int gm = mode;
+  while (gm > 1 && cdiv(tiles_m, gm) < 16) gm >>= 1;
+  const long groups = cdiv(tiles_m, gm), rounds = cdivl(groups, 8);
+  const long gx = rounds * 8 * gm * tiles_n;
+  if (gx > 0x7fffffffL) return 0;
+  *grid_x = (unsigned)gx;
+  return gm;
+}
+
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats,
               int extra_lds_bytes) {
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -330,6 +373,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   p.gate = GemmGate{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
   p.tiles_n = tiles_n;
+  p.tiles_m = tiles_m;
   const long tiles = (long)tiles_m * tiles_n;
   // split-K only when the tile grid cannot fill the chip and K is long enough to amortise the reduce pass
   int splits = 1;
@@ -345,7 +389,10 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   p.splits = splits;
   p.k_chunk = k_chunk;
   if (splits > 1) p.C = ws;
-  dim3 grid((unsigned)tiles, (unsigned)splits), block(256);
+  unsigned gx = 0;
+  p.gm = xcd_group_rows(tiles_m, tiles_n, &gx);
+  if (synth) p.gm = 0;
+  dim3 grid(p.gm ? gx : (unsigned)tiles, (unsigned)splits), block(256);
   // measured on MI355X: the branch-free loads win only when both operands are k-contiguous (111 vs 107 TF); with an
   // m/n-contiguous operand the guarded code is faster (NN 107 vs 100 TF, tall-K TN 93 vs 67 TF), so it stays guarded
   const bool guard = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % BK) != 0 || !(a_kc && b_kc);
@@ -354,7 +401,6 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
-  static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
   if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
     static bool warned = false;
     if (!warned) { fprintf(stderr, "eesen_hip: EESEN_GEMM_SYNTH=%d -- weight gradients are NOT computed (timing probe)\n", synth); warned = true; }
@@ -384,14 +430,16 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.alpha = 1.f; p.beta = 0.f;
-  p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN;
+  p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN; p.tiles_m = M / BM;
   p.gate = gate;
+  unsigned gx = (unsigned)(p.tiles_m * p.tiles_n);
+  p.gm = xcd_group_rows(p.tiles_m, p.tiles_n, &gx);
   // Occupancy cap: waiting tiles SPIN, so they must never keep the producing (cooperative) kernel's workgroups from
   // becoming resident.  26 KB of unused dynamic LDS on top of the 33 KB static makes at most two of these workgroups
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
   static const int gate_lds = (getenv("EESEN_GATE_LDS_KB") ? atoi(getenv("EESEN_GATE_LDS_KB")) : 26) * 1024;
-  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3((unsigned)((M / BM) * (N / BN))), dim3(256), gate_lds, st, p);
+  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");
 }
 

@@ -170,12 +170,15 @@ Net::~Net() {
   for (auto& e : ev_grad) if (e) (void)hipEventDestroy(e);
   if (ev_gate_reset) (void)hipEventDestroy(ev_gate_reset);
   if (ev_gate_done) (void)hipEventDestroy(ev_gate_done);
+  for (auto& e : ev_ready) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_bucket) if (e) (void)hipEventDestroy(e);
   if (own_stream) (void)hipStreamDestroy(st);
 }
 
 void Net::sync() {
   EESEN_HIP_CHECK(hipSetDevice(device));
   EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  wait_buckets_host();  // gradient buckets still in flight on the communicator's stream
   check_device_error();
 }
 
@@ -604,6 +607,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   ws2.reserve(need_ws);
   int dg_slot = 0;
   bool side_pending[2] = {false, false};
+  bucket_log.clear();
 
   // backpropagate_buf_[L] = out_diff (net.cc:96), into a buffer whose rows are 16-byte aligned
   const int Kout = layers.back().dout;
@@ -640,6 +644,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats);
       col_sums(st, d, rows, L.dout, ld_d, fr + L.off_b, ws.p, ws_floats);
       timer.end(st, ti_); }
+      bucket_allreduce(li, st);
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
       const LstmLayerDev v = lstm_view(*this, L);
@@ -686,6 +691,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
                  fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, ws2.cap, side_lds);
       lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, ws2.cap);
       timer.end(sg, ti_); }
+      bucket_allreduce(li, sg);  // this layer's gradients are complete: sum them over the ranks under the lower layers' backward pass
       if (overlap) {
         EESEN_HIP_CHECK(hipEventRecord(ev_grad[dg_slot], st2));
         side_pending[dg_slot] = true;
@@ -707,8 +713,14 @@ void Net::update() {
   EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
   EESEN_HIP_CHECK(hipSetDevice(device));
   { const int ti_ = timer.begin(st, 5);
-  for (Layer& L : layers)
+  // top-down, the order in which Backpropagate completed (and all-reduced) the layers' gradients
+  for (int li = (int)layers.size() - 1; li >= 0; --li) {
+    Layer& L = layers[li];
     if (L.p_n) {
+      if (comm && li < (int)bucket_pending.size() && bucket_pending[li]) {
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_bucket[li], 0));
+        bucket_pending[li] = 0;
+      }
       if (rule == 0) {
         sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
       } else {  // the adaptive rules do not apply learn_rate_coef (bilstm-layer.h:865-869 multiplies only in the SGD branch)
@@ -717,6 +729,7 @@ void Net::update() {
                         L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2);
       }
     }
+  }
   refresh_derived();
   timer.end(st, ti_); }
   if (persistent) arm_device_error_poll();

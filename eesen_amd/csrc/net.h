@@ -63,6 +63,8 @@ class PhaseTimer {
   bool on_ = false, accumulate_ = false;
 };
 
+struct Comm;  // comm.cpp: RCCL communicator (one rank per GPU)
+
 struct Net {
   int device = 0;
   hipStream_t st = nullptr;
@@ -119,6 +121,18 @@ struct Net {
   void get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* info4);
   size_t ws_floats = 0;
   PhaseTimer timer;
+  // data-parallel exchange (comm.cpp): with a communicator attached, Backpropagate sums every layer's fresh gradients
+  // over the ranks on the communicator's stream as soon as that layer's weight-gradient kernels are enqueued (the point
+  // of the reference's per-layer Update, net.cc:98-104), and Update waits bucket by bucket
+  Comm* comm = nullptr;                       // not owned
+  std::vector<hipEvent_t> ev_ready, ev_bucket;
+  std::vector<char> bucket_pending;
+  std::vector<int> bucket_log;                // layer order of the last Backpropagate's buckets (tests)
+  void set_comm(Comm* c);
+  void bucket_allreduce(int li, hipStream_t producer);
+  void wait_buckets_host();
+  void backpropagate_zero();
+  void allreduce_grads(Comm* c);
 
   Net(int device, void* stream);
   ~Net();
@@ -148,6 +162,25 @@ struct Ctc {
   double obj_sum = 0;
   long sequences = 0, frames = 0, err_tokens = 0, ref_tokens = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  PhaseTimer timer;  // eesen_ctc_set_profiling(2): spans accumulate over many calls, read once (no per-call synchronisation)
+  // Nothing in a training step has to stall the host: label staging goes through two alternating pinned slots, and the
+  // per-sequence ln p / the greedy-decode ids of a call whose caller did not ask for them (NULL result pointers) come
+  // back through pinned slots that are folded into the statistics at the next call that needs them ("deferred").
+  struct Pin {
+    void* p = nullptr;
+    size_t cap = 0;            // bytes
+    hipEvent_t ev = nullptr;   // last use of the slot by the device
+    bool busy = false;
+  };
+  Pin stage[2];                // label expansion + class position lists (H2D)
+  unsigned stage_idx = 0;
+  struct PendingPzx { Pin pin; int S = 0; bool active = false; } ppzx[2];
+  struct PendingErr { Pin pin; int S = 0; bool active = false; std::vector<int> frames, ids, off; } perr[2];
+  unsigned ppzx_idx = 0, perr_idx = 0;
+  void* pin_reserve(Pin& pin, size_t bytes);  // waits for the slot's last use, grows it, returns the host pointer
+  void flush_pzx(PendingPzx& q);
+  void flush_err(PendingErr& q, int* num_err, int* num_ref);
+  void flush();                // fold every deferred result into the statistics (blocks until they have arrived)
 
   Ctc(int device, void* stream);
   ~Ctc();

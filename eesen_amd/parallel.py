@@ -7,8 +7,13 @@ are summed with ONE all-reduce over RCCL/xGMI between backprop and update, so th
 equal the reference run with --num-sequence = N*S: corr = momentum*corr + sum_ranks(g), clip, update
 (momentum and clipping are applied AFTER the sum).
 
-torch is used only as plumbing here: `torch.distributed` (backend "nccl" = RCCL on ROCm, "gloo" in the CPU
-tests) and a zero-copy tensor view of the library's gradient buffer.
+Two transports for that exchange:
+  * the library's own RCCL communicator (eesen_amd.api.Comm + Net.SetComm: per-layer buckets on a communication
+    stream, overlapped with the lower layers' backward pass; no torch in the process) -- what bench.py and the
+    trainers use;
+  * `GradAllReducer`, the same sum as a `net.grad_hook` over `torch.distributed` (backend "nccl" = RCCL on ROCm,
+    "gloo" in the CPU tests): one bulk all-reduce of the contiguous gradient buffer, for hosts that already live
+    inside a torch process group.  torch is plumbing only: a zero-copy tensor view of the library's buffer.
 """
 from __future__ import annotations
 
@@ -65,10 +70,33 @@ class GradAllReducer:
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.t = grad_tensor(net)
+        # a Net over the C-ABI exposes a device pointer; any other host of the recipe (the CPU tests' oracle-backed
+        # stand-in) may expose its contiguous gradient buffer as a torch tensor directly
+        self.t = net.grad_tensor() if hasattr(net, "grad_tensor") else grad_tensor(net)
 
     def __call__(self, net):
         self.dist.all_reduce(self.t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def minibatch_owner(index: int, world: int) -> int:
+    """Which rank trains minibatch `index` when all ranks read the SAME feature list: consecutive minibatches go to
+    consecutive ranks, so that the N minibatches of one synchronous step are N neighbouring groups of the length-sorted
+    list (similar T_max on every rank) -- the counterpart of the reference's round-robin deal of length-sorted batches to
+    jobs (/root/reference/asr_egs/wsj/utils/prep_scps.sh:37-76)."""
+    return index % world
+
+
+def shard_minibatches(batches, rank: int, world: int):
+    """Filter an iterator of minibatches down to the ones `rank` owns (see minibatch_owner)."""
+    for i, b in enumerate(batches):
+        if minibatch_owner(i, world) == rank:
+            yield b
+
+
+def job_rspecifier(rspecifier: str, rank: int) -> str:
+    """Kaldi's queue scripts substitute the literal JOB in per-job arguments (`JOB=1:$nj ... feats.JOB.scp`,
+    /root/reference/asr_egs/wsj/steps/train_ctc_parallel_h.sh); do the same for a rank (job id = rank + 1)."""
+    return rspecifier.replace("JOB", str(rank + 1))
 
 
 def allreduce_stats(values, group=None, device=None):

@@ -62,9 +62,9 @@ int eesen_net_add_layer(eesen_net_t* net, int kind, int in_dim, int out_dim,
 /* Allocates parameters (zero) + optimiser state; must follow the last add_layer. */
 int eesen_net_finalize(eesen_net_t* net);
 /* Net::Read (src/net/net.cc:279-309): parse a Kaldi-stream <Nnet> file (text or \0B binary), build
- * the layers and upload the weights (and the Adagrad/RMSProp accumulators when the file carries them).  Fails
- * (EESEN_ERR_INVALID) on non-zero dropout options or layer kinds outside the list above.  Resets learn_rate to 0 as the
- * reference does (net.cc:294). */
+ * the layers and upload the weights (and the Adagrad/RMSProp accumulators when the file carries them; the nine dropout
+ * options of a BiLstm layer are kept, see the dropout section below).  Fails (EESEN_ERR_INVALID) on layer kinds outside
+ * the list above.  Resets learn_rate to 0 as the reference does (net.cc:294). */
 int eesen_net_read(eesen_net_t* net, const char* path);
 /* Net::Write (src/net/net.cc:325-334), same byte format as the reference for these layer kinds. */
 int eesen_net_write(eesen_net_t* net, const char* path, int binary);
@@ -132,13 +132,53 @@ int eesen_net_synchronize(eesen_net_t* net);
 int eesen_net_set_profiling(eesen_net_t* net, int on);
 int eesen_net_get_phase_times(eesen_net_t* net, float* out6);
 
+/* ---- data-parallel exchange: one process per GPU, RCCL over xGMI ------------------------------------------------------
+ * Replaces the reference's multi-job mode (--num-jobs / --job-id / --utts-per-avg, src/netbin/train-ctc-parallel.cc:208-235):
+ * comm_avg_weights (src/net/communicator.h:39-119) averages whole MODELS through files every few hundred utterances and
+ * comm_touch_done (:121-170) merges the error counts through "done" files.  Here every rank runs the same Net on its own
+ * utterances and the FRESH gradients (sums over frames) are summed over the ranks every minibatch, so that N ranks x S
+ * utterances equal one process with --num-sequence = N*S (momentum and clipping act on the summed gradient).
+ *
+ * Rendezvous: rank 0 draws the 128-byte RCCL unique id (eesen_comm_get_unique_id) and hands it to the other ranks --
+ * through any channel the host has (eesen_comm_create), or through the library's own TCP hand-out
+ * (eesen_comm_create_tcp: rank 0 listens on addr:port, the others connect, retrying until `timeout_s`).
+ * eesen_comm_exchange is that hand-out on its own (any <= 4 KB blob; needs no GPU). */
+typedef struct eesen_comm eesen_comm_t;
+int eesen_comm_get_unique_id(char* id128);
+int eesen_comm_exchange(const char* addr, int port, int rank, int world, char* buf, int nbytes, int timeout_s);
+int eesen_comm_create(int device, const char* id128, int rank, int world, eesen_comm_t** out);
+int eesen_comm_create_tcp(int device, const char* addr, int port, int rank, int world, int timeout_s, eesen_comm_t** out);
+int eesen_comm_destroy(eesen_comm_t* comm);
+int eesen_comm_info(eesen_comm_t* comm, int* rank, int* world);
+/* Sum (op 0) or max (op 1) of n <= 64 host doubles over the ranks, in place; blocks.  Carries the statistics the
+ * reference merges through done-files (sum ln p, error / reference tokens, frames), "does any rank still have a
+ * minibatch", and doubles as a barrier. */
+int eesen_comm_allreduce_host(eesen_comm_t* comm, double* values, int n, int op);
+/* Attach a communicator to a Net (NULL detaches).  From then on eesen_net_backpropagate sums every layer's fresh
+ * gradients over the ranks -- one all-reduce(SUM, fp32) per trainable layer, issued on the communicator's own stream as
+ * soon as that layer's weight-gradient kernels are enqueued, i.e. where the reference updates the layer
+ * (src/net/net.cc:98-104), so the exchange of the upper layers runs under the backward pass of the lower ones -- and
+ * eesen_net_update waits bucket by bucket.  Every rank must call the same sequence of backpropagate / update. */
+int eesen_net_set_comm(eesen_net_t* net, eesen_comm_t* comm);
+/* The same exchange as ONE all-reduce of the whole gradient buffer on the Net's stream, for hosts that keep the
+ * communicator detached: call between eesen_net_backpropagate and eesen_net_update. */
+int eesen_net_allreduce_grads(eesen_net_t* net, eesen_comm_t* comm);
+/* For a rank that has run out of minibatches while others have not: zero gradient, the attached communicator's
+ * per-layer all-reduces in the order a real Backpropagate issues them; follow with eesen_net_update. */
+int eesen_net_backpropagate_zero(eesen_net_t* net);
+/* Debug / test accessor: the layer indices whose buckets the last Backpropagate issued, in issue order. */
+int eesen_net_bucket_order(eesen_net_t* net, int* layers_out, int cap, int* n);
+/* hipDeviceSynchronize of `device` (bench.py brackets its timed region with it). */
+int eesen_device_synchronize(int device);
+
 /* ---- Ctc (src/net/ctc-loss.h:31-90) ------------------------------------------------------------ */
 int eesen_ctc_create(int device, void* stream, eesen_ctc_t** out);
 int eesen_ctc_destroy(eesen_ctc_t* ctc);
 /* Ctc::EvalParallel (src/net/ctc-loss.cc:101-194).  net_out_dev: [T*S x K] softmax outputs (device),
  * frame_num_utt: host int[S]; labels in CSR form on the host: label_off int[S+1], label_ids (no
  * blanks, blank id is 0).  Writes diff_dev [T*S x K] (device, ld given) = d(-ln p)/d(logits), zero
- * on rows t >= frame_num_utt[s]; pzx_host (may be NULL): ln p(z|x) per sequence.  Accumulates the
+ * on rows t >= frame_num_utt[s]; pzx_host (may be NULL: then nothing waits for the device and ln p joins the
+ * objective sum once it has arrived): ln p(z|x) per sequence.  Accumulates the
  * objective / frame counters reported by eesen_ctc_report.  Every sequence needs >= 1 label and a
  * feasible alignment is the caller's business (ln p ~ -1e30 otherwise, as in the reference). */
 int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
@@ -146,7 +186,9 @@ int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, c
                             float* diff_dev, int diff_ld, float* pzx_host);
 /* Ctc::ErrorRateMSeq (ctc-loss.cc:235-298): greedy decode (argmax on the device, collapse repeats,
  * drop blanks) and Levenshtein distance against the references (host).  Accumulates error / ref
- * token counts; also returns this call's counts. */
+ * token counts; also returns this call's counts.  With num_err == num_ref == NULL the call only ENQUEUES the argmax
+ * and the copy of the ids: the host part runs at the next call / eesen_ctc_stats, under the device's backward pass
+ * (the reference's call returns void and only accumulates). */
 int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
                               int rows, int K, int ld, const int* label_ids, const int* label_off,
                               int* num_err, int* num_ref);
@@ -158,7 +200,10 @@ int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* fr
  * [T*S x L'] (row t*S+s, L' = 2*max_U+1), host pointers, either may be NULL. Cells the reference
  * leaves at -1e30 (padding) read -1e30. */
 int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_host, int* Lprime);
-/* seconds of the last EvalParallel's device work (HIP events): out[0]=log, [1]=alpha/beta sweep, [2]=error+jacobian */
+/* seconds of the last EvalParallel's device work (HIP events): out[0]=log, [1]=alpha/beta sweep, [2]=error+jacobian.
+ * eesen_ctc_set_profiling(ctc, 2): the spans of ALL calls since the last read are summed instead, so that a timed
+ * multi-step region needs no host synchronisation per step (0 = back to last-call timing). */
+int eesen_ctc_set_profiling(eesen_ctc_t* ctc, int mode);
 int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3);
 
 /* ---- dropout variants of BiLstm(Parallel) (src/net/bilstm-parallel-layer.h:46-94,209-377,604-879) ------

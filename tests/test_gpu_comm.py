@@ -1,0 +1,76 @@
+"""-m gpu: the library's RCCL communicator at world size 1 (the only size a single-GPU box offers): creation through the TCP
+rendezvous path, the per-layer bucket order, and bit-equality of the bucketed / bulk / detached gradient paths.
+N > 1 is covered on CPU by tests/test_parallel_cpu.py (product reducer over gloo, sharding, rendezvous between processes)."""
+import numpy as np
+import pytest
+
+from eesen_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _steps(net, ctc, batch, n=3):
+    out = []
+    for _ in range(n):
+        net.SetSeqLengths(batch.lens)
+        o = net.Propagate(batch.feats)
+        d = ctc.EvalParallel(batch.lens, o, batch.labels)
+        net.BackpropagateNoUpdate(d)
+        if net.grad_hook is not None:
+            net.grad_hook(net)
+        g = net.GetGrads()
+        net.Update()
+        out.append((g, net.GetParams()))
+    return out
+
+
+@pytest.fixture(scope="module")
+def comm(gpu):
+    from eesen_amd.api import Comm
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    c = Comm(0, 0, 1, "127.0.0.1", port, 30)
+    assert (c.rank, c.world) == (0, 1)
+    return c
+
+
+def test_host_scalars_and_barrier(comm):
+    assert comm.allreduce([1.5, -2.0, 7.0]) == [1.5, -2.0, 7.0]
+    assert comm.allreduce([3.0, 4.0], comm.MAX) == [3.0, 4.0]
+    comm.barrier()
+
+
+@pytest.mark.parametrize("cfg_name,over", [("small_bi", {}), ("cfg2", dict(T=40, S=16, layers=3)), ("tiny_bi", dict(layers=3, proj=12, H=12, T=20, S=4))])
+def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name, over):
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config(cfg_name); cfg.update(over)
+    layers = synth.make_model(max_grad=0.5, **cfg)
+    batch = synth.make_batch(**cfg)
+
+    def run(mode):
+        net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+        if mode == "bucket":
+            net.SetComm(comm)
+        elif mode == "bulk":
+            net.grad_hook = lambda n: n.AllReduceGrads(comm)
+        r = _steps(net, ctc, batch)
+        return r, net
+
+    ref, _ = run("none")
+    buck, nb = run("bucket")
+    bulk, _ = run("bulk")
+    for (g0, p0), (g1, p1), (g2, p2) in zip(ref, buck, bulk):
+        assert np.array_equal(g0, g1) and np.array_equal(g0, g2)
+        assert np.array_equal(p0, p1) and np.array_equal(p0, p2)
+    # one bucket per TRAINABLE layer, top-down: the order in which Backpropagate completes their gradients, i.e. where the
+    # reference calls Update per layer (net.cc:98-104)
+    trainable = [i for i, L in enumerate(layers) if L["params"]]
+    assert nb.BucketOrder() == trainable[::-1]
+    # a rank without a minibatch: zero gradient through the same collectives, momentum still decays the step
+    before = nb.GetParams()
+    nb.BackpropagateZero()
+    assert nb.BucketOrder() == trainable[::-1]
+    assert not np.any(nb.GetGrads())
+    nb.Update()
+    assert not np.array_equal(before, nb.GetParams())      # momentum 0.9 carries the previous direction on
+    nb.SetComm(None)

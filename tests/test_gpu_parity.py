@@ -204,9 +204,15 @@ def test_error_behaviour(gpu, tmp_path):
     with pytest.raises(EesenError):       # Backpropagate before Propagate
         net.Backpropagate(CuMatrix(6, cfg["K"]))
     bad = str(tmp_path / "bad.txt")
-    open(bad, "w").write("<Nnet>\n<BiLstmParallel> <InputDim> 4 <CellDim> 8\n<LearnRateCoef> 1 <MaxGrad> 0 <ForwardDropoutFactor> 0.2 ")
-    with pytest.raises(EesenError):       # dropout is out of scope and must be refused, not ignored
+    open(bad, "w").write("<Nnet>\n<BiLstmParallel> <InputDim> 4 <CellDim> 8\n<LearnRateCoef> 1 <MaxGrad> 0 ")
+    with pytest.raises(EesenError):       # truncated model file (Net::Read throws, net.cc:279-309)
         Net().Read(bad)
+    unk = str(tmp_path / "unknown.txt")
+    open(unk, "w").write("<Nnet>\n<Tanh> <InputDim> 4 <OutputDim> 4\n</Nnet>\n")
+    with pytest.raises(EesenError):       # a layer kind outside the hot path is refused, not skipped
+        Net().Read(unk)
+    with pytest.raises(EesenError):       # dropout factor outside [0, 1)
+        net.SetLayerDropout(0, dict(forward=1.5, fw_step=True))
     with pytest.raises(EesenError):
         Net().Read(str(tmp_path / "does-not-exist"))
     ctc = Ctc()

@@ -1,0 +1,163 @@
+"""-m gpu: the HIP path against THE REFERENCE ITSELF at the benchmarked size.
+
+cfg2 exactly as bench.py runs it (S=32 utterances, T_max=1000, 4x512 BiLSTM, seed 777; lr=1 / momentum 0 / MaxGrad 0 so
+that the parameter delta is the gradient): one trainer step of oracle/_ref (the reference's src/net + src/cpucompute
+compiled unmodified, its CUDA CTC kernel bodies emulated per thread) against one step of libeesen_hip.so, both the
+persistent recurrence and the per-step fallback, plus one 1024-cell layer at T=1000 (the wide persistent tiles).
+When oracle/_ref is absent the compact fixture tests/golden/full_*.npz (made by `python -m oracle.fullsize` from the
+reference) is the arbiter.  Bars (north_star): ln p, net_out, in_diff and every gradient tensor within 1e-4 relative;
+`diff` against the fp64 arbiter, with the measured fp32 floors written to gpurun_out/parity_*.json (copied to profiles/).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import fullsize
+from tests.util import rel_err, valid_mask, split_params
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hip_step(layers, batch, persistent: bool):
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    old = os.environ.get("EESEN_PERSISTENT")
+    os.environ["EESEN_PERSISTENT"] = "1" if persistent else "0"      # read when the Net is created
+    try:
+        net = Net.from_layers(layers)
+    finally:
+        if old is None:
+            del os.environ["EESEN_PERSISTENT"]
+        else:
+            os.environ["EESEN_PERSISTENT"] = old
+    net.SetTrainOptions(1.0, 0.0)
+    ctc = Ctc()
+    net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats)
+    diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+    errs = ctc.ErrorRateMSeq(batch.lens, out, batch.labels)
+    idf = CuMatrix(batch.T * batch.S, batch.feats.shape[1])
+    net.BackpropagateNoUpdate(diff, idf)
+    before = net.GetParams().astype(np.float64)
+    grads = net.GetGrads()
+    net.Update()
+    net.Synchronize()
+    delta = before - net.GetParams().astype(np.float64)     # what the reference exposes: theta_before - theta_after
+    return dict(net_out=out.numpy(), pzx=ctc.pzx.copy(), diff=diff.numpy(), in_diff=idf.numpy(), grads=grads, delta=delta,
+                errors=errs)
+
+
+_REF_CACHE = {}
+
+
+def _reference(name):
+    """Live reference step when oracle/_ref is on the box, else None (the fixture is then the arbiter)."""
+    if name not in _REF_CACHE:
+        from oracle import refbind
+        cfg, layers, batch = fullsize.case(name)
+        r = None
+        if refbind.available():
+            t0 = time.time()
+            r = fullsize.reference_step(layers, batch)
+            r["seconds"] = time.time() - t0
+        _REF_CACHE[name] = (cfg, layers, batch, r)
+    return _REF_CACHE[name]
+
+
+def _ctc_floor(net_out, batch, diff32):
+    """fp64 arbiter of the CTC stage on the SAME probabilities: distance of an fp32 `diff` to it."""
+    from oracle import net as onet
+    arb = onet.ctc_eval_parallel(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off, "f64")
+    return arb, rel_err(diff32, arb["diff"])
+
+
+def _check(name, persistent, record):
+    cfg, layers, batch, ref = _reference(name)
+    hip = _hip_step(layers, batch, persistent)
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    rep = dict(case=name, persistent=persistent, S=batch.S, T=batch.T, reference="live oracle/_ref" if ref else "fixture tests/golden/%s.npz" % name)
+    # the HIP gradient accessor and the black-box delta the reference exposes agree (lr = 1: delta = gradient)
+    assert rel_err(hip["delta"], hip["grads"]) < 2e-6
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    if ref is not None:
+        # the committed fixture is what this very reference code produced in the authoring container
+        assert rel_err(fullsize.compact(layers, ref)["pzx"], fx["pzx"]) < 1e-5
+        rep["reference_seconds"] = ref["seconds"]
+        rep["ln_p"] = dict(hip=float(hip["pzx"].astype(np.float64).sum()), reference=float(ref["pzx"].astype(np.float64).sum()),
+                           rel_err_per_sequence=rel_err(hip["pzx"], ref["pzx"]))
+        rep["net_out_valid"] = rel_err(hip["net_out"][vm], ref["net_out"][vm])
+        rep["in_diff"] = rel_err(hip["in_diff"], ref["in_diff"])
+        rep["grads"] = {}
+        for (li, nm, a), (_, _, b) in zip(split_params(layers, hip["grads"]), split_params(layers, ref["grads"])):
+            rep["grads"][f"L{li}.{nm}"] = rel_err(a, b)
+        # diff: the end-to-end distance and, per side, the distance to an fp64 CTC on that side's own probabilities
+        arb_h, floor_h = _ctc_floor(hip["net_out"], batch, hip["diff"])
+        arb_r, floor_r = _ctc_floor(ref["net_out"], batch, ref["diff"])
+        rep["diff"] = dict(hip_vs_reference_fp32=rel_err(hip["diff"], ref["diff"]), hip_vs_fp64_on_hip_probs=floor_h,
+                           reference_fp32_vs_fp64_on_reference_probs=floor_r,
+                           fp64_hip_probs_vs_fp64_reference_probs=rel_err(arb_h["diff"], arb_r["diff"]),
+                           frame_sums_hip_vs_reference=rel_err(hip["diff"].reshape(batch.T, batch.S, -1).sum(0),
+                                                               ref["diff"].reshape(batch.T, batch.S, -1).sum(0)))
+        rep["errors"] = dict(hip=list(hip["errors"]), reference=list(ref["errors"]))
+    else:
+        c = fullsize.compact(layers, hip)
+        rep["ln_p"] = dict(hip=float(hip["pzx"].astype(np.float64).sum()), reference=float(fx["pzx"].astype(np.float64).sum()),
+                           rel_err_per_sequence=rel_err(hip["pzx"], fx["pzx"]))
+        rs = fullsize.ROW_STRIDE
+        rep["net_out_valid"] = rel_err(c["net_out_rows"][vm[::rs]], fx["net_out_rows"][vm[::rs]])
+        rep["in_diff"] = float(np.max(np.abs(c["in_diff_rows"].astype(np.float64) - fx["in_diff_rows"])) / float(fx["in_diff_absmax"]))
+        st, fs = c["grad_stats"], fx["grad_stats"]
+        rep["grads"] = {f"tensor{i}": float(max(abs(st[i, 0] - fs[i, 0]) / fs[i, 0], abs(st[i, 1] - fs[i, 1]) / fs[i, 2],
+                                                abs(st[i, 2] - fs[i, 2]) / fs[i, 2])) for i in range(len(fs))}
+        rep["grads"]["sample"] = float(np.max(np.abs(c["grad_sample"].astype(np.float64) - fx["grad_sample"])) / np.max(np.abs(fx["grad_sample"])))
+        arb_h, floor_h = _ctc_floor(hip["net_out"], batch, hip["diff"])
+        rep["diff"] = dict(hip_vs_reference_fp32=float(np.max(np.abs(c["diff_rows"].astype(np.float64) - fx["diff_rows"])) / float(fx["diff_absmax"])),
+                           hip_vs_fp64_on_hip_probs=floor_h)
+        rep["errors"] = dict(hip=list(hip["errors"]), reference=[int(x) for x in fx["errors"]])
+    record(rep)
+    assert rep["ln_p"]["rel_err_per_sequence"] < TOL
+    assert rep["net_out_valid"] < TOL
+    assert rep["in_diff"] < TOL
+    for k, v in rep["grads"].items():
+        assert v < TOL, f"gradient tensor {k}: {v}"
+    # `diff` = y*sum(gamma) - gamma with gamma = exp(alpha + beta - ln p - ln y): the exponent carries the fp32 round-off of
+    # |alpha| ~ 1e3 (ulp 6e-5), so an fp32 evaluation sits ~1e-4..1e-3 from the fp64 value at T = 1000 whoever computes it.
+    # The HIP result must be as close to fp64 as the reference's own fp32 arithmetic is (x1.5), and its per-sequence frame
+    # sums -- what reaches the parameter gradients -- within 1e-4 of the reference's.
+    d = rep["diff"]
+    if "reference_fp32_vs_fp64_on_reference_probs" in d:
+        assert d["hip_vs_fp64_on_hip_probs"] < max(TOL, 1.5 * d["reference_fp32_vs_fp64_on_reference_probs"])
+        assert d["frame_sums_hip_vs_reference"] < TOL
+        assert tuple(hip["errors"]) == tuple(ref["errors"])
+    else:
+        assert d["hip_vs_fp64_on_hip_probs"] < 2e-3
+    assert np.all(hip["diff"][~vm] == 0) and np.all(hip["in_diff"][~vm] == 0)
+
+
+@pytest.fixture(scope="module")
+def record():
+    reps = []
+    yield reps.append
+    out_dir = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_fullsize.json"), "w") as f:
+            json.dump(reps, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_cfg2_full_length_against_reference(gpu, record):
+    _check("full_cfg2", True, record)
+
+
+def test_cfg2_full_length_per_step_kernels_against_reference(gpu, record):
+    _check("full_cfg2", False, record)
+
+
+def test_cfg4_wide_layer_full_length_against_reference(gpu, record):
+    _check("full_cfg4_layer", True, record)

@@ -1,7 +1,8 @@
-"""CPU, world_size 2 over gloo: the data-parallel recipe (shard deal, all-reduce(SUM) of FRESH gradients, then
-momentum / clip / update on every rank) equals one process on the whole minibatch — the parity statement of
-SURVEY.md section 8(e): N ranks x S == --num-sequence = N*S.  The per-rank arithmetic here is the oracle's; the
-host logic under test (eesen_amd/parallel.py) is what bench.py runs over RCCL."""
+"""CPU, world_size 2: the data-parallel recipe (shard deal, all-reduce(SUM) of FRESH gradients, then momentum / clip /
+update on every rank) equals one process on the whole minibatch — the parity statement of SURVEY.md section 8(e):
+N ranks x S == --num-sequence = N*S.  The per-rank arithmetic is the oracle's; the exchange is the PRODUCT's
+(eesen_amd.parallel.GradAllReducer over gloo, installed as grad_hook exactly as the trainers install it), and so are the
+sharding helpers and the library's TCP rendezvous (eesen_comm_exchange), which need no GPU."""
 import os
 import socket
 
@@ -36,43 +37,63 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class _HostNet:
+    """The reference operator interface (Propagate / BackpropagateNoUpdate / grad_hook / Update, eesen_amd.api.Net) over the CPU
+    oracle, so that the PRODUCT's exchange (`eesen_amd.parallel.GradAllReducer` installed as `grad_hook`) can run without a
+    GPU: the per-rank arithmetic is the oracle's, the data-parallel step is the product's."""
+
+    def __init__(self, layers, lr, mmt):
+        import torch
+        from oracle import net as onet
+        self.o = onet.OracleNet(layers, "f32")
+        self.o.set_train_options(lr, mmt)
+        self.n = int(sum(p.size for L in self.o.layers for p in L["params"]))
+        self._g = torch.zeros(self.n, dtype=torch.float32)          # the contiguous fresh-gradient buffer
+        self.grad_hook = None
+
+    def grad_tensor(self):
+        return self._g
+
+    def step(self, batch):
+        from oracle import net as onet
+        o = self.o
+        o.set_seq_lengths(batch.lens)
+        out = o.propagate(batch.feats)
+        c = onet.ctc_eval_parallel(out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off, "f32")
+        # BackpropagateNoUpdate: fresh gradients only (momentum term kept out), into the contiguous buffer
+        mmt, o.momentum = o.momentum, 0.0
+        self.saved = [[x.copy() for x in L["corr"]] for L in o.layers]
+        for L in o.layers:
+            for x in L["corr"]: x[...] = 0
+        o.backpropagate(c["diff"], update=False)
+        o.momentum = mmt
+        self._g.numpy()[:] = np.concatenate([x.ravel() for L in o.layers for x in L["corr"]])
+        if self.grad_hook is not None:
+            self.grad_hook(self)                                    # the one exchange step
+        g = self._g.numpy(); i = 0                                  # Update: corr = momentum * corr + summed gradient, clip, step
+        for L, sv in zip(o.layers, self.saved):
+            for x, s0 in zip(L["corr"], sv):
+                x[...] = mmt * s0 + g[i:i + x.size].reshape(x.shape); i += x.size
+        for li, L in enumerate(o.layers):
+            if L["params"]: o.update_layer(li)
+        return float(c["pzx"].sum())
+
+
 def _worker(rank, world, port, cfg, steps, q):
-    import torch
     import torch.distributed as dist
-    from oracle import net as onet
+    from eesen_amd.parallel import GradAllReducer, allreduce_stats
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     layers = synth.make_model(max_grad=0.05, **cfg)
     full = synth.make_batch(**cfg)
     mine = shard_batch(full, rank, world)
-    net = onet.OracleNet(layers, "f32")
-    net.set_train_options(1e-3, 0.9)
+    net = _HostNet(layers, 1e-3, 0.9)
+    net.grad_hook = GradAllReducer(net)                             # what bench.py --comm torch and the trainers install
     lnp = 0.0
     for _ in range(steps):
-        net.set_seq_lengths(mine.lens)
-        out = net.propagate(mine.feats)
-        c = onet.ctc_eval_parallel(out, mine.T, mine.S, mine.lens, mine.label_ids, mine.label_off, "f32")
-        # backprop WITHOUT update and with the momentum term kept out: fresh gradients only
-        mmt, net.momentum = net.momentum, 0.0
-        saved = [[x.copy() for x in L["corr"]] for L in net.layers]
-        for L in net.layers:
-            for x in L["corr"]: x[...] = 0
-        net.backpropagate(c["diff"], update=False)
-        fresh = [[x.copy() for x in L["corr"]] for L in net.layers]
-        net.momentum = mmt
-        flat = torch.from_numpy(np.concatenate([g.ravel() for f in fresh for g in f]))
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)            # the one exchange step
-        g = flat.numpy(); i = 0
-        for L, sv in zip(net.layers, saved):
-            for x, s0 in zip(L["corr"], sv):
-                x[...] = mmt * s0 + g[i:i + x.size].reshape(x.shape); i += x.size
-        for li, L in enumerate(net.layers):
-            if L["params"]: net.update_layer(li)
-        t = torch.tensor([float(c["pzx"].sum())], dtype=torch.float64)
-        dist.all_reduce(t)
-        lnp = t.item()
+        lnp = allreduce_stats([net.step(mine)])[0]
     if rank == 0:
-        q.put((net.get_params(), lnp))
+        q.put((net.o.get_params(), lnp))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,3 +119,45 @@ def test_two_ranks_equal_one_process_on_the_whole_batch():
         o = onet.train_step(net, full, "f32")
     assert rel_err(params_dp, net.get_params()) < 1e-5
     assert abs(lnp_dp - float(o["pzx"].sum())) / abs(float(o["pzx"].sum())) < 1e-5
+
+
+def test_minibatch_sharding_is_a_partition_and_job_substitution():
+    from eesen_amd.parallel import shard_minibatches, minibatch_owner, job_rspecifier
+    batches = [f"mb{i}" for i in range(11)]
+    for world in (1, 2, 3, 8):
+        parts = [list(shard_minibatches(iter(batches), r, world)) for r in range(world)]
+        assert sorted(x for p in parts for x in p) == sorted(batches)
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+        # consecutive minibatches (neighbours in the length-sorted list) train in the same synchronous step
+        for i in range(len(batches)):
+            assert batches[i] in parts[minibatch_owner(i, world)]
+    assert job_rspecifier("scp:feats.JOB.scp", 2) == "scp:feats.3.scp" and job_rspecifier("ark:x.ark", 5) == "ark:x.ark"
+
+
+def _rdv(rank, world, port, q):
+    import ctypes as C
+    from eesen_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        buf.raw = bytes(range(128))
+    rc = lib.eesen_comm_exchange(b"127.0.0.1", port, rank, world, buf, 128, 30)
+    q.put((rank, rc, buf.raw == bytes(range(128))))
+
+
+def test_library_tcp_rendezvous_hands_the_id_to_every_rank():
+    """eesen_comm_exchange (the hand-out of the RCCL unique id, include/eesen_hip.h) between three processes; the late
+    starter is rank 0, so the others exercise their connect-retry loop."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rdv, args=(r, 3, port, q)) for r in (1, 2)]
+    for p in procs: p.start()
+    time.sleep(0.5)
+    p0 = ctx.Process(target=_rdv, args=(0, 3, port, q)); p0.start(); procs.append(p0)
+    got = sorted(q.get(timeout=60) for _ in range(3))
+    for p in procs:
+        p.join(timeout=30); assert p.exitcode == 0
+    assert got == [(0, 0, True), (1, 0, True), (2, 0, True)]
