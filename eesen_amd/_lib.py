@@ -54,6 +54,8 @@ SIGNATURES = {
     "eesen_net_set_profiling": (_i, [_vp, _i]),
     "eesen_net_get_phase_times": (_i, [_vp, _vp]),
     "eesen_device_synchronize": (_i, [_i]),
+    "eesen_set_gemm_mode": (_i, [_i]),
+    "eesen_get_gemm_mode": (_i, [_pi]),
     "eesen_comm_get_unique_id": (_i, [_vp]),
     "eesen_comm_exchange": (_i, [C.c_char_p, _i, _i, _i, _vp, _i, _i]),
     "eesen_comm_create": (_i, [_i, _vp, _i, _i, C.POINTER(_vp)]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "eesen_ctc_stats": (_i, [_vp, _pd, _pl, _pl, _pl, _pl]),
     "eesen_ctc_get_alpha_beta": (_i, [_vp, _vp, _vp, _pi]),
     "eesen_ctc_set_profiling": (_i, [_vp, _i]),
+    "eesen_ctc_set_sequence_out_file": (_i, [_vp, C.c_char_p]),
     "eesen_ctc_get_phase_times": (_i, [_vp, _vp]),
     "eesen_net_set_train_mode": (_i, [_vp, _i]),
     "eesen_net_set_dropout_seed": (_i, [_vp, C.c_ulonglong]),

@@ -434,6 +434,10 @@ class Ctc:
         check(self.lib.eesen_ctc_get_alpha_beta(self.h, _np_ptr(a), _np_ptr(b), C.byref(L)))
         return a, b
 
+    def SetSequenceOutFile(self, path: Optional[str]):
+        """--sequence-out-file (train-ctc-parallel.cc:53-54,134-137): ErrorRateMSeq appends `utt | label frame prob | ...` lines."""
+        check(self.lib.eesen_ctc_set_sequence_out_file(self.h, path.encode() if path else None))
+
     def SetProfiling(self, accumulate: bool):
         """accumulate=True: PhaseTimes() returns the sums over all EvalParallel calls since the last read (no per-call sync)."""
         check(self.lib.eesen_ctc_set_profiling(self.h, 2 if accumulate else 0))

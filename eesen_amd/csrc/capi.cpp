@@ -1,5 +1,6 @@
 // capi.cpp -- the extern "C" boundary declared in include/eesen_hip.h.  Every wrapper converts internal
 // exceptions into a status code and a thread-local message; no exception leaves the library.
+#include <cstdio>
 #include <cstring>
 
 #include "guard.h"
@@ -28,6 +29,16 @@ int eesen_device_count(int* count) {
     if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
     *count = n;
   });
+}
+
+int eesen_set_gemm_mode(int mode) {
+  return guard([&] {
+    EESEN_REQUIRE(mode >= -1 && mode <= 1, EESEN_ERR_INVALID, "gemm mode must be -1 (environment), 0 (f32 MFMA) or 1 (bf16 split)");
+    set_gemm_mode(mode);
+  });
+}
+int eesen_get_gemm_mode(int* mode) {
+  return guard([&] { REQ_PTR(mode); *mode = gemm_mode(); });
 }
 
 int eesen_device_synchronize(int device) {
@@ -208,6 +219,14 @@ int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* fr
 }
 int eesen_ctc_get_alpha_beta(eesen_ctc_t* ctc, float* alpha_host, float* beta_host, int* Lprime) {
   return guard([&] { REQ_PTR(ctc); ctc->get_alpha_beta(alpha_host, beta_host, Lprime); });
+}
+int eesen_ctc_set_sequence_out_file(eesen_ctc_t* ctc, const char* path) {
+  return guard([&] {
+    REQ_PTR(ctc);
+    ctc->flush();
+    ctc->seq_out = path ? path : "";
+    if (!ctc->seq_out.empty()) std::remove(ctc->seq_out.c_str());  // train-ctc-parallel.cc:134-137
+  });
 }
 int eesen_ctc_set_profiling(eesen_ctc_t* ctc, int mode) {
   return guard([&] { REQ_PTR(ctc); ctc->timer.enable(mode == 2); ctc->timer.set_accumulate(mode == 2); });

@@ -3,6 +3,7 @@
 // :235-298).  The lattice arithmetic itself is in ctc.hip.
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 
 #include "net.h"
 
@@ -30,7 +31,7 @@ Ctc::~Ctc() {
   };
   for (auto& x : stage) drop(x);
   for (auto& x : ppzx) drop(x.pin);
-  for (auto& x : perr) drop(x.pin);
+  for (auto& x : perr) { drop(x.pin); drop(x.probs); }
   if (own_stream) (void)hipStreamDestroy(st);
 }
 
@@ -229,20 +230,33 @@ void Ctc::flush_err(PendingErr& q, int* num_err, int* num_ref) {
   const int* ids = static_cast<const int*>(q.pin.p);
   const int S = q.S;
   int err = 0, ref = 0;
-  std::vector<int> hyp;
+  std::vector<int> hyp, frm;
+  std::ofstream output;
+  if (q.with_probs) {
+    EESEN_HIP_CHECK(hipEventSynchronize(q.probs.ev));
+    q.probs.busy = false;
+    output.open(seq_out, std::ofstream::out | std::ofstream::app);  // ctc-loss.cc:247-250
+  }
+  const float* probs = static_cast<const float*>(q.probs.p);
   for (int s = 0; s < S; ++s) {
-    hyp.clear();
+    hyp.clear(); frm.clear();
     int last = -1;
     for (int f = 0; f < q.frames[s]; ++f) {  // collapse repeats, drop blanks (ctc-loss.cc:252-275)
       const int id = ids[(size_t)f * S + s];
       if (f == 0 || id != last) {
-        if (id != 0) hyp.push_back(id);
+        if (id != 0) { hyp.push_back(id); frm.push_back(f); }
       }
       last = id;
     }
     const int U = q.off[s + 1] - q.off[s];
     err += levenshtein(q.ids.data() + q.off[s], U, hyp);
     ref += U;
+    if (q.with_probs) {  // :282-291: the index of the phone, the frame, and the probability
+      output << "utt";
+      for (size_t i = 0; i < hyp.size(); ++i)
+        output << " | " << hyp[i] << " " << frm[i] << " " << probs[((size_t)frm[i] * S + s) * q.K + hyp[i]];
+      output << "\n";
+    }
   }
   err_tokens += err;
   ref_tokens += ref;
@@ -266,7 +280,15 @@ void Ctc::error_rate_mseq(const int* frame_num_utt, int S, const float* net_out,
   int* pinned = static_cast<int*>(pin_reserve(q.pin, (size_t)rows * sizeof(int)));
   EESEN_HIP_CHECK(hipMemcpyAsync(pinned, ids_d.p, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, st));
   EESEN_HIP_CHECK(hipEventRecord(q.pin.ev, st));
-  q.pin.busy = true; q.S = S; q.active = true;
+  q.pin.busy = true; q.S = S; q.K = K; q.active = true;
+  q.with_probs = !seq_out.empty();
+  if (q.with_probs) {  // "This is inefficient, but ok for now" (ctc-loss.cc:283): the whole posterior matrix comes back
+    float* pp = static_cast<float*>(pin_reserve(q.probs, (size_t)rows * K * sizeof(float)));
+    EESEN_HIP_CHECK(hipMemcpy2DAsync(pp, (size_t)K * sizeof(float), net_out, (size_t)ld * sizeof(float), (size_t)K * sizeof(float), rows,
+                                     hipMemcpyDeviceToHost, st));
+    EESEN_HIP_CHECK(hipEventRecord(q.probs.ev, st));
+    q.probs.busy = true;
+  }
   q.frames.assign(frame_num_utt, frame_num_utt + S);
   q.off.assign(label_off, label_off + S + 1);
   for (int& o : q.off) o -= label_off[0];

@@ -16,6 +16,8 @@
 //     ordinary fp32 GEMM results -- no TF32-like truncation anywhere.
 //   * split-K (deterministic two-pass: partial slabs + reduce kernel) for the weight-gradient shapes
 //     whose M x N tile count cannot fill 256 CUs (e.g. 2048 x 512 with K = T*S = 32000).
+#include <cstring>
+
 #include "kernels.h"
 
 namespace eesen {
@@ -139,12 +141,47 @@ __device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const 
   }
 }
 
-template <bool A_KC, bool B_KC, bool GUARD, bool GATED = false>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][BM + LDP], float (*Bs)[BK][BN + LDP]) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+// C/D map of the 32x32 MFMA (all input types): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int split, int wm,
+                                              int wn, int lr, int lk) {
+  float* C = p.C;
+  size_t ldc = p.ldc;
+  const bool partial = p.splits > 1;
+  if (partial) {  // raw partial sums into slab `split` of the workspace, dense [M x N]
+    C = p.C + (size_t)split * p.M * p.N;
+    ldc = p.N;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + lr;
+      if (col >= p.N) continue;
+      const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= p.M) continue;
+        float* dst = C + (size_t)row * ldc + col;
+        if (partial) {
+          *dst = acc[mi][ni][r];
+        } else {
+          float v = p.alpha * acc[mi][ni][r] + bv;
+          if (p.beta != 0.f) v += p.beta * *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
+// Which output tile this workgroup computes, and -- for the gated variant -- the wait until the producing recurrence has
+// passed the tile's frames.  Returns false when the block has nothing to do (ragged edge of the XCD map, or the bounded
+// spin gave up and raised the error word).
+template <bool GATED>
+__device__ __forceinline__ bool gemm_prologue(const GemmParams& p, int& m0, int& n0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tm, tn;
-  if (!tile_of(p, tm, tn)) return;
+  if (!tile_of(p, tm, tn)) return false;
   if (GATED) {  // middle-out over time: row tiles in the order in which a bidirectional layer completes their frames
     const int tiles_m = p.tiles_m, mid = tiles_m / 2;
     // i = 0, 1, 2, 3, ... -> mid, mid-1, mid+1, mid-2, ...; when one side runs out the other side continues
@@ -153,7 +190,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
     if (i < 2 * pairs) tm = (i & 1) ? mid - (i + 1) / 2 : mid + i / 2;
     else tm = hi_cnt > lo_cnt ? mid + (i - pairs) : mid - 1 - (i - pairs);
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  m0 = tm * BM; n0 = tn * BN;
   if (GATED) {
     __shared__ int s_go;
     const GemmGate& g = p.gate;
@@ -177,8 +214,17 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
       if (lane == 0) s_go = go ? 1 : 0;
     }
     __syncthreads();
-    if (!s_go) return;
+    if (!s_go) return false;
   }
+  return true;
+}
+
+template <bool A_KC, bool B_KC, bool GUARD, bool GATED = false>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][BM + LDP], float (*Bs)[BK][BN + LDP]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  if (!gemm_prologue<GATED>(p, m0, n0)) return;
   const int split = blockIdx.y;
   const int kbeg = split * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
@@ -236,35 +282,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
     __syncthreads();
   }
 
-  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  float* C = p.C;
-  size_t ldc = p.ldc;
-  const bool partial = p.splits > 1;
-  if (partial) {  // raw partial sums into slab `split` of the workspace, dense [M x N]
-    C = p.C + (size_t)split * p.M * p.N;
-    ldc = p.N;
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + lr;
-      if (col >= p.N) continue;
-      const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= p.M) continue;
-        float* dst = C + (size_t)row * ldc + col;
-        if (partial) {
-          *dst = acc[mi][ni][r];
-        } else {
-          float v = p.alpha * acc[mi][ni][r] + bv;
-          if (p.beta != 0.f) v += p.beta * *dst;
-          *dst = v;
-        }
-      }
-    }
+  gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
 }
 
 // GUARD = false is launched only when EVERY tile of the grid is interior and every split holds whole k-tiles (decided on
@@ -281,6 +299,169 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
   __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LDP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LDP];
   gemm_body<true, true, false, true>(p, As, Bs);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix pipe with fp32-class accuracy ("3-way split").
+//
+// gfx950 runs f32-input MFMA at the f32 VECTOR rate -- 1/16 of the bf16 MFMA rate (CDNA4 guide, section 3) -- and has no
+// TF32-like form.  An fp32 value is EXACTLY the sum of three bf16 values: hi = top 8 significant bits (truncation),
+// mid = top 8 bits of x - hi, lo = top 8 bits of x - hi - mid (each subtraction is exact in fp32; 8 + 8 + 8 = 24 bits).
+// So a*b = sum of nine bf16 x bf16 products, each exact in fp32; the three smallest (mid*lo, lo*mid, lo*lo <= 2^-23 |ab|
+// together) are dropped and the other six go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//     a*b ~ hi*hi' + (hi*mid' + mid*hi') + (hi*lo' + lo*hi' + mid*mid'),   |error| <= 2^-23 |a*b|  (one fp32 rounding: 2^-24)
+// Six MFMAs of K = 16 at 32 cycles against eight f32 MFMAs of K = 2 at 64 cycles for the same 32x32x16 block: 2.67x the
+// f32 matrix rate at the accuracy of an fp32 GEMM (tests/test_gpu_gemm.py measures both against fp64).  The split costs
+// ~5 VALU operations per element, once per element per workgroup, on the way into LDS; VALU and matrix pipe are separate.
+//
+// LDS: per operand and stage 3 planes (hi, mid, lo) x 2 k-halves x 128 rows x 8 bf16 (16 B): lane l of an MFMA reads row
+// l & 31, k-half l >> 5 with ONE conflict-free ds_read_b128 (consecutive rows are consecutive 16-byte slots); the k-halves
+// are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
+constexpr int SP_HS = 128 * 16 + 64;        // bytes per k-half (128 rows x 16 B, + 16 banks)
+constexpr int SP_PS = 2 * SP_HS;            // bytes per plane
+constexpr int SP_OP = 3 * SP_PS;            // bytes per operand per stage
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// (row, k-quad) units: each thread brings 2 units of 4 consecutive-k floats per operand and k-tile.
+//   KC (k contiguous in HBM):  unit f = tid + 256 i -> row f >> 2, quad f & 3: one float4
+//   !KC (row contiguous):      row tid & 127, quad (tid >> 7) + 2 i: four dword loads, coalesced along the rows
+// Branch-free on purpose (see load_tile): a guarded load makes hipcc wait for every load separately, which serialises the
+// HBM latency of the four loads of a k-tile (measured: the first, branchy version of this kernel ran at 106 TF, BELOW the
+// f32 kernel).  Out-of-range rows / k are clamped to a valid address and zeroed by selects afterwards.
+// Branch-free on purpose (see load_tile): a guarded load makes hipcc wait for every load separately, which serialises the
+// HBM latency of the four loads of a k-tile.  Out-of-range rows / k are clamped to a valid address here; split_store zeroes
+// them -- AFTER the MFMA block, so that nothing touches the loaded registers (and waits for them) before it.
+template <bool KC>
+__device__ __forceinline__ void split_load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, int tid,
+                                           float4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (KC) {
+      const int f = tid + i * 256, r = r0 + (f >> 2), k = k0 + ((f & 3) << 2);
+      // rows are padded to a multiple of 4 floats (ld % 4 == 0, checked on the host), so k + 3 < ld whenever k < K
+      const int kc = min(k, max(kend - 1, 0) & ~3);
+      v[i] = *reinterpret_cast<const float4*>(P + (size_t)min(r, R - 1) * ld + kc);
+    } else {
+      const int r = r0 + (tid & 127), k = k0 + (((tid >> 7) + 2 * i) << 2);
+      const float* col = P + min(r, R - 1);
+      const int kl = max(kend - 1, 0);
+      v[i].x = col[(size_t)min(k + 0, kl) * ld];
+      v[i].y = col[(size_t)min(k + 1, kl) * ld];
+      v[i].z = col[(size_t)min(k + 2, kl) * ld];
+      v[i].w = col[(size_t)min(k + 3, kl) * ld];
+    }
+  }
+}
+
+// top 16 bits of two floats packed as two bf16 (low half = first): v_perm_b32
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
+
+template <bool KC, bool GUARD>
+__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, q;
+    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
+    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+    float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    if (GUARD) {
+      const bool ok = r0 + row < R;
+      const int k = k0 + q * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
+    }
+    float hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hi[j] = trunc_bf16(x[j]);
+      const float r1 = x[j] - hi[j];     // exact
+      mid[j] = trunc_bf16(r1);
+      lo[j] = r1 - mid[j];               // exact; its own top 16 bits are taken by the pack below
+    }
+    unsigned char* dst = base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
+    *reinterpret_cast<uint2*>(dst + SP_PS) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
+    *reinterpret_cast<uint2*>(dst + 2 * SP_PS) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+  }
+}
+
+template <bool A_KC, bool B_KC, bool GUARD, bool GATED>
+__device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
+  // stage s: A planes at s * 2 * SP_OP, B planes at s * 2 * SP_OP + SP_OP (indexed as an array, so the accesses stay ds_* ones)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * SP_OP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int m0, n0;
+  if (!gemm_prologue<GATED>(p, m0, n0)) return;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  constexpr int SBK = 16;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  const int nk = (kend - kbeg + SBK - 1) / SBK;
+  if (nk > 0) {
+    split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, tid, ra);
+    split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
+    split_store<A_KC, GUARD>(&lds[0], tid, ra, p.M, m0, kbeg, kend);
+    split_store<B_KC, GUARD>(&lds[SP_OP], tid, rb, p.N, n0, kbeg, kend);
+  }
+  __syncthreads();
+
+  const int lr = lane & 31, lk = lane >> 5;
+  const int a_off = lk * SP_HS + (wm * 64 + lr) * 16, b_off = SP_OP + lk * SP_HS + (wn * 64 + lr) * 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = (kt & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
+    if (kt + 1 < nk) {
+      split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg + (kt + 1) * SBK, kend, tid, ra);
+      split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * SBK, kend, tid, rb);
+    }
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + a_off + i * 32 * 16]);
+        b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + b_off + i * 32 * 16]);
+      }
+    __builtin_amdgcn_sched_barrier(0);  // the global prefetch and the fragment reads are issued before the MFMA block
+    // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi'; the four output blocks in turn,
+    // so that dependent MFMAs are four issues apart
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t]], b[ni][PB[t]], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads the prefetched registers (a vmcnt wait) moves above them
+    if (kt + 1 < nk) {
+      split_store<A_KC, GUARD>(&lds[nxt], tid, ra, p.M, m0, kbeg + (kt + 1) * SBK, kend);
+      split_store<B_KC, GUARD>(&lds[nxt + SP_OP], tid, rb, p.N, n0, kbeg + (kt + 1) * SBK, kend);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
+}
+
+template <bool A_KC, bool B_KC, bool GUARD>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmParams p) {
+  gemm_split_body<A_KC, B_KC, GUARD, false>(p);
+}
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
+  gemm_split_body<true, true, false, true>(p);
 }
 
 // Interference probes (EESEN_GEMM_SYNTH=1|2|3, side-stream launches only; results are garbage, timing experiments only):
@@ -345,6 +526,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
+// 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy,
+// 2.67x the matrix rate).  EESEN_GEMM_MODE=f32|split; read per call so that tests can flip it inside one process.
+static int g_gemm_mode = -1;
+int gemm_mode() {
+  if (g_gemm_mode >= 0) return g_gemm_mode;
+  const char* e = getenv("EESEN_GEMM_MODE");
+  return (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : 0;
+}
+void set_gemm_mode(int mode) { g_gemm_mode = mode; }
+
 // Row-group height of the XCD-aware tile map (0 = plain row-major) and the grid it needs.  Groups of 8 tile-rows once
 // every XCD gets at least two of them; fewer rows per group for short grids so that all eight XCDs still get work.
 static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
@@ -366,6 +557,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
+  const bool use_split = gemm_mode() == 1 && !synth;
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -383,7 +575,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     splits = std::max(1, std::min(splits, 64));
     while (splits > 1 && (size_t)splits * M * N > ws_floats) --splits;
   }
-  int k_chunk = cdiv(cdiv(K, splits), BK) * BK;
+  int k_chunk = cdiv(cdiv(K, splits), 16) * 16;   // whole k-tiles of either kernel (BK = 16 both)
   if (k_chunk < BK) k_chunk = BK;
   splits = std::max(1, cdiv(K, k_chunk));
   p.splits = splits;
@@ -401,7 +593,23 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
-  if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
+  if (use_split) {
+    // 49.5 KB of LDS per workgroup: the occupancy caps of the callers (unused dynamic LDS) are sized for the 33 KB of the f32
+    // kernel; keep the same workgroups-per-CU they ask for
+    const int extra = extra_lds_bytes > 0 ? std::max(0, extra_lds_bytes + 33792 - 4 * SP_OP) : 0;
+    // every tile interior and every split made of whole k-tiles: no clamps, no selects
+    const bool sg = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % 16) != 0;
+#define EESEN_SPLIT_LAUNCH(AK, BKC)                                                                                   \
+  do {                                                                                                                \
+    if (sg) hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, true>), grid, block, extra, st, p);               \
+    else hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, false>), grid, block, extra, st, p);                 \
+  } while (0)
+    if (a_kc && b_kc) EESEN_SPLIT_LAUNCH(true, true);
+    else if (a_kc && !b_kc) EESEN_SPLIT_LAUNCH(true, false);
+    else if (!a_kc && b_kc) EESEN_SPLIT_LAUNCH(false, true);
+    else EESEN_SPLIT_LAUNCH(false, false);
+#undef EESEN_SPLIT_LAUNCH
+  } else if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
     static bool warned = false;
     if (!warned) { fprintf(stderr, "eesen_hip: EESEN_GEMM_SYNTH=%d -- weight gradients are NOT computed (timing probe)\n", synth); warned = true; }
     if (synth == 1) hipLaunchKernelGGL(gemm_synth_kernel<1>, grid, block, extra_lds_bytes, st, p);
@@ -439,7 +647,8 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
   static const int gate_lds = (getenv("EESEN_GATE_LDS_KB") ? atoi(getenv("EESEN_GATE_LDS_KB")) : 26) * 1024;
-  hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
+  if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 4 * SP_OP), st, p);
+  else hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");
 }
 

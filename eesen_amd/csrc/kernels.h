@@ -15,6 +15,11 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
               size_t ws_floats, int extra_lds_bytes = 0);  // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
 
+// Arithmetic of every gemm_f32 / gemm_f32_nt_gated call: 0 = f32-input MFMA, 1 = 3-way bf16 split (gemm.hip); -1 = follow
+// EESEN_GEMM_MODE.  Process-wide.
+int gemm_mode();
+void set_gemm_mode(int mode);
+
 // Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
 // shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.
 constexpr int kShards = 8, kShardStride = 32;  // words

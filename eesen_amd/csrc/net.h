@@ -175,7 +175,8 @@ struct Ctc {
   Pin stage[2];                // label expansion + class position lists (H2D)
   unsigned stage_idx = 0;
   struct PendingPzx { Pin pin; int S = 0; bool active = false; } ppzx[2];
-  struct PendingErr { Pin pin; int S = 0; bool active = false; std::vector<int> frames, ids, off; } perr[2];
+  struct PendingErr { Pin pin, probs; int S = 0, K = 0; bool active = false, with_probs = false; std::vector<int> frames, ids, off; } perr[2];
+  std::string seq_out;         // --sequence-out-file of the trainer (ctc-loss.cc:247-250,282-291): decoded sequences are appended here
   unsigned ppzx_idx = 0, perr_idx = 0;
   void* pin_reserve(Pin& pin, size_t bytes);  // waits for the slot's last use, grows it, returns the host pointer
   void flush_pzx(PendingPzx& q);

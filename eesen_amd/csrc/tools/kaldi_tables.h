@@ -5,16 +5,86 @@
 // (src/util/kaldi-holder-inl.h:190-260), script files `key path[:offset]` (src/util/kaldi-table.h).
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <ext/stdio_filebuf.h>
 #include <fstream>
 #include <iostream>
 #include <map>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <vector>
 
 namespace ktab {
+
+// The "extended filenames" of src/util/kaldi-io.cc that the recipes use: a plain path, `-` (stdin / stdout), `cmd |` (read
+// the command's output) and `| cmd` (write into the command) -- steps/train_ctc_parallel.sh:95-115 always hands the
+// trainer `ark,s,cs:apply-cmvn ... |` and `ark:gunzip -c labels.tr.gz|`, the decoding scripts pipe `net-output-extract ... ark:-`.
+class InStream {
+ public:
+  explicit InStream(const std::string& xname) {
+    std::string n = xname;
+    while (!n.empty() && n.back() == ' ') n.pop_back();
+    if (n == "-") { is_ = &std::cin; return; }
+    if (!n.empty() && n.back() == '|') {
+      n.pop_back();
+      pipe_ = popen(n.c_str(), "r");
+      if (!pipe_) throw std::runtime_error("cannot run '" + n + "'");
+      buf_.reset(new __gnu_cxx::stdio_filebuf<char>(pipe_, std::ios::in | std::ios::binary));
+      own_.reset(new std::istream(buf_.get()));
+      is_ = own_.get();
+      return;
+    }
+    auto f = new std::ifstream(n, std::ios::binary);
+    own_.reset(f);
+    if (!*f) throw std::runtime_error("cannot open " + n);
+    is_ = f;
+  }
+  ~InStream() {
+    own_.reset(); buf_.reset();
+    if (pipe_) pclose(pipe_);
+  }
+  InStream(const InStream&) = delete;
+  std::istream& get() { return *is_; }
+ private:
+  std::istream* is_ = nullptr;
+  std::unique_ptr<std::istream> own_;
+  std::unique_ptr<__gnu_cxx::stdio_filebuf<char>> buf_;
+  FILE* pipe_ = nullptr;
+};
+class OutStream {
+ public:
+  explicit OutStream(const std::string& xname) {
+    std::string n = xname;
+    if (n == "-") { os_ = &std::cout; return; }
+    if (!n.empty() && n.front() == '|') {
+      pipe_ = popen(n.c_str() + 1, "w");
+      if (!pipe_) throw std::runtime_error("cannot run '" + n.substr(1) + "'");
+      buf_.reset(new __gnu_cxx::stdio_filebuf<char>(pipe_, std::ios::out | std::ios::binary));
+      own_.reset(new std::ostream(buf_.get()));
+      os_ = own_.get();
+      return;
+    }
+    auto f = new std::ofstream(n, std::ios::binary);
+    own_.reset(f);
+    if (!*f) throw std::runtime_error("cannot open " + n + " for writing");
+    os_ = f;
+  }
+  ~OutStream() {
+    if (os_) os_->flush();
+    own_.reset(); buf_.reset();
+    if (pipe_) pclose(pipe_);
+  }
+  OutStream(const OutStream&) = delete;
+  std::ostream& get() { return *os_; }
+ private:
+  std::ostream* os_ = nullptr;
+  std::unique_ptr<std::ostream> own_;
+  std::unique_ptr<__gnu_cxx::stdio_filebuf<char>> buf_;
+  FILE* pipe_ = nullptr;
+};
 
 struct Mat {
   std::vector<float> v;
@@ -133,17 +203,12 @@ inline Spec parse_spec(const std::string& s) {
   if (c == std::string::npos) throw std::runtime_error("bad table specifier '" + s + "' (expected ark:... or scp:...)");
   Spec sp{s.substr(0, s.find_first_of(",:")), s.substr(c + 1)};
   if (sp.kind != "ark" && sp.kind != "scp") throw std::runtime_error("unsupported table kind in '" + s + "'");
-  if (!sp.path.empty() && (sp.path.back() == '|' || sp.path.front() == '|')) throw std::runtime_error("pipes in table specifiers are not supported");
   return sp;
 }
 // SequentialBaseFloatMatrixReader (train-ctc-parallel.cc:124)
 class FeatureReader {
  public:
-  explicit FeatureReader(const std::string& rspecifier) : sp_(parse_spec(rspecifier)) {
-    f_.open(sp_.path, std::ios::binary);
-    if (!f_) throw std::runtime_error("cannot open " + sp_.path);
-    Next();
-  }
+  explicit FeatureReader(const std::string& rspecifier) : sp_(parse_spec(rspecifier)), in_(sp_.path), f_(in_.get()) { Next(); }
   bool Done() const { return done_; }
   const std::string& Key() const { return key_; }
   Mat& Value() { return val_; }
@@ -165,6 +230,13 @@ class FeatureReader {
         off = std::stoll(loc.substr(c + 1));
         loc = loc.substr(0, c);
       }
+      const size_t rest = line.find(loc);   // a script entry may itself be a command: `key cmd args |`
+      const std::string whole = rest == std::string::npos ? loc : line.substr(rest);
+      if (!whole.empty() && whole.find_last_not_of(" \t") != std::string::npos && whole[whole.find_last_not_of(" \t")] == '|') {
+        InStream a(whole);
+        val_ = read_matrix(a.get());
+        return;
+      }
       std::ifstream a(loc, std::ios::binary);
       if (!a) throw std::runtime_error("cannot open " + loc);
       a.seekg(off);
@@ -175,7 +247,8 @@ class FeatureReader {
   }
  private:
   Spec sp_;
-  std::ifstream f_;
+  InStream in_;
+  std::istream& f_;
   std::string key_;
   Mat val_;
   bool done_ = false;
@@ -184,8 +257,8 @@ class FeatureReader {
 inline std::map<std::string, std::vector<int32_t>> read_targets(const std::string& rspecifier) {
   const Spec sp = parse_spec(rspecifier);
   if (sp.kind != "ark") throw std::runtime_error("labels: only ark: tables are supported");
-  std::ifstream f(sp.path, std::ios::binary);
-  if (!f) throw std::runtime_error("cannot open " + sp.path);
+  InStream in(sp.path);
+  std::istream& f = in.get();
   std::map<std::string, std::vector<int32_t>> t;
   for (;;) {
     const std::string k = read_key(f);
@@ -203,10 +276,10 @@ class MatrixWriter {
     const Spec sp = parse_spec(wspecifier);
     if (sp.kind != "ark") throw std::runtime_error("only ark: output is supported");
     text_ = wspecifier.substr(0, wspecifier.find(':')).find(",t") != std::string::npos;
-    f_.open(sp.path, std::ios::binary);
-    if (!f_) throw std::runtime_error("cannot open " + sp.path + " for writing");
+    out_.reset(new OutStream(sp.path));
   }
   void Write(const std::string& key, const float* data, int rows, int cols, int ld) {
+    std::ostream& f_ = out_->get();
     f_ << key << ' ';
     if (text_) {
       f_ << " [";
@@ -223,10 +296,11 @@ class MatrixWriter {
       for (int i = 0; i < 2; ++i) { f_.write(&four, 1); f_.write(reinterpret_cast<const char*>(&rc[i]), 4); }
       for (int r = 0; r < rows; ++r) f_.write(reinterpret_cast<const char*>(data + (size_t)r * ld), (size_t)cols * 4);
     }
+    f_.flush();   // every utterance leaves at once: downstream tools of a pipe (`... ark:- | latgen-faster ...`) start on it
     if (!f_) throw std::runtime_error("write error");
   }
  private:
-  std::ofstream f_;
+  std::unique_ptr<OutStream> out_;
   bool text_ = false;
 };
 

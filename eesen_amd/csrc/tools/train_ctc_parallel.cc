@@ -1,10 +1,18 @@
 // train_ctc_parallel.cc -- the reference's trainer binary (src/netbin/train-ctc-parallel.cc) over the C-ABI of include/eesen_hip.h.
 //
 // Host C++ only: no HIP headers, no torch, no Python.  Same options, positional arguments, stderr protocol and exit codes
-// as the reference binary; one GPU (multi-GPU is one process per GPU with an all-reduce of eesen_net_grad_buffer(), see
-// eesen_amd/train_ctc_parallel.py for the torch.distributed launcher that does it).  What differs from the reference's
-// loop (:144-215) is only where the work happens: minibatch padding + interleave + upload run on the device feeder's own
-// stream under the previous step (eesen_feeder_*), and Propagate / CTC / Backpropagate are the HIP path.
+// as the reference binary.  What differs from the reference's loop (:144-215) is only where the work happens: minibatch
+// padding + interleave + upload run on the device feeder's own stream under the previous step (eesen_feeder_*), and
+// Propagate / CTC / Backpropagate are the HIP path.
+//
+// Multi-GPU: --num-jobs=N --job-id=J (J = 1..N, as the recipes pass them: train_ctc_parallel_h.sh `JOB=1:$nj`) start one
+// process per GPU.  Instead of the reference's file-based model averaging every --utts-per-avg utterances (:208-235,
+// src/net/communicator.h) the jobs form an RCCL communicator (rank = J-1; job 1 hands out the id over TCP on
+// --comm-addr / --comm-port, default $MASTER_ADDR and $EESEN_COMM_PORT | $MASTER_PORT+17 | 29517) and sum their
+// gradients every minibatch (eesen_net_set_comm: per-layer buckets under the backward pass).  Data: a feature
+// rspecifier containing the literal JOB is each job's own list (JOB -> J, as queue.pl substitutes it); otherwise all
+// jobs read the same list and job J trains minibatches J-1, J-1+N, ... .  Jobs that run out of minibatches keep stepping
+// with a zero gradient until all are done.  Job 1 writes the model and prints the merged TOKEN_ACCURACY.
 //
 // Tables: `ark:file`, `ark,t:file`, `scp:file` for the features (float matrices: binary FM, text, compressed CM / CM2 --
 // src/cpucompute/matrix.cc:968-994, compressed-matrix.cc:437-520) and the labels (int32 vectors, binary or text --
@@ -46,9 +54,10 @@ std::string fmt_g(double v) {  // what operator<< prints for a float/double by d
 struct Options {  // train-ctc-parallel.cc:45-80, NetTrainOptions train-opts.h:29-62
   float learn_rate = 0.008f, momentum = 0.f, adagrad_epsilon = 1e-6f, rms_prop_rho = 0.9f;
   bool binary = true, cross_validate = false;
-  int num_sequence = 5, report_step = 100, num_jobs = 1, job_id = 1, utts_per_avg = 500, verbose = 0, device = 0;
+  int num_sequence = 5, report_step = 100, num_jobs = 1, job_id = 1, utts_per_avg = 500, verbose = 0, device = -1;
+  int comm_port = 0, comm_timeout = 300;
   double frame_limit = 100000;
-  std::string opt_algorithm = "SGD", sequence_out_file;
+  std::string opt_algorithm = "SGD", sequence_out_file, comm_addr;
   std::vector<std::string> args;
 };
 bool parse_bool(const std::string& v) {
@@ -80,6 +89,9 @@ Options parse_options(int argc, char** argv) {
     else if (k == "opt-algorithm") o.opt_algorithm = v;
     else if (k == "verbose") o.verbose = std::stoi(v);
     else if (k == "device") o.device = std::stoi(v);
+    else if (k == "comm-addr") o.comm_addr = v;
+    else if (k == "comm-port") o.comm_port = std::stoi(v);
+    else if (k == "comm-timeout") o.comm_timeout = std::stoi(v);
     else throw std::runtime_error("unknown option --" + k);
   }
   return o;
@@ -101,22 +113,43 @@ int main(int argc, char** argv) {
       std::cerr << "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n";
       return 1;
     }
-    if (o.num_jobs != 1) throw std::runtime_error("--num-jobs > 1: file-based model averaging is replaced by one process per GPU with a gradient all-reduce (python -m torch.distributed.run -m eesen_amd.train_ctc_parallel)");
-    if (!o.sequence_out_file.empty()) throw std::runtime_error("--sequence-out-file is not supported");
-    const std::string feature_rspecifier = o.args[0], targets_rspecifier = o.args[1], model_filename = o.args[2];
+    if (o.num_jobs < 1 || o.job_id < 1 || o.job_id > o.num_jobs) throw std::runtime_error("--job-id must lie in 1..--num-jobs");
+    const int world = o.num_jobs, rank = o.job_id - 1;
+    std::string feature_rspecifier = o.args[0];
+    const std::string targets_rspecifier = o.args[1], model_filename = o.args[2];
     const std::string target_model_filename = o.cross_validate ? "" : o.args[3];
+    bool own_list = false;   // the rspecifier names this job's own shard (JOB substituted, as queue.pl does)
+    for (size_t at; (at = feature_rspecifier.find("JOB")) != std::string::npos; own_list = true)
+      feature_rspecifier.replace(at, 3, std::to_string(o.job_id));
+    const int device = o.device >= 0 ? o.device : (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : (world > 1 ? rank : 0));
 
     eesen_net_t* net = nullptr;
     eesen_ctc_t* ctc = nullptr;
     eesen_feeder_t* feeder = nullptr;
-    ck(eesen_net_create(o.device, nullptr, &net));
+    eesen_comm_t* comm = nullptr;
+    if (world > 1) {
+      const std::string addr = !o.comm_addr.empty() ? o.comm_addr : (getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1");
+      const int port = o.comm_port ? o.comm_port : getenv("EESEN_COMM_PORT") ? atoi(getenv("EESEN_COMM_PORT"))
+                                                 : getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 17 : 29517;
+      ck(eesen_comm_create_tcp(device, addr.c_str(), port, rank, world, o.comm_timeout, &comm));
+      log_line("LOG", "job " + std::to_string(o.job_id) + " of " + std::to_string(world) + " joined the RCCL communicator on GPU " + std::to_string(device));
+    }
+    ck(eesen_net_create(device, nullptr, &net));
     ck(eesen_net_read(net, model_filename.c_str()));                                   // :111
     ck(eesen_net_set_train_options(net, o.learn_rate, o.momentum));                    // :112-113
     ck(eesen_net_set_adaptive_options(net, o.adagrad_epsilon, o.rms_prop_rho));
     ck(eesen_net_set_update_algorithm(net, o.opt_algorithm.c_str()));                  // :114
     ck(eesen_net_set_train_mode(net, o.cross_validate ? 0 : 1));                       // :116-119
-    ck(eesen_ctc_create(o.device, nullptr, &ctc));
-    ck(eesen_feeder_create(o.device, nullptr, 2, &feeder));
+    if (comm) {
+      ck(eesen_net_set_dropout_seed(net, 777ull + (unsigned long long)rank));          // every job its own masks
+      if (!o.cross_validate) ck(eesen_net_set_comm(net, comm));
+    }
+    ck(eesen_ctc_create(device, nullptr, &ctc));
+    ck(eesen_feeder_create(device, nullptr, 2, &feeder));
+    if (!o.sequence_out_file.empty()) {                                                // :134-137
+      log_line("LOG", "Sequences will be written to " + o.sequence_out_file + " in order from feature file");
+      ck(eesen_ctc_set_sequence_out_file(ctc, o.sequence_out_file.c_str()));
+    }
     int feat_dim = 0, K = 0;
     ck(eesen_net_input_dim(net, &feat_dim));
     ck(eesen_net_output_dim(net, &K));
@@ -130,7 +163,8 @@ int main(int argc, char** argv) {
     std::vector<std::string> warnings;
 
     // the while(1) loop of :144-183: greedy groups of up to num_sequence utterances within frame_limit padded frames
-    auto next_batch = [&](Minibatch* mb) -> bool {
+    long batch_index = 0;
+    auto next_group = [&](Minibatch* mb) -> bool {
       mb->mats.clear(); mb->labels.clear(); mb->frames.clear(); mb->T = 0;
       int max_frame_num = 0;
       for (; !feature_reader.Done(); feature_reader.Next()) {
@@ -158,6 +192,14 @@ int main(int argc, char** argv) {
       mb->T = max_frame_num;
       return !mb->mats.empty();
     };
+    auto next_batch = [&](Minibatch* mb) -> bool {  // with a shared list, job J trains groups J-1, J-1+N, ...: neighbours in the
+      for (;;) {                                    // length-sorted list land in the same synchronous step (prep_scps.sh:37-76 deals alike)
+        if (!next_group(mb)) return false;
+        const bool mine = own_list || world == 1 || batch_index % world == rank;
+        ++batch_index;
+        if (mine) return true;
+      }
+    };
     auto stage = [&](const Minibatch& mb) -> int {  // padding + interleave + upload on the feeder's stream (replaces :186-195)
       std::vector<const float*> ptr(mb.mats.size());
       for (size_t s = 0; s < mb.mats.size(); ++s) ptr[s] = mb.mats[s].v.data();
@@ -173,7 +215,18 @@ int main(int argc, char** argv) {
     long diff_cap = 0;
     double obj_prog = 0, err_prog = 0, ref_prog = 0;
     long seq_since_report = 0;
-    while (have) {
+    for (;;) {
+      if (comm) {  // jobs may hold different numbers of minibatches: all keep stepping until every one is out of data
+        double flag = have ? 1.0 : 0.0;
+        ck(eesen_comm_allreduce_host(comm, &flag, 1, 0));
+        if (flag == 0.0) break;
+        if (!have) {
+          if (!o.cross_validate) { ck(eesen_net_backpropagate_zero(net)); ck(eesen_net_update(net)); }
+          continue;
+        }
+      } else if (!have) {
+        break;
+      }
       const int S = (int)cur.mats.size();
       float* feats = nullptr;
       int T = 0, S2 = 0, ld = 0;
@@ -186,14 +239,14 @@ int main(int argc, char** argv) {
       std::vector<int> ids, off(1, 0);
       for (const auto& l : cur.labels) { ids.insert(ids.end(), l.begin(), l.end()); off.push_back((int)ids.size()); }
       if ((long)T * S * out_ld > diff_cap) {
-        if (diff) ck(eesen_dev_free(o.device, diff));
+        if (diff) { ck(eesen_net_synchronize(net)); ck(eesen_dev_free(device, diff)); }
         diff_cap = (long)T * S * out_ld;
-        ck(eesen_dev_alloc(o.device, diff_cap * 4, reinterpret_cast<void**>(&diff)));
+        ck(eesen_dev_alloc(device, diff_cap * 4, reinterpret_cast<void**>(&diff)));
       }
-      std::vector<float> pzx(S);
-      ck(eesen_ctc_eval_parallel(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), diff, out_ld, pzx.data()));  // :199
-      int ne = 0, nr = 0;
-      ck(eesen_ctc_error_rate_mseq(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), &ne, &nr));             // :202
+      // Neither call waits for the device: ln p and the decoded ids come back through pinned slots and join the statistics when
+      // they are read (the reference's calls return nothing either and only accumulate, ctc-loss.cc:171-192,235-298)
+      ck(eesen_ctc_eval_parallel(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), diff, out_ld, nullptr));  // :199
+      ck(eesen_ctc_error_rate_mseq(ctc, cur.frames.data(), S, net_out, T * S, out_cols, out_ld, ids.data(), off.data(), nullptr, nullptr));     // :202
       if (!o.cross_validate) {                                                          // :206-208
         ck(eesen_net_backpropagate(net, diff, out_ld, nullptr, 0));
         ck(eesen_net_update(net));
@@ -202,31 +255,42 @@ int main(int argc, char** argv) {
       slot = have ? stage(nxt) : -1;
       num_done += S;
       total_frames += (double)T * S;                                                    // padded frames, as the reference counts them (:215)
-      for (float p : pzx) obj_prog += p;
-      err_prog += ne; ref_prog += nr; seq_since_report += S;
-      if (o.verbose >= 1 && seq_since_report >= o.report_step) {                        // ctc-loss.cc:180-192
+      seq_since_report += S;
+      if (o.verbose >= 1 && seq_since_report >= o.report_step) {                        // ctc-loss.cc:180-192: progress since the last report
         double obj; long seqs, frames, e, r;
         ck(eesen_ctc_stats(ctc, &obj, &seqs, &frames, &e, &r));
         log_line("VLOG[1]", "After " + std::to_string(seqs) + " sequences (" + fmt_g(frames / (100.0 * 3600)) + "Hr): Obj(log[Pzx]) = " +
-                                fmt_g(obj_prog / seq_since_report) + "   TokenAcc = " + fmt_g(100.0 * (1.0 - err_prog / std::max(ref_prog, 1.0))) + "%");
-        obj_prog = err_prog = ref_prog = 0; seq_since_report = 0;
+                                fmt_g((obj - obj_prog) / seq_since_report) + "   TokenAcc = " +
+                                fmt_g(100.0 * (1.0 - (e - err_prog) / std::max((double)r - ref_prog, 1.0))) + "%");
+        obj_prog = obj; err_prog = (double)e; ref_prog = (double)r; seq_since_report = 0;
       }
       std::swap(cur, nxt);
     }
     for (const auto& w : warnings) log_line("WARNING", w);
     ck(eesen_net_synchronize(net));
-    if (!o.cross_validate) ck(eesen_net_write(net, target_model_filename.c_str(), o.binary ? 1 : 0));   // :244-246
+    if (!o.cross_validate && rank == 0) ck(eesen_net_write(net, target_model_filename.c_str(), o.binary ? 1 : 0));   // :244-246 (all ranks hold the same model)
     const double el = std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     log_line("LOG", "Done " + std::to_string(num_done) + " files, " + std::to_string(num_no_tgt_mat) + " with no targets, " +
                         std::to_string(num_other_error) + " with other errors. [" + (o.cross_validate ? "CROSS-VALIDATION" : "TRAINING") + ", " +
                         fmt_g(el / 60) + " min, fps" + fmt_g(total_frames / el) + "]");              // :247-252
     double obj; long seqs, frames, e, r;
     ck(eesen_ctc_stats(ctc, &obj, &seqs, &frames, &e, &r));
-    log_line("LOG", "\nTOKEN_ACCURACY >> " + fmt_g(100.0 * (1.0 - (double)e / (double)r)) + "% <<");     // ctc-loss.cc:300-304
-    if (diff) eesen_dev_free(o.device, diff);
+    if (comm) {  // comm_touch_done (communicator.h:121-170): job 1 merges the jobs' Errors / Refs and reports the total
+      double tot[2] = {(double)e, (double)r};
+      ck(eesen_comm_allreduce_host(comm, tot, 2, 0));
+      if (rank == 0) {
+        log_line("LOG", "\nTOTAL TOKEN_ACCURACY >> " + fmt_g(100.0 * (1.0 - tot[0] / tot[1])) + "% <<");
+        log_line("LOG", "\nTOKEN_ACCURACY >> " + fmt_g(100.0 * (1.0 - tot[0] / tot[1])) + "% <<");       // the line the recipes grep, once per run
+      }
+    } else {
+      log_line("LOG", "\nTOKEN_ACCURACY >> " + fmt_g(100.0 * (1.0 - (double)e / (double)r)) + "% <<");     // ctc-loss.cc:300-304
+    }
+    if (diff) eesen_dev_free(device, diff);
     eesen_feeder_destroy(feeder);
     eesen_ctc_destroy(ctc);
+    if (comm) eesen_net_set_comm(net, nullptr);
     eesen_net_destroy(net);
+    if (comm) eesen_comm_destroy(comm);
     return 0;
   } catch (const std::exception& e) {  // :260-263
     std::cerr << e.what() << std::endl;

@@ -12,13 +12,16 @@ Host-side data loading for the CLI mirror (eesen_amd/train_ctc_parallel.py); for
     (one byte per element, per-column 16-bit percentile header) or `CM2 ` (uint16 per element) + GlobalHeader without its
     format field {float min_value, float range, int32 rows, int32 cols}; decoded here with the reference's own fp32/fp64
     expression order (`Uint16ToFloat` :244-250, `CharToFloat` :363-373) -- bit-exact against its CopyToMat (tests).
-Supported specifiers: `ark:path`, `ark,t:path`, `scp:path`, and `ark:-` for stdin.  Pipes and double-precision matrices
-are outside the hot path and raise.
+Supported specifiers: `ark:path`, `ark,t:path`, `scp:path`, and the "extended filenames" of src/util/kaldi-io.cc the recipes
+use: `-` (stdin for readers, stdout for writers), `cmd |` (read the command's output: steps/train_ctc_parallel.sh:95-115
+always passes `ark,s,cs:apply-cmvn ... |` and `ark:gunzip -c labels.tr.gz|`) and `| cmd` (write into the command).
+Double-precision matrices are outside the hot path and raise.
 """
 from __future__ import annotations
 
 import io
 import struct
+import subprocess
 import sys
 from typing import BinaryIO, Dict, Iterator, List, Tuple
 
@@ -37,8 +40,6 @@ def _parse_specifier(spec: str) -> Tuple[str, str, bool]:
     kind = opts[0]
     if kind not in ("ark", "scp"):
         raise KaldiIOError(f"unsupported table kind in '{spec}'")
-    if path.endswith("|") or path.startswith("|"):
-        raise KaldiIOError("pipes in table specifiers are not supported by this reader")
     return kind, path, "t" in opts[1:]
 
 
@@ -152,8 +153,73 @@ def _read_int_vector(f: BinaryIO) -> np.ndarray:
     return np.array(line.split(), dtype=np.int32)
 
 
-def _open(path: str) -> BinaryIO:
-    return sys.stdin.buffer if path == "-" else open(path, "rb")
+class _PipeIn:
+    """`cmd |`: the command's stdout as a binary stream; a non-zero exit status is an error at close, as in the reference
+    (src/util/kaldi-io.cc PipeInputImpl::Close)."""
+
+    def __init__(self, cmd: str):
+        self.cmd = cmd
+        self.p = subprocess.Popen(cmd, shell=True, stdout=subprocess.PIPE)
+        self.f = self.p.stdout
+
+    def __enter__(self):
+        return self.f
+
+    def __exit__(self, *exc):
+        self.f.close()
+        rc = self.p.wait()
+        if rc != 0 and exc[0] is None:
+            raise KaldiIOError(f"command '{self.cmd}' exited with status {rc}")
+        return False
+
+
+class _Keep:
+    """stdin / stdout as a context manager that does not close them."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __enter__(self):
+        return self.f
+
+    def __exit__(self, *exc):
+        self.f.flush() if self.f.writable() else None
+        return False
+
+
+def _open(path: str):
+    path = path.strip()
+    if path == "-":
+        return _Keep(sys.stdin.buffer)
+    if path.endswith("|"):
+        return _PipeIn(path[:-1])
+    return open(path, "rb")
+
+
+class _PipeOut:
+    def __init__(self, cmd: str):
+        self.cmd = cmd
+        self.p = subprocess.Popen(cmd, shell=True, stdin=subprocess.PIPE)
+        self.f = self.p.stdin
+
+    def __enter__(self):
+        return self.f
+
+    def __exit__(self, *exc):
+        self.f.close()
+        rc = self.p.wait()
+        if rc != 0 and exc[0] is None:
+            raise KaldiIOError(f"command '{self.cmd}' exited with status {rc}")
+        return False
+
+
+def _open_out(path: str):
+    path = path.strip()
+    if path == "-":
+        return _Keep(sys.stdout.buffer)
+    if path.startswith("|"):
+        return _PipeOut(path[1:])
+    return open(path, "wb")
 
 
 def _iter_table(spec: str, read_obj) -> Iterator[Tuple[str, np.ndarray]]:
@@ -172,6 +238,10 @@ def _iter_table(spec: str, read_obj) -> Iterator[Tuple[str, np.ndarray]]:
                 if not line:
                     continue
                 key, loc = line.split(None, 1)
+                if loc.rstrip().endswith("|"):      # a script entry may itself be a command
+                    with _open(loc) as f:
+                        yield key, read_obj(f)
+                    continue
                 off = 0
                 if ":" in loc and loc.rsplit(":", 1)[1].isdigit():
                     loc, o = loc.rsplit(":", 1)
@@ -193,29 +263,32 @@ def read_vec_int_table(spec: str) -> Dict[str, np.ndarray]:
 
 # ---------------------------------------------------------------------------------------------- writers
 def write_mat_ark(path: str, items, text: bool = False, scp_path: str = None):
-    """BaseFloatMatrixWriter to `ark:path` (optionally also an scp with byte offsets, like ark,scp:)."""
+    """BaseFloatMatrixWriter to `ark:path` (optionally also an scp with byte offsets, like ark,scp:).  `path` may be `-`
+    (stdout) or `| cmd`; `items` may be a generator: every entry is written (and flushed) as it is produced, so a
+    downstream tool of a pipe starts on the first utterance."""
     scp = open(scp_path, "w") if scp_path else None
-    with open(path, "wb") as f:
+    with _open_out(path) as f:
+        pos = 0
         for key, m in items:
             m = np.ascontiguousarray(m, np.float32)
             f.write(key.encode() + b" ")
+            pos += len(key.encode()) + 1
             if scp:
-                scp.write(f"{key} {path}:{f.tell()}\n")
+                scp.write(f"{key} {path}:{pos}\n")
             if text:
-                f.write(b" [")
-                for r in m:
-                    f.write(b"\n  " + " ".join(repr(float(np.float32(v))) for v in r).encode() + b" ")
-                f.write(b"]\n")
+                body = b" [" + b"".join(b"\n  " + " ".join(repr(float(np.float32(v))) for v in r).encode() + b" " for r in m) + b"]\n"
             else:
-                f.write(b"\x00BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]))
-                f.write(m.tobytes())
+                body = b"\x00BFM " + b"\x04" + struct.pack("<i", m.shape[0]) + b"\x04" + struct.pack("<i", m.shape[1]) + m.tobytes()
+            f.write(body)
+            pos += len(body)
+            f.flush()
     if scp:
         scp.close()
 
 
 def write_vec_int_ark(path: str, items, text: bool = False):
     """Int32VectorWriter to `ark:path` / `ark,t:path`."""
-    with open(path, "wb") as f:
+    with _open_out(path) as f:
         for key, v in items:
             v = np.ascontiguousarray(v, np.int32)
             f.write(key.encode() + b" ")

@@ -72,10 +72,12 @@ def main(argv=None) -> int:
             raise kaldi_io.KaldiIOError(f"Dimensionality mismatch, class_frame_counts {log_pri.size} class_output_llk {K}")
         t0 = time.time()
         num_done = tot_t = 0
-        results = []
 
         def flush(group):
+            """Propagates one group and returns its (key, matrix) results: the writer streams them out as they are produced
+            (the decoding scripts pipe this tool: `net-output-extract ... ark:- | latgen-faster ...`, decode_ctc_lat.sh:100)."""
             nonlocal num_done, tot_t
+            results = []
             feats, lens, T = interleave([m for _, m in group], net.InputDim())
             net.SetSeqLengths(lens)
             out = net.Propagate(feats)
@@ -86,15 +88,19 @@ def main(argv=None) -> int:
             for s, (key, m) in enumerate(group):
                 results.append((key, np.ascontiguousarray(host[: m.shape[0], s, :])))
                 num_done += 1; tot_t += m.shape[0]
+            return results
 
-        group, max_len = [], 0
-        for key, mat in kaldi_io.read_mat_table(feature_rspecifier):
-            if group and (len(group) == o.num_sequence or max(max_len, mat.shape[0]) * (len(group) + 1) > o.frame_limit):
-                flush(group); group, max_len = [], 0
-            group.append((key, mat)); max_len = max(max_len, mat.shape[0])
-        if group:
-            flush(group)
-        kaldi_io.write_mat_ark(out_path, results, text=text)
+        def produce():
+            group, max_len = [], 0
+            for key, mat in kaldi_io.read_mat_table(feature_rspecifier):
+                if group and (len(group) == o.num_sequence or max(max_len, mat.shape[0]) * (len(group) + 1) > o.frame_limit):
+                    yield from flush(group)
+                    group, max_len = [], 0
+                group.append((key, mat)); max_len = max(max_len, mat.shape[0])
+            if group:
+                yield from flush(group)
+
+        kaldi_io.write_mat_ark(out_path, produce(), text=text)
         el = max(time.time() - t0, 1e-9)
         print(f"LOG (net-output-extract:main()) Done {num_done} files in {el / 60:g}min, (fps {tot_t / el:g})", file=sys.stderr)
         return 0 if num_done else 255

@@ -7,9 +7,14 @@ e.g.:  python -m eesen_amd.train_ctc_parallel --learn-rate=4e-5 --momentum=0.9 -
 
 Same options, same <Nnet> model files, same stderr contract (`TOKEN_ACCURACY >> x% <<`, grepped by
 asr_egs/wsj/steps/train_ctc_parallel.sh:146,158), exit code 0 / 255 (the reference returns -1, :259-263).
-Multi-GPU: instead of --num-jobs/--job-id file averaging (src/net/communicator.h), launch one process per GPU with
-torch.distributed.run; every rank reads ITS OWN feature list (as the reference's per-job scp shards) and the fresh
-gradients are all-reduced over RCCL every minibatch (eesen_amd/parallel.py).
+Multi-GPU: one process per GPU -- either `--num-jobs=N --job-id=J` (J = 1..N, as the recipes pass them,
+train_ctc_parallel_h.sh) or a launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run).  Instead of
+the reference's file-based model averaging every --utts-per-avg utterances (src/net/communicator.h) the ranks form an
+RCCL communicator inside libeesen_hip.so (no torch in the process) and sum their FRESH gradients every minibatch, one
+bucket per layer under the backward pass.  Data: a feature rspecifier containing the literal JOB is each rank's own
+list (JOB -> rank + 1, as queue.pl substitutes it); otherwise all ranks read the same list and rank r trains
+minibatches r, r + N, ... (eesen_amd.parallel.shard_minibatches).  Ranks that run out of minibatches keep stepping with
+a zero gradient until every rank is done.  Rank 0 writes the model and prints the merged TOKEN_ACCURACY.
 """
 from __future__ import annotations
 
@@ -77,7 +82,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--utts-per-avg", type=int, default=500)
     ap.add_argument("--opt-algorithm", default="SGD", help="Optimization algorithm (SGD|Adagrad|RMSProp)")
     ap.add_argument("--verbose", type=int, default=0)
-    ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK, else job-id - 1, else 0)")
+    ap.add_argument("--comm-addr", default="", help="rendezvous address of job 1 (default $MASTER_ADDR or 127.0.0.1)")
+    ap.add_argument("--comm-port", type=int, default=0, help="rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)")
+    ap.add_argument("--comm-timeout", type=int, default=300)
     ap.add_argument("args", nargs="*")
     return ap
 
@@ -96,21 +104,22 @@ def main(argv=None) -> int:
         from eesen_amd.api import Net, Ctc, CuMatrix, EesenError, Feeder
         from eesen_amd.batching import assemble, AssemblyStats
 
-        world = int(os.environ.get("WORLD_SIZE", "1"))
-        rank = int(os.environ.get("RANK", "0"))
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        if o.num_jobs != 1 and world == 1:
-            raise EesenError(-1, "--num-jobs > 1: file-based model averaging is replaced by the RCCL gradient all-reduce; "
-                                 "launch one process per GPU with `python -m torch.distributed.run --nproc-per-node N`")
-        if o.sequence_out_file:
-            raise EesenError(-1, "--sequence-out-file is not supported")
-        dist = None
+        from eesen_amd.api import Comm
+        from eesen_amd.parallel import shard_minibatches, job_rspecifier
+
+        if o.num_jobs > 1:                      # the reference's own way to say "I am job J of N"
+            world, rank = o.num_jobs, o.job_id - 1
+            if not 0 <= rank < world:
+                raise EesenError(-1, "--job-id must lie in 1..--num-jobs")
+        else:
+            world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank if world > 1 else 0)))
+        dev = o.device if o.device is not None else local
+        comm = None
         if world > 1:
-            import torch
-            import torch.distributed as dist
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dev = o.device if o.device is not None else (local if world > 1 else 0)
+            port = o.comm_port or int(os.environ.get("EESEN_COMM_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29500")) + 17
+            comm = Comm(dev, rank, world, o.comm_addr or os.environ.get("MASTER_ADDR", "127.0.0.1"), port, o.comm_timeout)
+            log(f"job {rank + 1} of {world} joined the RCCL communicator on GPU {dev}")
 
         net = Net(dev).Read(model_filename)
         net.SetTrainOptions(o.learn_rate, o.momentum)
@@ -119,23 +128,28 @@ def main(argv=None) -> int:
             net.SetTestMode()
         else:
             net.SetTrainMode()
-            if dist is not None:      # every rank its own masks
-                net.SetDropoutSeed(777 + rank)
-        if dist is not None and not o.cross_validate:
-            from eesen_amd.parallel import GradAllReducer
-            net.grad_hook = GradAllReducer(net)
+            if comm is not None:
+                net.SetDropoutSeed(777 + rank)     # every rank its own masks
+                net.SetComm(comm)                  # per-layer gradient buckets, summed under the backward pass
         ctc = Ctc(dev)
+        if o.sequence_out_file:                                                       # :134-137
+            log(f"Sequences will be written to {o.sequence_out_file} in order from feature file")
+            ctc.SetSequenceOutFile(o.sequence_out_file)
         feat_dim = net.InputDim()
         targets = kaldi_io.read_vec_int_table(targets_rspecifier)
         stats = AssemblyStats()
         log(("CROSS-VALIDATION" if o.cross_validate else "TRAINING") + " STARTED")
         t0 = time.time()
         num_done, total_frames, seq_since_report = 0, 0, 0
-        obj_prog = err_prog = ref_prog = 0.0
+        last = dict(obj_sum=0.0, err_tokens=0, ref_tokens=0)
         # the reader thread parses the archives; padding + interleave + H2D of batch n+1 run on the device feeder's own
         # stream while batch n trains (the reference pads on the host and copies synchronously, train-ctc-parallel.cc:186-198)
-        batches = _prefetch(assemble(kaldi_io.read_mat_table(feature_rspecifier), targets, o.num_sequence, o.frame_limit, feat_dim, stats,
-                                     interleaved=False))
+        own_list = "JOB" in feature_rspecifier
+        groups = assemble(kaldi_io.read_mat_table(job_rspecifier(feature_rspecifier, rank)), targets, o.num_sequence, o.frame_limit,
+                          feat_dim, stats, interleaved=False)
+        if world > 1 and not own_list:
+            groups = shard_minibatches(groups, rank, world)
+        batches = _prefetch(groups)
         feeder = Feeder(dev, slots=2)
 
         def stage():
@@ -146,41 +160,37 @@ def main(argv=None) -> int:
         staged = stage()
         while True:
             mb, slot = staged
-            if dist is not None:     # ranks may hold different numbers of minibatches: keep stepping until all are done
-                import torch
-                flag = torch.tensor([1.0 if mb is not None else 0.0], device=f"cuda:{local}")
-                dist.all_reduce(flag)
-                if flag.item() == 0:
+            if comm is not None:     # ranks may hold different numbers of minibatches: keep stepping until all are done
+                if comm.allreduce([1.0 if mb is not None else 0.0])[0] == 0:
                     break
+                if mb is None:       # out of data while others are not: zero gradient through the same collectives
+                    if not o.cross_validate:
+                        net.BackpropagateZero()
+                        net.Update()
+                    continue
             elif mb is None:
                 break
-            if mb is not None:
-                net.SetSeqLengths(mb.lens)
-                net_out = net.Propagate(feeder.acquire(slot))
-                feeder.release(slot)
-                if diff is None or diff.rows != net_out.rows:
-                    diff = CuMatrix(net_out.rows, net_out.cols, dev, zero=False)
-                ctc.EvalParallel(mb.lens, net_out, mb.labels, diff)
-                ne, nr = ctc.ErrorRateMSeq(mb.lens, net_out, mb.labels)
-                if not o.cross_validate:
-                    net.Backpropagate(diff)
-                staged = stage()                     # next batch: staged while the GPU runs this one's backward pass
-                num_done += mb.S
-                total_frames += mb.T * mb.S          # padded frames, as the reference counts them (:215)
-                obj_prog += float(ctc.pzx.sum()); err_prog += ne; ref_prog += nr; seq_since_report += mb.S
-                if o.verbose >= 1 and seq_since_report >= o.report_step:     # ctc-loss.cc:180-192
-                    st = ctc.stats()
-                    log(f"After {st['sequences']} sequences ({st['frames'] / (100.0 * 3600):g}Hr): Obj(log[Pzx]) = {obj_prog / seq_since_report:g}"
-                        f"   TokenAcc = {100.0 * (1.0 - err_prog / max(ref_prog, 1)):g}%", "VLOG[1]")
-                    obj_prog = err_prog = ref_prog = 0.0; seq_since_report = 0
-            elif not o.cross_validate:
-                # this rank is out of data but others are not: contribute a zero gradient to the collective
-                import torch
-                from eesen_amd.parallel import grad_tensor
-                grad_tensor(net).zero_()
-                net.grad_hook(net)
-                net.Update()
-                staged = stage()
+            net.SetSeqLengths(mb.lens)
+            net_out = net.Propagate(feeder.acquire(slot))
+            feeder.release(slot)
+            if diff is None or diff.rows != net_out.rows:
+                net.Synchronize()                # the old matrix may still be read by queued kernels
+                diff = CuMatrix(net_out.rows, net_out.cols, dev, zero=False)
+            # neither call waits for the device (the reference's calls return nothing and only accumulate, ctc-loss.cc:171-192)
+            ctc.EvalParallel(mb.lens, net_out, mb.labels, diff, want_pzx=False)
+            ctc.ErrorRateMSeq(mb.lens, net_out, mb.labels, deferred=True)
+            if not o.cross_validate:
+                net.Backpropagate(diff)
+            staged = stage()                     # next batch: staged while the GPU runs this one's backward pass
+            num_done += mb.S
+            total_frames += mb.T * mb.S          # padded frames, as the reference counts them (:215)
+            seq_since_report += mb.S
+            if o.verbose >= 1 and seq_since_report >= o.report_step:     # ctc-loss.cc:180-192: progress since the last report
+                st = ctc.stats()
+                log(f"After {st['sequences']} sequences ({st['frames'] / (100.0 * 3600):g}Hr): "
+                    f"Obj(log[Pzx]) = {(st['obj_sum'] - last['obj_sum']) / seq_since_report:g}"
+                    f"   TokenAcc = {100.0 * (1.0 - (st['err_tokens'] - last['err_tokens']) / max(st['ref_tokens'] - last['ref_tokens'], 1)):g}%", "VLOG[1]")
+                last = st; seq_since_report = 0
         for w in stats.warnings:
             log(w, "WARNING")
         net.Synchronize()
@@ -189,14 +199,15 @@ def main(argv=None) -> int:
         el = max(time.time() - t0, 1e-9)
         log(f"Done {num_done} files, {stats.num_no_tgt_mat} with no targets, 0 with other errors. "
             f"[{'CROSS-VALIDATION' if o.cross_validate else 'TRAINING'}, {el / 60:g} min, fps{total_frames / el:g}]")
-        if dist is not None:
-            from eesen_amd.parallel import allreduce_stats
+        if comm is not None:     # comm_touch_done (communicator.h:121-170): job 1 merges the jobs' Errors / Refs; ONE accuracy line per run
             st = ctc.stats()
-            tot = allreduce_stats([st["err_tokens"], st["ref_tokens"]], device=f"cuda:{local}")
+            tot = comm.allreduce([st["err_tokens"], st["ref_tokens"]])
             if rank == 0:
                 log(f"\nTOTAL TOKEN_ACCURACY >> {100.0 * (1.0 - tot[0] / max(tot[1], 1)):g}% <<")
-            dist.destroy_process_group()
-        log(ctc.Report())
+                log(f"\nTOKEN_ACCURACY >> {100.0 * (1.0 - tot[0] / max(tot[1], 1)):g}% <<")
+            net.SetComm(None)
+        else:
+            log(ctc.Report())
         return 0
     except Exception as e:      # train-ctc-parallel.cc:260-263
         print(str(e), file=sys.stderr)

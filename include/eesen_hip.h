@@ -46,6 +46,16 @@ const char* eesen_version(void);
  * visible HIP devices (0 is not an error here; creating a handle then fails loudly). */
 int eesen_device_count(int* count);
 
+/* Arithmetic of the dense contractions outside the time recurrence (what the reference sends to cublasSgemm through
+ * CuMatrixBase::AddMatMat, src/gpucompute/cuda-matrix.cc:604-639), process-wide:
+ *   0  f32-input MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit a k-ordered fp32 fmaf chain, at the f32 vector rate;
+ *   1  3-way bf16 split: every fp32 operand is EXACTLY hi + mid + lo (three bf16), six of the nine cross products run on
+ *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; error <= 2^-23 |a*b| per product, i.e. fp32-GEMM class, at 2.67x the
+ *      f32 matrix rate (gfx950 runs f32 MFMA at 1/16 of the bf16 rate and has no TF32 form);
+ *  -1  follow the environment (EESEN_GEMM_MODE=f32|split), the initial state. */
+int eesen_set_gemm_mode(int mode);
+int eesen_get_gemm_mode(int* mode);
+
 /* ---- Net: construction, model I/O ------------------------------------------------------------ */
 /* New empty net on `device`.  `stream` is a hipStream_t to enqueue on (e.g. the caller framework's
  * current stream) or NULL for the device's default stream.  A Net and the Ctc it feeds must share a
@@ -192,6 +202,11 @@ int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, c
 int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
                               int rows, int K, int ld, const int* label_ids, const int* label_off,
                               int* num_err, int* num_ref);
+/* --sequence-out-file of the trainer (src/netbin/train-ctc-parallel.cc:53-54,134-137; written by Ctc::ErrorRateMSeq,
+ * ctc-loss.cc:247-250,282-291): every later eesen_ctc_error_rate_mseq appends one line per utterance,
+ * `utt | <label> <frame> <probability> | ...` for the greedy-decoded sequence.  The file is removed first, as the
+ * reference's trainer does; NULL or "" switches the output off. */
+int eesen_ctc_set_sequence_out_file(eesen_ctc_t* ctc, const char* path);
 /* Running totals: Ctc::NumErrorTokens/NumRefTokens (ctc-loss.h:58-59) and the sums behind
  * Ctc::Report (ctc-loss.cc:300-308): obj = sum of ln p, sequences, frames. */
 int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* frames, long* err_tokens,

@@ -1,0 +1,96 @@
+"""-m gpu: the two arithmetic modes of the dense GEMM (include/eesen_hip.h `eesen_set_gemm_mode`) against an fp64 product.
+
+Mode 0 (f32-input MFMA) is an exact fp32 fmaf chain.  Mode 1 splits every fp32 operand into three bf16 terms and runs
+six bf16 MFMA products with fp32 accumulation; its error bound is 2^-23 |a*b| per product, the class of ONE fp32 rounding.
+The test measures both against fp64, normalised by sum_k |a||b| (the quantity round-off scales with), over every operand
+layout, ragged shapes, split-K shapes and the bias / alpha / beta epilogue, and requires the split mode to be as accurate
+as the fp32 chain."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [(1, 1, 256, 256, 64), (1, 1, 1000, 2048, 1024), (1, 0, 700, 300, 4096), (0, 0, 2048, 512, 32000), (0, 0, 184, 40, 8000),
+          (0, 1, 257, 130, 50), (1, 1, 33, 46, 1024), (1, 0, 640, 1024, 46), (0, 0, 128, 128, 17), (1, 1, 129, 127, 19)]
+
+
+def _run(gpu, mode, a_kc, b_kc, A, B, C0, bias, alpha, beta):
+    from eesen_amd.api import CuMatrix
+    assert gpu.eesen_set_gemm_mode(mode) == 0
+    M, K = A.shape; N = B.shape[1]
+    dA = CuMatrix.from_numpy(A if a_kc else np.ascontiguousarray(A.T))
+    dB = CuMatrix.from_numpy(np.ascontiguousarray(B.T) if b_kc else B)
+    dC = CuMatrix.from_numpy(C0)
+    db = CuMatrix.from_numpy(bias[None, :])
+    rc = gpu.eesen_op_gemm(0, None, a_kc, b_kc, M, N, K, alpha, C.c_void_p(dA.ptr), dA.stride, C.c_void_p(dB.ptr), dB.stride,
+                           beta, C.c_void_p(dC.ptr), dC.stride, C.c_void_p(db.ptr))
+    assert rc == 0, gpu.eesen_last_error()
+    return dC.numpy()
+
+
+@pytest.fixture(scope="module")
+def report():
+    rows = []
+    yield rows.append
+    try:
+        out = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
+        os.makedirs(out, exist_ok=True)
+        json.dump(rows, open(os.path.join(out, "gemm_accuracy.json"), "w"), indent=1)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("a_kc,b_kc,M,N,K", SHAPES)
+def test_split_mode_is_as_accurate_as_the_fp32_chain(gpu, report, a_kc, b_kc, M, N, K):
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    # wide dynamic range on purpose: magnitudes over ~6 decades, so that the low-order split terms matter
+    A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-7, 7, (M, K)))).astype(np.float32)
+    B = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-7, 7, (K, N)))).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    alpha, beta = 0.75, 0.5
+    try:
+        got = {m: _run(gpu, m, a_kc, b_kc, A, B, C0, bias, alpha, beta) for m in (0, 1)}
+    finally:
+        gpu.eesen_set_gemm_mode(-1)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    want = alpha * (A64 @ B64) + beta * C0 + bias[None, :]
+    scale = alpha * (np.abs(A64) @ np.abs(B64)) + np.abs(beta * C0) + np.abs(bias)[None, :]
+    err = {m: float(np.max(np.abs(got[m] - want) / scale)) for m in (0, 1)}
+    report(dict(a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, err_f32_mfma=err[0], err_bf16_split=err[1]))
+    assert err[0] < 4e-6                      # fp32 chain vs fp64, normalised by sum |a||b|: round-off class (grows slowly with K)
+    assert err[1] < max(1.5 * err[0], 2.4e-7), f"split {err[1]:.3g} vs fp32 chain {err[0]:.3g}"
+
+
+def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
+    """One full step (small_bi) with every GEMM in split mode against the oracle, at the 1e-4 bar of the fp32 path, and the
+    distance between the two modes' gradients."""
+    from eesen_amd import synth
+    from eesen_amd.api import Net, Ctc
+    from oracle import net as onet
+    from tests.util import rel_err
+    cfg = synth.config("cfg2"); cfg.update(T=40, S=16, layers=2)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(1.0, 0.0)
+    o = onet.train_step(ora, batch, "f32")
+    grads = {}
+    try:
+        for mode in (0, 1):
+            gpu.eesen_set_gemm_mode(mode)
+            net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            net.BackpropagateNoUpdate(diff)
+            grads[mode] = net.GetGrads()
+            assert rel_err(ctc.pzx, o["pzx"]) < 1e-4 and rel_err(diff.numpy(), o["diff"]) < 1e-4
+            assert rel_err(grads[mode], ora.fresh_grads_flat()) < 1e-4
+    finally:
+        gpu.eesen_set_gemm_mode(-1)
+    assert rel_err(grads[1], grads[0]) < 2e-5
