@@ -17,6 +17,7 @@
 //   * split-K (deterministic two-pass: partial slabs + reduce kernel) for the weight-gradient shapes
 //     whose M x N tile count cannot fill 256 CUs (e.g. 2048 x 512 with K = T*S = 32000).
 #include <cstring>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -317,6 +318,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
 // LDS: per operand and stage 3 planes (hi, mid, lo) x 2 k-halves x 128 rows x 8 bf16 (16 B): lane l of an MFMA reads row
 // l & 31, k-half l >> 5 with ONE conflict-free ds_read_b128 (consecutive rows are consecutive 16-byte slots); the k-halves
 // are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
+#ifndef EESEN_SPLIT_PF2
+#define EESEN_SPLIT_PF2 1   // measured (profiles/r02_gemm_variants.md): 171 -> 178 TF, with three workgroups per CU 189 TF
+#endif
+#ifndef EESEN_SPLIT_VPM
+#define EESEN_SPLIT_VPM 6
+#endif
+#ifndef EESEN_SPLIT_MINW
+#define EESEN_SPLIT_MINW 3
+#endif
 constexpr int SP_HS = 128 * 16 + 64;        // bytes per k-half (128 rows x 16 B, + 16 banks)
 constexpr int SP_PS = 2 * SP_HS;            // bytes per plane
 constexpr int SP_OP = 3 * SP_PS;            // bytes per operand per stage
@@ -388,6 +398,50 @@ __device__ __forceinline__ void split_store(unsigned char* base, int tid, const 
   }
 }
 
+// The same split in three stages per (row, k-quad) unit, so that the k loop can place each stage in the shadow of MFMAs
+// (see gemm_split_body): A: guard, hi plane, first residual; B: mid plane, second residual; C: lo plane + the three LDS writes.
+struct SplitUnit {
+  float r[4];
+  unsigned ph[2], pm[2];
+};
+// "these values exist HERE": pure arithmetic has no place of its own in the instruction stream -- the compiler emits it next
+// to its first use, i.e. behind the MFMAs it is meant to hide under.  An empty volatile asm that takes the values as
+// read-write operands is a use at this point, and it keeps its place among the scheduling fences.
+#define EESEN_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+template <bool KC, bool GUARD>
+__device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int i, int tid, int R, int r0, int k0, int kend) {
+  float x[4] = {v.x, v.y, v.z, v.w};
+  if (GUARD) {
+    int row, q;
+    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
+    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+    const bool ok = r0 + row < R;
+    const int k = k0 + q * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
+  }
+  u.ph[0] = pack_hi16(x[0], x[1]);
+  u.ph[1] = pack_hi16(x[2], x[3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u.r[j] = x[j] - trunc_bf16(x[j]);   // exact
+}
+__device__ __forceinline__ void split_stage_b(SplitUnit& u) {
+  u.pm[0] = pack_hi16(u.r[0], u.r[1]);
+  u.pm[1] = pack_hi16(u.r[2], u.r[3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u.r[j] = u.r[j] - trunc_bf16(u.r[j]);   // exact; the lo plane takes its top 16 bits
+}
+template <bool KC>
+__device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char* base, int i, int tid) {
+  int row, q;
+  if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
+  else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+  unsigned char* dst = base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8;
+  *reinterpret_cast<uint2*>(dst) = make_uint2(u.ph[0], u.ph[1]);
+  *reinterpret_cast<uint2*>(dst + SP_PS) = make_uint2(u.pm[0], u.pm[1]);
+  *reinterpret_cast<uint2*>(dst + 2 * SP_PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
+}
+
 template <bool A_KC, bool B_KC, bool GUARD, bool GATED>
 __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   // stage s: A planes at s * 2 * SP_OP, B planes at s * 2 * SP_OP + SP_OP (indexed as an array, so the accesses stay ds_* ones)
@@ -409,24 +463,22 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], rb[2];
   const int nk = (kend - kbeg + SBK - 1) / SBK;
-  if (nk > 0) {
-    split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg, kend, tid, ra);
-    split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
-    split_store<A_KC, GUARD>(&lds[0], tid, ra, p.M, m0, kbeg, kend);
-    split_store<B_KC, GUARD>(&lds[SP_OP], tid, rb, p.N, n0, kbeg, kend);
-  }
-  __syncthreads();
-
   const int lr = lane & 31, lk = lane >> 5;
   const int a_off = lk * SP_HS + (wm * 64 + lr) * 16, b_off = SP_OP + lk * SP_HS + (wn * 64 + lr) * 16;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = (kt & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
-    if (kt + 1 < nk) {
-      split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg + (kt + 1) * SBK, kend, tid, ra);
-      split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * SBK, kend, tid, rb);
-    }
+
+  // tile t of the k loop: HBM -> registers / registers -> split -> LDS stage / LDS stage -> 24 MFMAs
+  auto load = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
+    split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
+    split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
+  };
+  auto store = [&](int t, const float4 (&ra)[2], const float4 (&rb)[2]) {
+    const int st = (t & 1) * 2 * SP_OP;
+    split_store<A_KC, GUARD>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend);
+    split_store<B_KC, GUARD>(&lds[st + SP_OP], tid, rb, p.N, n0, kbeg + t * SBK, kend);
+  };
+  auto compute_issue = [&](int t) {   // fragment reads + the 24 MFMAs of tile t (no scheduling fence behind them)
+    const int cur = (t & 1) * 2 * SP_OP;
     bf16x8 a[2][3], b[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -435,32 +487,110 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
         a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + a_off + i * 32 * 16]);
         b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + b_off + i * 32 * 16]);
       }
-    __builtin_amdgcn_sched_barrier(0);  // the global prefetch and the fragment reads are issued before the MFMA block
+    __builtin_amdgcn_sched_barrier(0);  // global prefetches and fragment reads are issued before the MFMA block
     // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi'; the four output blocks in turn,
     // so that dependent MFMAs are four issues apart
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t6 = 0; t6 < 6; ++t6)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t]], b[ni][PB[t]], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads the prefetched registers (a vmcnt wait) moves above them
-    if (kt + 1 < nk) {
-      split_store<A_KC, GUARD>(&lds[nxt], tid, ra, p.M, m0, kbeg + (kt + 1) * SBK, kend);
-      split_store<B_KC, GUARD>(&lds[nxt + SP_OP], tid, rb, p.N, n0, kbeg + (kt + 1) * SBK, kend);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
+  };
+  auto compute = [&](int t) {
+    compute_issue(t);
+    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads prefetched registers (a vmcnt wait) moves above them
+  };
+
+#if EESEN_SPLIT_PF2
+  // Two k-tiles of HBM prefetch in registers: tile t+2 is requested right after tile t+1 has left its registers for LDS, and is
+  // consumed two MFMA blocks later.  In the steady state (step<true>) the split of tile t+1 -- ~140 VALU instructions and 24
+  // ds_write_b64 per wave -- is INTERLEAVED with the 24 MFMAs of tile t inside the same wave: MFMA and VALU share the SIMD's
+  // issue port (one 4-cycle slot each; a 32-cycle MFMA leaves room for ~5-6 others), and with the split after the MFMA block
+  // the port, not the matrix pipe, was the limit (PMC: matrix pipe 55 % busy, VALU 40 %, summing to ~100 %).
+  float4 ra0[2], rb0[2], ra1[2], rb1[2];
+  // steady state: MFMAs of tile t with the split of tile t + 1 in their shadow -- per unit  M M [A]  M M [B]  M M [C], every
+  // bracket ~10 VALU (40 issue cycles) behind two 32-cycle MFMAs; scheduling fences pin the order
+  auto fused = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
+    const int cur = (t & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
+    const int k1 = kbeg + (t + 1) * SBK;
+    bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + a_off + i * 32 * 16]);
+        b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + b_off + i * 32 * 16]);
+      }
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    auto mm = [&](int idx) {   // MFMA number idx of the tile: product idx / 4, output block idx % 4
+      const int t6 = idx >> 2, mi = (idx >> 1) & 1, ni = idx & 1;
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
+    };
+    SplitUnit su;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      mm(6 * u + 0); mm(6 * u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u < 2) split_stage_a<A_KC, GUARD>(su, ra[u], u, tid, p.M, m0, k1, kend);
+      else split_stage_a<B_KC, GUARD>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend);
+      EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(6 * u + 2); mm(6 * u + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      split_stage_b(su);
+      EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.pm[0], su.pm[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(6 * u + 4); mm(6 * u + 5);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u < 2) split_stage_c<A_KC>(su, &lds[nxt], u, tid);
+      else split_stage_c<B_KC>(su, &lds[nxt + SP_OP], u - 2, tid);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load(t + 3, ra, rb);
+    __syncthreads();
+  };
+  auto step = [&](int t, float4 (&ra)[2], float4 (&rb)[2], bool do_store, bool do_load) {
+    compute(t);
+    if (do_store) store(t + 1, ra, rb);
+    if (do_load) load(t + 3, ra, rb);
+    __syncthreads();
+  };
+  if (nk > 0) { load(0, ra0, rb0); store(0, ra0, rb0); }
+  if (nk > 1) load(1, ra0, rb0);
+  if (nk > 2) load(2, ra1, rb1);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 4 < nk; kt += 2) {   // steady state: tiles t + 1 and t + 3 exist
+    fused(kt, ra0, rb0);
+    fused(kt + 1, ra1, rb1);
+  }
+  for (; kt < nk; kt += 2) {
+    step(kt, ra0, rb0, kt + 1 < nk, kt + 3 < nk);
+    if (kt + 1 < nk) step(kt + 1, ra1, rb1, kt + 2 < nk, kt + 4 < nk);
+  }
+#else
+  float4 ra[2], rb[2];
+  if (nk > 0) { load(0, ra, rb); store(0, ra, rb); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load(kt + 1, ra, rb);
+    compute(kt);
+    if (kt + 1 < nk) store(kt + 1, ra, rb);
     __syncthreads();
   }
+#endif
   gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
 }
 
 template <bool A_KC, bool B_KC, bool GUARD>
-__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_kernel(GemmParams p) {
   gemm_split_body<A_KC, B_KC, GUARD, false>(p);
 }
-__global__ __launch_bounds__(256, 2) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
   gemm_split_body<true, true, false, true>(p);
 }
 
@@ -526,13 +656,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-// 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class accuracy,
-// 2.67x the matrix rate).  EESEN_GEMM_MODE=f32|split; read per call so that tests can flip it inside one process.
+// 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1 (default): 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class
+// accuracy, 2.67x the matrix rate).  EESEN_GEMM_MODE=f32|split; read per call so that tests can flip it inside one process.
 static int g_gemm_mode = -1;
 int gemm_mode() {
   if (g_gemm_mode >= 0) return g_gemm_mode;
-  const char* e = getenv("EESEN_GEMM_MODE");
-  return (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : 0;
+  const char* e = getenv("EESEN_GEMM_MODE");   // default: the split kernel
+  return (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
 }
 void set_gemm_mode(int mode) { g_gemm_mode = mode; }
 

@@ -125,7 +125,9 @@ Net::Net(int dev, void* stream) : device(dev) {
   // arrival counters (gemm_f32_nt_gated).  Measured on MI355X (cfg2), bit-identical results: with the 32x4 forward tiles
   // it lost (74.7 vs 73.0 ms/step: the hand-off chain slowed more than the 7 ms of GEMM it hid; wave priority did not
   // help); with the 16x8 tiles and capped side-stream occupancy it wins: 62.0 -> 60.0 ms/step.
-  gate_fwd = !(getenv("EESEN_GATE_FWD") && atoi(getenv("EESEN_GATE_FWD")) == 0);
+  // With the bf16-split GEMM (1.7x faster) the gated GEMM no longer pays: the spinning tiles cost the recurrence more than the
+  // 1.5 ms of GEMM per layer they hide (measured, cfg2: 50.5 ms/step gated, 48.9 not).  Default: gate only in f32 mode.
+  gate_fwd = getenv("EESEN_GATE_FWD") ? atoi(getenv("EESEN_GATE_FWD")) != 0 : gemm_mode() == 0;
   if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
   // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on MI355X, cfg2: with the
   // one-launch-per-step recurrence it is neutral (105.1 vs 104.9 ms/step: the step kernels slow down by what the
@@ -678,7 +680,8 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // CU.  Measured on cfg2 (3 runs of 20 steps each, same box): uncapped 58.0, 48 KB (one per CU) 55.3, 32 KB 54.7 ms/step --
       // with one per CU the side stream itself became the critical path (12 ms of gradient GEMMs per layer against 9 ms of
       // recurrence + input-gradient GEMM); before the recurrence kernels overlapped fetch and MFMA the ranking was the reverse.
-      static const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : 32) * 1024;
+      // (with the bf16-split GEMM: one per CU -- 47.6 vs 48.9 ms/step; the gradient GEMMs are short enough not to become the critical path)
+      const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : (gemm_mode() == 1 ? 48 : 32)) * 1024;
       const int side_lds = overlap ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);

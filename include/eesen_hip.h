@@ -52,7 +52,7 @@ int eesen_device_count(int* count);
  *   1  3-way bf16 split: every fp32 operand is EXACTLY hi + mid + lo (three bf16), six of the nine cross products run on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; error <= 2^-23 |a*b| per product, i.e. fp32-GEMM class, at 2.67x the
  *      f32 matrix rate (gfx950 runs f32 MFMA at 1/16 of the bf16 rate and has no TF32 form);
- *  -1  follow the environment (EESEN_GEMM_MODE=f32|split), the initial state. */
+ *  -1  follow the environment (EESEN_GEMM_MODE=f32|split; split when unset), the initial state. */
 int eesen_set_gemm_mode(int mode);
 int eesen_get_gemm_mode(int* mode);
 
