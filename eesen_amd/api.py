@@ -341,6 +341,12 @@ class Net:
         check(self.lib.eesen_net_grad_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def RecurrenceInfo(self) -> dict:
+        """Which recurrence kernels the last Propagate / Backpropagate used (debug accessor)."""
+        a = (C.c_int * 3)()
+        check(self.lib.eesen_net_recurrence_info(self.h, a))
+        return dict(lstm_layers=a[0], fwd_persistent=a[1], bwd_persistent=a[2])
+
     def Synchronize(self):
         check(self.lib.eesen_net_synchronize(self.h))
 

@@ -55,6 +55,10 @@ struct LstmLayerDev {
   // drop_mode 0 none, 1 no-memory-loss (mask multiplies g*i), 2 RNNDrop (mask multiplies the whole new cell)
   const float* rmask = nullptr;
   int drop_mode = 0;
+  // sequence window of one persistent launch: sequences [s_begin, s_begin + s_count) of the S interleaved ones.  Shapes whose
+  // whole batch needs more workgroups than can be co-resident (S = 64 at H = 1024: BASELINE config 5) run as several
+  // launches, one window each -- the sequences are independent chains.  s_count = 0 means all S.
+  int s_begin = 0, s_count = 0;
 };
 // EESEN_NO_DROPOUT (build flag, A/B only): compiles the recurrent-dropout branches out of the recurrence kernels
 #ifdef EESEN_NO_DROPOUT
@@ -80,6 +84,9 @@ void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float
 // out[r][c] = a[r][c] * m[r][c]   (MulElements, :416 / :895)
 void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int ldm, float* out, int ldo, long rows, int cols);
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg = nullptr);
+// sequence windows (= cooperative launches) the persistent forward pass of this layer takes: 1 for every shape whose
+// workgroups are co-resident at once, 2+ for S = 64 at H = 1024, 0 when no persistent tile fits (per-step kernels then)
+int lstm_fwd_persistent_windows(const LstmLayerDev& L);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
   const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
-  const int u0 = bx * UB, s0 = bz * ST;
+  const int u0 = bx * UB, s0 = L.s_begin + bz * ST;
+  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);   // sequence window of this launch
   unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
   const unsigned nblk = R.nblk;
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   }
   const int es = tid / UB, eu = tid % UB;
   const int s_e = s0 + es;
-  const bool e_ok = tid < ST * UB && s_e < S;
+  const bool e_ok = tid < ST * UB && s_e < s_end;
   float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;  // c_{t-1} of this thread's (sequence, unit) never leaves the register
   int len = 0;
   if (e_ok) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int sa = s0 + m * 16 + li;
-          ld8_sc1(rY, ybase + (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[m][c]);
+          ld8_sc1(rY, ybase + (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < s_end, a[m][c]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA (else they are issued lazily, 2 at a time)
@@ -294,7 +295,7 @@ template <int CPW, int ST, bool DROP>  // ST = sequences per workgroup (16, or 8
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerDev L, const float* __restrict__ dY,
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
                                                                       unsigned* err, int spin_limit, unsigned long long* trace,
-                                                                      Role R) {
+                                                                      Role R, int chunk) {
   __shared__ float red[NW][16][17];
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   const int H = L.H, S = L.S, T = L.T;
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
   const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
-  const int u0 = bx * 16, s0 = bz * ST;
+  const int u0 = bx * 16, s0 = L.s_begin + bz * ST;
+  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);   // sequence window of this launch
   unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
   const unsigned nblk = R.nblk;
 
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   }
   const int es = tid >> 4, eu = tid & 15;
   const int s_e = s0 + es, u_e = u0 + eu;
-  const bool e_ok = tid < ST * 16 && s_e < S && u_e < H;
+  const bool e_ok = tid < ST * 16 && s_e < s_end && u_e < H;
   float p_i = 0.f, p_f = 0.f, p_o = 0.f;
   int len = 0;
   if (e_ok) {
@@ -359,13 +361,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
     }
   }
-  // ONE loop-invariant buffer resource over all of DG (at most 2 GB, checked on the host).  Re-basing it on the time step's
-  // row block every step (to lift the 2 GB limit) was measured: +0.27 us per step, 1 ms per cfg2 minibatch -- not worth it.
-  const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
+  // 32-bit buffer offsets reach 2 GB, DG can be larger (config 5: T*S*8H*4 = 6.3 GB).  The buffer resource is re-based once
+  // per CHUNK of `chunk` steps on the first row block the chunk touches (re-basing every step was measured: +0.27 us per
+  // step); a chunk spans chunk + 1 row blocks, which the host sizes to stay below 2 GB.  Shapes below 2 GB: one chunk.
+  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
+  int tbS = 0;   // first row (t * S) the current resource is based on
 
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
+    if (chunk < T && step % chunk == 0) {   // uniform across the workgroup
+      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
+      tbS = tb * S;
+      rDG = make_rsrc(DG + (size_t)tbS * ldG);
+    }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     EESEN_STAMP(0);
     if (step > 0) {
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
-      const int tnb = tn * S;
+      const int tnb = tn * S - tbS;
       const size_t arow = ((size_t)(tnb + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row in block tn
       if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
         // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         // half of the chunk reaches rows 0-7 through a rotate-by-8 DPP move inside each 16-lane row; rows 8-15 of the
         // product are garbage that nobody reads.
         const unsigned arow8 = (unsigned)(((size_t)(tnb + s0 + (li & 7)) * ldG + (size_t)dir * K4) * 4);
-        const bool rok = s0 + (li & 7) < S;
+        const bool rok = s0 + (li & 7) < s_end;
         const int seg = (li >> 3) * 4 + kq;
         f32x4 a4[CPW];
 #pragma unroll
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
             const int k = (wave + (h + c) * NW) * 32 + kq * 8;
-            ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < S, a[c]);
+            ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, K4, li < ST && sa < s_end, a[c]);
           }
           __builtin_amdgcn_sched_barrier(0);  // all loads of the round in flight BEFORE its first MFMA
 #pragma unroll
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       float carry = dcx * f;
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
-      const unsigned ooff = (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4);
+      const unsigned ooff = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
       if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
       else __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 }
 
 template <class K>
-bool fits(K kernel, dim3 grid, int threads) {
+bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -538,55 +547,90 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
   if (units_per_wg) *units_per_wg = 4 * ft.nt;
 }
 
-bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, unsigned* err, int spin_limit,
+// Sequence windows: the smallest number of equal windows (each a multiple of the sequence tile) whose workgroups can all be
+// co-resident.  1 for every configuration but the largest (S = 64 at H = 1024 needs 512 workgroups of the wide tiles: two
+// windows of 32 sequences, run one after the other -- the sequences are independent chains).
+template <class F>
+static int pick_windows(int S, int seq_tile, F fits_with) {
+  for (int nwin = 1; nwin <= 8; nwin *= 2) {
+    if (S % nwin != 0 || (S / nwin) % seq_tile != 0) { if (nwin == 1 && fits_with(S)) return 1; continue; }
+    if (fits_with(S / nwin)) return nwin;
+  }
+  return 0;
+}
+
+int lstm_fwd_persistent_windows(const LstmLayerDev& L);
+
+bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace, hipEvent_t after_reset) {
-  const int nch = (L.H + 31) / 32;
+  const int nch = (L0.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
-  const FwdTile ft = fwd_tile(L);
-  dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.S, 16 * ft.mt)), block(NW * 64);
-  const dim3 grid1(grid.x * grid.y * grid.z);
-  const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
-  if (need > 4 || (ft.nt == 2 && need > 2) || L.H % (4 * ft.nt) != 0 || L.T < 2 ||
-      (size_t)grid.y * grid.z * kShards * kShardStride > 8192)
-    return false;
+  const FwdTile ft = fwd_tile(L0);
+  if (need > 4 || (ft.nt == 2 && need > 2) || L0.H % (4 * ft.nt) != 0 || L0.T < 2) return false;
   // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
   // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
   // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
   // and is read back stale one step later (seen at S = 17, H = 20).  Such shapes use the per-step kernels.
-  if (((size_t)L.S * L.ndir * L.H * sizeof(float)) % 128 != 0) return false;
-  if ((size_t)(L.T + 2) * L.S * L.ndir * L.H * sizeof(float) >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of Y
-  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
-  if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
+  if (((size_t)L0.S * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;
+  if ((size_t)(L0.T + 2) * L0.S * L0.ndir * L0.H * sizeof(float) >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of Y
+  const int nwin = lstm_fwd_persistent_windows(L0);
+  if (nwin == 0) return false;
+  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
+  for (int w = 0; w < nwin; ++w) {
+    LstmLayerDev L = L0;
+    L.s_count = L0.S / nwin;
+    L.s_begin = w * L.s_count;
+    dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.s_count, 16 * ft.mt)), block(NW * 64);
+    const dim3 grid1(grid.x * grid.y * grid.z);
+    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+    if ((size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+    if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
 #define EESEN_FP(CPW, MT, NT)                                                                          \
   do {                                                                                                  \
-    if (L.drop_mode) {                                                                                  \
-      if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid, NW * 64)) return false;            \
-      coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
-    } else {                                                                                            \
-      if (!fits(lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid, NW * 64)) return false;           \
-      coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid1, block, L, cnt, err, spin_limit, trace, role); \
-    }                                                                                                   \
+    if (L.drop_mode) coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
+    else coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid1, block, L, cnt, err, spin_limit, trace, role); \
   } while (0)
-  if (ft.nt == 4) {
-    if (need <= 1) EESEN_FP(1, 1, 4);
-    else if (need <= 2) EESEN_FP(2, 1, 4);
-    else EESEN_FP(4, 1, 4);
-  } else if (ft.nt == 2) {
-    if (need <= 1) EESEN_FP(1, 1, 2);
-    else EESEN_FP(2, 1, 2);
-  } else {
-    if (need <= 1) EESEN_FP(1, 2, 1);
-    else if (need <= 2) EESEN_FP(2, 2, 1);
-    else EESEN_FP(4, 2, 1);
-  }
+    if (ft.nt == 4) {
+      if (need <= 1) EESEN_FP(1, 1, 4);
+      else if (need <= 2) EESEN_FP(2, 1, 4);
+      else EESEN_FP(4, 1, 4);
+    } else if (ft.nt == 2) {
+      if (need <= 1) EESEN_FP(1, 1, 2);
+      else EESEN_FP(2, 1, 2);
+    } else {
+      if (need <= 1) EESEN_FP(1, 2, 1);
+      else if (need <= 2) EESEN_FP(2, 2, 1);
+      else EESEN_FP(4, 2, 1);
+    }
 #undef EESEN_FP
+  }
   return true;
 }
 
-bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
-                         unsigned* err, int spin_limit, unsigned long long* trace) {
-  const int nch = (4 * L.H + 31) / 32;
+// number of sequence windows the forward pass of this layer takes (0: no persistent tile fits; 1: the whole batch at once)
+int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
+  const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
+  const FwdTile ft = fwd_tile(L);
+  auto fits_with = [&](int Sw) {
+    dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(Sw, 16 * ft.mt));
+#define EESEN_FF(CPW, MT, NT) return L.drop_mode ? fits(lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid, NW * 64) \
+                                                 : fits(lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid, NW * 64)
+    if (ft.nt == 4) { if (need <= 1) EESEN_FF(1, 1, 4); else if (need <= 2) EESEN_FF(2, 1, 4); else EESEN_FF(4, 1, 4); }
+    else if (ft.nt == 2) { if (need <= 1) EESEN_FF(1, 1, 2); else EESEN_FF(2, 1, 2); }
+    else { if (need <= 1) EESEN_FF(1, 2, 1); else if (need <= 2) EESEN_FF(2, 2, 1); else EESEN_FF(4, 2, 1); }
+#undef EESEN_FF
+  };
+  return pick_windows(L.S, 16 * ft.mt, fits_with);
+}
+
+bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY, int lddy, float* DG, unsigned* cnt,
+                         unsigned* err, int spin_limit, unsigned long long* trace) {
+  const int nch = (4 * L0.H + 31) / 32;
+  const int need = (nch + NW - 1) / NW;
+  if (need > 16 || L0.T < 2) return false;
+  if (((size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
   // Sequences per workgroup: 16 fills the MFMA rows; 8 wastes half of them but halves the 128 KB of DG_next each workgroup
   // must fetch per step, which is what bounds the step (measured: 3.75 us of fetch at ~34 GB/s per CU vs 1.8 us of MFMA).
   // Take 8 whenever 16 would leave half of the chip's CUs without a workgroup.
@@ -594,34 +638,51 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY,
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   static const int force_st = getenv("EESEN_BWD_SEQ_TILE") ? atoi(getenv("EESEN_BWD_SEQ_TILE")) : 0;
-  const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
-  const int stile = force_st ? force_st : (2 * blocks16 <= ncu && L.S > 8 ? 8 : 16);
-  dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, stile)), block(NW * 64);
-  const dim3 grid1(grid.x * grid.y * grid.z);
-  const int ngroups = (int)(grid.y * grid.z);
-  const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
-  if (need > 16 || L.T < 2 || (size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
-  if ((size_t)L.T * L.S * L.ndir * 4 * L.H * 4 >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of DG
-  if (((size_t)L.S * L.ndir * 4 * L.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
-  EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
+  const long blocks16 = (long)cdiv(L0.H, 16) * L0.ndir * cdiv(L0.S, 16);
+  const int stile = force_st ? force_st : (2 * blocks16 <= ncu && L0.S > 8 ? 8 : 16);
+  // 32-bit buffer offsets: the kernel re-bases its DG resource every `chunk` steps; a chunk touches chunk + 1 row blocks
+  const size_t blk_bytes = (size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float);
+  const long max_blocks = (long)((((size_t)1 << 31) - 1) / blk_bytes);
+  if (max_blocks < 3) return false;
+  int chunk = (int)std::min<long>(L0.T, max_blocks - 1);
+  if (chunk < L0.T) { int p2 = 1; while (p2 * 2 <= chunk) p2 *= 2; chunk = p2; }   // a power of two keeps `step % chunk` cheap
+  auto launch = [&](const LstmLayerDev& L, bool dry) -> bool {
+    const int Sw = L.s_count ? L.s_count : L.S;
+    dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(Sw, stile)), block(NW * 64);
+    const dim3 grid1(grid.x * grid.y * grid.z);
+    const int ngroups = (int)(grid.y * grid.z);
+    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
+    if ((size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
+    if (!dry) EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \
     if (L.drop_mode) {                                                                                            \
-      if (!fits(lstm_bwd_persistent_kernel<CPW, STV, true>, grid, NW * 64)) return false;                         \
-      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+      if (dry) return fits(lstm_bwd_persistent_kernel<CPW, STV, true>, grid, NW * 64);                            \
+      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role, chunk); \
     } else {                                                                                                      \
-      if (!fits(lstm_bwd_persistent_kernel<CPW, STV, false>, grid, NW * 64)) return false;                        \
-      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+      if (dry) return fits(lstm_bwd_persistent_kernel<CPW, STV, false>, grid, NW * 64);                           \
+      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role, chunk); \
     }                                                                                                             \
   } while (0)
 #define EESEN_BP(CPW) do { if (stile == 8) EESEN_BP2(CPW, 8); else EESEN_BP2(CPW, 16); } while (0)
-  if (need <= 1) EESEN_BP(1);
-  else if (need <= 2) EESEN_BP(2);
-  else if (need <= 4) EESEN_BP(4);
-  else if (need <= 8) EESEN_BP(8);
-  else EESEN_BP(16);
+    if (need <= 1) EESEN_BP(1);
+    else if (need <= 2) EESEN_BP(2);
+    else if (need <= 4) EESEN_BP(4);
+    else if (need <= 8) EESEN_BP(8);
+    else EESEN_BP(16);
 #undef EESEN_BP2
 #undef EESEN_BP
+    return true;
+  };
+  const int nwin = pick_windows(L0.S, stile, [&](int Sw) { LstmLayerDev L = L0; L.s_count = Sw; return launch(L, true); });
+  if (nwin == 0) return false;
+  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return false;
+  for (int w = 0; w < nwin; ++w) {
+    LstmLayerDev L = L0;
+    L.s_count = L0.S / nwin;
+    L.s_begin = w * L.s_count;
+    if (!launch(L, false)) return false;
+  }
   return true;
 }
 

@@ -489,6 +489,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
                                    rows, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   const float* x = input.p;
   int ldx = D4;
+  info_fwd_persistent = info_lstm_layers = 0;
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
   for (Layer& L : layers) {
@@ -530,6 +531,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       // (the 16-unit tile of wide layers fills the register file -- 2 x 206 VGPRs per SIMD -- so spinning GEMM workgroups
       // could keep its cooperative kernel from becoming resident: no gating there)
       const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows >= 128 &&
+                             lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
       const LstmLayerDev v = lstm_view(*this, L);
@@ -537,6 +539,8 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
                                                           plan_gate ? ev_gate_reset : nullptr);
       if (!pers)
         for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
+      info_fwd_persistent += pers ? 1 : 0;
+      ++info_lstm_layers;
       check_launch("lstm_fwd");
       timer.end(st, ti_);
       if (pers && plan_gate) {
@@ -610,6 +614,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   int dg_slot = 0;
   bool side_pending[2] = {false, false};
   bucket_log.clear();
+  info_bwd_persistent = 0;
 
   // backpropagate_buf_[L] = out_diff (net.cc:96), into a buffer whose rows are 16-byte aligned
   const int Kout = layers.back().dout;
@@ -660,7 +665,9 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         side_pending[dg_slot] = false;
       }
       { const int ti_ = timer.begin(st, 3);
-      if (!(persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr)))
+      if (persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr))
+        ++info_bwd_persistent;
+      else
         for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
       check_launch("lstm_bwd");
       timer.end(st, ti_); }

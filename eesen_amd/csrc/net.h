@@ -98,6 +98,7 @@ struct Net {
   bool gate_fwd = true;
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
+  int info_fwd_persistent = 0, info_bwd_persistent = 0, info_lstm_layers = 0;   // of the last Propagate / Backpropagate (tests)
   int spin_limit = 400000;
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error();

@@ -113,3 +113,56 @@ def test_full_width_short_length_against_oracle(gpu, name, over):
     assert rel_err(idf.numpy(), o["in_diff"]) < 1e-4
     for (li, nm, a), (_, _, b) in zip(split_params(layers, net.GetGrads()), split_params(layers, ora.fresh_grads_flat())):
         assert rel_err(a, b) < 1e-4, f"layer {li} {nm}"
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5 (6x1024, S = 64, T <= 3000)
+def test_cfg5_width_and_batch_against_oracle_on_the_persistent_kernels(gpu):
+    """S = 64 utterances at H = 1024 needs 512 wide-tile workgroups: the persistent kernels run as two sequence windows of 32
+    (two cooperative launches per layer pass).  Reduced length, full width and batch, against the oracle; the persistent
+    kernels must have been selected for every layer, forward and backward."""
+    from eesen_amd.api import Net, Ctc
+    from oracle import net as onet
+    cfg = synth.config("cfg5"); cfg.update(T=12, layers=2)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
+    out, diff, idf = _step(net, ctc, batch, in_diff=True)
+    info = net.RecurrenceInfo()
+    assert info == dict(lstm_layers=2, fwd_persistent=2, bwd_persistent=2), info
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(1.0, 0.0)
+    o = onet.train_step(ora, batch, "f32")
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(out.numpy()[vm], o["net_out"][vm]) < 1e-4
+    assert rel_err(ctc.pzx, o["pzx"]) < 1e-4
+    assert rel_err(diff.numpy(), o["diff"]) < 1e-4
+    assert rel_err(idf.numpy(), o["in_diff"]) < 1e-4
+    for (li, nm, a), (_, _, b) in zip(split_params(layers, net.GetGrads()), split_params(layers, ora.fresh_grads_flat())):
+        assert rel_err(a, b) < 1e-4, f"layer {li} {nm}"
+
+
+def test_cfg5_full_length_layer_persistent_equals_per_step_kernels(gpu, monkeypatch):
+    """One 1024-cell BiLSTM layer at the FULL cfg5 size (S = 64, T = 3000): the gate-gradient buffer is 6.3 GB, beyond 32-bit
+    buffer offsets (the backward kernel re-bases its resource per chunk of steps), and the batch takes two sequence windows.
+    The persistent path must reproduce the one-launch-per-step kernels (forward bit for bit, backward to the last bits)."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config("cfg5"); cfg.update(layers=1)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EESEN_PERSISTENT", mode)
+        net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+        idf = CuMatrix(batch.T * batch.S, cfg["D"])
+        net.BackpropagateNoUpdate(diff, idf)
+        info = net.RecurrenceInfo()
+        assert info["fwd_persistent"] == info["bwd_persistent"] == (1 if mode == "1" else 0), info
+        res[mode] = (out.numpy(), ctc.pzx.copy(), idf.numpy(), net.GetGrads())
+        del net, ctc, out, diff, idf
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
+    assert rel_err(res["1"][2], res["0"][2]) < 1e-5
+    assert rel_err(res["1"][3], res["0"][3]) < 1e-5
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert np.all(np.isfinite(res["1"][3])) and np.all(res["1"][2][~vm] == 0)
