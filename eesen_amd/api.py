@@ -343,8 +343,9 @@ class Net:
 
     def RecurrenceInfo(self) -> dict:
         """Which recurrence kernels the last Propagate / Backpropagate used (debug accessor)."""
-        a = (C.c_int * 3)()
+        a = (C.c_int * 4)()
         check(self.lib.eesen_net_recurrence_info(self.h, a))
+        self.recoveries = a[3]
         return dict(lstm_layers=a[0], fwd_persistent=a[1], bwd_persistent=a[2])
 
     def Synchronize(self):

@@ -175,10 +175,11 @@ int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n) {
 int eesen_net_update(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->update(); });
 }
-int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {
+int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {  // four ints
   return guard([&] {
     REQ_PTR(net); REQ_PTR(out3);
     out3[0] = net->info_lstm_layers; out3[1] = net->info_fwd_persistent; out3[2] = net->info_bwd_persistent;
+    out3[3] = net->recoveries;
   });
 }
 int eesen_net_synchronize(eesen_net_t* net) {

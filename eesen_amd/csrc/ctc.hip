@@ -13,9 +13,9 @@
 // and beta sweeps of all S utterances run concurrently (2S wavefronts).  The next step's log-probability
 // gather is issued one step ahead so its latency sits under the current step's log-add-exp.  alpha/beta
 // rows are written utterance-major [S][T][64*PL] so every store is one coalesced line-aligned row.
-// The per-frame gradient is then a bulk pass (one wavefront per frame) that stages alpha+beta in LDS
-// and lets lane k fold class k's lattice positions (precomputed per utterance), emitting
-// d(-ln p)/d(logits) directly.
+// The per-frame gradient is then a bulk pass (one wavefront per frame) that stages alpha+beta in LDS, reduces the
+// blank's ~L'/2 positions across the wave and lets lane k >= 1 fold class k's few lattice positions (precomputed per
+// utterance), emitting d(-ln p)/d(logits) directly.
 #include "kernels.h"
 
 namespace eesen {
@@ -232,8 +232,15 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 }
 
 // ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per frame -----
+// gamma_k = log sum_{j: l'_j = k} exp(alpha_j + beta_j).  The reference folds every class serially (thread (frame, k) loops
+// over ALL L' positions).  The blank owns every second lattice position (~(L'+1)/2 = 101 at cfg2), every other class two or
+// three: a class-per-lane fold is one lane grinding through 101 dependent log-add-exps while 63 wait (round 1: 0.19 ms for
+// 32 000 frames, 5 % of the HBM roofline).  Here the blank is reduced ACROSS the wave -- max, then sum of exp(v - max), two
+// shuffle trees -- and lane k >= 1 folds class k's few positions in the reference's order with the reference's LogAPlusB.
+// Only the L'_s positions the utterance has are read (the lattice rows are padded to 64 * PL for the sweep's stores).
 __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __restrict__ probs, int ld, int T, int S, int K,
                                                              int Lpad, const int* __restrict__ lens,
+                                                             const int* __restrict__ lablens,
                                                              const int* __restrict__ cls_off,
                                                              const int* __restrict__ cls_pos,
                                                              const float* __restrict__ alpha,
@@ -254,8 +261,20 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
   float* ek = ab + Lpad;
   const float* ar = alpha + ((size_t)s * T + t) * Lpad;
   const float* br = beta + ((size_t)s * T + t) * Lpad;
-  for (int j = lane; j < Lpad; j += 64) ab[j] = AddAB(ar[j], br[j]);
+  const int Ls = lablens[s];
+  float bmax = kLogZero;                       // blank positions are the even ones (ctc-loss.cc:116-129)
+  for (int j = lane; j < Ls; j += 64) {
+    const float v = AddAB(ar[j], br[j]);
+    ab[j] = v;
+    if ((j & 1) == 0) bmax = fmaxf(bmax, v);
+  }
   __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
+  bmax = wave_max(bmax);
+  float bsum = 0.f;
+  if (bmax > kLogZero)
+    for (int j = 2 * lane; j < Ls; j += 128) bsum += ExpA(SubAB(ab[j], bmax));
+  bsum = wave_sum(bsum);
+  const float err_blank = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
   const float* yr = probs + (size_t)r * ld;
   const int* co = cls_off + (size_t)s * (K + 1);
   const int* cp = cls_pos + (size_t)s * Lpad;
@@ -263,8 +282,12 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
   float rsum = 0.f;
   for (int k = lane; k < K; k += 64) {
     float err = kLogZero;
-    const int e = co[k + 1];
-    for (int idx = co[k]; idx < e; ++idx) err = LogAPlusB(err, ab[cp[idx]]);              // :1617-1624
+    if (k == 0) {
+      err = err_blank;
+    } else {
+      const int e = co[k + 1];
+      for (int idx = co[k]; idx < e; ++idx) err = LogAPlusB(err, ab[cp[idx]]);            // :1617-1624
+    }
     const float y = yr[k];
     const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
     const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
@@ -345,13 +368,13 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
 }
 
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
-                    const int* cls_off, const int* cls_pos, const float* alpha, const float* beta, const float* pzx,
-                    float* diff, int ldd) {
+                    const int* lablens, const int* cls_off, const int* cls_pos, const float* alpha, const float* beta,
+                    const float* pzx, float* diff, int ldd) {
   const int rows = T * S;
   if (rows <= 0) return;
   const size_t smem = (size_t)4 * (Lpad + K) * sizeof(float);
   hipLaunchKernelGGL(ctc_error_diff_kernel, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens,
-                     cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
+                     lablens, cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
   check_launch("ctc_error_diff");
 }
 

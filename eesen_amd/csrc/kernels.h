@@ -112,8 +112,8 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
 // diff[t*S+s][k] = y*rowsum(e) - gamma ... (error kernel + softmax Jacobian, ctc-loss.cc:156-168)
 // cls_off [S x (K+1)], cls_pos [S x Lpad]: per sequence the lattice positions of each class, ascending.
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
-                    const int* cls_off, const int* cls_pos, const float* alpha, const float* beta, const float* pzx,
-                    float* diff, int ldd);
+                    const int* lablens, const int* cls_off, const int* cls_pos, const float* alpha, const float* beta,
+                    const float* pzx, float* diff, int ldd);
 // in place: m = (apply_log ? log m : m) - prior_scale * log_prior[col]; log_prior may be null (net-output-extract.cc:103-112)
 void log_sub_prior(hipStream_t st, float* m, int ld, int rows, int K, bool apply_log, const float* log_prior, float prior_scale);
 // ids[r] = argmax_k m[r][k], first maximum wins (CuMatrixBase::FindRowMaxId, cuda-matrix.cc:1038-1095)
@@ -121,11 +121,12 @@ void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* id
 
 // ---------------------------------------------------------------------------------------- optim.hip
 // corr = mmt*corr + fresh; clip to +-max_grad when max_grad > 0; param -= lr_coef*corr
+// skip (may be null): device word; when non-zero at execution time the update is a no-op (see optim.hip)
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
-                float max_grad);
+                float max_grad, const unsigned* skip = nullptr);
 // Adagrad (rmsprop = false) / RMSProp update of one flat parameter block, see optim.hip
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
-                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop);
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip = nullptr);
 // dst[c][r] = src[r][c]  (rows x cols -> cols x rows), dense
 void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst);
 // dst[r][0..cols) = src[r][0..cols) with different leading dimensions

@@ -189,9 +189,17 @@ void Net::check_device_error() {
   unsigned e = 0;
   EESEN_HIP_CHECK(hipMemcpy(&e, ctl.p + kCtlWords - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (e) {
+    // The step that raised the word was not applied (the update kernels skip on it).  Without a data-parallel communicator the
+    // run simply continues on the one-launch-per-step kernels -- one minibatch is lost, the model is intact; with one, the
+    // other ranks HAVE applied their step, so the ranks would diverge: that stays fatal.
+    EESEN_HIP_CHECK(hipStreamSynchronize(st));
     EESEN_HIP_CHECK(hipMemset(ctl.p + kCtlWords - 1, 0, sizeof(unsigned)));
-    throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
-                               "resident?); rerun with EESEN_PERSISTENT=0");
+    persistent = 0; gate_fwd = false; overlap = false;
+    ++recoveries;
+    if (comm) throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
+                                         "resident?) in a data-parallel run; rerun with EESEN_PERSISTENT=0");
+    fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
+                    "the minibatch in flight was NOT applied; continuing with the one-launch-per-step kernels\n");
   }
 }
 
@@ -722,6 +730,10 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
 void Net::update() {
   EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
   EESEN_HIP_CHECK(hipSetDevice(device));
+  // A persistent recurrence kernel that gave up waiting for a peer (error word raised) leaves garbage gradients: the update
+  // kernels read the word ON THE DEVICE and do nothing then, so a failed step never reaches the parameters; the host notices
+  // at its next poll and continues on the per-step kernels (check_device_error).
+  const unsigned* skip = persistent ? ctl.p + kCtlWords - 1 : nullptr;
   { const int ti_ = timer.begin(st, 5);
   // top-down, the order in which Backpropagate completed (and all-reduced) the layers' gradients
   for (int li = (int)layers.size() - 1; li >= 0; --li) {
@@ -732,11 +744,11 @@ void Net::update() {
         bucket_pending[li] = 0;
       }
       if (rule == 0) {
-        sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad);
+        sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad, skip);
       } else {  // the adaptive rules do not apply learn_rate_coef (bilstm-layer.h:865-869 multiplies only in the SGD branch)
         init_accu();
         adaptive_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, accu.p + L.p_off, (long)L.p_n, mmt, lr,
-                        L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2);
+                        L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2, skip);
       }
     }
   }

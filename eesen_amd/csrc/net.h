@@ -100,6 +100,7 @@ struct Net {
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
   int info_fwd_persistent = 0, info_bwd_persistent = 0, info_lstm_layers = 0;   // of the last Propagate / Backpropagate (tests)
   int spin_limit = 400000;
+  int recoveries = 0;         // times a timed-out persistent kernel made the net fall back to the per-step kernels
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error();
   // set_seq_lengths does not drain the stream: the lengths go through a pinned staging word-array (the previous copy has

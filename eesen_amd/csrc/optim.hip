@@ -14,7 +14,10 @@ namespace {
 
 __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ param, float* __restrict__ corr,
                                                          const float* __restrict__ fresh, long n, float mmt,
-                                                         float lr_coef, float max_grad) {
+                                                         float lr_coef, float max_grad, const unsigned* __restrict__ skip) {
+  // `skip`: the error word of the persistent recurrence kernels.  If one of them gave up waiting for a peer in THIS step, the
+  // gradients are garbage: leave parameters and momentum untouched (the host then drops to the per-step kernels, net.cpp).
+  if (skip && *skip) return;
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -46,7 +49,9 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ par
 __global__ __launch_bounds__(256) void adaptive_update_kernel(float* __restrict__ param, float* __restrict__ corr,
                                                               const float* __restrict__ fresh, float* __restrict__ accu,
                                                               long n, float mmt, float lr, float max_grad, float eps,
-                                                              float rho, float one_minus_rho, int rmsprop) {
+                                                              float rho, float one_minus_rho, int rmsprop,
+                                                              const unsigned* __restrict__ skip) {
+  if (skip && *skip) return;   // see sgd_update_kernel
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float c = mmt * corr[i] + fresh[i];
@@ -92,19 +97,19 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
 }  // namespace
 
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
-                float max_grad) {
+                float max_grad, const unsigned* skip) {
   if (n <= 0) return;
   const int blocks = (int)std::min<long>(cdivl(n / 4 + 1, 256), 2048);
-  hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad);
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad, skip);
   check_launch("sgd_update");
 }
 
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
-                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop) {
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip) {
   if (n <= 0) return;
   const int blocks = (int)std::min<long>(cdivl(n, 256), 4096);
   hipLaunchKernelGGL(adaptive_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, accu, n, mmt, lr, max_grad, eps,
-                     rho, one_minus_rho, rmsprop ? 1 : 0);
+                     rho, one_minus_rho, rmsprop ? 1 : 0, skip);
   check_launch("adaptive_update");
 }
 

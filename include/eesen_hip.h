@@ -133,10 +133,13 @@ int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n);
  * affine-trans-layer.h:174-195): corr = momentum*corr + fresh; clip corr to +-max_grad if
  * max_grad > 0; param -= learn_rate*learn_rate_coef*corr. */
 int eesen_net_update(eesen_net_t* net);
-/* Debug / test accessor: out3 = {LSTM layers, layers whose forward time loop ran as ONE cooperative launch per sequence
- * window (lstm_persistent.hip), layers whose backward time loop did} for the last Propagate / Backpropagate; the rest
- * took the one-launch-per-step kernels. */
-int eesen_net_recurrence_info(eesen_net_t* net, int* out3);
+/* Debug / test accessor: out4 = {LSTM layers, layers whose forward time loop ran as ONE cooperative launch per sequence
+ * window (lstm_persistent.hip), layers whose backward time loop did} for the last Propagate / Backpropagate (the rest
+ * took the one-launch-per-step kernels), and the number of recoveries so far.  A recovery: a cooperative recurrence
+ * kernel whose bounded spin gave up (its workgroups were not all resident -- GPU shared or preempted) raises a device
+ * word; the update kernels of that step see it and leave the model untouched, and the handle continues on the per-step
+ * kernels with a WARNING on stderr (fatal only when a communicator is attached: the other ranks did apply their step). */
+int eesen_net_recurrence_info(eesen_net_t* net, int* out4);
 /* Block until everything enqueued on the handle's stream has finished. */
 int eesen_net_synchronize(eesen_net_t* net);
 /* Seconds spent (HIP events on the handle's stream) in the phases of the last step, for bench.py:

@@ -39,8 +39,10 @@ def case(name: str):
     return cfg, synth.make_model(**cfg), synth.make_batch(**cfg)
 
 
-def reference_step(layers, batch, blas_threads: int = 0) -> dict:
-    """Runs the reference. Returns net_out, pzx, diff, in_diff, grads (Net::GetParams order), alpha-free (too large)."""
+def reference_step(layers, batch, blas_threads: int = 0, diff_override=None) -> dict:
+    """Runs the reference. Returns net_out, pzx, diff, in_diff, grads (Net::GetParams order), alpha-free (too large).
+    diff_override: backpropagate THIS matrix instead of the reference CTC's own gradient (e.g. an fp64 evaluation of the CTC on the
+    reference's probabilities: how far the reference's fp32 CTC round-off moves the reference's own gradients)."""
     from oracle import refbind
     if blas_threads <= 0:
         blas_threads = min(16, os.cpu_count() or 1)
@@ -57,7 +59,7 @@ def reference_step(layers, batch, blas_threads: int = 0) -> dict:
     net_out = ref.propagate(batch.feats)
     ctc = refbind.cuda_ctc_eval_parallel(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
     ne, nr = ref.error_rate_mseq(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
-    in_diff = ref.backpropagate(ctc["diff"], True)
+    in_diff = ref.backpropagate(ctc["diff"] if diff_override is None else np.ascontiguousarray(diff_override, np.float32), True)
     grads = before.astype(np.float64) - ref.get_params().astype(np.float64)    # lr = 1, momentum = 0, no clipping
     return dict(net_out=net_out, pzx=ctc["pzx"], diff=ctc["diff"], in_diff=in_diff, grads=grads.astype(np.float32),
                 errors=(ne, nr))

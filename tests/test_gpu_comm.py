@@ -74,3 +74,20 @@ def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name,
     nb.Update()
     assert not np.array_equal(before, nb.GetParams())      # momentum 0.9 carries the previous direction on
     nb.SetComm(None)
+
+
+def test_timed_out_recurrence_is_fatal_in_a_data_parallel_run(gpu, comm, monkeypatch):
+    """With a communicator attached the other ranks HAVE applied the step a failed rank skipped: continuing would let the ranks
+    diverge, so the failure is raised instead of recovered (cf. test_gpu_parity.py::test_recovery_from_a_timed_out_persistent_kernel)."""
+    from eesen_amd.api import Net, Ctc, EesenError
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    monkeypatch.setenv("EESEN_SPIN_LIMIT", "0")
+    net = Net.from_layers(layers)
+    monkeypatch.delenv("EESEN_SPIN_LIMIT")
+    net.SetComm(comm)
+    net.SetSeqLengths(batch.lens)
+    with pytest.raises(EesenError, match="gave up waiting for a peer workgroup"):
+        net.Propagate(batch.feats)
+        net.Synchronize()
+    net.SetComm(None)

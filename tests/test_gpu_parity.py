@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from eesen_amd import synth, nnet_io
-from tests.util import rel_err, valid_mask, split_params
+from tests.util import rel_err, valid_mask, split_params, diff_bound
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -126,8 +126,9 @@ def test_train_step_parity(gpu, cfg_name):
     assert rel_err(r["net_out"][vm], o["net_out"][vm]) < TOL
     assert rel_err(r["pzx"], o["pzx"]) < TOL
     assert abs(r["pzx"].sum() - o["pzx"].sum()) / abs(o["pzx"].sum()) < TOL
-    assert rel_err(r["diff"], o["diff"]) < TOL
-    assert rel_err(r["in_diff"], o["in_diff"]) < TOL
+    bound, diff64 = diff_bound(o["net_out"], batch, o["diff"], TOL)     # 1e-4 unless fp32 itself cannot hold it (T = 200 here)
+    assert rel_err(r["diff"], o["diff"]) < bound and rel_err(r["diff"], diff64) < bound
+    assert rel_err(r["in_diff"], o["in_diff"]) < bound
     worst = 0.0
     for (li, name, g), (_, _, w) in zip(split_params(layers, r["grads"]), split_params(layers, r["ora_grads"])):
         e = rel_err(g, w); worst = max(worst, e)
@@ -311,23 +312,28 @@ def test_l2_local_handoff_option(gpu, monkeypatch):
             assert np.array_equal(r[0], res["0"][0][0]) and np.array_equal(r[1], res["0"][0][1])
 
 
-def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch):
-    """A hand-off that cannot complete (here: a spin bound of zero polls) must surface as EesenError at the next
-    synchronisation point, never as a hang or as silently wrong numbers; the per-step fallback then still works."""
-    from eesen_amd.api import Net, EesenError
+def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, capfd):
+    """A hand-off that cannot complete (here: a spin bound of zero polls) must surface at the next synchronisation point --
+    never as a hang or as silently wrong numbers: a WARNING on stderr and a fall-back to the per-step kernels (an exception
+    when a data-parallel communicator is attached, tests/test_gpu_comm.py), after which the handle works."""
+    from eesen_amd.api import Net
     cfg = synth.config("small_bi")
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
     monkeypatch.setenv("EESEN_SPIN_LIMIT", "0")
     net = Net.from_layers(layers)
-    net.SetSeqLengths(batch.lens)
-    with pytest.raises(EesenError, match="persistent recurrence kernel gave up"):
-        net.Propagate(batch.feats)
-        net.Synchronize()
-    monkeypatch.setenv("EESEN_PERSISTENT", "0")
     monkeypatch.delenv("EESEN_SPIN_LIMIT")
+    net.SetSeqLengths(batch.lens)
+    net.Propagate(batch.feats)
+    net.Synchronize()
+    assert "gave up waiting for a peer workgroup" in capfd.readouterr().err
+    net.RecurrenceInfo()
+    assert net.recoveries == 1
+    net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats).numpy()
+    assert net.RecurrenceInfo()["fwd_persistent"] == 0
+    monkeypatch.setenv("EESEN_PERSISTENT", "0")
     ok = Net.from_layers(layers); ok.SetSeqLengths(batch.lens)
-    out = ok.Propagate(batch.feats).numpy()
-    assert np.all(np.isfinite(out))
+    assert np.array_equal(out, ok.Propagate(batch.feats).numpy())
 
 
 @pytest.mark.parametrize("over", [dict(S=1, T=37), dict(S=2, T=2), dict(S=17, T=9, H=20), dict(S=33, T=5, H=36, layers=1),
@@ -367,3 +373,35 @@ def test_ctc_edge_cases(gpu):
     assert np.all(np.isfinite(diff)) and rel_err(diff, want["diff"]) < TOL
     with pytest.raises(EesenError, match="above 1024"):
         ctc.EvalParallel([1300], CuMatrix(1300, K), [np.ones(600, np.int32)])
+
+
+def test_recovery_from_a_timed_out_persistent_kernel(gpu, monkeypatch, capfd):
+    """A cooperative recurrence kernel whose bounded spin gives up (here: a spin bound of one poll) must not corrupt the
+    model: the update of that step is skipped ON THE DEVICE, the handle falls back to the per-step kernels with a warning,
+    and training continues exactly as a per-step run from the same parameters would."""
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(max_grad=1.0, **cfg)
+    batch = synth.make_batch(**cfg)
+
+    def step(net, ctc):
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+        net.Backpropagate(diff)
+
+    monkeypatch.setenv("EESEN_SPIN_LIMIT", "1")
+    bad = Net.from_layers(layers); bad.SetTrainOptions(1e-3, 0.9); cb = Ctc()
+    monkeypatch.delenv("EESEN_SPIN_LIMIT")
+    p0 = bad.GetParams()
+    step(bad, cb)                                  # the persistent kernels give up: garbage gradients, update skipped
+    assert np.array_equal(bad.GetParams(), p0)     # (GetParams synchronises: the host notices and falls back here)
+    bad.RecurrenceInfo()
+    assert bad.recoveries == 1
+    assert "NOT applied" in capfd.readouterr().err
+    step(bad, cb)
+    assert bad.RecurrenceInfo()["fwd_persistent"] == 0 and bad.recoveries == 1
+    monkeypatch.setenv("EESEN_PERSISTENT", "0")
+    ref = Net.from_layers(layers); ref.SetTrainOptions(1e-3, 0.9); cr = Ctc()
+    step(ref, cr)
+    assert np.array_equal(bad.GetParams(), ref.GetParams())

@@ -68,3 +68,14 @@ def golden_masks(layers, g):
             fwd, rec = g[f"m{li}_fwd"], g[f"m{li}_rec"]
             out.append((li, fwd if fwd.size else None, rec if rec.size else None, int(g[f"m{li}_coin"])))
     return out
+
+
+def diff_bound(net_out, batch, diff32, tol=1e-4):
+    """Bar for comparing two fp32 evaluations of the CTC gradient `diff` = y*sum(gamma) - gamma, gamma = exp(alpha + beta - ln p - ln y):
+    the exponent carries the fp32 round-off of |alpha| ~ T, so two CORRECT fp32 evaluations with a different summation order
+    (the HIP bulk pass reduces the blank's positions across the wave, the reference folds them serially) differ by ~ulp(|alpha|)
+    relative: 1e-4 where that floor allows, else 3x the fp32 oracle's own distance to an fp64 evaluation on the same
+    probabilities.  Returns (bound, fp64 diff)."""
+    from oracle import net as onet
+    arb = onet.ctc_eval_parallel(net_out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off, "f64")
+    return max(tol, 3.0 * rel_err(diff32, arb["diff"])), arb["diff"]
