@@ -63,8 +63,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn, file=sys.stderr)
-    if jobs or force or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
+    if jobs or force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
+            ["-ldl", "-Wl,-Bsymbolic", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
     # host-only C++ tools over the C-ABI (no HIP in these sources): the reference's trainer binary, natively
     os.makedirs(BINDIR, exist_ok=True)
     cxx = shutil.which("g++") or "g++"

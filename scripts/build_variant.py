@@ -24,5 +24,6 @@ for s in B.SOURCES:
         subprocess.check_call([B.hipcc()] + defs + B.FLAGS + ["-c", os.path.join(ROOT, "eesen_amd", "csrc", s), "-o", obj])
     objs.append(obj)
 lib = os.path.join(out_dir, f"libeesen_hip_{name}.so")
-subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs +
+                      ["-ldl", "-Wl,-Bsymbolic", "-Wl,--version-script=" + os.path.join(ROOT, "eesen_amd", "csrc", "exports.map")])
 print(lib)

@@ -173,3 +173,39 @@ def test_native_net_output_extract_equals_python_mirror(gpu, tmp_path):
     a = dict(kaldi_io.read_mat_table("ark:" + o_cc))
     assert r3.returncode == 0 and all(np.array_equal(a[k], b[k]) for k in a)
     assert subprocess.run([exe, model], capture_output=True).returncode == 1
+
+
+def test_reference_trainer_source_compiled_against_the_seam(gpu, tmp_path):
+    """The C++ seam, COMPILED: oracle/_ref/train-ctc-parallel-seam is the reference's OWN src/netbin/train-ctc-parallel.cc,
+    unmodified, built by oracle/ref_build/Makefile against include/eesen_hip_net.h (eesen::Net / eesen::Ctc / CuMatrix over the
+    C-ABI; the reference's base / util / cpucompute stay).  Its loop (:144-215: the reference's own table readers, greedy
+    grouping, host padding + interleave) drives libeesen_hip.so; the native trainer of this repository must write the same
+    model, byte for byte, and report the same accuracy -- pipes (`ark:cat ... |`), --sequence-out-file and cross-validation included."""
+    seam = os.path.join(ROOT, "oracle", "_ref", "train-ctc-parallel-seam")
+    exe = os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")
+    if not os.path.exists(seam):
+        pytest.skip("oracle/_ref/train-ctc-parallel-seam is built where /root/reference exists (make -C oracle/ref_build seam)")
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    feats, labs, scp, lab = _dataset(tmp_path, D=cfg["D"], K=cfg["K"])
+    m_in = str(tmp_path / "nnet.init")
+    nnet_io.write_nnet(m_in, layers, binary=True)
+    opts = ["--learn-rate=0.01", "--momentum=0.9", "--num-sequence=4", "--frame-limit=90", "--report-step=4", "--verbose=1"]
+    ark = str(tmp_path / "feats.ark")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "eesen_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for fspec, lspec in (("scp:" + scp, "ark:" + lab), (f"ark:cat {ark} |", f"ark:cat {lab} |")):
+        o_ref, o_cc = str(tmp_path / "seam.nnet"), str(tmp_path / "cc.nnet")
+        s_ref, s_cc = str(tmp_path / "seq_seam.txt"), str(tmp_path / "seq_cc.txt")
+        r1 = subprocess.run([seam] + opts + ["--sequence-out-file=" + s_ref, fspec, lspec, m_in, o_ref], capture_output=True, text=True, timeout=600, env=env)
+        r2 = subprocess.run([exe] + opts + ["--sequence-out-file=" + s_cc, fspec, lspec, m_in, o_cc], capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-2500:], r2.stderr[-1500:])
+        assert open(o_ref, "rb").read() == open(o_cc, "rb").read()
+        acc = [re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r.stderr).group(1) for r in (r1, r2)]
+        assert acc[0] == acc[1]
+        assert "TRAINING STARTED" in r1.stderr and re.search(r"Done 14 files, 0 with no targets, 0 with other errors", r1.stderr)
+        assert open(s_ref).read() == open(s_cc).read() and open(s_ref).read().count("utt") == 14
+    cv = ["--cross-validate=true", "--num-sequence=4", "--frame-limit=90", "scp:" + scp, "ark:" + lab, o_ref]
+    r1 = subprocess.run([seam] + cv, capture_output=True, text=True, timeout=600, env=env)
+    r2 = subprocess.run([exe] + cv, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
+    assert re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r1.stderr).group(1) == re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r2.stderr).group(1)
