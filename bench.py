@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL communicator, per-layer gradient all-reduce) even with one rank (debug)")
+    ap.add_argument("--forward-precision", choices=["f32", "bf16"], default="f32",
+                    help="bf16: BASELINE config 4's variant -- forward GEMM operands rounded to bf16, one bf16 MFMA product, fp32 accumulate; "
+                         "never the headline (reported with dtype bf16-fwd/f32)")
     ap.add_argument("--comm", choices=["native", "bulk", "torch"], default="native",
                     help="gradient exchange: native = the library's RCCL communicator, one bucket per layer overlapped with the backward "
                          "pass (default); bulk = the same communicator, one all-reduce after the backward pass; torch = torch.distributed")
@@ -159,10 +162,13 @@ def main():
     batch = synth.make_batch(**{**cfg, "seed": 777 + rank})         # every rank its own shard of the global batch
     dev = local if multi else 0
 
-    def make_net():
+    def make_net(attach=True):
         n = Net.from_layers(layers, device=dev)
         n.SetTrainOptions(4e-5, 0.9)
         n.SetProfiling(True)
+        n.SetForwardPrecision(args.forward_precision == "bf16")
+        if not attach:
+            return n
         if comm is not None and args.comm == "native":
             n.SetComm(comm)                                   # per-layer buckets, overlapped with the backward pass
         elif comm is not None:
@@ -172,7 +178,7 @@ def main():
             n.grad_hook = GradAllReducer(n)
         return n
 
-    net = make_net()
+    net = make_net(attach=False)      # the probing step below runs WITHOUT the exchange: a rank that fails must not strand the others in a collective
     ctc = Ctc(device=dev)
     feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # inputs resident in HBM before the timed region
     diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
@@ -204,7 +210,7 @@ def main():
         ok = 1.0 - all_reduce([1.0 - ok], Comm.MAX)[0]        # any rank failed -> every rank falls back
     if ok == 0.0:
         os.environ["EESEN_PERSISTENT"] = "0"
-        net = make_net()
+    net = make_net()                  # same initial weights on every rank (seed 777), now with the gradient exchange attached
     for _ in range(args.warmup):
         step()
     barrier()
@@ -364,7 +370,7 @@ def main():
             "metric": "CTC training frames/sec (whole node), 4x512 BiLSTM",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seed 777: N(0,1) 40-d features, lengths U{0.8T..T}, T/10 labels per utterance, U(-0.1,0.1) weights)",
+            "dtype": "f32" if args.forward_precision == "f32" else "bf16-fwd/f32", "data": "synthetic (seed 777: N(0,1) 40-d features, lengths U{0.8T..T}, T/10 labels per utterance, U(-0.1,0.1) weights)",
             "config": {"workload": f"{args.config}: {nl}x{H} {'Bi' if nd == 2 else ''}LSTM + affine + softmax + CTC, D={cfg['D']}, K={cfg['K']}, "
                                    f"S={S} utterances/GPU, T_max={T}, SGD lr=4e-5 momentum=0.9 max_grad=50",
                        "global_batch_utterances": S * world, "parallelism": f"dp{world}",

@@ -50,6 +50,7 @@ SIGNATURES = {
     "eesen_net_grad_buffer": (_i, [_vp, C.POINTER(_vp), _pl]),
     "eesen_net_get_grads": (_i, [_vp, _vp, _l]),
     "eesen_net_update": (_i, [_vp]),
+    "eesen_net_set_forward_precision": (_i, [_vp, _i]),
     "eesen_net_recurrence_info": (_i, [_vp, _pi]),
     "eesen_net_synchronize": (_i, [_vp]),
     "eesen_net_set_profiling": (_i, [_vp, _i]),

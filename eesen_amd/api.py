@@ -341,6 +341,10 @@ class Net:
         check(self.lib.eesen_net_grad_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def SetForwardPrecision(self, bf16: bool):
+        """BASELINE config 4: forward GEMMs on bf16-rounded operands (one bf16 MFMA product, fp32 accumulate); everything else fp32."""
+        check(self.lib.eesen_net_set_forward_precision(self.h, int(bool(bf16))))
+
     def RecurrenceInfo(self) -> dict:
         """Which recurrence kernels the last Propagate / Backpropagate used (debug accessor)."""
         a = (C.c_int * 4)()

@@ -175,6 +175,9 @@ int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n) {
 int eesen_net_update(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->update(); });
 }
+int eesen_net_set_forward_precision(eesen_net_t* net, int bf16) {
+  return guard([&] { REQ_PTR(net); net->fwd_bf16 = bf16 != 0; });
+}
 int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {  // four ints
   return guard([&] {
     REQ_PTR(net); REQ_PTR(out3);

@@ -48,6 +48,7 @@ struct GemmParams {
   int tiles_n;
   int tiles_m;
   int gm;       // > 0: XCD-aware tile map with row groups of gm tiles (see tile_of); 0: row-major
+  int nprod;    // split kernel: 6 = fp32-class (hi/mid/lo cross products), 1 = bf16 x bf16 only (operands rounded to bf16)
   GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
 
@@ -442,6 +443,31 @@ __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char*
   *reinterpret_cast<uint2*>(dst + 2 * SP_PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
 }
 
+// nprod == 1 ("bf16 forward", BASELINE config 4): both operands rounded to nearest-even bf16, ONE MFMA product, fp32 accumulation.
+__device__ __forceinline__ unsigned rne_bf16_bits(float x) {
+  const unsigned b = __builtin_bit_cast(unsigned, x);
+  return b + 0x7fffu + ((b >> 16) & 1u);   // top 16 bits = round-to-nearest-even bf16
+}
+template <bool KC, bool GUARD>
+__device__ __forceinline__ void bf16_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, q;
+    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
+    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+    float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    if (GUARD) {
+      const bool ok = r0 + row < R;
+      const int k = k0 + q * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
+    }
+    const unsigned b0 = rne_bf16_bits(x[0]), b1 = rne_bf16_bits(x[1]), b2 = rne_bf16_bits(x[2]), b3 = rne_bf16_bits(x[3]);
+    *reinterpret_cast<uint2*>(base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8) =
+        make_uint2(__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u));
+  }
+}
+
 template <bool A_KC, bool B_KC, bool GUARD, bool GATED>
 __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   // stage s: A planes at s * 2 * SP_OP, B planes at s * 2 * SP_OP + SP_OP (indexed as an array, so the accesses stay ds_* ones)
@@ -504,6 +530,38 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads prefetched registers (a vmcnt wait) moves above them
   };
 
+  if (p.nprod == 1) {   // bf16 x bf16 only: the hi plane, one product, four MFMAs per k-tile
+    float4 ra[2], rb[2];
+    if (nk > 0) {
+      load(0, ra, rb);
+      bf16_store<A_KC, GUARD>(&lds[0], tid, ra, p.M, m0, kbeg, kend);
+      bf16_store<B_KC, GUARD>(&lds[SP_OP], tid, rb, p.N, n0, kbeg, kend);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = (kt & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
+      if (kt + 1 < nk) load(kt + 1, ra, rb);
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_off + i * 32 * 16]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_off + i * 32 * 16]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        bf16_store<A_KC, GUARD>(&lds[nxt], tid, ra, p.M, m0, kbeg + (kt + 1) * SBK, kend);
+        bf16_store<B_KC, GUARD>(&lds[nxt + SP_OP], tid, rb, p.N, n0, kbeg + (kt + 1) * SBK, kend);
+      }
+      __syncthreads();
+    }
+    gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
+    return;
+  }
 #if EESEN_SPLIT_PF2
   // Two k-tiles of HBM prefetch in registers: tile t+2 is requested right after tile t+1 has left its registers for LDS, and is
   // consumed two MFMA blocks later.  In the steady state (step<true>) the split of tile t+1 -- ~140 VALU instructions and 24
@@ -682,17 +740,18 @@ static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
 
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats,
-              int extra_lds_bytes) {
+              int extra_lds_bytes, bool bf16_operands) {
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
-  const bool use_split = gemm_mode() == 1 && !synth;
+  const bool use_split = (gemm_mode() == 1 || bf16_operands) && !synth;
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.alpha = alpha; p.beta = beta;
   p.gate = GemmGate{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  p.nprod = bf16_operands ? 1 : 6;
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
   p.tiles_n = tiles_n;
   p.tiles_m = tiles_m;
@@ -770,6 +829,7 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   p.alpha = 1.f; p.beta = 0.f;
   p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN; p.tiles_m = M / BM;
   p.gate = gate;
+  p.nprod = 6;
   unsigned gx = (unsigned)(p.tiles_m * p.tiles_n);
   p.gm = xcd_group_rows(p.tiles_m, p.tiles_n, &gx);
   // Occupancy cap: waiting tiles SPIN, so they must never keep the producing (cooperative) kernel's workgroups from

@@ -13,7 +13,8 @@ namespace eesen {
 // CuMatrixBase::AddMatMat (/root/reference/src/gpucompute/cuda-matrix.cc:604-639).
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
-              size_t ws_floats, int extra_lds_bytes = 0);  // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
+              size_t ws_floats, int extra_lds_bytes = 0,   // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
+              bool bf16_operands = false);                 // round both operands to bf16, one bf16 MFMA product, fp32 accumulate
 
 // Arithmetic of every gemm_f32 / gemm_f32_nt_gated call: 0 = f32-input MFMA, 1 = 3-way bf16 split (gemm.hip); -1 = follow
 // EESEN_GEMM_MODE.  Process-wide.

@@ -519,7 +519,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
         if (gated_rows < rows) {  // the last, partial row tile (T*S not a multiple of 128): its frames are the last to complete anyway
           const int ti_ = timer.begin(st, 0);
           gemm_f32(st, true, true, rows - gated_rows, ldG, L.din, 1.f, x + (size_t)gated_rows * ldx, ldx, params.p + L.p_off + L.off_wx,
-                   pad4(L.din), 0.f, L.G.p + (size_t)gated_rows * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0);
+                   pad4(L.din), 0.f, L.G.p + (size_t)gated_rows * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
           timer.end(st, ti_);
         }
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
@@ -527,7 +527,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       } else {
         const int ti_ = timer.begin(st, 0);
         gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
-                 params.p + L.p_off + L.off_bias, nullptr, 0);
+                 params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
         timer.end(st, ti_);
       }
       // The NEXT LSTM layer's input GEMM can run on the side stream WHILE this layer's persistent kernel is running:
@@ -538,7 +538,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       // (with forward dropout the next layer reads the MASKED output, which exists only after the recurrence: no gating)
       // (the 16-unit tile of wide layers fills the register file -- 2 x 206 VGPRs per SIMD -- so spinning GEMM workgroups
       // could keep its cooperative kernel from becoming resident: no gating there)
-      const bool plan_gate = persistent && overlap && gate_fwd && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows >= 128 &&
+      const bool plan_gate = persistent && overlap && gate_fwd && !fwd_bf16 && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows >= 128 &&
                              lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
       { const int ti_ = timer.begin(st, 1);
@@ -573,7 +573,7 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
       { const int ti_ = timer.begin(st, 2);
       gemm_f32(st, true, true, rows, L.dout, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, L.out.p, ldo,
-               params.p + L.p_off + L.off_b, nullptr, 0);
+               params.p + L.p_off + L.off_b, nullptr, 0, 0, fwd_bf16);
       timer.end(st, ti_); }
       x = L.out.p;
       ldx = ldo;

@@ -96,6 +96,7 @@ struct Net {
   bool overlap = true;
   hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated input GEMM of the next layer (forward)
   bool gate_fwd = true;
+  bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1): forward GEMMs on bf16-rounded operands (BASELINE config 4)
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
   int info_fwd_persistent = 0, info_bwd_persistent = 0, info_lstm_layers = 0;   // of the last Propagate / Backpropagate (tests)

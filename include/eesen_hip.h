@@ -133,6 +133,13 @@ int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n);
  * affine-trans-layer.h:174-195): corr = momentum*corr + fresh; clip corr to +-max_grad if
  * max_grad > 0; param -= learn_rate*learn_rate_coef*corr. */
 int eesen_net_update(eesen_net_t* net);
+/* BASELINE config 4's "bf16 forward / fp32 CTC accumulate" variant (no counterpart in the reference, whose BaseFloat is float,
+ * src/base/kaldi-types.h:26-30): with bf16 != 0 the GEMMs of Propagate (input->gates, affine / projection) round both
+ * operands to nearest-even bf16 and run ONE v_mfma_f32_32x32x16_bf16 product with fp32 accumulation; the time recurrence
+ * (m_{t-1} W_m), softmax, CTC, the whole backward pass and the update stay fp32.  Default 0.  Tolerance against the fp32
+ * path: tests/test_gpu_gemm.py::test_bf16_forward_variant (measured at cfg4 width, profiles/r02_bf16_forward.json: 8e-4 on ln p,
+ * 8e-3 on the softmax outputs, ~1e-2 on the gradient tensors). */
+int eesen_net_set_forward_precision(eesen_net_t* net, int bf16);
 /* Debug / test accessor: out4 = {LSTM layers, layers whose forward time loop ran as ONE cooperative launch per sequence
  * window (lstm_persistent.hip), layers whose backward time loop did} for the last Propagate / Backpropagate (the rest
  * took the one-launch-per-step kernels), and the number of recoveries so far.  A recovery: a cooperative recurrence

@@ -94,3 +94,39 @@ def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
     finally:
         gpu.eesen_set_gemm_mode(-1)
     assert rel_err(grads[1], grads[0]) < 2e-5
+
+
+def test_bf16_forward_variant(gpu):
+    """BASELINE config 4's "bf16 forward / fp32 CTC accumulate" (eesen_net_set_forward_precision): forward GEMM operands rounded
+    to bf16, everything else fp32.  No reference counterpart exists (BaseFloat = float), so the statement is a MEASURED distance
+    to the fp32 path at cfg4's layer width (1024 cells + 512-d projections), written to gpurun_out/bf16_forward.json:
+    ln p within 1e-2 relative, softmax outputs within 5e-2 of their maximum, gradient tensors within 0.15 (max-norm relative;
+    a bf16 operand carries 2^-9 = 2e-3 relative rounding, which the recurrence amplifies over the layers)."""
+    from eesen_amd import synth
+    from eesen_amd.api import Net, Ctc
+    from tests.util import rel_err, valid_mask, split_params
+    cfg = synth.config("cfg4"); cfg.update(T=120, S=16, layers=3)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    res = {}
+    for bf16 in (False, True):
+        net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
+        net.SetForwardPrecision(bf16)
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+        net.BackpropagateNoUpdate(diff)
+        res[bf16] = (out.numpy(), ctc.pzx.copy(), net.GetGrads())
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    rep = dict(config="cfg4 width: 3 x 1024-cell BiLSTM + 512-d projections, S=16, T=120",
+               ln_p=rel_err(res[True][1], res[False][1]), net_out=rel_err(res[True][0][vm], res[False][0][vm]),
+               grads={f"L{li}.{nm}": rel_err(a, b) for (li, nm, a), (_, _, b) in zip(split_params(layers, res[True][2]), split_params(layers, res[False][2]))})
+    try:
+        out_dir = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
+        os.makedirs(out_dir, exist_ok=True)
+        json.dump(rep, open(os.path.join(out_dir, "bf16_forward.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert not np.array_equal(res[True][0], res[False][0])          # the option does something
+    assert rep["ln_p"] < 1e-2 and rep["net_out"] < 5e-2
+    assert max(rep["grads"].values()) < 0.15, rep["grads"]
