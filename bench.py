@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="profiling runs: skip the secondary legs (f32-MFMA-GEMM comparison, PCIe-inclusive loop, standalone GEMM, CPU baseline)")
     ap.add_argument("--T", type=int, default=0, help="override T_max (debug)")
     ap.add_argument("--H", type=int, default=0, help="override cells per direction (debug)")
     ap.add_argument("--S", type=int, default=0, help="override utterances per GPU (debug)")
@@ -238,7 +240,7 @@ def main():
     # chain) instead of the default 3-way bf16 split (fp32-class accuracy on the bf16 matrix pipe, tests/test_gpu_gemm.py) -- so
     # that both arithmetic modes are on record from the same box and process.
     f32_only = None
-    if world == 1 and os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"):
+    if world == 1 and not args.main_only and os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"):
         lib = _lib.load()
         _lib.check(lib.eesen_set_gemm_mode(0))
         try:
@@ -260,7 +262,7 @@ def main():
     # Not the headline: the same K steps with the features handed over as HOST matrices each step (what the trainer does):
     # packed into the feeder's pinned slot, copied and interleaved on its own stream while the previous step trains.
     pcie_fps = None
-    if world == 1:
+    if world == 1 and not args.main_only:
         from eesen_amd.api import Feeder
         f3 = batch.feats.reshape(batch.T, batch.S, cfg["D"])
         mats = [np.ascontiguousarray(f3[: batch.lens[s], s, :]) for s in range(batch.S)]
@@ -325,6 +327,8 @@ def main():
         # are GATED on the recurrence's arrival counters and run under it, so their in-step duration says nothing about the
         # matrix pipe.  This is the figure to hold against the >= 60 % MFMA target on the gate GEMMs.
         try:
+            if args.main_only:
+                raise RuntimeError("skipped (--main-only)")
             import ctypes as C
             Mg, Ng, Kg = T * S, nd * 4 * H, nd * H
             rg = np.random.default_rng(1)   # random operands: all-zero inputs would flatter the clocks
@@ -388,7 +392,7 @@ def main():
             "phase_ms_per_step": {k: 1e3 * v / K for k, v in {**phases, **{'ctc_' + a: b for a, b in ctc_ph.items()}}.items()},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.main_only:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
