@@ -48,6 +48,7 @@ struct GemmParams {
   int tiles_n;
   int tiles_m;
   int gm;       // > 0: XCD-aware tile map with row groups of gm tiles (see tile_of); 0: row-major
+  int bm, bn;   // output tile of the kernel flavour being launched (128 x 128, or 256 x 256 for the big split kernel)
   int nprod;    // split kernel: 6 = fp32-class (hi/mid/lo cross products), 1 = bf16 x bf16 only (operands rounded to bf16)
   GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
@@ -143,9 +144,11 @@ __device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const 
   }
 }
 
-// C/D map of the 32x32 MFMA (all input types): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int split, int wm,
-                                              int wn, int lr, int lk) {
+// C/D map of the 32x32 MFMA (all input types): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// row_w / col_w: offset of this wave's BMW x BNW blocks inside the workgroup's tile.
+template <int BMW, int BNW>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[BMW][BNW], int m0, int n0, int split, int row_w,
+                                              int col_w, int lr, int lk) {
   float* C = p.C;
   size_t ldc = p.ldc;
   const bool partial = p.splits > 1;
@@ -154,15 +157,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
     ldc = p.N;
   }
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < BMW; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn * 64 + ni * 32 + lr;
+    for (int ni = 0; ni < BNW; ++ni) {
+      const int col = n0 + col_w + ni * 32 + lr;
       if (col >= p.N) continue;
       const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + row_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= p.M) continue;
         float* dst = C + (size_t)row * ldc + col;
         if (partial) {
@@ -192,11 +195,11 @@ __device__ __forceinline__ bool gemm_prologue(const GemmParams& p, int& m0, int&
     if (i < 2 * pairs) tm = (i & 1) ? mid - (i + 1) / 2 : mid + i / 2;
     else tm = hi_cnt > lo_cnt ? mid + (i - pairs) : mid - 1 - (i - pairs);
   }
-  m0 = tm * BM; n0 = tn * BN;
+  m0 = tm * p.bm; n0 = tn * p.bn;
   if (GATED) {
     __shared__ int s_go;
     const GemmGate& g = p.gate;
-    const int t_lo = m0 / g.S, t_hi = min(p.M - 1, m0 + BM - 1) / g.S;
+    const int t_lo = m0 / g.S, t_hi = min(p.M - 1, m0 + p.bm - 1) / g.S;
     if (wave == 0) {
       const int groups = g.ndir * g.nz;
       const bool mine = lane < groups * kShards;
@@ -284,7 +287,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
     __syncthreads();
   }
 
-  gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
+  gemm_epilogue<2, 2>(p, acc, m0, n0, split, wm * 64, wn * 64, lr, lk);
 }
 
 // GUARD = false is launched only when EVERY tile of the grid is interior and every split holds whole k-tiles (decided on
@@ -319,41 +322,59 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
 // LDS: per operand and stage 3 planes (hi, mid, lo) x 2 k-halves x 128 rows x 8 bf16 (16 B): lane l of an MFMA reads row
 // l & 31, k-half l >> 5 with ONE conflict-free ds_read_b128 (consecutive rows are consecutive 16-byte slots); the k-halves
 // are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
-#ifndef EESEN_SPLIT_PF2
-#define EESEN_SPLIT_PF2 1   // measured (profiles/r02_gemm_variants.md): 171 -> 178 TF, with three workgroups per CU 189 TF
-#endif
-#ifndef EESEN_SPLIT_VPM
-#define EESEN_SPLIT_VPM 6
-#endif
 #ifndef EESEN_SPLIT_MINW
-#define EESEN_SPLIT_MINW 3
+#define EESEN_SPLIT_MINW 3   // measured (profiles/r02_gemm_variants.md): 171 -> 178 TF with two tiles of prefetch, 189 with three workgroups per CU
 #endif
-constexpr int SP_HS = 128 * 16 + 64;        // bytes per k-half (128 rows x 16 B, + 16 banks)
-constexpr int SP_PS = 2 * SP_HS;            // bytes per plane
-constexpr int SP_OP = 3 * SP_PS;            // bytes per operand per stage
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// (row, k-quad) units: each thread brings 2 units of 4 consecutive-k floats per operand and k-tile.
-//   KC (k contiguous in HBM):  unit f = tid + 256 i -> row f >> 2, quad f & 3: one float4
-//   !KC (row contiguous):      row tid & 127, quad (tid >> 7) + 2 i: four dword loads, coalesced along the rows
+// Geometry of one split-kernel flavour.  TM x TN output tile, WGM x WGN waves, each wave (TM/WGM) x (TN/WGN) = BMW x BNW MFMA
+// blocks of 32 x 32.  Two flavours are built:
+//   128 x 128, 2 x 2 waves (256 threads, 24 MFMAs per wave and k-tile): <= 168 VGPRs, three workgroups per CU or ONE beside a
+//     512-thread recurrence workgroup -- the side-stream (overlapped) GEMMs and everything small;
+//   256 x 256, 2 x 4 waves (512 threads, 48 MFMAs per wave and k-tile): the same 16 floats to split per thread for twice the
+//     MFMAs -- the kernel is bound by the SIMD issue port (split instructions), not by the matrix pipe -- one workgroup per
+//     CU: the main-stream GEMMs of large shapes.
+template <int TM_, int TN_, int WGM_, int WGN_>
+struct SplitGeo {
+  static constexpr int TM = TM_, TN = TN_, WGM = WGM_, WGN = WGN_;
+  static constexpr int THREADS = WGM * WGN * 64;
+  static constexpr int BMW = TM / WGM / 32, BNW = TN / WGN / 32;
+  static constexpr int UA = TM * 4 / THREADS, UB = TN * 4 / THREADS;   // (row, k-quad) units per thread and k-tile, per operand
+  static constexpr int HS_A = TM * 16 + 64, HS_B = TN * 16 + 64;       // bytes per k-half (rows x 16 B, + 16 banks)
+  static constexpr int PS_A = 2 * HS_A, PS_B = 2 * HS_B;               // bytes per plane
+  static constexpr int OP_A = 3 * PS_A, OP_B = 3 * PS_B;               // bytes per operand and stage
+  static constexpr int STAGE = OP_A + OP_B;
+  static constexpr int NMFMA = 6 * BMW * BNW;                          // per wave and k-tile
+  static_assert(UA == 2 && UB == 2, "the k loop below is written for two units per thread and operand");
+};
+using GeoSmall = SplitGeo<128, 128, 2, 2>;
+using GeoBig = SplitGeo<256, 256, 2, 4>;
+
+// (row, k-quad) units of an operand tile of ROWS rows x 16 k: each thread brings 2 units of 4 consecutive-k floats per k-tile.
+//   KC (k contiguous in HBM):  unit f = tid + THREADS i -> row f >> 2, quad f & 3: one float4
+//   !KC (row contiguous):      row tid % ROWS, quad tid / ROWS + (THREADS / ROWS) i: four dword loads, coalesced along the rows
+template <bool KC, int THREADS, int ROWS>
+__device__ __forceinline__ void unit_of(int tid, int i, int& row, int& q) {
+  if (KC) { const int f = tid + i * THREADS; row = f >> 2; q = f & 3; }
+  else { row = tid % ROWS; q = tid / ROWS + (THREADS / ROWS) * i; }
+}
+
 // Branch-free on purpose (see load_tile): a guarded load makes hipcc wait for every load separately, which serialises the
-// HBM latency of the four loads of a k-tile (measured: the first, branchy version of this kernel ran at 106 TF, BELOW the
-// f32 kernel).  Out-of-range rows / k are clamped to a valid address and zeroed by selects afterwards.
-// Branch-free on purpose (see load_tile): a guarded load makes hipcc wait for every load separately, which serialises the
-// HBM latency of the four loads of a k-tile.  Out-of-range rows / k are clamped to a valid address here; split_store zeroes
+// HBM latency of the four loads of a k-tile.  Out-of-range rows / k are clamped to a valid address here; the store side zeroes
 // them -- AFTER the MFMA block, so that nothing touches the loaded registers (and waits for them) before it.
-template <bool KC>
+template <bool KC, int THREADS, int ROWS>
 __device__ __forceinline__ void split_load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, int tid,
                                            float4 (&v)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    int row, q;
+    unit_of<KC, THREADS, ROWS>(tid, i, row, q);
+    const int r = r0 + row, k = k0 + (q << 2);
     if (KC) {
-      const int f = tid + i * 256, r = r0 + (f >> 2), k = k0 + ((f & 3) << 2);
       // rows are padded to a multiple of 4 floats (ld % 4 == 0, checked on the host), so k + 3 < ld whenever k < K
       const int kc = min(k, max(kend - 1, 0) & ~3);
       v[i] = *reinterpret_cast<const float4*>(P + (size_t)min(r, R - 1) * ld + kc);
     } else {
-      const int r = r0 + (tid & 127), k = k0 + (((tid >> 7) + 2 * i) << 2);
       const float* col = P + min(r, R - 1);
       const int kl = max(kend - 1, 0);
       v[i].x = col[(size_t)min(k + 0, kl) * ld];
@@ -370,37 +391,8 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b) {
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u); }
 
-template <bool KC, bool GUARD>
-__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row, q;
-    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
-    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
-    float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-    if (GUARD) {
-      const bool ok = r0 + row < R;
-      const int k = k0 + q * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
-    }
-    float hi[4], mid[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hi[j] = trunc_bf16(x[j]);
-      const float r1 = x[j] - hi[j];     // exact
-      mid[j] = trunc_bf16(r1);
-      lo[j] = r1 - mid[j];               // exact; its own top 16 bits are taken by the pack below
-    }
-    unsigned char* dst = base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8;
-    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]));
-    *reinterpret_cast<uint2*>(dst + SP_PS) = make_uint2(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]));
-    *reinterpret_cast<uint2*>(dst + 2 * SP_PS) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
-  }
-}
-
-// The same split in three stages per (row, k-quad) unit, so that the k loop can place each stage in the shadow of MFMAs
-// (see gemm_split_body): A: guard, hi plane, first residual; B: mid plane, second residual; C: lo plane + the three LDS writes.
+// The split in three stages per unit, so that the k loop can place each stage in the shadow of MFMAs: A: guard, hi plane, first
+// residual; B: mid plane, second residual; C: lo plane + the three LDS writes.
 struct SplitUnit {
   float r[4];
   unsigned ph[2], pm[2];
@@ -409,13 +401,12 @@ struct SplitUnit {
 // to its first use, i.e. behind the MFMAs it is meant to hide under.  An empty volatile asm that takes the values as
 // read-write operands is a use at this point, and it keeps its place among the scheduling fences.
 #define EESEN_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
-template <bool KC, bool GUARD>
+template <bool KC, bool GUARD, int THREADS, int ROWS>
 __device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int i, int tid, int R, int r0, int k0, int kend) {
   float x[4] = {v.x, v.y, v.z, v.w};
   if (GUARD) {
     int row, q;
-    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
-    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+    unit_of<KC, THREADS, ROWS>(tid, i, row, q);
     const bool ok = r0 + row < R;
     const int k = k0 + q * 4;
 #pragma unroll
@@ -432,15 +423,25 @@ __device__ __forceinline__ void split_stage_b(SplitUnit& u) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) u.r[j] = u.r[j] - trunc_bf16(u.r[j]);   // exact; the lo plane takes its top 16 bits
 }
-template <bool KC>
+template <bool KC, int THREADS, int ROWS>
 __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char* base, int i, int tid) {
+  constexpr int HS = ROWS * 16 + 64, PS = 2 * HS;
   int row, q;
-  if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
-  else { row = tid & 127; q = (tid >> 7) + 2 * i; }
-  unsigned char* dst = base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8;
+  unit_of<KC, THREADS, ROWS>(tid, i, row, q);
+  unsigned char* dst = base + (q >> 1) * HS + row * 16 + (q & 1) * 8;
   *reinterpret_cast<uint2*>(dst) = make_uint2(u.ph[0], u.ph[1]);
-  *reinterpret_cast<uint2*>(dst + SP_PS) = make_uint2(u.pm[0], u.pm[1]);
-  *reinterpret_cast<uint2*>(dst + 2 * SP_PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
+  *reinterpret_cast<uint2*>(dst + PS) = make_uint2(u.pm[0], u.pm[1]);
+  *reinterpret_cast<uint2*>(dst + 2 * PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
+}
+template <bool KC, bool GUARD, int THREADS, int ROWS>
+__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    SplitUnit u;
+    split_stage_a<KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend);
+    split_stage_b(u);
+    split_stage_c<KC, THREADS, ROWS>(u, base, i, tid);
+  }
 }
 
 // nprod == 1 ("bf16 forward", BASELINE config 4): both operands rounded to nearest-even bf16, ONE MFMA product, fp32 accumulation.
@@ -448,13 +449,13 @@ __device__ __forceinline__ unsigned rne_bf16_bits(float x) {
   const unsigned b = __builtin_bit_cast(unsigned, x);
   return b + 0x7fffu + ((b >> 16) & 1u);   // top 16 bits = round-to-nearest-even bf16
 }
-template <bool KC, bool GUARD>
+template <bool KC, bool GUARD, int THREADS, int ROWS>
 __device__ __forceinline__ void bf16_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
+  constexpr int HS = ROWS * 16 + 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int row, q;
-    if (KC) { const int f = tid + i * 256; row = f >> 2; q = f & 3; }
-    else { row = tid & 127; q = (tid >> 7) + 2 * i; }
+    unit_of<KC, THREADS, ROWS>(tid, i, row, q);
     float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
     if (GUARD) {
       const bool ok = r0 + row < R;
@@ -463,17 +464,18 @@ __device__ __forceinline__ void bf16_store(unsigned char* base, int tid, const f
       for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
     }
     const unsigned b0 = rne_bf16_bits(x[0]), b1 = rne_bf16_bits(x[1]), b2 = rne_bf16_bits(x[2]), b3 = rne_bf16_bits(x[3]);
-    *reinterpret_cast<uint2*>(base + (q >> 1) * SP_HS + row * 16 + (q & 1) * 8) =
+    *reinterpret_cast<uint2*>(base + (q >> 1) * HS + row * 16 + (q & 1) * 8) =
         make_uint2(__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u));
   }
 }
 
-template <bool A_KC, bool B_KC, bool GUARD, bool GATED>
+template <class G, bool A_KC, bool B_KC, bool GUARD, bool GATED>
 __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
-  // stage s: A planes at s * 2 * SP_OP, B planes at s * 2 * SP_OP + SP_OP (indexed as an array, so the accesses stay ds_* ones)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * SP_OP];
+  constexpr int TM = G::TM, TN = G::TN, TH = G::THREADS, BMW = G::BMW, BNW = G::BNW;
+  // stage s: A planes at s * STAGE, B planes at s * STAGE + OP_A (indexed as an array, so the accesses stay ds_* ones)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / G::WGN, wn = wave % G::WGN;
   int m0, n0;
   if (!gemm_prologue<GATED>(p, m0, n0)) return;
   const int split = blockIdx.y;
@@ -481,138 +483,137 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   const int kend = min(p.K, kbeg + p.k_chunk);
   constexpr int SBK = 16;
 
-  f32x16 acc[2][2];
+  f32x16 acc[BMW][BNW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < BMW; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < BNW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (kend - kbeg + SBK - 1) / SBK;
   const int lr = lane & 31, lk = lane >> 5;
-  const int a_off = lk * SP_HS + (wm * 64 + lr) * 16, b_off = SP_OP + lk * SP_HS + (wn * 64 + lr) * 16;
+  const int a_off = lk * G::HS_A + (wm * (TM / G::WGM) + lr) * 16, b_off = G::OP_A + lk * G::HS_B + (wn * (TN / G::WGN) + lr) * 16;
 
-  // tile t of the k loop: HBM -> registers / registers -> split -> LDS stage / LDS stage -> 24 MFMAs
+  // tile t of the k loop: HBM -> registers / registers -> split -> LDS stage / LDS stage -> NMFMA MFMAs
   auto load = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
-    split_load<A_KC>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
-    split_load<B_KC>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
+    split_load<A_KC, TH, TM>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
+    split_load<B_KC, TH, TN>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
   };
   auto store = [&](int t, const float4 (&ra)[2], const float4 (&rb)[2]) {
-    const int st = (t & 1) * 2 * SP_OP;
-    split_store<A_KC, GUARD>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend);
-    split_store<B_KC, GUARD>(&lds[st + SP_OP], tid, rb, p.N, n0, kbeg + t * SBK, kend);
+    const int st = (t & 1) * G::STAGE;
+    split_store<A_KC, GUARD, TH, TM>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend);
+    split_store<B_KC, GUARD, TH, TN>(&lds[st + G::OP_A], tid, rb, p.N, n0, kbeg + t * SBK, kend);
   };
-  auto compute_issue = [&](int t) {   // fragment reads + the 24 MFMAs of tile t (no scheduling fence behind them)
-    const int cur = (t & 1) * 2 * SP_OP;
-    bf16x8 a[2][3], b[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + a_off + i * 32 * 16]);
-        b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + b_off + i * 32 * 16]);
-      }
-    __builtin_amdgcn_sched_barrier(0);  // global prefetches and fragment reads are issued before the MFMA block
-    // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi'; the four output blocks in turn,
-    // so that dependent MFMAs are four issues apart
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-    for (int t6 = 0; t6 < 6; ++t6)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
-  };
-  auto compute = [&](int t) {
-    compute_issue(t);
-    __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads prefetched registers (a vmcnt wait) moves above them
-  };
+  // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi'; the output blocks in turn, so that
+  // dependent MFMAs are BMW * BNW issues apart
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 
-  if (p.nprod == 1) {   // bf16 x bf16 only: the hi plane, one product, four MFMAs per k-tile
+  if (p.nprod == 1) {   // bf16 x bf16 only: the hi plane, one product
     float4 ra[2], rb[2];
     if (nk > 0) {
       load(0, ra, rb);
-      bf16_store<A_KC, GUARD>(&lds[0], tid, ra, p.M, m0, kbeg, kend);
-      bf16_store<B_KC, GUARD>(&lds[SP_OP], tid, rb, p.N, n0, kbeg, kend);
+      bf16_store<A_KC, GUARD, TH, TM>(&lds[0], tid, ra, p.M, m0, kbeg, kend);
+      bf16_store<B_KC, GUARD, TH, TN>(&lds[G::OP_A], tid, rb, p.N, n0, kbeg, kend);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-      const int cur = (kt & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
+      const int cur = (kt & 1) * G::STAGE, nxt = G::STAGE - cur;
       if (kt + 1 < nk) load(kt + 1, ra, rb);
-      bf16x8 a[2], b[2];
+      bf16x8 a[BMW], b[BNW];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_off + i * 32 * 16]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_off + i * 32 * 16]);
-      }
+      for (int i = 0; i < BMW; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + a_off + i * 32 * 16]);
+#pragma unroll
+      for (int i = 0; i < BNW; ++i) b[i] = *reinterpret_cast<const bf16x8*>(&lds[cur + b_off + i * 32 * 16]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < BMW; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < BNW; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) {
-        bf16_store<A_KC, GUARD>(&lds[nxt], tid, ra, p.M, m0, kbeg + (kt + 1) * SBK, kend);
-        bf16_store<B_KC, GUARD>(&lds[nxt + SP_OP], tid, rb, p.N, n0, kbeg + (kt + 1) * SBK, kend);
+        bf16_store<A_KC, GUARD, TH, TM>(&lds[nxt], tid, ra, p.M, m0, kbeg + (kt + 1) * SBK, kend);
+        bf16_store<B_KC, GUARD, TH, TN>(&lds[nxt + G::OP_A], tid, rb, p.N, n0, kbeg + (kt + 1) * SBK, kend);
       }
       __syncthreads();
     }
-    gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
+    gemm_epilogue<BMW, BNW>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk);
     return;
   }
-#if EESEN_SPLIT_PF2
+
   // Two k-tiles of HBM prefetch in registers: tile t+2 is requested right after tile t+1 has left its registers for LDS, and is
-  // consumed two MFMA blocks later.  In the steady state (step<true>) the split of tile t+1 -- ~140 VALU instructions and 24
-  // ds_write_b64 per wave -- is INTERLEAVED with the 24 MFMAs of tile t inside the same wave: MFMA and VALU share the SIMD's
-  // issue port (one 4-cycle slot each; a 32-cycle MFMA leaves room for ~5-6 others), and with the split after the MFMA block
-  // the port, not the matrix pipe, was the limit (PMC: matrix pipe 55 % busy, VALU 40 %, summing to ~100 %).
+  // consumed two MFMA blocks later.  In the steady state the split of tile t+1 -- ~90 VALU instructions and 12 ds_write_b64 per
+  // thread -- is INTERLEAVED with the MFMAs of tile t inside the same wave: MFMA and VALU share the SIMD's issue port (one
+  // 4-cycle slot each; a 32-cycle MFMA leaves room for ~5-6 others), and with the split after the MFMA block the port, not the
+  // matrix pipe, was the limit (PMC: matrix pipe 55 % busy, VALU 40 %, summing to ~100 %).
   float4 ra0[2], rb0[2], ra1[2], rb1[2];
-  // steady state: MFMAs of tile t with the split of tile t + 1 in their shadow -- per unit  M M [A]  M M [B]  M M [C], every
-  // bracket ~10 VALU (40 issue cycles) behind two 32-cycle MFMAs; scheduling fences pin the order
+  // fragments of tile t: every plane of every block row / column of this wave
+  auto frags = [&](int t, bf16x8 (&a)[BMW][3], bf16x8 (&b)[BNW][3]) {
+    const int cur = (t & 1) * G::STAGE;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < BMW; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * G::PS_A + a_off + i * 32 * 16]);
+#pragma unroll
+      for (int i = 0; i < BNW; ++i) b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * G::PS_B + b_off + i * 32 * 16]);
+    }
+  };
+  // steady state: MFMAs of tile t with the split of tile t + 1 in their shadow -- per unit  M..M [A]  M..M [B]  M..M [C], every
+  // bracket ~10 VALU (40 issue cycles) behind NMFMA / 12 32-cycle MFMAs; scheduling fences pin the order
   auto fused = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
-    const int cur = (t & 1) * 2 * SP_OP, nxt = 2 * SP_OP - cur;
+    const int nxt = G::STAGE - (t & 1) * G::STAGE;
     const int k1 = kbeg + (t + 1) * SBK;
-    bf16x8 a[2][3], b[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + a_off + i * 32 * 16]);
-        b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * SP_PS + b_off + i * 32 * 16]);
-      }
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-    auto mm = [&](int idx) {   // MFMA number idx of the tile: product idx / 4, output block idx % 4
-      const int t6 = idx >> 2, mi = (idx >> 1) & 1, ni = idx & 1;
+    bf16x8 a[BMW][3], b[BNW][3];
+    frags(t, a, b);
+    auto mm = [&](int idx) {   // MFMA number idx of the tile: product idx / (BMW * BNW), output block idx % (BMW * BNW)
+      const int t6 = idx / (BMW * BNW), blk = idx % (BMW * BNW), mi = blk / BNW, ni = blk % BNW;
       acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
     };
+    constexpr int PER = G::NMFMA / 12;   // MFMAs next to every split stage
     SplitUnit su;
+    // (Running every bracket BEFORE its MFMA group in the upper half of the waves, so that the two waves of a SIMD alternate
+    // between multiplying and splitting, was measured on the eight-wave flavour: 204 vs 203 TF -- not kept.)
+    auto group = [&](int g) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) mm(g * PER + j);
+    };
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       __builtin_amdgcn_sched_barrier(0);
-      mm(6 * u + 0); mm(6 * u + 1);
+      group(3 * u);
       __builtin_amdgcn_sched_barrier(0);
-      if (u < 2) split_stage_a<A_KC, GUARD>(su, ra[u], u, tid, p.M, m0, k1, kend);
-      else split_stage_a<B_KC, GUARD>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend);
+      if (u < 2) split_stage_a<A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend);
+      else split_stage_a<B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend);
       EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
       __builtin_amdgcn_sched_barrier(0);
-      mm(6 * u + 2); mm(6 * u + 3);
+      group(3 * u + 1);
       __builtin_amdgcn_sched_barrier(0);
       split_stage_b(su);
       EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.pm[0], su.pm[1]);
       __builtin_amdgcn_sched_barrier(0);
-      mm(6 * u + 4); mm(6 * u + 5);
+      group(3 * u + 2);
       __builtin_amdgcn_sched_barrier(0);
-      if (u < 2) split_stage_c<A_KC>(su, &lds[nxt], u, tid);
-      else split_stage_c<B_KC>(su, &lds[nxt + SP_OP], u - 2, tid);
+      if (u < 2) split_stage_c<A_KC, TH, TM>(su, &lds[nxt], u, tid);
+      else split_stage_c<B_KC, TH, TN>(su, &lds[nxt + G::OP_A], u - 2, tid);
     }
     __builtin_amdgcn_sched_barrier(0);
     load(t + 3, ra, rb);
     __syncthreads();
   };
   auto step = [&](int t, float4 (&ra)[2], float4 (&rb)[2], bool do_store, bool do_load) {
-    compute(t);
+    {
+      bf16x8 a[BMW][3], b[BNW][3];
+      frags(t, a, b);
+      __builtin_amdgcn_sched_barrier(0);  // global prefetches and fragment reads are issued before the MFMA block
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int mi = 0; mi < BMW; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < BNW; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads prefetched registers (a vmcnt wait) moves above them
+    }
     if (do_store) store(t + 1, ra, rb);
     if (do_load) load(t + 3, ra, rb);
     __syncthreads();
@@ -630,26 +631,20 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     step(kt, ra0, rb0, kt + 1 < nk, kt + 3 < nk);
     if (kt + 1 < nk) step(kt + 1, ra1, rb1, kt + 2 < nk, kt + 4 < nk);
   }
-#else
-  float4 ra[2], rb[2];
-  if (nk > 0) { load(0, ra, rb); store(0, ra, rb); }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load(kt + 1, ra, rb);
-    compute(kt);
-    if (kt + 1 < nk) store(kt + 1, ra, rb);
-    __syncthreads();
-  }
-#endif
-  gemm_epilogue(p, acc, m0, n0, split, wm, wn, lr, lk);
+  gemm_epilogue<BMW, BNW>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk);
 }
 
 template <bool A_KC, bool B_KC, bool GUARD>
 __global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_kernel(GemmParams p) {
-  gemm_split_body<A_KC, B_KC, GUARD, false>(p);
+  gemm_split_body<GeoSmall, A_KC, B_KC, GUARD, false>(p);
 }
 __global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
-  gemm_split_body<true, true, false, true>(p);
+  gemm_split_body<GeoSmall, true, true, false, true>(p);
+}
+// 256 x 256 tiles, eight waves: unguarded shapes only (every tile interior, whole k-tiles; the host checks)
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_f32_split_bf16_big_kernel(GemmParams p) {
+  gemm_split_body<GeoBig, A_KC, B_KC, false, false>(p);
 }
 
 // Interference probes (EESEN_GEMM_SYNTH=1|2|3, side-stream launches only; results are garbage, timing experiments only):
@@ -752,13 +747,21 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   p.alpha = alpha; p.beta = beta;
   p.gate = GemmGate{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   p.nprod = bf16_operands ? 1 : 6;
-  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+  // The 256 x 256 flavour of the split kernel: main-stream GEMMs (no occupancy cap requested) of shapes made of whole big tiles.
+  // A side-stream GEMM has to fit beside a 512-thread recurrence workgroup (<= 168 VGPRs x one wave per SIMD): small flavour.
+  static const int big_env = getenv("EESEN_GEMM_BIG") ? atoi(getenv("EESEN_GEMM_BIG")) : 1;
+  const bool big = use_split && big_env && !bf16_operands && extra_lds_bytes == 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 &&
+                   (long)(M / 256) * (N / 256) >= 16;
+  const int TB = big ? 256 : BM;
+  p.bm = p.bn = TB;
+  const int tiles_m = cdiv(M, TB), tiles_n = cdiv(N, TB);
   p.tiles_n = tiles_n;
   p.tiles_m = tiles_m;
   const long tiles = (long)tiles_m * tiles_n;
   // split-K only when the tile grid cannot fill the chip and K is long enough to amortise the reduce pass
   int splits = 1;
-  static const int target = getenv("EESEN_GEMM_TARGET_BLOCKS") ? atoi(getenv("EESEN_GEMM_TARGET_BLOCKS")) : 1024;  // >= 4 workgroups per CU (measured: tall-K W_x gradient 92 -> 110 TF)
+  static const int target_env = getenv("EESEN_GEMM_TARGET_BLOCKS") ? atoi(getenv("EESEN_GEMM_TARGET_BLOCKS")) : 1024;  // >= 4 workgroups per CU (measured: tall-K W_x gradient 92 -> 110 TF)
+  const int target = big ? 256 : target_env;   // the big flavour runs one workgroup per CU
   if (ws && tiles < target && K >= 2048) {
     splits = (int)std::min<long>((target + tiles - 1) / tiles, K / 1024);
     splits = std::max(1, std::min(splits, 64));
@@ -773,7 +776,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   unsigned gx = 0;
   p.gm = xcd_group_rows(tiles_m, tiles_n, &gx);
   if (synth) p.gm = 0;
-  dim3 grid(p.gm ? gx : (unsigned)tiles, (unsigned)splits), block(256);
+  dim3 grid(p.gm ? gx : (unsigned)tiles, (unsigned)splits), block(big ? 512 : 256);
   // measured on MI355X: the branch-free loads win only when both operands are k-contiguous (111 vs 107 TF); with an
   // m/n-contiguous operand the guarded code is faster (NN 107 vs 100 TF, tall-K TN 93 vs 67 TF), so it stays guarded
   const bool guard = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % BK) != 0 || !(a_kc && b_kc);
@@ -782,10 +785,15 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
-  if (use_split) {
+  if (big) {   // K and k_chunk are multiples of 16: every split is made of whole k-tiles, every tile is interior
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, false>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<false, false>), grid, block, 0, st, p);
+  } else if (use_split) {
     // 49.5 KB of LDS per workgroup: the occupancy caps of the callers (unused dynamic LDS) are sized for the 33 KB of the f32
     // kernel; keep the same workgroups-per-CU they ask for
-    const int extra = extra_lds_bytes > 0 ? std::max(0, extra_lds_bytes + 33792 - 4 * SP_OP) : 0;
+    const int extra = extra_lds_bytes > 0 ? std::max(0, extra_lds_bytes + 33792 - 2 * GeoSmall::STAGE) : 0;
     // every tile interior and every split made of whole k-tiles: no clamps, no selects
     const bool sg = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % 16) != 0;
 #define EESEN_SPLIT_LAUNCH(AK, BKC)                                                                                   \
@@ -830,6 +838,7 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN; p.tiles_m = M / BM;
   p.gate = gate;
   p.nprod = 6;
+  p.bm = p.bn = BM;
   unsigned gx = (unsigned)(p.tiles_m * p.tiles_n);
   p.gm = xcd_group_rows(p.tiles_m, p.tiles_n, &gx);
   // Occupancy cap: waiting tiles SPIN, so they must never keep the producing (cooperative) kernel's workgroups from
@@ -837,7 +846,7 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
   static const int gate_lds = (getenv("EESEN_GATE_LDS_KB") ? atoi(getenv("EESEN_GATE_LDS_KB")) : 26) * 1024;
-  if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 4 * SP_OP), st, p);
+  if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmall::STAGE), st, p);
   else hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");
 }

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SHAPES = [(1, 1, 256, 256, 64), (1, 1, 1000, 2048, 1024), (1, 0, 700, 300, 4096), (0, 0, 2048, 512, 32000), (0, 0, 184, 40, 8000),
-          (0, 1, 257, 130, 50), (1, 1, 33, 46, 1024), (1, 0, 640, 1024, 46), (0, 0, 128, 128, 17), (1, 1, 129, 127, 19)]
+          (0, 1, 257, 130, 50), (1, 1, 33, 46, 1024), (1, 0, 640, 1024, 46), (0, 0, 128, 128, 17), (1, 1, 129, 127, 19),
+          # whole 256 x 256 tiles, >= 16 of them: the eight-wave flavour of the split kernel (all four layouts, split-K, short K)
+          (1, 1, 1024, 1024, 512), (1, 0, 2048, 512, 4096), (0, 0, 1024, 1024, 8000), (0, 1, 1280, 1024, 48), (1, 1, 4096, 256, 16)]
 
 
 def _run(gpu, mode, a_kc, b_kc, A, B, C0, bias, alpha, beta):
