@@ -84,8 +84,8 @@ def test_timed_out_recurrence_is_fatal_in_a_data_parallel_run(gpu, comm, monkeyp
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
     monkeypatch.setenv("EESEN_SPIN_LIMIT", "0")
     net = Net.from_layers(layers)
+    net.SetComm(comm)                      # (an explicit EESEN_SPIN_LIMIT is respected; otherwise attaching raises the bound)
     monkeypatch.delenv("EESEN_SPIN_LIMIT")
-    net.SetComm(comm)
     net.SetSeqLengths(batch.lens)
     with pytest.raises(EesenError, match="gave up waiting for a peer workgroup"):
         net.Propagate(batch.feats)
