@@ -26,6 +26,8 @@ class Minibatch:
 class AssemblyStats:
     num_no_tgt_mat: int = 0      # utterances without targets (train-ctc-parallel.cc:152-156)
     num_too_long: int = 0        # utterances above the frame limit (:161-164)
+    num_other_error: int = 0     # utterances the CTC cannot take: empty transcript (the reference reads alpha column -1 there,
+                                 # ctc-loss.cc:151) or more than 511 labels (expanded length above the 1024 lattice positions of a sweep)
     warnings: List[str] = field(default_factory=list)
 
 
@@ -65,6 +67,12 @@ def assemble(features: Iterable[Tuple[str, np.ndarray]], targets: Dict[str, np.n
             if utt not in targets:
                 stats.num_no_tgt_mat += 1
                 stats.warnings.append(f"{utt}, missing targets")
+                pending = None
+                continue
+            n_lab = len(targets[utt])
+            if n_lab == 0 or n_lab > 511:
+                stats.num_other_error += 1
+                stats.warnings.append(f"{utt}, {'empty transcript' if n_lab == 0 else f'{n_lab} labels exceed the 511 a lattice sweep holds'}; ignoring")
                 pending = None
                 continue
             if mat.shape[0] > frame_limit:

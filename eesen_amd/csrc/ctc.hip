@@ -373,6 +373,14 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
   const int rows = T * S;
   if (rows <= 0) return;
   const size_t smem = (size_t)4 * (Lpad + K) * sizeof(float);
+  if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
+    EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (4 * (L' + K) floats of LDS per workgroup exceed 160 KB)");
+    static size_t granted = 0;
+    if (smem > granted) {
+      EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_error_diff_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      granted = smem;
+    }
+  }
   hipLaunchKernelGGL(ctc_error_diff_kernel, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens,
                      lablens, cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
   check_launch("ctc_error_diff");

@@ -175,6 +175,11 @@ int main(int argc, char** argv) {
           ++num_no_tgt_mat;
           continue;
         }
+        if (tg->second.empty() || tg->second.size() > 511) {  // what the CTC cannot take (the reference reads alpha column -1 for an empty transcript, ctc-loss.cc:151)
+          warnings.push_back(utt + (tg->second.empty() ? ", empty transcript; ignoring" : ", more labels than the 511 a lattice sweep holds; ignoring"));
+          ++num_other_error;
+          continue;
+        }
         Mat& mat = feature_reader.Value();
         if (mat.rows > o.frame_limit) {                                                 // :161-164
           warnings.push_back(utt + ", has too many frames; ignoring: " + std::to_string(mat.rows) + " > " + fmt_g(o.frame_limit));

@@ -197,7 +197,7 @@ def main(argv=None) -> int:
         if not o.cross_validate and rank == 0:
             net.Write(target_model_filename, o.binary)
         el = max(time.time() - t0, 1e-9)
-        log(f"Done {num_done} files, {stats.num_no_tgt_mat} with no targets, 0 with other errors. "
+        log(f"Done {num_done} files, {stats.num_no_tgt_mat} with no targets, {stats.num_other_error} with other errors. "
             f"[{'CROSS-VALIDATION' if o.cross_validate else 'TRAINING'}, {el / 60:g} min, fps{total_frames / el:g}]")
         if comm is not None:     # comm_touch_done (communicator.h:121-170): job 1 merges the jobs' Errors / Refs; ONE accuracy line per run
             st = ctc.stats()

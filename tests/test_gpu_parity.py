@@ -405,3 +405,17 @@ def test_recovery_from_a_timed_out_persistent_kernel(gpu, monkeypatch, capfd):
     ref = Net.from_layers(layers); ref.SetTrainOptions(1e-3, 0.9); cr = Ctc()
     step(ref, cr)
     assert np.array_equal(bad.GetParams(), ref.GetParams())
+
+
+def test_ctc_with_thousands_of_classes(gpu):
+    """Word / BPE-sized output layers: the gradient pass stages 4 * (L' + K) floats in LDS per workgroup, beyond the default 64 KB
+    of dynamic LDS at K ~ 4000 (the kernel then asks for up to 160 KB)."""
+    from eesen_amd.api import CuMatrix, Ctc
+    from oracle import net as onet
+    S, T, K = 3, 30, 5000
+    lens, probs, labels = _random_ctc_case(S, T, K, 8, seed=99)
+    ids = np.concatenate(labels); off = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    want = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f32")
+    ctc = Ctc()
+    diff = ctc.EvalParallel(lens, CuMatrix.from_numpy(probs), labels).numpy()
+    assert rel_err(ctc.pzx, want["pzx"]) < 1e-6 and rel_err(diff, want["diff"]) < TOL

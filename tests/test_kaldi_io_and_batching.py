@@ -144,3 +144,32 @@ def test_compressed_feature_archive_against_reference(tmp_path):
     assert lib.ref_write_compressed_feats(("ark:" + path).encode(), n, keys, ptrs, rows, 40, decoded.ctypes.data_as(C.c_void_p)) == 0
     got = np.concatenate([m for _, m in kaldi_io.read_mat_table("ark:" + path)])
     assert np.array_equal(got, decoded)
+
+
+def test_assembly_skips_utterances_the_ctc_cannot_take():
+    """Empty transcripts (the reference reads alpha column -1 there, ctc-loss.cc:151) and transcripts beyond 511 labels are dropped
+    with a warning and counted as `other errors` instead of aborting the run."""
+    from eesen_amd.batching import assemble, AssemblyStats
+    rng = np.random.default_rng(3)
+    feats = [(f"u{i}", rng.standard_normal((10 + i, 4)).astype(np.float32)) for i in range(5)]
+    targets = {"u0": np.array([1, 2], np.int32), "u1": np.zeros(0, np.int32), "u2": np.array([3], np.int32),
+               "u3": np.ones(600, np.int32), "u4": np.array([2, 2], np.int32)}
+    st = AssemblyStats()
+    got = list(assemble(iter(feats), targets, 2, 1e5, 4, st))
+    assert [k for mb in got for k in mb.keys] == ["u0", "u2", "u4"]
+    assert st.num_other_error == 2 and any("empty transcript" in w for w in st.warnings) and any("511" in w for w in st.warnings)
+
+
+def test_pipe_and_stdin_specifiers(tmp_path):
+    """`cmd |` rspecifiers (what steps/train_ctc_parallel.sh:95-115 always passes) and `| cmd` wspecifiers."""
+    from eesen_amd import kaldi_io
+    rng = np.random.default_rng(4)
+    mats = [(f"k{i}", rng.standard_normal((3 + i, 5)).astype(np.float32)) for i in range(4)]
+    ark, out = str(tmp_path / "f.ark"), str(tmp_path / "o.ark")
+    kaldi_io.write_mat_ark(ark, mats)
+    got = list(kaldi_io.read_mat_table(f"ark:cat {ark} |"))
+    assert [k for k, _ in got] == [k for k, _ in mats] and all(np.array_equal(a, b) for (_, a), (_, b) in zip(got, mats))
+    kaldi_io.write_mat_ark(f"| cat > {out}", iter(mats))
+    assert open(out, "rb").read() == open(ark, "rb").read()
+    with pytest.raises(kaldi_io.KaldiIOError):
+        list(kaldi_io.read_mat_table("ark:false |"))
