@@ -115,6 +115,9 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise EesenError(-2, f"{LIB_PATH} is missing: build it with `python -m eesen_amd.build` "
                                  "(there is no CPU fallback for the HIP path)")
+        # multi-process GPU work (RCCL peer access) needs dmabuf IPC on this driver stack; the ROCr runtime reads the variable when
+        # it initialises, i.e. at the first HIP call made through this library
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError = a declared symbol is not exported

@@ -108,6 +108,7 @@ struct Minibatch {
 
 int main(int argc, char** argv) {
   try {
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite*/ 0);   // dmabuf IPC for RCCL peer access; read when the ROCr runtime initialises
     const Options o = parse_options(argc, argv);
     if ((int)o.args.size() != 4 - (o.cross_validate ? 1 : 0)) {  // :82-85
       std::cerr << "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n";
