@@ -235,14 +235,17 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 // gamma_k = log sum_{j: l'_j = k} exp(alpha_j + beta_j).  The reference folds every class serially (thread (frame, k) loops
 // over ALL L' positions).  The blank owns every second lattice position (~(L'+1)/2 = 101 at cfg2), every other class two or
 // three: a class-per-lane fold is one lane grinding through 101 dependent log-add-exps while 63 wait (round 1: 0.19 ms for
-// 32 000 frames, 5 % of the HBM roofline).  Here the blank is reduced ACROSS the wave -- max, then sum of exp(v - max), two
-// shuffle trees -- and lane k >= 1 folds class k's few positions in the reference's order with the reference's LogAPlusB.
+// 32 000 frames, 5 % of the HBM roofline).  Here the work is POSITIONS-major: lane l owns positions l, l + 64, ...; the blank
+// (even positions) is reduced across the wave -- max, then sum of exp(v - max), two shuffle trees --, the labels (odd
+// positions) through two LDS atomics per position into their class's slot: an unsigned min on the bit pattern (all values are
+// <= 0, so the smallest pattern is the largest value) and a float add of exp(v - max_k).  One wave owns a frame and its LDS
+// slots, and same-address lanes of one LDS atomic are served in lane order, so the sums are reproducible run to run.
 // Only the L'_s positions the utterance has are read (the lattice rows are padded to 64 * PL for the sweep's stores).
+template <int MAXP>   // lattice positions per lane: L' <= 64 * MAXP
 __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __restrict__ probs, int ld, int T, int S, int K,
                                                              int Lpad, const int* __restrict__ lens,
                                                              const int* __restrict__ lablens,
-                                                             const int* __restrict__ cls_off,
-                                                             const int* __restrict__ cls_pos,
+                                                             const int* __restrict__ labx,
                                                              const float* __restrict__ alpha,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ pzx, float* __restrict__ diff,
@@ -257,45 +260,57 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
     for (int k = lane; k < K; k += 64) drow[k] = 0.f;
     return;
   }
-  float* ab = smem + (size_t)w * (Lpad + K);
-  float* ek = ab + Lpad;
+  unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * K;   // per class: bit pattern of the maximum ...
+  float* sm = smem + (size_t)w * 2 * K + K;                                 // ... and sum of exp(v - max); later e_k
+  for (int k = lane; k < K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
   const float* ar = alpha + ((size_t)s * T + t) * Lpad;
   const float* br = beta + ((size_t)s * T + t) * Lpad;
+  const int* lx = labx + (size_t)s * Lpad;
   const int Ls = lablens[s];
-  float bmax = kLogZero;                       // blank positions are the even ones (ctc-loss.cc:116-129)
-  for (int j = lane; j < Ls; j += 64) {
-    const float v = AddAB(ar[j], br[j]);
-    ab[j] = v;
-    if ((j & 1) == 0) bmax = fmaxf(bmax, v);
+  float v[MAXP];
+  int cls[MAXP];
+  float bmax = kLogZero;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = kLogZero; cls[i] = 0;
+    if (j < Ls) {
+      v[i] = AddAB(ar[j], br[j]);
+      cls[i] = lx[j];
+      if (cls[i] == 0) bmax = fmaxf(bmax, v[i]);
+      else if (v[i] > kLogZero) atomicMin(&mxb[cls[i]], __builtin_bit_cast(unsigned, v[i]));
+    }
   }
   __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
   bmax = wave_max(bmax);
   float bsum = 0.f;
-  if (bmax > kLogZero)
-    for (int j = 2 * lane; j < Ls; j += 128) bsum += ExpA(SubAB(ab[j], bmax));
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int j = lane + 64 * i;
+    if (j < Ls && v[i] > kLogZero) {
+      if (cls[i] == 0) bsum += ExpA(SubAB(v[i], bmax));
+      else atomicAdd(&sm[cls[i]], ExpA(SubAB(v[i], __builtin_bit_cast(float, mxb[cls[i]]))));
+    }
+  }
   bsum = wave_sum(bsum);
-  const float err_blank = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
+  __builtin_amdgcn_wave_barrier();
   const float* yr = probs + (size_t)r * ld;
-  const int* co = cls_off + (size_t)s * (K + 1);
-  const int* cp = cls_pos + (size_t)s * Lpad;
   const float pz = pzx[s];
   float rsum = 0.f;
   for (int k = lane; k < K; k += 64) {
-    float err = kLogZero;
-    if (k == 0) {
-      err = err_blank;
-    } else {
-      const int e = co[k + 1];
-      for (int idx = co[k]; idx < e; ++idx) err = LogAPlusB(err, ab[cp[idx]]);            // :1617-1624
-    }
+    float err;
+    if (k == 0) err = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
+    else err = mxb[k] != 0xffffffffu ? __builtin_bit_cast(float, mxb[k]) + logf(sm[k]) : kLogZero;                                   // :1617-1624
     const float y = yr[k];
     const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
     const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
-    ek[k] = e_k;
+    sm[k] = e_k;
     rsum += e_k;
   }
   rsum = wave_sum(rsum);                                                                   // ctc-loss.cc:162
-  for (int k = lane; k < K; k += 64) drow[k] = ek[k] - yr[k] * rsum;                       // :164-168
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < K; k += 64) drow[k] = sm[k] - yr[k] * rsum;                       // :164-168
 }
 
 // m = (apply_log ? log(m) : m) - prior_scale * log_prior[col]   (net-output-extract.cc:103-112: ApplyLog, then
@@ -368,21 +383,27 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
 }
 
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
-                    const int* lablens, const int* cls_off, const int* cls_pos, const float* alpha, const float* beta,
+                    const int* lablens, const int* labx, const float* alpha, const float* beta,
                     const float* pzx, float* diff, int ldd) {
   const int rows = T * S;
   if (rows <= 0) return;
-  const size_t smem = (size_t)4 * (Lpad + K) * sizeof(float);
+  const size_t smem = (size_t)4 * 2 * K * sizeof(float);
   if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
-    EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (4 * (L' + K) floats of LDS per workgroup exceed 160 KB)");
-    static size_t granted = 0;
-    if (smem > granted) {
-      EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_error_diff_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (8 K floats of LDS per workgroup exceed 160 KB)");
+  }
+  auto launch = [&](auto kern, size_t& granted) {
+    if (smem > 64 * 1024 && smem > granted) {
+      EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       granted = smem;
     }
-  }
-  hipLaunchKernelGGL(ctc_error_diff_kernel, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens,
-                     lablens, cls_off, cls_pos, alpha, beta, pzx, diff, ldd);
+    hipLaunchKernelGGL(kern, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
+                       beta, pzx, diff, ldd);
+  };
+  static size_t granted[3] = {0, 0, 0};
+  EESEN_REQUIRE(Lpad <= 1024, EESEN_ERR_INVALID, "ctc: expanded label length above 1024");
+  if (Lpad <= 256) launch(ctc_error_diff_kernel<4>, granted[0]);
+  else if (Lpad <= 512) launch(ctc_error_diff_kernel<8>, granted[1]);
+  else launch(ctc_error_diff_kernel<16>, granted[2]);
   check_launch("ctc_error_diff");
 }
 

@@ -95,17 +95,13 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   EESEN_REQUIRE(PL <= 16, EESEN_ERR_INVALID, "expanded label length above 1024 is not supported");
   const int Lpad = 64 * PL;
 
-  // label expansion (ctc-loss.cc:116-129) + per-class position lists, all in one staging vector
-  const size_t n_labx = (size_t)S * Lpad, n_off = (size_t)S * (K + 1);
-  std::vector<int> h(n_labx + n_labx + n_off + 2 * (size_t)S);
+  // label expansion (ctc-loss.cc:116-129), sequence and expanded-label lengths: one staging vector
+  const size_t n_labx = (size_t)S * Lpad;
+  std::vector<int> h(n_labx + 2 * (size_t)S);
   int* labx_h = h.data();
-  int* pos_h = labx_h + n_labx;
-  int* off_h = pos_h + n_labx;
-  int* lens_h = off_h + n_off;
+  int* lens_h = labx_h + n_labx;
   int* ll_h = lens_h + S;
   std::fill(labx_h, labx_h + n_labx, -1);
-  std::fill(pos_h, pos_h + n_labx, 0);
-  std::vector<int> cnt(K + 1);
   for (int s = 0; s < S; ++s) {
     const int U = label_off[s + 1] - label_off[s];
     const int* lab = label_ids + label_off[s];
@@ -114,14 +110,6 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
     lx[2 * U] = 0;
     lens_h[s] = frame_num_utt[s];
     ll_h[s] = 2 * U + 1;
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (int j = 0; j < 2 * U + 1; ++j) cnt[lx[j] + 1]++;
-    int* co = off_h + (size_t)s * (K + 1);
-    co[0] = 0;
-    for (int k = 0; k < K; ++k) co[k + 1] = co[k] + cnt[k + 1];
-    std::vector<int> fill(co, co + K);
-    int* cp = pos_h + (size_t)s * Lpad;
-    for (int j = 0; j < 2 * U + 1; ++j) cp[fill[lx[j]]++] = j;  // ascending j within each class, as the error kernel's loop visits them
   }
   // Stream-ordered upload through a pinned slot: kernels of the previous call that still read labx are ahead of this copy on
   // the stream, and the slot written here was last read by the copy of two calls ago -- nothing drains the stream.
@@ -134,9 +122,7 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   EESEN_HIP_CHECK(hipEventRecord(sp.ev, st));
   sp.busy = true;
   const int* labx_d = labx.p;
-  const int* pos_d = labx_d + n_labx;
-  const int* off_d = pos_d + n_labx;
-  const int* lens_dd = off_d + n_off;
+  const int* lens_dd = labx_d + n_labx;
   const int* ll_d = lens_dd + S;
 
   if (logp.cap < (size_t)rows * K || alpha.cap < (size_t)S * T * Lpad || pzx_d.cap < (size_t)S) EESEN_HIP_CHECK(hipStreamSynchronize(st));
@@ -152,7 +138,7 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   if (acc) { timer.end(st, sp0); sp1 = timer.begin(st, 1); } else EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
   ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p);  // :136-153
   if (acc) { timer.end(st, sp1); sp2 = timer.begin(st, 2); } else EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
-  ctc_error_diff(st, net_out, ld, T, S, K, Lpad, lens_dd, ll_d, off_d, pos_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
+  ctc_error_diff(st, net_out, ld, T, S, K, Lpad, lens_dd, ll_d, labx_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
   if (acc) timer.end(st, sp2); else EESEN_HIP_CHECK(hipEventRecord(ev[3], st));
 
   // ln p(z|x) per sequence (ctc-loss.cc:146-153 reads it element by element): back through a pinned slot.  A caller that wants

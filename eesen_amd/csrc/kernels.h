@@ -111,9 +111,9 @@ void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
                     const int* lablens, float* alpha, float* beta, float* pzx);
 // diff[t*S+s][k] = y*rowsum(e) - gamma ... (error kernel + softmax Jacobian, ctc-loss.cc:156-168)
-// cls_off [S x (K+1)], cls_pos [S x Lpad]: per sequence the lattice positions of each class, ascending.
+// labx [S x Lpad]: the expanded labels (blank 0 at even positions), lablens [S] = 2 U_s + 1
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
-                    const int* lablens, const int* cls_off, const int* cls_pos, const float* alpha, const float* beta,
+                    const int* lablens, const int* labx, const float* alpha, const float* beta,
                     const float* pzx, float* diff, int ldd);
 // in place: m = (apply_log ? log m : m) - prior_scale * log_prior[col]; log_prior may be null (net-output-extract.cc:103-112)
 void log_sub_prior(hipStream_t st, float* m, int ld, int rows, int K, bool apply_log, const float* log_prior, float prior_scale);
