@@ -133,7 +133,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or args.force_dist
+    from eesen_amd.api import Net, Ctc, CuMatrix, Comm
+    from eesen_amd import _lib
     dist = None
+    comm = None
+    if multi and args.comm != "torch":
+        try:
+            comm = Comm.from_env(device=local)   # the library's own RCCL communicator: no torch in the process
+        except Exception as e:  # rendezvous port taken, librccl not loadable, ...: fails on every rank alike, so every rank takes the same fallback
+            print(f"[bench] rank {rank}: native communicator unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+            args.comm = "torch"
     if multi and args.comm == "torch":
         import torch
         import torch.distributed as dist
@@ -141,10 +150,6 @@ def main():
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    from eesen_amd.api import Net, Ctc, CuMatrix, Comm
-    from eesen_amd import _lib
-    comm = Comm.from_env(device=local) if (multi and dist is None) else None   # the library's own RCCL communicator: no torch in the process
 
     def all_reduce(values, op=Comm.SUM):
         """Host scalars over the ranks (sum / max), whatever the transport."""

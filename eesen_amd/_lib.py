@@ -12,11 +12,12 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EESEN_HIP_LIBRARY") or os.path.join(_DIR, "lib", "libeesen_hip.so")
 
 OK = 0
-LAYER_AFFINE, LAYER_SOFTMAX, LAYER_LSTM_PARALLEL, LAYER_BILSTM_PARALLEL = 1, 2, 3, 4
+LAYER_AFFINE, LAYER_SOFTMAX, LAYER_LSTM_PARALLEL, LAYER_BILSTM_PARALLEL, LAYER_SIGMOID, LAYER_TANH = 1, 2, 3, 4, 5, 6
 KIND_OF = {"AffineTransform": LAYER_AFFINE, "Softmax": LAYER_SOFTMAX, "LstmParallel": LAYER_LSTM_PARALLEL,
-           "BiLstmParallel": LAYER_BILSTM_PARALLEL, "Lstm": LAYER_LSTM_PARALLEL, "BiLstm": LAYER_BILSTM_PARALLEL}
+           "BiLstmParallel": LAYER_BILSTM_PARALLEL, "Lstm": LAYER_LSTM_PARALLEL, "BiLstm": LAYER_BILSTM_PARALLEL,
+           "Sigmoid": LAYER_SIGMOID, "Tanh": LAYER_TANH}
 NAME_OF = {LAYER_AFFINE: "AffineTransform", LAYER_SOFTMAX: "Softmax", LAYER_LSTM_PARALLEL: "LstmParallel",
-           LAYER_BILSTM_PARALLEL: "BiLstmParallel"}
+           LAYER_BILSTM_PARALLEL: "BiLstmParallel", LAYER_SIGMOID: "Sigmoid", LAYER_TANH: "Tanh"}
 
 # every symbol include/eesen_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long

@@ -83,6 +83,9 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L, unsigned* cnt, u
 // draws one value per column and repeats it down the rows (SetRandUniformCol, cpucompute/matrix.cc:952-965).
 void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float p, unsigned long long seed, bool per_column);
 // out[r][c] = a[r][c] * m[r][c]   (MulElements, :416 / :895)
+// <Sigmoid> / <Tanh> layers: y = f(x) (cuda-kernels.cu:687-697, 713-727) and d *= f'(y) in place (:699-709, :730-740)
+void activation_rows(hipStream_t st, bool tanh_, const float* x, int ldx, float* y, int ldy, long rows, int cols);
+void activation_diff_rows(hipStream_t st, bool tanh_, const float* y, int ldy, float* d, int ldd, long rows, int cols);
 void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int ldm, float* out, int ldo, long rows, int cols);
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg = nullptr);
 // sequence windows (= cooperative launches) the persistent forward pass of this layer takes: 1 for every shape whose

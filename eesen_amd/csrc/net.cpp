@@ -242,6 +242,10 @@ void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
     case EESEN_LAYER_SOFTMAX:
       EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "Softmax needs InputDim == OutputDim");
       break;
+    case EESEN_LAYER_SIGMOID:
+    case EESEN_LAYER_TANH:
+      EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "an activation layer needs InputDim == OutputDim");
+      break;
     default:
       layers.pop_back();
       throw Error(EESEN_ERR_INVALID, "unsupported layer kind " + std::to_string(kind));
@@ -577,6 +581,14 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       timer.end(st, ti_); }
       x = L.out.p;
       ldx = ldo;
+    } else if (L.is_activation()) {  // sigmoid-layer.h:44-46, tanh-layer.h:44-46
+      const int ldo = pad4(L.dout);
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      { const int ti_ = timer.begin(st, 2);
+      activation_rows(st, L.kind == EESEN_LAYER_TANH, x, ldx, L.out.p, ldo, rows, L.dout);
+      timer.end(st, ti_); }
+      x = L.out.p;
+      ldx = ldo;
     } else {  // Softmax
       const int ldo = pad4(L.dout);
       if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
@@ -648,6 +660,11 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     float* fr = fresh.p + L.p_off;
     if (L.kind == EESEN_LAYER_SOFTMAX) {
       continue;  // softmax-layer.h:49-57: CTC already delivers d/d(logits)
+    } else if (L.is_activation()) {  // in_diff = out_diff * f'(y), from the layer's OUTPUT (sigmoid-layer.h:48-51, tanh-layer.h:48-51); same shape: in place
+      { const int ti_ = timer.begin(st, 4);
+      activation_diff_rows(st, L.kind == EESEN_LAYER_TANH, L.out.p, pad4(L.dout), d, ld_d, rows, L.dout);
+      timer.end(st, ti_); }
+      continue;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       { const int ti_ = timer.begin(st, 4);
       if (want_in) {  // in_diff = out_diff * W  (affine-trans-layer.h:171)

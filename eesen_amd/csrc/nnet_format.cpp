@@ -123,6 +123,8 @@ int marker_kind(const std::string& m) {
   if (m == "<LstmParallel>" || m == "<Lstm>") return EESEN_LAYER_LSTM_PARALLEL;
   if (m == "<AffineTransform>") return EESEN_LAYER_AFFINE;
   if (m == "<Softmax>") return EESEN_LAYER_SOFTMAX;
+  if (m == "<Sigmoid>") return EESEN_LAYER_SIGMOID;
+  if (m == "<Tanh>") return EESEN_LAYER_TANH;
   return 0;
 }
 
@@ -153,13 +155,13 @@ void Net::read(const std::string& path) {
     }
     ParsedLayer P;
     P.kind = marker_kind(tok);
-    if (!P.kind) throw Error(EESEN_ERR_INVALID, "layer kind " + tok + " is outside the MI355X hot path (supported: BiLstmParallel, LstmParallel, AffineTransform, Softmax)");
+    if (!P.kind) throw Error(EESEN_ERR_INVALID, "layer kind " + tok + " is outside the MI355X hot path (supported: BiLstmParallel, LstmParallel, AffineTransform, Softmax, Sigmoid, Tanh)");
     c.expect("<InputDim>");
     P.din = c.basic<int32_t>();
     const bool lstm = P.kind == EESEN_LAYER_BILSTM_PARALLEL || P.kind == EESEN_LAYER_LSTM_PARALLEL;
     c.expect(lstm ? "<CellDim>" : "<OutputDim>");
     P.dout = c.basic<int32_t>();
-    if (P.kind != EESEN_LAYER_SOFTMAX) {
+    if (lstm || P.kind == EESEN_LAYER_AFFINE) {   // the other kinds carry nothing but their dimensions (layer.cc:195-205)
       const int nd = P.kind == EESEN_LAYER_BILSTM_PARALLEL ? 2 : 1;
       if (lstm && P.dout % nd) c.fail("odd <CellDim> for a BiLstm layer");
       const int H = lstm ? P.dout / nd : 0;
@@ -283,6 +285,8 @@ void Net::write(const std::string& path, bool binary) {
     const char* marker = L.kind == EESEN_LAYER_BILSTM_PARALLEL ? "<BiLstmParallel>"
                          : L.kind == EESEN_LAYER_LSTM_PARALLEL ? "<LstmParallel>"
                          : L.kind == EESEN_LAYER_AFFINE        ? "<AffineTransform>"
+                         : L.kind == EESEN_LAYER_SIGMOID       ? "<Sigmoid>"
+                         : L.kind == EESEN_LAYER_TANH          ? "<Tanh>"
                                                                : "<Softmax>";
     put_token(os, marker);
     put_token(os, "<InputDim>");
@@ -290,7 +294,7 @@ void Net::write(const std::string& path, bool binary) {
     put_token(os, L.is_lstm() ? "<CellDim>" : "<OutputDim>");
     put_int(os, binary, L.dout);
     if (!binary) os << "\n";
-    if (L.kind == EESEN_LAYER_SOFTMAX) continue;
+    if (!L.trainable()) continue;
     put_token(os, "<LearnRateCoef>");
     put_float(os, binary, L.coef);
     put_token(os, "<MaxGrad>");

@@ -154,7 +154,51 @@ __global__ __launch_bounds__(256) void mul_elements_kernel(const float* __restri
     out[r * ldo + c] = a[r * lda + c] * m[r * ldm + c];
   }
 }
+// y = 1 / (1 + exp(-x))  |  (exp(2x) - 1) / (exp(2x) + 1), 1 where exp(2x) overflows: the reference's device formulas
+template <bool TANH>
+__global__ __launch_bounds__(256) void activation_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long rows, int cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float v = x[r * ldx + c];
+    float o;
+    if (TANH) {
+      const float e = expf(2.0f * v);
+      o = isinf(e) ? 1.0f : (e - 1.0f) / (e + 1.0f);
+    } else {
+      o = 1.0f / (1.0f + expf(-v));
+    }
+    y[r * ldy + c] = o;
+  }
+}
+template <bool TANH>
+__global__ __launch_bounds__(256) void activation_diff_kernel(const float* __restrict__ y, int ldy, float* __restrict__ d, int ldd, long rows, int cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float o = y[r * ldy + c];
+    d[r * ldd + c] *= TANH ? (1.0f - o * o) : o * (1.0f - o);
+  }
+}
 }  // namespace
+
+void activation_rows(hipStream_t st, bool tanh_, const float* x, int ldx, float* y, int ldy, long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(rows * cols, 256), 256L * 16);
+  if (tanh_) hipLaunchKernelGGL(activation_kernel<true>, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, rows, cols);
+  else hipLaunchKernelGGL(activation_kernel<false>, dim3(blocks), dim3(256), 0, st, x, ldx, y, ldy, rows, cols);
+  check_launch("activation_rows");
+}
+
+void activation_diff_rows(hipStream_t st, bool tanh_, const float* y, int ldy, float* d, int ldd, long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return;
+  const int blocks = (int)std::min<long>(cdivl(rows * cols, 256), 256L * 16);
+  if (tanh_) hipLaunchKernelGGL(activation_diff_kernel<true>, dim3(blocks), dim3(256), 0, st, y, ldy, d, ldd, rows, cols);
+  else hipLaunchKernelGGL(activation_diff_kernel<false>, dim3(blocks), dim3(256), 0, st, y, ldy, d, ldd, rows, cols);
+  check_launch("activation_diff_rows");
+}
 
 void dropout_mask(hipStream_t st, float* out, long rows, int cols, int ld, float p, unsigned long long seed, bool per_column) {
   if (rows <= 0 || cols <= 0) return;

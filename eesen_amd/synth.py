@@ -51,7 +51,8 @@ class Batch:
 
 
 def make_model(kind: str, layers: int, H: int, D: int, K: int, seed: int = 777, max_grad: float = 0.0,
-               learn_rate_coef: float = 1.0, proj: int = 0, param_range: float = 0.1, **_) -> List[dict]:
+               learn_rate_coef: float = 1.0, proj: int = 0, param_range: float = 0.1, proj_act=None, **_) -> List[dict]:
+    """proj_act: None, "Sigmoid", "Tanh" or a list cycled over the projections: an activation layer after each projection."""
     rng = np.random.default_rng(seed)
     u = lambda *sh: rng.uniform(-param_range, param_range, size=sh).astype(np.float32)
     out, din = [], D
@@ -67,6 +68,9 @@ def make_model(kind: str, layers: int, H: int, D: int, K: int, seed: int = 777, 
             out.append(dict(type="AffineTransform", input_dim=din, output_dim=proj, learn_rate_coef=learn_rate_coef,
                             max_grad=max_grad, params=[u(proj, din), u(proj)]))
             din = proj
+            if proj_act:
+                acts = [proj_act] if isinstance(proj_act, str) else list(proj_act)
+                out.append(dict(type=acts[li % len(acts)], input_dim=din, output_dim=din, params=[]))
     out.append(dict(type="AffineTransform", input_dim=din, output_dim=K, learn_rate_coef=learn_rate_coef,
                     max_grad=max_grad, params=[u(K, din), u(K)]))
     out.append(dict(type="Softmax", input_dim=K, output_dim=K, params=[]))

@@ -35,6 +35,8 @@ extern "C" {
 #define EESEN_LAYER_SOFTMAX 2         /* <Softmax>          src/net/softmax-layer.h                */
 #define EESEN_LAYER_LSTM_PARALLEL 3   /* <LstmParallel>     src/net/lstm-parallel-layer.h          */
 #define EESEN_LAYER_BILSTM_PARALLEL 4 /* <BiLstmParallel>   src/net/bilstm-parallel-layer.h        */
+#define EESEN_LAYER_SIGMOID 5         /* <Sigmoid>          src/net/sigmoid-layer.h (no parameters) */
+#define EESEN_LAYER_TANH 6            /* <Tanh>             src/net/tanh-layer.h    (no parameters) */
 
 typedef struct eesen_net eesen_net_t; /* replaces eesen::Net, src/net/net.h:37-175           */
 typedef struct eesen_ctc eesen_ctc_t; /* replaces eesen::Ctc, src/net/ctc-loss.h:31-90       */

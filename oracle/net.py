@@ -123,6 +123,14 @@ class OracleNet:
                 out = np.empty((rows, L["dout"]), self.dt)
                 self.lib.orc_softmax_rows(rows, L["dout"], _p(x), _p(out))
                 self.state.append(None)
+            elif t == "Sigmoid":       # sigmoid-layer.h:44-46 -> cuda-kernels.cu:687-697: 1 / (1 + exp(-x))
+                out = (1.0 / (1.0 + np.exp(-x.astype(self.dt)))).astype(self.dt)
+                self.state.append(None)
+            elif t == "Tanh":          # tanh-layer.h:44-46 -> cuda-kernels.cu:713-727: (e^2x - 1) / (e^2x + 1), 1 where e^2x overflows
+                with np.errstate(over="ignore", invalid="ignore"):
+                    e = np.exp(self.dt(2.0) * x.astype(self.dt))
+                    out = np.where(np.isinf(e), self.dt(1.0), (e - 1.0) / (e + 1.0)).astype(self.dt)
+                self.state.append(None)
             else:
                 raise NotImplementedError(t)
             x = out
@@ -160,6 +168,12 @@ class OracleNet:
                 self.lib.orc_affine_grads(rows, L["din"], L["dout"], _p(x), _p(d), mmt, _p(L["corr"][0]), _p(L["corr"][1]))
             elif t == "Softmax":
                 in_diff = d.copy()                                                   # softmax-layer.h:49-57
+            elif t == "Sigmoid":
+                y = self.acts[li + 1]
+                in_diff = (y * (1.0 - y) * d).astype(self.dt)                        # sigmoid-layer.h:48-51 -> cuda-kernels.cu:699-709
+            elif t == "Tanh":
+                y = self.acts[li + 1]
+                in_diff = ((1.0 - y * y) * d).astype(self.dt)                        # tanh-layer.h:48-51 -> cuda-kernels.cu:730-740
             # fresh gradient of this step = corr_after - momentum * corr_before (pre-clipping)
             self.fresh[li] = [c - self.momentum * b0 for c, b0 in zip(L["corr"], before)]
             if update and L["params"]:

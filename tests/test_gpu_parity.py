@@ -168,6 +168,30 @@ def test_projection_layers(gpu):
         assert rel_err(g, w) < TOL, f"layer {li} {name}"
 
 
+def test_sigmoid_and_tanh_layers(gpu, tmp_path):
+    """<Sigmoid> / <Tanh> (layer.cc:43-44; sigmoid-layer.h, tanh-layer.h) after the projections: forward, in_diff and every
+    gradient against the oracle (itself pinned to the reference's layers in tests/test_oracle_vs_reference.py), and the model
+    file with the two parameterless markers through Net::Read / Net::Write."""
+    from eesen_amd.api import Net
+    layers, batch, res = _run_both("small_bi", lr=1.0, mmt=0.0, max_grad=0.0, proj=24, layers=3, proj_act=["Tanh", "Sigmoid"])
+    assert [L["type"] for L in layers].count("Tanh") == 1 and [L["type"] for L in layers].count("Sigmoid") == 1
+    r = res[0]; o = r["o"]
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(r["net_out"][vm], o["net_out"][vm]) < TOL
+    assert rel_err(r["pzx"], o["pzx"]) < TOL
+    assert rel_err(r["in_diff"], o["in_diff"]) < TOL
+    for (li, name, g), (_, _, w) in zip(split_params(layers, r["grads"]), split_params(layers, r["ora_grads"])):
+        assert rel_err(g, w) < TOL, f"layer {li} {name}"
+    p_txt = str(tmp_path / "m.txt"); p_bin = str(tmp_path / "m.bin")
+    nnet_io.write_nnet(p_txt, layers, binary=False)
+    net = Net().Read(p_txt)
+    assert np.array_equal(net.GetParams(), nnet_io.flatten_params(layers))
+    net.Write(p_bin, binary=True)
+    ours = str(tmp_path / "host.bin")
+    nnet_io.write_nnet(ours, layers, binary=True)
+    assert open(p_bin, "rb").read() == open(ours, "rb").read()
+
+
 def test_model_file_roundtrip(gpu, tmp_path):
     """Net::Read of a text file written by the host tool; Net::Write binary and text; all agree bit for bit."""
     from eesen_amd.api import Net

@@ -41,6 +41,29 @@ def test_three_sgd_steps_with_momentum_and_clipping(cfg_name, seed):
         assert rel_err(ora.get_params(), ref.get_params()) < 1e-5
 
 
+def test_sigmoid_and_tanh_layers():
+    """<Sigmoid> / <Tanh> (sigmoid-layer.h, tanh-layer.h) after the projections of a cfg4-shaped stack: the restatement against
+    the reference's own layers (its CPU forms: cpucompute/matrix.cc Sigmoid / Tanh; the device forms differ in the last bits)."""
+    cfg = synth.config("small_bi"); cfg.update(layers=3, proj=24, proj_act=["Tanh", "Sigmoid"])
+    layers = synth.make_model(seed=11, **cfg)
+    assert [L["type"] for L in layers].count("Tanh") == 1 and [L["type"] for L in layers].count("Sigmoid") == 1
+    batch = synth.make_batch(**{**cfg, "seed": 11})
+    ref = _ref_net(layers)
+    ref.set_train_options(1.0, 0.0)
+    ora = onet.OracleNet(layers, "f32")
+    ora.set_train_options(1.0, 0.0)
+    ref.set_seq_lengths(batch.lens)
+    out = ref.propagate(batch.feats)
+    c = refbind.cuda_ctc_eval_parallel(out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+    in_diff = ref.backpropagate(c["diff"], True)
+    ora.set_seq_lengths(batch.lens)
+    o_out = ora.propagate(batch.feats)
+    o_in = ora.backpropagate(c["diff"], update=True)
+    assert rel_err(o_out, out) < 1e-5
+    assert rel_err(o_in, in_diff) < 1e-5
+    assert rel_err(ora.get_params(), ref.get_params()) < 1e-5
+
+
 def test_ctc_restatement_on_random_lattices():
     rng = np.random.default_rng(5)
     for S, T, K, U in [(2, 9, 4, 3), (4, 40, 12, 9), (3, 120, 46, 30)]:
