@@ -90,6 +90,10 @@ SIGNATURES = {
     "eesen_feeder_submit": (_i, [_vp, C.POINTER(_vp), _pi, _pi, _i, _i, _pi]),
     "eesen_feeder_acquire": (_i, [_vp, _i, C.POINTER(_vp), _pi, _pi, _pi]),
     "eesen_feeder_release": (_i, [_vp, _i]),
+    "eesen_feeder_set_pipeline": (_i, [_vp, _vp, _i]),
+    "eesen_feeder_pipeline_shape": (_i, [_vp, _i, _i, _pi, _pi]),
+    "eesen_feeder_submit_raw": (_i, [_vp, C.POINTER(_vp), _pi, _pi, C.POINTER(_vp), _i, _i, _pi]),
+    "eesen_cmvn_norm": (_i, [_pd, _i, _i, _i, _pf]),
     "eesen_dev_alloc": (_i, [_i, _l, C.POINTER(_vp)]),
     "eesen_dev_free": (_i, [_i, _vp]),
     "eesen_dev_copy": (_i, [_i, _vp, _vp, _l, _i]),

@@ -18,7 +18,7 @@ library's own allocator, so the product path has no framework dependency.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -483,9 +483,53 @@ class Feeder:
                 pass
             self.h = None
 
+    def set_pipeline(self, stages: Sequence[Tuple[int, int, int]]):
+        """The feature filters of the recipes' rspecifier pipe, run on the device between the PCIe copy and the interleave
+        (`eesen_feeder_set_pipeline`; stages = [(EESEN_FEAT_*, a, b)], see eesen_amd.frontend).  Empty list: none."""
+        arr = (C.c_int * (3 * max(len(stages), 1)))()
+        for i, (k, a, b) in enumerate(stages):
+            arr[3 * i], arr[3 * i + 1], arr[3 * i + 2] = int(k), int(a), int(b)
+        check(self.lib.eesen_feeder_set_pipeline(self.h, C.cast(arr, C.c_void_p), len(stages)))
+        self._has_pipeline = len(stages) > 0
+
+    def pipeline_shape(self, D_in: int, frames_in: int) -> Tuple[int, int]:
+        """(frames, feature dimension) behind the pipeline for an utterance of [frames_in x D_in]."""
+        d, t = C.c_int(), C.c_int()
+        check(self.lib.eesen_feeder_pipeline_shape(self.h, int(D_in), int(frames_in), C.byref(d), C.byref(t)))
+        return t.value, d.value
+
+    def submit_raw(self, mats: Sequence[np.ndarray], cmvn: Optional[Sequence[np.ndarray]] = None) -> int:
+        """RAW utterance matrices [T_s x D_in] (+ per utterance the [2 x Dc] CMVN offsets / scales when the pipeline has a
+        CMVN stage); the assembled batch is [T*S x D_out] with T = the longest utterance behind the pipeline."""
+        if not len(mats):
+            raise EesenError(-1, "empty minibatch")
+        mats = [np.ascontiguousarray(m, np.float32) for m in mats]
+        D = mats[0].shape[1]
+        for m in mats:
+            if m.ndim != 2 or m.shape[1] != D:
+                raise EesenError(-1, f"feature dimension {m.shape[1] if m.ndim == 2 else m.shape} does not match {D}")
+        S = len(mats)
+        ptrs = (C.c_void_p * S)(*[m.ctypes.data for m in mats])
+        frames = np.array([m.shape[0] for m in mats], np.int32)
+        cptr = None
+        if cmvn is not None:
+            if len(cmvn) != S:
+                raise EesenError(-1, "one CMVN vector pair per utterance")
+            cmvn = [np.ascontiguousarray(c, np.float32) for c in cmvn]
+            for c in cmvn:
+                if c.ndim != 2 or c.shape[0] != 2 or c.shape[1] != cmvn[0].shape[1]:
+                    raise EesenError(-1, "CMVN vectors must be [2 x dim] (offsets, scales)")
+            cptr = (C.c_void_p * S)(*[c.ctypes.data for c in cmvn])
+        slot = C.c_int()
+        check(self.lib.eesen_feeder_submit_raw(self.h, ptrs, frames.ctypes.data_as(C.POINTER(C.c_int)), None, cptr, S, D, C.byref(slot)))
+        self._dims[slot.value] = self.pipeline_shape(D, 1)[1]
+        return slot.value
+
     def submit(self, mats: Sequence[np.ndarray]) -> int:
         if not len(mats):
             raise EesenError(-1, "empty minibatch")
+        if hasattr(mats[0], "raw"):     # eesen_amd.frontend.RawUtt: raw matrix + CMVN vectors, shape = behind the pipeline
+            return self.submit_raw([m.raw for m in mats], [m.cmvn for m in mats] if mats[0].cmvn is not None else None)
         mats = [m if (m.dtype == np.float32 and m.ndim == 2 and m.strides[1] == 4 and m.strides[0] % 4 == 0 and m.strides[0] >= 4 * m.shape[1])
                 else np.ascontiguousarray(m, np.float32) for m in mats]
         D = mats[0].shape[1]

@@ -13,6 +13,7 @@
 
 #include "../../../include/eesen_hip.h"
 #include "kaldi_tables.h"
+#include "feat_pipeline.h"
 
 namespace {
 using namespace ktab;
@@ -91,21 +92,33 @@ int main(int argc, char** argv) {
       if ((int)log_pri.size() != K)
         throw std::runtime_error("Dimensionality mismatch, class_frame_counts " + std::to_string(log_pri.size()) + " class_output_llk " + std::to_string(K));
     }
-    FeatureReader reader(args[1]);
+    // decode_ctc_lat.sh:92-95 feeds this tool `apply-cmvn ... | splice-feats ... | subsample-feats ... | add-deltas ... |`: recognised,
+    // the raw table is read here and the filters run on the device (feat_pipeline.h)
+    Pipeline pipe;
+    const bool piped = !getenv("EESEN_HOST_FEATURE_PIPES") && parse_feature_pipeline(args[1], &pipe);
+    std::unique_ptr<CmvnTable> cmvn_table;
+    if (piped) {
+      ck(eesen_feeder_set_pipeline(feeder, pipe.stages.data(), (int)pipe.stages.size()));
+      if (!pipe.cmvn.empty()) cmvn_table.reset(new CmvnTable(pipe.cmvn, pipe.utt2spk, pipe.norm_vars));
+    }
+    FeatureReader reader(piped ? pipe.source : args[1]);
     MatrixWriter writer(args[2]);
     const auto t0 = std::chrono::steady_clock::now();
     long num_done = 0;
     double tot_t = 0;
     std::vector<std::pair<std::string, Mat>> group;
+    std::vector<int> out_frames;            // per utterance of the group: frames behind the pipeline
+    std::vector<const float*> cmvn;
     std::vector<float> host;
     auto flush = [&]() {
       const int S = (int)group.size();
       std::vector<const float*> ptr(S);
-      std::vector<int> frames(S);
-      for (int s = 0; s < S; ++s) { ptr[s] = group[s].second.v.data(); frames[s] = group[s].second.rows; }
+      std::vector<int> frames(out_frames), raw_frames(S);
+      for (int s = 0; s < S; ++s) { ptr[s] = group[s].second.v.data(); raw_frames[s] = group[s].second.rows; }
       int slot = 0, T = 0, S2 = 0, ld = 0;
       float* feats = nullptr;
-      ck(eesen_feeder_submit(feeder, ptr.data(), frames.data(), nullptr, S, D, &slot));
+      if (piped) ck(eesen_feeder_submit_raw(feeder, ptr.data(), raw_frames.data(), nullptr, cmvn_table ? cmvn.data() : nullptr, S, group[0].second.cols, &slot));
+      else ck(eesen_feeder_submit(feeder, ptr.data(), frames.data(), nullptr, S, D, &slot));
       ck(eesen_feeder_acquire(feeder, slot, &feats, &T, &S2, &ld));
       ck(eesen_net_set_seq_lengths(net, frames.data(), S));
       const float* out = nullptr;
@@ -122,17 +135,34 @@ int main(int argc, char** argv) {
         ++num_done;
         tot_t += frames[s];
       }
-      group.clear();
+      group.clear(); out_frames.clear(); cmvn.clear();
     };
     int max_len = 0;
     for (; !reader.Done(); reader.Next()) {
       Mat& m = reader.Value();
-      if (m.cols != D) throw std::runtime_error("feature dimension " + std::to_string(m.cols) + " does not match the net's InputDim " + std::to_string(D));
-      if (!group.empty() && ((int)group.size() == num_sequence || (double)std::max(max_len, m.rows) * (group.size() + 1) > frame_limit)) {
+      int rows = m.rows, cols = m.cols;
+      const float* cm = nullptr;
+      if (piped) {  // what the filters would have dropped (apply-cmvn.cc:87-92, add-deltas.cc:55-58, subsample-feats.cc:87-92)
+        const std::string& utt = reader.Key();
+        if (cmvn_table) {
+          const std::vector<float>* n = cmvn_table->lookup(utt);
+          if (!n) { std::cerr << "WARNING (net-output-extract:main()) No normalization statistics available for key " << utt << ", producing no output for this utterance" << std::endl; continue; }
+          if (CmvnTable::dim(*n) != m.cols)
+            throw std::runtime_error("Dim mismatch in ApplyCmvn: cmvn 2x" + std::to_string(CmvnTable::dim(*n) + 1) + ", feats " + std::to_string(m.rows) + "x" + std::to_string(m.cols));
+          cm = n->data();
+        }
+        if (m.rows == 0) { std::cerr << "WARNING (net-output-extract:main()) Empty feature matrix for key " << utt << std::endl; continue; }
+        ck(eesen_feeder_pipeline_shape(feeder, m.cols, m.rows, &cols, &rows));
+        if (rows == 0) { std::cerr << "WARNING (net-output-extract:main()) For utterance " << utt << ", output would have no rows, producing no output." << std::endl; continue; }
+      }
+      if (cols != D) throw std::runtime_error("feature dimension " + std::to_string(cols) + " does not match the net's InputDim " + std::to_string(D));
+      if (!group.empty() && ((int)group.size() == num_sequence || (double)std::max(max_len, rows) * (group.size() + 1) > frame_limit)) {
         flush();
         max_len = 0;
       }
-      max_len = std::max(max_len, m.rows);
+      max_len = std::max(max_len, rows);
+      out_frames.push_back(rows);
+      cmvn.push_back(cm);
       group.emplace_back(reader.Key(), std::move(m));
     }
     if (!group.empty()) flush();

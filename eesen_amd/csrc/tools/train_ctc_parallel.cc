@@ -34,6 +34,7 @@
 
 #include "../../../include/eesen_hip.h"
 #include "kaldi_tables.h"
+#include "feat_pipeline.h"
 
 namespace {
 using namespace ktab;
@@ -100,7 +101,9 @@ Options parse_options(int argc, char** argv) {
 struct Minibatch {
   std::vector<Mat> mats;
   std::vector<std::vector<int32_t>> labels;
-  std::vector<int> frames;
+  std::vector<int> frames;              // what the net and the CTC see: frames BEHIND the feature pipeline
+  std::vector<int> raw_frames;          // rows of the matrices handed to the feeder
+  std::vector<const float*> cmvn;       // per utterance [2 x D_raw] offsets / scales (device feature front end with a CMVN stage)
   int T = 0;
 };
 
@@ -155,7 +158,16 @@ int main(int argc, char** argv) {
     ck(eesen_net_input_dim(net, &feat_dim));
     ck(eesen_net_output_dim(net, &K));
 
-    FeatureReader feature_reader(feature_rspecifier);
+    // A feature rspecifier that is a pipe of the reference's own filters (apply-cmvn | splice-feats | subsample-feats | add-deltas,
+    // steps/train_ctc_parallel.sh:95-110): read the RAW table here, run the filters on the device inside the batch assembly.
+    Pipeline pipe;
+    const bool piped = !getenv("EESEN_HOST_FEATURE_PIPES") && parse_feature_pipeline(feature_rspecifier, &pipe);
+    std::unique_ptr<CmvnTable> cmvn_table;
+    if (piped) {
+      ck(eesen_feeder_set_pipeline(feeder, pipe.stages.data(), (int)pipe.stages.size()));
+      if (!pipe.cmvn.empty()) cmvn_table.reset(new CmvnTable(pipe.cmvn, pipe.utt2spk, pipe.norm_vars));
+    }
+    FeatureReader feature_reader(piped ? pipe.source : feature_rspecifier);
     const std::map<std::string, std::vector<int32_t>> targets_reader = read_targets(targets_rspecifier);
     log_line("LOG", std::string(o.cross_validate ? "CROSS-VALIDATION" : "TRAINING") + " STARTED");   // :133
     const auto t0 = std::chrono::steady_clock::now();
@@ -166,7 +178,7 @@ int main(int argc, char** argv) {
     // the while(1) loop of :144-183: greedy groups of up to num_sequence utterances within frame_limit padded frames
     long batch_index = 0;
     auto next_group = [&](Minibatch* mb) -> bool {
-      mb->mats.clear(); mb->labels.clear(); mb->frames.clear(); mb->T = 0;
+      mb->mats.clear(); mb->labels.clear(); mb->frames.clear(); mb->raw_frames.clear(); mb->cmvn.clear(); mb->T = 0;
       int max_frame_num = 0;
       for (; !feature_reader.Done(); feature_reader.Next()) {
         const std::string utt = feature_reader.Key();
@@ -182,15 +194,31 @@ int main(int argc, char** argv) {
           continue;
         }
         Mat& mat = feature_reader.Value();
-        if (mat.rows > o.frame_limit) {                                                 // :161-164
-          warnings.push_back(utt + ", has too many frames; ignoring: " + std::to_string(mat.rows) + " > " + fmt_g(o.frame_limit));
+        int rows = mat.rows, cols = mat.cols;
+        const float* cm = nullptr;
+        if (piped) {  // what the filters would have dropped never reaches the trainer (apply-cmvn.cc:87-92, add-deltas.cc:55-58, subsample-feats.cc:87-92)
+          if (cmvn_table) {
+            const std::vector<float>* n = cmvn_table->lookup(utt);
+            if (!n) { warnings.push_back("No normalization statistics available for key " + utt + ", producing no output for this utterance"); continue; }
+            if (CmvnTable::dim(*n) != mat.cols)
+              throw std::runtime_error("Dim mismatch in ApplyCmvn: cmvn 2x" + std::to_string(CmvnTable::dim(*n) + 1) + ", feats " + std::to_string(mat.rows) + "x" + std::to_string(mat.cols));
+            cm = n->data();
+          }
+          if (mat.rows == 0) { warnings.push_back("Empty feature matrix for key " + utt); continue; }
+          ck(eesen_feeder_pipeline_shape(feeder, mat.cols, mat.rows, &cols, &rows));
+          if (rows == 0) { warnings.push_back("For utterance " + utt + ", output would have no rows, producing no output."); continue; }
+        }
+        if (rows > o.frame_limit) {                                                     // :161-164
+          warnings.push_back(utt + ", has too many frames; ignoring: " + std::to_string(rows) + " > " + fmt_g(o.frame_limit));
           continue;
         }
-        if (mat.cols != feat_dim) throw std::runtime_error("feature dimension " + std::to_string(mat.cols) + " does not match the net's InputDim " + std::to_string(feat_dim));
-        const int new_max = std::max(max_frame_num, mat.rows);
+        if (cols != feat_dim) throw std::runtime_error("feature dimension " + std::to_string(cols) + " does not match the net's InputDim " + std::to_string(feat_dim));
+        const int new_max = std::max(max_frame_num, rows);
         if ((double)new_max * (mb->mats.size() + 1) > o.frame_limit) break;             // :170-172: opens the next group, reader not advanced
         max_frame_num = new_max;
-        mb->frames.push_back(mat.rows);
+        mb->frames.push_back(rows);
+        mb->raw_frames.push_back(mat.rows);
+        mb->cmvn.push_back(cm);
         mb->labels.push_back(tg->second);
         mb->mats.push_back(std::move(mat));
         if ((int)mb->mats.size() == o.num_sequence) { feature_reader.Next(); break; }   // :179-182
@@ -210,7 +238,11 @@ int main(int argc, char** argv) {
       std::vector<const float*> ptr(mb.mats.size());
       for (size_t s = 0; s < mb.mats.size(); ++s) ptr[s] = mb.mats[s].v.data();
       int slot = -1;
-      ck(eesen_feeder_submit(feeder, ptr.data(), mb.frames.data(), nullptr, (int)mb.mats.size(), feat_dim, &slot));
+      if (piped)
+        ck(eesen_feeder_submit_raw(feeder, ptr.data(), mb.raw_frames.data(), nullptr, cmvn_table ? mb.cmvn.data() : nullptr, (int)mb.mats.size(),
+                                   mb.mats[0].cols, &slot));
+      else
+        ck(eesen_feeder_submit(feeder, ptr.data(), mb.frames.data(), nullptr, (int)mb.mats.size(), feat_dim, &slot));
       return slot;
     };
 

@@ -135,6 +135,34 @@ def _read_matrix(f: BinaryIO) -> np.ndarray:
     return np.array(rows, dtype=np.float32)
 
 
+def _read_matrix64(f: BinaryIO) -> np.ndarray:
+    """Matrix<double>::Read (cpucompute/matrix.cc:1012-1100): `DM`, or `FM` converted, or text.  CMVN statistics are doubles
+    (featbin/compute-cmvn-stats.cc writes Matrix<double>)."""
+    hdr = f.read(2)
+    if hdr == b"\x00B":
+        tok = f.read(3)
+        if tok not in (b"DM ", b"FM "):
+            raise KaldiIOError(f"expected DM or FM, got {tok!r}")
+        rows, cols = _read_sized_int(f), _read_sized_int(f)
+        w = 8 if tok == b"DM " else 4
+        buf = f.read(w * rows * cols)
+        if len(buf) != w * rows * cols:
+            raise KaldiIOError("truncated matrix")
+        return np.frombuffer(buf, dtype="<f8" if w == 8 else "<f4").reshape(rows, cols).astype(np.float64)
+    txt = bytearray(hdr)
+    while b"]" not in txt:
+        chunk = f.readline()
+        if not chunk:
+            raise KaldiIOError("unterminated text matrix")
+        txt += chunk
+    s = txt.decode()
+    body = s[s.index("[") + 1: s.index("]")]
+    rows = [r.split() for r in body.strip().split("\n") if r.strip()]
+    if not rows:
+        return np.zeros((0, 0), np.float64)
+    return np.array(rows, dtype=np.float64)
+
+
 def _read_int_vector(f: BinaryIO) -> np.ndarray:
     c0 = f.read(1)
     if c0 == b"\n" or not c0:       # text mode, empty vector
@@ -254,6 +282,37 @@ def _iter_table(spec: str, read_obj) -> Iterator[Tuple[str, np.ndarray]]:
 def read_mat_table(spec: str) -> Iterator[Tuple[str, np.ndarray]]:
     """SequentialBaseFloatMatrixReader (train-ctc-parallel.cc:124)."""
     return _iter_table(spec, _read_matrix)
+
+
+def read_mat64_table(spec: str) -> Iterator[Tuple[str, np.ndarray]]:
+    """RandomAccessDoubleMatrixReader (featbin/apply-cmvn.cc:80): CMVN statistics per utterance or speaker."""
+    return _iter_table(spec, _read_matrix64)
+
+
+def read_mat64_file(rxfilename: str) -> np.ndarray:
+    """Input ki(rxfilename); Matrix<double>::Read (apply-cmvn.cc:118-122): `file`, `file:offset` or `cmd |`."""
+    loc, off = rxfilename, 0
+    if not loc.rstrip().endswith("|") and ":" in loc and loc.rsplit(":", 1)[1].isdigit():
+        loc, o = loc.rsplit(":", 1)
+        off = int(o)
+    with _open(loc) as f:
+        if off:
+            f.seek(off)
+        return _read_matrix64(f)
+
+
+def read_token_map(spec: str) -> Dict[str, str]:
+    """The utt2spk map behind RandomAccessTableReaderMapped (util/kaldi-table.h): a text archive of `utt spk` lines."""
+    kind, path, _ = _parse_specifier(spec)
+    if kind != "ark":
+        raise KaldiIOError("utt2spk: only ark: tables are supported")
+    out = {}
+    with _open(path) as f:
+        for line in f:
+            parts = line.decode().split()
+            if len(parts) >= 2:
+                out[parts[0]] = parts[1]
+    return out
 
 
 def read_vec_int_table(spec: str) -> Dict[str, np.ndarray]:

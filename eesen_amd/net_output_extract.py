@@ -12,6 +12,7 @@ which changes nothing on valid frames because padding is masked in both directio
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 import time
 
@@ -58,7 +59,7 @@ def main(argv=None) -> int:
     model_filename, feature_rspecifier, feature_wspecifier = o.args
     try:
         import ctypes as C
-        from eesen_amd import kaldi_io, _lib
+        from eesen_amd import kaldi_io, _lib, frontend
         from eesen_amd.api import Net, CuMatrix
         from eesen_amd.batching import interleave
         kind, out_path, text = kaldi_io._parse_specifier(feature_wspecifier)
@@ -72,15 +73,33 @@ def main(argv=None) -> int:
             raise kaldi_io.KaldiIOError(f"Dimensionality mismatch, class_frame_counts {log_pri.size} class_output_llk {K}")
         t0 = time.time()
         num_done = tot_t = 0
+        # decode_ctc_lat.sh:92-95 feeds this tool `apply-cmvn ... | splice-feats ... | subsample-feats ... | add-deltas ... |`
+        pipe = frontend.parse_feature_pipeline(feature_rspecifier) if not os.environ.get("EESEN_HOST_FEATURE_PIPES") else None
+        feeder = None
+        if pipe is not None:
+            from eesen_amd.api import Feeder
+            feeder = Feeder(o.device, slots=1)
+            feeder.set_pipeline(pipe.stages)
 
         def flush(group):
             """Propagates one group and returns its (key, matrix) results: the writer streams them out as they are produced
             (the decoding scripts pipe this tool: `net-output-extract ... ark:- | latgen-faster ...`, decode_ctc_lat.sh:100)."""
             nonlocal num_done, tot_t
             results = []
-            feats, lens, T = interleave([m for _, m in group], net.InputDim())
-            net.SetSeqLengths(lens)
-            out = net.Propagate(feats)
+            if pipe is not None:    # raw matrices: the filters of the rspecifier pipe run on the device (eesen_amd.frontend)
+                for _, m in group:
+                    if m.shape[1] != net.InputDim():
+                        raise kaldi_io.KaldiIOError(f"feature dimension {m.shape[1]} does not match the net's InputDim {net.InputDim()}")
+                lens = np.array([m.shape[0] for _, m in group], np.int32)
+                T = int(lens.max())
+                slot = feeder.submit([m for _, m in group])
+                net.SetSeqLengths(lens)
+                out = net.Propagate(feeder.acquire(slot))
+                feeder.release(slot)
+            else:
+                feats, lens, T = interleave([m for _, m in group], net.InputDim())
+                net.SetSeqLengths(lens)
+                out = net.Propagate(feats)
             if o.apply_log or log_pri is not None:
                 _lib.check(_lib.load().eesen_op_log_sub_prior(o.device, None, C.c_void_p(out.ptr), out.rows, out.cols, out.stride, int(o.apply_log),
                                                               log_pri.ctypes.data_as(C.c_void_p) if log_pri is not None else None, o.prior_scale))
@@ -92,7 +111,9 @@ def main(argv=None) -> int:
 
         def produce():
             group, max_len = [], 0
-            for key, mat in kaldi_io.read_mat_table(feature_rspecifier):
+            table = (frontend.read_raw(pipe, warn=lambda m: print(f"WARNING (net-output-extract:main()) {m}", file=sys.stderr))
+                     if pipe is not None else kaldi_io.read_mat_table(feature_rspecifier))
+            for key, mat in table:
                 if group and (len(group) == o.num_sequence or max(max_len, mat.shape[0]) * (len(group) + 1) > o.frame_limit):
                     yield from flush(group)
                     group, max_len = [], 0

@@ -100,7 +100,7 @@ def main(argv=None) -> int:
     feature_rspecifier, targets_rspecifier, model_filename = o.args[:3]
     target_model_filename = None if o.cross_validate else o.args[3]
     try:
-        from eesen_amd import kaldi_io
+        from eesen_amd import kaldi_io, frontend
         from eesen_amd.api import Net, Ctc, CuMatrix, EesenError, Feeder
         from eesen_amd.batching import assemble, AssemblyStats
 
@@ -145,12 +145,19 @@ def main(argv=None) -> int:
         # the reader thread parses the archives; padding + interleave + H2D of batch n+1 run on the device feeder's own
         # stream while batch n trains (the reference pads on the host and copies synchronously, train-ctc-parallel.cc:186-198)
         own_list = "JOB" in feature_rspecifier
-        groups = assemble(kaldi_io.read_mat_table(job_rspecifier(feature_rspecifier, rank)), targets, o.num_sequence, o.frame_limit,
-                          feat_dim, stats, interleaved=False)
+        feeder = Feeder(dev, slots=2)
+        # a feature rspecifier that is a pipe of the reference's own filters (apply-cmvn | splice-feats | subsample-feats |
+        # add-deltas, train_ctc_parallel.sh:95-110): read the raw table here and run the filters on the device
+        pipe = frontend.parse_feature_pipeline(job_rspecifier(feature_rspecifier, rank)) if not os.environ.get("EESEN_HOST_FEATURE_PIPES") else None
+        if pipe is not None:
+            feeder.set_pipeline(pipe.stages)
+            table = frontend.read_raw(pipe, warn=lambda m: log(m, "WARNING"))
+        else:
+            table = kaldi_io.read_mat_table(job_rspecifier(feature_rspecifier, rank))
+        groups = assemble(table, targets, o.num_sequence, o.frame_limit, feat_dim, stats, interleaved=False)
         if world > 1 and not own_list:
             groups = shard_minibatches(groups, rank, world)
         batches = _prefetch(groups)
-        feeder = Feeder(dev, slots=2)
 
         def stage():
             b = next(batches, None)

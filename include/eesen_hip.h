@@ -276,6 +276,36 @@ int eesen_feeder_submit(eesen_feeder_t* f, const float* const* utts, const int* 
 int eesen_feeder_acquire(eesen_feeder_t* f, int slot, float** feats_dev, int* T, int* S, int* ld);
 int eesen_feeder_release(eesen_feeder_t* f, int slot);
 
+/* ---- feature front end fused into the batch assembly (the step in front of the path) --------
+ * The recipes hand the trainer its features through a pipe of host filters (asr_egs/wsj/steps/train_ctc_parallel.sh:95-110,
+ * decode_ctc_lat.sh:92-95, librispeech/steps/train_ctc_parallel_mult.sh:110-133):
+ *   apply-cmvn [--norm-vars] --utt2spk=... scp:cmvn.scp scp:train.scp ark:- | splice-feats --left-context=L --right-context=R
+ *   ark:- ark:- | subsample-feats --n=N --offset=O ark:- ark:- | add-deltas ark:- ark:- |
+ * With a pipeline set, submit_raw takes the RAW utterance matrices (what scp:train.scp points at) and the stages run on
+ * the device, in the given order, between the PCIe copy and the interleave; acquire() then returns [T*S x D_out] with
+ * T = the longest utterance AFTER the pipeline.  Stage arithmetic is the reference tool's, operation for operation:
+ *   EESEN_FEAT_CMVN       src/featbin/apply-cmvn.cc, ApplyCmvn src/feat/cmvn.cc:110-117: x * scale[d] + offset[d]; the two
+ *                         vectors per utterance come with submit_raw (eesen_cmvn_norm computes them from the stats matrix)
+ *   EESEN_FEAT_SPLICE     src/featbin/splice-feats.cc, SpliceFrames src/feat/feature-functions.cc:391-412; a = left, b = right
+ *   EESEN_FEAT_SUBSAMPLE  src/featbin/subsample-feats.cc:77-108; a = n (n < 0: repeat every frame -n times), b = offset
+ *   EESEN_FEAT_DELTAS     src/featbin/add-deltas.cc, DeltaFeatures src/feat/feature-functions.cc:210-267; a = order, b = window
+ * An utterance that the pipeline leaves without frames (subsampling offset beyond its end) contributes no rows, like the
+ * reference tool, which writes no output for it; the caller drops it from the labels (eesen_feeder_pipeline_shape tells). */
+#define EESEN_FEAT_CMVN 1
+#define EESEN_FEAT_SPLICE 2
+#define EESEN_FEAT_SUBSAMPLE 3
+#define EESEN_FEAT_DELTAS 4
+typedef struct eesen_feat_stage { int kind, a, b; } eesen_feat_stage_t;
+int eesen_feeder_set_pipeline(eesen_feeder_t* f, const eesen_feat_stage_t* stages, int n_stages); /* 0 stages: plain submit */
+/* feature dimension / frame count behind the pipeline for an utterance of [frames_in x D_in] (either output may be NULL) */
+int eesen_feeder_pipeline_shape(eesen_feeder_t* f, int D_in, int frames_in, int* D_out, int* frames_out);
+/* cmvn[s] -> 2 x Dc floats (offsets, then scales), Dc = the dimension in front of the CMVN stage; NULL without such a stage */
+int eesen_feeder_submit_raw(eesen_feeder_t* f, const float* const* utts, const int* frames, const int* strides,
+                            const float* const* cmvn, int S, int D_in, int* slot);
+/* ApplyCmvn's normaliser (src/feat/cmvn.cc:78-108) on the host: stats = [rows x cols] doubles as apply-cmvn reads them
+ * (row 0: sums and, last, the count; row 1: sums of squares), cols = dim + 1 -> offset_scale[2 x dim] */
+int eesen_cmvn_norm(const double* stats, int rows, int cols, int norm_vars, float* offset_scale);
+
 /* ---- raw device helpers for hosts that own no GPU allocator --------------------------------- */
 int eesen_dev_alloc(int device, long bytes, void** dev_ptr);
 int eesen_dev_free(int device, void* dev_ptr);
