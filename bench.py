@@ -99,6 +99,76 @@ def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
     return out
 
 
+def frontend_leg(dev: int, S: int = 32, T: int = 1000, D: int = 40, iters: int = 20) -> dict:
+    """Not the headline: the feature front end in front of the path on one cfg2-shaped minibatch of RAW
+    features -- the wsj recipe's `apply-cmvn --norm-vars=true ... | add-deltas` (train_ctc_parallel.sh:95-110), 40 -> 120 columns.
+    `device`: raw matrices over PCIe, CMVN + deltas + interleave on the GPU (eesen_feeder_submit_raw); `host_filtered`: what the
+    reference pipeline hands over, 120-column matrices, interleave only.  `cpu_baseline`: the reference's own filter processes
+    (oracle/_ref/featbin, when present) on the same table."""
+    import subprocess
+    import tempfile
+    from eesen_amd import _lib, frontend as fe, kaldi_io
+    from eesen_amd.api import Feeder
+    rng = np.random.default_rng(777)
+    lens = np.sort(rng.integers(int(0.8 * T), T + 1, size=S)); lens[-1] = T
+    utts = [(f"spk{s % 4}_utt{s:03d}", (rng.standard_normal((int(lens[s]), D)) * 2 + 0.5).astype(np.float32)) for s in range(S)]
+    stats = {}
+    for k, m in utts:
+        st = stats.setdefault(k.split("_")[0], np.zeros((2, D + 1)))
+        st[0, :D] += m.sum(0, dtype=np.float64); st[1, :D] += (m.astype(np.float64) ** 2).sum(0); st[0, D] += m.shape[0]
+    cm = [fe.cmvn_norm(stats[k.split("_")[0]], True) for k, _ in utts]
+    raw = [m for _, m in utts]
+    lib = _lib.load()
+
+    def timed(feeder, submit):
+        for _ in range(3):
+            slot = submit(); feeder.acquire(slot); feeder.release(slot)
+        _lib.check(lib.eesen_device_synchronize(dev))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            slot = submit(); feeder.acquire(slot); feeder.release(slot)
+        _lib.check(lib.eesen_device_synchronize(dev))
+        return (time.perf_counter() - t0) / iters
+
+    f1 = Feeder(dev, slots=2)
+    f1.set_pipeline([(fe.CMVN, 1, 0), (fe.DELTAS, 2, 2)])
+    t_dev = timed(f1, lambda: f1.submit_raw(raw, cm))
+    got = f1.acquire(f1.submit_raw(raw, cm)).numpy()
+    filtered = [np.ascontiguousarray(got.reshape(T, S, 3 * D)[: lens[s], s, :]) for s in range(S)]
+    f2 = Feeder(dev, slots=2)
+    t_host = timed(f2, lambda: f2.submit(filtered))
+    frames = float(lens.sum())
+    # algorithmic bytes per real frame: CMVN reads and writes D floats, the deltas read D and write 3D, the interleave moves 3D
+    alg = 4.0 * (2 * D + 4 * D + 6 * D)
+    out = {"workload": f"S={S} utterances x ~{T} frames, {D} -> {3 * D} columns (apply-cmvn --norm-vars=true | add-deltas)",
+           "device": {"ms_per_batch": 1e3 * t_dev, "frames_per_s": frames / t_dev, "pcie_bytes_per_batch": int(frames * D * 4),
+                      "note": "pinned pack + H2D of the RAW features + 2 stage kernels + interleave, end to end per batch"},
+           "host_filtered": {"ms_per_batch": 1e3 * t_host, "frames_per_s": frames / t_host, "pcie_bytes_per_batch": int(frames * 3 * D * 4)},
+           "algorithmic_bytes_per_frame": alg}
+    bindir = os.path.join(ROOT, "oracle", "_ref", "featbin")
+    if os.path.isfile(os.path.join(bindir, "apply-cmvn")):
+        with tempfile.TemporaryDirectory() as tmp:
+            ark, scp = os.path.join(tmp, "raw.ark"), os.path.join(tmp, "raw.scp")
+            kaldi_io.write_mat_ark(ark, utts * 8, scp_path=None)      # 8 x the batch: ~0.25 M frames
+            with open(os.path.join(tmp, "utt2spk"), "w") as f:
+                for k, _ in utts:
+                    f.write(f"{k} {k.split('_')[0]}\n")
+            import struct
+            with open(os.path.join(tmp, "cmvn.ark"), "wb") as f:
+                for spk, st in stats.items():
+                    f.write(spk.encode() + b" \x00BDM \x04" + struct.pack("<i", 2) + b"\x04" + struct.pack("<i", D + 1) + st.astype("<f8").tobytes())
+            env = dict(os.environ, PATH=bindir + os.pathsep + os.environ.get("PATH", ""))
+            cmd = (f"apply-cmvn --norm-vars=true --utt2spk=ark:{tmp}/utt2spk ark:{tmp}/cmvn.ark ark:{ark} ark:- 2>/dev/null | "
+                   f"add-deltas ark:- ark:/dev/null 2>/dev/null")
+            t0 = time.perf_counter()
+            rc = subprocess.run(cmd, shell=True, env=env).returncode
+            el = time.perf_counter() - t0
+            if rc == 0:
+                out["cpu_baseline"] = {"value": 8 * frames / el, "unit": "frames/s", "cores": 2, "kind": "reference",
+                                       "sample": f"{int(8 * frames)} frames through the reference's apply-cmvn | add-deltas processes (one core each)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +472,11 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        if world == 1 and not args.main_only:
+            try:
+                line["frontend"] = frontend_leg(dev)
+            except Exception as e:  # never takes the headline down
+                line["frontend"] = {"error": str(e)}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi:
         all_reduce([0.0])
