@@ -11,7 +11,8 @@
 //   producer: payload with write-through (sc1) stores -> every storing wave drains vmcnt -> workgroup barrier ->
 //             one lane bumps its shard of the (direction, sequence-tile) group's arrival counters (8 shards on separate
 //             128-byte lines, relaxed agent-scope atomic);
-//   consumer: 8 lanes of wave 0 poll the 8 shards (relaxed, agent scope, s_sleep between polls, BOUNDED spin) ->
+//   consumer: 8 lanes of ONE wave (wave 7, after a first-poll delay; see EESEN_POLL_WAVE below) poll the 8 shards (relaxed,
+//             agent scope, s_sleep between polls, BOUNDED spin) ->
 //             workgroup barrier -> every wave reads the payload with plain loads of lines nobody has read before (see below;
 //             EESEN_SC1_LOADS=1 builds the L1-bypassing variant, measured slower).
 // Workgroup roles are laid out so that, with the observed block -> XCD round-robin, the workgroups of one group share an L2
@@ -51,18 +52,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 // launch, so neither the CU's L1 nor the XCD's L2 can hold an older copy, (ii) the producers' sc1 stores write through
 // and drop the line from their L2, and (iii) no load is issued before the arrival counters say every producer has
 // drained its stores -- and they let the 16 workgroups of an XCD share one fabric fetch through the L2.
-// Polling wave and back-off.  Wave 0 also prefetches the next step's epilogue operands from HBM right after the publish;
-// vmcnt is in-order, so its first poll completes only when those arrive -- a natural back-off.  Measured: polling from a
-// wave without that delay (EESEN_POLL_WAVE=7) is SLOWER (backward 16.8 -> 19.8 ms): eager polls of 256 workgroups crowd
-// the counter lines and delay the increments they are waiting for.
+// Polling wave and back-off (round 2, measured on cfg2 with nothing overlapped: forward recurrences 14.2 -> 12.9 ms, backward
+// 17.7 -> 17.1 ms; step 45.8 -> 44.5 ms with the default overlap).  The poller is wave 7, which has NO other memory traffic in
+// flight: waves 0-1 finish the cell, store, drain, publish and prefetch the next step's epilogue operands from HBM, and vmcnt
+// returns in order -- a poll issued by wave 0 came back only after its own counter increment had been acknowledged (hipcc puts an
+// s_waitcnt vmcnt(0) in front of the prefetch: 0.5 us) AND the HBM prefetch had landed.  A free wave polling at once is worse
+// than that (forward 16.6 ms): 256 eager pollers crowd the counter lines and delay the very increments they wait for.  So the
+// first poll is DELAYED by about the time the peers' increments need to land (s_sleep 20 = 1280 cycles forward, 14 backward:
+// flat optimum 16-24 / 12-16; 12 forward or 8 backward give the gain away, 48 costs 10 %), and then usually succeeds at once.
 #ifndef EESEN_POLL_WAVE
-#define EESEN_POLL_WAVE 0
+#define EESEN_POLL_WAVE 7
 #endif
 #ifndef EESEN_POLL_DELAY
-#define EESEN_POLL_DELAY 0
+#define EESEN_POLL_DELAY -1
+#endif
+#ifndef EESEN_POLL_DELAY_FWD
+#define EESEN_POLL_DELAY_FWD (EESEN_POLL_DELAY >= 0 ? EESEN_POLL_DELAY : 20)
+#endif
+#ifndef EESEN_POLL_DELAY_BWD
+#define EESEN_POLL_DELAY_BWD (EESEN_POLL_DELAY >= 0 ? EESEN_POLL_DELAY : 14)
 #endif
 #ifndef EESEN_POLL_SLEEP
 #define EESEN_POLL_SLEEP 1
+#endif
+// EESEN_NO_SYNC=1: TIMING-ONLY experiment (results are garbage): no arrival counters, no drain, no publish -- the floor a
+// hand-off without separate synchronisation traffic (e.g. readiness carried by the payload) could approach.
+#ifndef EESEN_NO_SYNC
+#define EESEN_NO_SYNC 0
 #endif
 #ifndef EESEN_BWD_FULL_LINES
 #define EESEN_BWD_FULL_LINES 1
@@ -113,12 +129,11 @@ struct Role {
 // Arrival counters are sharded 8 ways (shard = unit group & 7, one 128-byte line each) so that the increments of a
 // step do not serialise on one address.  Lanes 0-7 of wave 0 each poll one shard until it reaches its own target
 // (workgroups in that shard x steps).  Returns false (and raises *err) when the bound is hit or a peer gave up.
+template <int DELAY>
 __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
                                               int lane) {
   const unsigned mine = lane < kShards ? ((nblk - lane + kShards - 1) / kShards) * step : 0u;
-#if EESEN_POLL_DELAY > 0
-  __builtin_amdgcn_s_sleep(EESEN_POLL_DELAY);  // nobody can have arrived yet: the peers are still in their own step
-#endif
+  if constexpr (DELAY > 0) __builtin_amdgcn_s_sleep(DELAY);  // nobody can have arrived yet: the peers are still in their own step
   for (int spins = 0; spins < spin_limit; ++spins) {
     bool ok = true;
     if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        const bool go = EESEN_NO_SYNC ? true : wait_counters<EESEN_POLL_DELAY_FWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -278,10 +293,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     }
     EESEN_STAMP(3);
     {  // published after EVERY step: the last one is what a gated GEMM of the next layer waits for
-      if (tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (ST * UB is a multiple of 64)
+      if (!EESEN_NO_SYNC && tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (ST * UB is a multiple of 64)
       __syncthreads();                                                 // (also fences `red` for the next step)
       EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!EESEN_NO_SYNC && tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok && step + 1 < T)  // next step's gate pre-activations: issued AFTER the publish so the drain never waits for HBM
         gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
     }
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        const bool go = EESEN_NO_SYNC ? true : wait_counters<EESEN_POLL_DELAY_BWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -472,10 +487,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     }
     EESEN_STAMP(3);
     if (step + 1 < T) {
-      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!EESEN_NO_SYNC && tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       EESEN_STAMP(4);
-      if (tid == 0) {
+      if (!EESEN_NO_SYNC && tid == 0) {
         unsigned* c = my_cnt + (bx & (kShards - 1)) * kShardStride;
         if (local) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // executes in the XCD's L2
         else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

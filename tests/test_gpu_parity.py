@@ -233,8 +233,8 @@ def test_error_behaviour(gpu, tmp_path):
     with pytest.raises(EesenError):       # truncated model file (Net::Read throws, net.cc:279-309)
         Net().Read(bad)
     unk = str(tmp_path / "unknown.txt")
-    open(unk, "w").write("<Nnet>\n<Tanh> <InputDim> 4 <OutputDim> 4\n</Nnet>\n")
-    with pytest.raises(EesenError):       # a layer kind outside the hot path is refused, not skipped
+    open(unk, "w").write("<Nnet>\n<Convolutional> <InputDim> 4 <OutputDim> 4\n</Nnet>\n")
+    with pytest.raises(EesenError):       # a marker outside the reference's registry (layer.cc:37-46: "Unknown marker") is refused, not skipped
         Net().Read(unk)
     with pytest.raises(EesenError):       # dropout factor outside [0, 1)
         net.SetLayerDropout(0, dict(forward=1.5, fw_step=True))
