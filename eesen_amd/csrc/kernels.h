@@ -23,7 +23,11 @@ void set_gemm_mode(int mode);
 
 // Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
 // shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.
-constexpr int kShards = 8, kShardStride = 32;  // words
+#ifndef EESEN_SHARDS
+#define EESEN_SHARDS 8
+#endif
+constexpr int kShards = EESEN_SHARDS, kShardStride = 32;  // words
+constexpr int kCtlHalf = 1024 * kShards;                  // words of counters per pass (forward / backward): 32 groups
 
 // "Gated" input->gates GEMM: C = A * B^T + bias where the rows of A are the time-major output [T*S x K] of an LSTM layer
 // whose persistent forward kernel is STILL RUNNING on another stream.  A tile of rows waits until the arrival counters
@@ -47,6 +51,11 @@ struct LstmLayerDev {
   float* G;         // [T*S x ndir*4H]   gate-interleaved (col = dir*4H + u*4 + q, q in g,i,f,o)
   float* C;         // [(T+2)*S x ndir*H] cell state, row (t+1)*S+s, boundary row-blocks zero
   float* Y;         // [(T+2)*S x ndir*H] cell output m, same indexing; rows S.. are the layer output
+  // Exchange copy of m for the persistent forward kernel (optional, may be null): the SAME values in the order the consumers
+  // fetch them -- per (t, dir, 16-sequence tile) a block [chunk of 32 units][k half][k quad][16 sequences][4 floats], so that
+  // 16 adjacent lanes of an operand load read 256 contiguous bytes (whole 128-byte lines, each requested once) instead of 16
+  // bytes out of 16 different rows of Y.  T * ndir * ceil(S/16) * ceil(H/32) * 512 floats.
+  float* X = nullptr;
   // parameters (internal layout)
   const float* Wm;   // [ndir][4H x H]   rows gate-interleaved (u*4+q)
   const float* WmT;  // [ndir][H x 4H]   transpose of the above

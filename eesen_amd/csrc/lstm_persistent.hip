@@ -179,7 +179,7 @@ __device__ __forceinline__ int xcd_census(unsigned* word, unsigned nwg, unsigned
 //                 crossed the fabric) is what bounds the step, so halving it is worth the second 16-row slice of W_m
 //                 in registers.
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int MT, int NT, bool DROP>
+template <int CPW, int MT, int NT, bool DROP, bool XCHG = false>
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
                                                                       int spin_limit, unsigned long long* trace, Role R) {
   constexpr int ST = 16 * MT, UB = 4 * NT, RW = 16 * NT + 4;  // sequences, units per workgroup; padded LDS row
@@ -218,7 +218,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
 
-  const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y);  // loop-invariant (re-basing it every step costs ~0.25 us per step)
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(XCHG ? L.X : L.Y);  // loop-invariant (re-basing it every step costs ~0.25 us per step)
+  // exchange layout (XCHG, MT == 1): block of (t, dir, sequence tile) = nch chunks x [2 halves][4 quads][16 sequences][4 floats]
+  const int nch = (H + 31) / 32;
+  const unsigned xblk = (unsigned)nch * 512u * 4u;                                   // bytes per block
+  const int zt = (L.s_begin / ST) + bz;                                              // tile index within the whole batch
+  const int nzall = (S + ST - 1) / ST;
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? step : T - 1 - step;
     const int tp = dir == 0 ? t - 1 : t + 1;
@@ -238,6 +243,22 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       EESEN_STAMP(1);
       const unsigned ybase = (unsigned)(((size_t)(tp + 1) * S * ldY + dir * H) * 4);  // < 2 GB, checked on the host
       float a[MT][CPW][8];
+      if constexpr (XCHG) {
+        // one request per line: lanes (kq, li) of one load are 16 adjacent 16-byte pieces = 256 contiguous bytes per quad
+        const unsigned xb = ((unsigned)(tp * L.ndir + dir) * (unsigned)nzall + (unsigned)zt) * xblk;
+        constexpr unsigned kOob = 0x80000000u;
+        const bool rok = s0 + li < s_end;
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const int ch = wave + c * NW;
+          const unsigned o0 = xb + (unsigned)((ch * 2 * 4 + kq) * 64 + li * 4) * 4u;
+          const bool ok = rok && ch < nch;
+          const f32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rY, ok ? o0 : kOob, 0, 0);
+          const f32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rY, ok ? o0 + 4u * 64u * 4u : kOob, 0, 0);
+          a[0][c][0] = lo[0]; a[0][c][1] = lo[1]; a[0][c][2] = lo[2]; a[0][c][3] = lo[3];
+          a[0][c][4] = hi[0]; a[0][c][5] = hi[1]; a[0][c][6] = hi[2]; a[0][c][7] = hi[3];
+        }
+      } else {
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave + c * NW) * 32 + kq * 8;
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
           const int sa = s0 + m * 16 + li;
           ld8_sc1(rY, ybase + (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < s_end, a[m][c]);
         }
+      }
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA (else they are issued lazily, 2 at a time)
 #pragma unroll
@@ -289,6 +311,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
       L.C[o1] = c;
       __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: other XCDs read it next step
+      if constexpr (XCHG) {  // the exchange copy, in the consumers' fetch order (see LstmLayerDev::X)
+        const int k = u0 + eu;
+        const size_t xo = ((size_t)(t * L.ndir + dir) * nzall + zt) * ((size_t)nch * 512) +
+                          (size_t)(((k >> 5) * 2 + ((k & 7) >> 2)) * 4 + ((k & 31) >> 3)) * 64 + es * 4 + (k & 3);
+        __hip_atomic_store(L.X + xo, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       cprev = c;
     }
     EESEN_STAMP(3);
@@ -598,26 +626,35 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
     dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.s_count, 16 * ft.mt)), block(NW * 64);
     const dim3 grid1(grid.x * grid.y * grid.z);
     const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
-    if ((size_t)grid.y * grid.z * kShards * kShardStride > 8192) return false;
+    if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
     EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
     if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
+    // exchange-layout operand fetch: 16-sequence tiles, whole 32-unit chunks, block offsets within 32 bits
+    const bool xchg = L.X != nullptr && ft.mt == 1 && L.H % 32 == 0 && !L.drop_mode &&
+                      (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 2048 < ((size_t)1 << 31);
 #define EESEN_FP(CPW, MT, NT)                                                                          \
   do {                                                                                                  \
     if (L.drop_mode) coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
     else coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid1, block, L, cnt, err, spin_limit, trace, role); \
   } while (0)
+#define EESEN_FPX(CPW, NT)                                                                             \
+  do {                                                                                                  \
+    if (xchg) coop_launch(st, lstm_fwd_persistent_kernel<CPW, 1, NT, false, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
+    else EESEN_FP(CPW, 1, NT);                                                                          \
+  } while (0)
     if (ft.nt == 4) {
-      if (need <= 1) EESEN_FP(1, 1, 4);
-      else if (need <= 2) EESEN_FP(2, 1, 4);
-      else EESEN_FP(4, 1, 4);
+      if (need <= 1) EESEN_FPX(1, 4);
+      else if (need <= 2) EESEN_FPX(2, 4);
+      else EESEN_FPX(4, 4);
     } else if (ft.nt == 2) {
-      if (need <= 1) EESEN_FP(1, 1, 2);
-      else EESEN_FP(2, 1, 2);
+      if (need <= 1) EESEN_FPX(1, 2);
+      else EESEN_FPX(2, 2);
     } else {
       if (need <= 1) EESEN_FP(1, 2, 1);
       else if (need <= 2) EESEN_FP(2, 2, 1);
       else EESEN_FP(4, 2, 1);
     }
+#undef EESEN_FPX
 #undef EESEN_FP
   }
   return true;
@@ -667,7 +704,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     const dim3 grid1(grid.x * grid.y * grid.z);
     const int ngroups = (int)(grid.y * grid.z);
     const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
-    if ((size_t)grid.y * grid.z * kShards * kShardStride + 32 > 8192) return false;
+    if ((size_t)grid.y * grid.z * kShards * kShardStride + 32 > (size_t)kCtlHalf) return false;
     if (!dry) EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \

@@ -16,7 +16,7 @@
 
 namespace eesen {
 
-constexpr size_t kCtlWords = 16384 + 32;  // counters [0, 8192) forward, [8192, 16384) backward, last word = error flag
+constexpr size_t kCtlWords = 2 * kCtlHalf + 32;  // counters [0, kCtlHalf) forward, [kCtlHalf, 2 kCtlHalf) backward, last word = error flag
 
 // ------------------------------------------------------------------------------------------ PhaseTimer
 PhaseTimer::~PhaseTimer() {
@@ -380,6 +380,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   LstmLayerDev d;
   d.T = net.T; d.S = net.S; d.H = L.H; d.ndir = L.ndir;
   d.G = L.G.p; d.C = L.C.p; d.Y = L.Y.p;
+  d.X = L.X.p;
   d.Wm = net.params.p + L.p_off + L.off_wm;
   d.WmT = L.WmT.p;
   d.peep = net.params.p + L.p_off + L.off_peep;
@@ -511,6 +512,10 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
       const size_t state = (size_t)(T + 2) * S * ldY;
       L.C.reserve(state);
       L.Y.reserve(state);
+      {  // exchange copy of Y for the persistent forward kernel (EESEN_FWD_XCHG=0: off)
+        static const bool xchg = !(getenv("EESEN_FWD_XCHG") && atoi(getenv("EESEN_FWD_XCHG")) == 0);
+        if (xchg && persistent && H % 32 == 0) L.X.reserve((size_t)T * nd * ((S + 15) / 16) * (size_t)(H / 32) * 512);
+      }
       // boundary row blocks t = -1 and t = T (bilstm-parallel-layer.h:393-394)
       const size_t blk = (size_t)S * ldY * sizeof(float);
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p, 0, blk, st));
@@ -690,7 +695,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         side_pending[dg_slot] = false;
       }
       { const int ti_ = timer.begin(st, 3);
-      if (persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + 8192, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr))
+      if (persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + kCtlHalf, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr))
         ++info_bwd_persistent;
       else
         for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);

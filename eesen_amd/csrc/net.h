@@ -19,6 +19,7 @@ struct Layer {
   size_t off_wx = 0, off_bias = 0, off_wm = 0, off_peep = 0;  // relative to p_off
   DevBuf<float> WmT;      // [ndir][H x 4H], rebuilt after every parameter change
   DevBuf<float> G, C, Y;  // activations
+  DevBuf<float> X;        // exchange copy of Y in the persistent forward kernel's fetch order (LstmLayerDev::X)
   // AffineTransform
   size_t off_w = 0, off_b = 0;
   DevBuf<float> out;  // affine / softmax output [rows x pad4(dout)]
