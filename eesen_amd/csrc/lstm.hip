@@ -28,9 +28,14 @@ constexpr int NW = 8;  // waves per workgroup in the step kernels
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the ~40-instruction libm expf and IEEE division: the cell update is on the
 // per-step critical path; the error (~2e-7 relative) is three orders below the parity bar
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// __frcp_rn compiles to the IEEE division sequence (v_div_scale / v_rcp / 3 fma / v_div_fmas / v_div_fixup, ~10 dependent
+// instructions); v_rcp_f32 alone is 1 ulp -- three orders below the parity bar, and the cell update is on the per-step critical path
+#ifndef EESEN_RCP
+#define EESEN_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) { return EESEN_RCP(1.f + __expf(-x)); }
 // tanh through exp(2x): exact limits at +-inf (exp -> inf => 1, exp -> 0 => -1)
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * EESEN_RCP(1.f + __expf(2.f * x)); }
 
 __device__ __forceinline__ void ld8(const float* __restrict__ row, int k, int kmax, bool ok, float (&v)[8]) {
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;

@@ -39,8 +39,13 @@ constexpr int kSc1 = 16;  // cache-policy bit of the raw-buffer builtins: sc1 = 
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the ~40-instruction libm expf and IEEE division: the cell update is on the
 // per-step critical path; the error (~2e-7 relative) is three orders below the parity bar
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+// __frcp_rn compiles to the IEEE division sequence (v_div_scale / v_rcp / 3 fma / v_div_fmas / v_div_fixup, ~10 dependent
+// instructions); v_rcp_f32 alone is 1 ulp -- three orders below the parity bar, and the cell update is on the per-step critical path
+#ifndef EESEN_RCP
+#define EESEN_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) { return EESEN_RCP(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * EESEN_RCP(1.f + __expf(2.f * x)); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
