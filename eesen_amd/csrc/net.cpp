@@ -708,6 +708,10 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DGl, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
                  nullptr, nullptr, 0);
         timer.end(st, ti_);
+        // The input-gradient GEMM is on the critical path (the next-lower recurrence waits for it), the weight-gradient GEMMs
+        // are not: they start behind it instead of beside it (EESEN_SIDE_AFTER_INDIFF=0: beside it, as before)
+        static const bool side_after = !(getenv("EESEN_SIDE_AFTER_INDIFF") && atoi(getenv("EESEN_SIDE_AFTER_INDIFF")) == 0);
+        if (side_after) EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
       }
       // Everything that only feeds the parameter gradients leaves the critical path: it runs on the side stream,
       // under the next layer's (latency-bound, mostly idle-chip) recurrence.
