@@ -723,7 +723,9 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // recurrence + input-gradient GEMM); before the recurrence kernels overlapped fetch and MFMA the ranking was the reverse.
       // (with the bf16-split GEMM: one per CU -- 47.6 vs 48.9 ms/step; the gradient GEMMs are short enough not to become the critical path)
       const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : (gemm_mode() == 1 ? 48 : 32)) * 1024;
-      const int side_lds = overlap ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
+      bool lstm_below = false;   // the cap protects the NEXT-LOWER recurrence's cooperative launch: the lowest LSTM layer's
+      for (int lj = 0; lj < li; ++lj) lstm_below |= layers[lj].is_lstm();   // gradient GEMMs have the chip to themselves
+      const int side_lds = overlap && lstm_below ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
