@@ -41,6 +41,7 @@ struct Layer {
   // the activation the next layer (and this layer's consumers) read
   const float* output(int S) const { return cur_fwd_drop ? Yd.p : Y.p + (size_t)S * ndir * H; }
   bool is_lstm() const { return kind == EESEN_LAYER_LSTM_PARALLEL || kind == EESEN_LAYER_BILSTM_PARALLEL; }
+  bool nonparallel = false;  // read from a <BiLstm> / <Lstm> marker (Net::Write keeps the layer's own marker, layer.cc:37-46)
   bool is_activation() const { return kind == EESEN_LAYER_SIGMOID || kind == EESEN_LAYER_TANH; }
   bool trainable() const { return is_lstm() || kind == EESEN_LAYER_AFFINE; }
   long file_params() const;

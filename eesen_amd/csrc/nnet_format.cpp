@@ -115,6 +115,7 @@ struct ParsedLayer {
   std::vector<float> flat;  // Net::GetParams order
   std::vector<float> accu;  // same order; empty unless the file carries <...Accus>
   float drop[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // dropout options, token order (Layer::drop)
+  bool nonparallel = false;  // the file said <BiLstm> / <Lstm> (layer.cc:39-42): same arithmetic here, and the marker is written back
 };
 
 int marker_kind(const std::string& m) {
@@ -155,6 +156,7 @@ void Net::read(const std::string& path) {
     }
     ParsedLayer P;
     P.kind = marker_kind(tok);
+    P.nonparallel = tok == "<BiLstm>" || tok == "<Lstm>";
     if (!P.kind) throw Error(EESEN_ERR_INVALID, "layer kind " + tok + " is outside the MI355X hot path (supported: BiLstmParallel, LstmParallel, AffineTransform, Softmax, Sigmoid, Tanh)");
     c.expect("<InputDim>");
     P.din = c.basic<int32_t>();
@@ -210,6 +212,7 @@ void Net::read(const std::string& path) {
   for (const ParsedLayer& P : parsed) {
     add_layer(P.kind, P.din, P.dout, P.coef, P.max_grad);
     for (int k = 0; k < 9; ++k) layers.back().drop[k] = P.drop[k];
+    layers.back().nonparallel = P.nonparallel;
   }
   finalize();
   std::vector<float> all;
@@ -282,8 +285,8 @@ void Net::write(const std::string& path, bool binary) {
   const float* p = all.data();
   const float* pa = acc.empty() ? nullptr : acc.data();
   for (const Layer& L : layers) {
-    const char* marker = L.kind == EESEN_LAYER_BILSTM_PARALLEL ? "<BiLstmParallel>"
-                         : L.kind == EESEN_LAYER_LSTM_PARALLEL ? "<LstmParallel>"
+    const char* marker = L.kind == EESEN_LAYER_BILSTM_PARALLEL ? (L.nonparallel ? "<BiLstm>" : "<BiLstmParallel>")
+                         : L.kind == EESEN_LAYER_LSTM_PARALLEL ? (L.nonparallel ? "<Lstm>" : "<LstmParallel>")
                          : L.kind == EESEN_LAYER_AFFINE        ? "<AffineTransform>"
                          : L.kind == EESEN_LAYER_SIGMOID       ? "<Sigmoid>"
                          : L.kind == EESEN_LAYER_TANH          ? "<Tanh>"

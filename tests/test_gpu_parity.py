@@ -192,6 +192,21 @@ def test_sigmoid_and_tanh_layers(gpu, tmp_path):
     assert open(p_bin, "rb").read() == open(ours, "rb").read()
 
 
+def test_nonparallel_markers_are_kept(gpu, tmp_path):
+    """A model in the non-parallel form (<BiLstm> / <Lstm>, what format-to-nonparallel writes for decoding) is read like its
+    parallel twin (Net::Read maps both onto the same arithmetic, layer.cc:164-170) and written back under its own markers."""
+    from eesen_amd.api import Net
+    for cfg_name in ("tiny_bi", "small_uni"):
+        cfg = synth.config(cfg_name)
+        layers = synth.make_model(**cfg)
+        for L in layers:
+            L["type"] = {"BiLstmParallel": "BiLstm", "LstmParallel": "Lstm"}.get(L["type"], L["type"])
+        src, dst = str(tmp_path / f"{cfg_name}.in"), str(tmp_path / f"{cfg_name}.out")
+        nnet_io.write_nnet(src, layers, binary=True)
+        Net().Read(src).Write(dst, binary=True)
+        assert open(src, "rb").read() == open(dst, "rb").read()
+
+
 def test_model_file_roundtrip(gpu, tmp_path):
     """Net::Read of a text file written by the host tool; Net::Write binary and text; all agree bit for bit."""
     from eesen_amd.api import Net
