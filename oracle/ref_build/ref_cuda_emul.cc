@@ -126,6 +126,52 @@ int ref_cuda_ctc_eval_parallel(const float* probs, int T, int S, int K, const in
   return exp_len_labels;
 }
 
+// The SINGLE-sequence path, Ctc::Eval (src/net/ctc-loss.cc:28-75) with the one-sequence kernels
+// (cuda-kernels.cu:1332-1408 alpha, :1448-1544 beta, :1584-1640 error; launch shapes cuda-matrix.cc:850-851, :987-988):
+// what the reference's train-ctc (one utterance at a time, <BiLstm> layers) computes.  probs [T x K], labels[U].
+// alpha / beta: [T x 2U+1], *pzx = ln p(z|x), diff [T x K] as Ctc::Eval leaves it.
+int ref_cuda_ctc_eval(const float* probs, int T, int K, const int* label, int U, float* alpha, float* beta, float* pzx, float* diff) {
+  const int num_frames = T, exp_len_labels = 2 * U + 1;                     // :36-37
+  std::vector<int> label_expand(exp_len_labels, 0);                          // :39-43
+  for (int l = 0; l < U; l++) label_expand[2 * l + 1] = label[l];
+  std::vector<float> log_nnet_out((size_t)T * K);                            // :46-47
+  for (size_t i = 0; i < log_nnet_out.size(); i++) log_nnet_out[i] = log(probs[i]);
+  MatrixDim dim_alpha = {num_frames, exp_len_labels, exp_len_labels};
+  MatrixDim dim_prob = {num_frames, K, K};
+  for (size_t i = 0; i < (size_t)T * exp_len_labels; i++) alpha[i] = beta[i] = 0.0f;   // Resize(..., kSetZero), :49-50
+  {
+    dim3 dimBlock(CU1DBLOCK), dimGrid(n_blocks(exp_len_labels, CU1DBLOCK));  // cuda-matrix.cc:850-851
+    for (int t = 0; t < T; t++)                                              // :51-53
+      emulate_launch(dimGrid, dimBlock, [&] {
+        cudaF_compute_ctc_alpha(dimGrid, dimBlock, alpha, t, dim_alpha, log_nnet_out.data(), dim_prob, label_expand.data());
+      });
+    for (int t = T - 1; t >= 0; t--)                                         // :54-56
+      emulate_launch(dimGrid, dimBlock, [&] {
+        cudaF_compute_ctc_beta(dimGrid, dimBlock, beta, t, dim_alpha, log_nnet_out.data(), dim_prob, label_expand.data());
+      });
+  }
+  const float tmp1 = alpha[(size_t)(T - 1) * exp_len_labels + exp_len_labels - 1];   // :59-61
+  const float tmp2 = alpha[(size_t)(T - 1) * exp_len_labels + exp_len_labels - 2];
+  *pzx = tmp1 + log(1 + ExpA(tmp2 - tmp1));
+  std::vector<float> ctc_err((size_t)T * K, 0.0f);                           // :64-65
+  {
+    MatrixDim dim_err = {num_frames, K, K};
+    dim3 dimBlock(CU2DBLOCK, CU2DBLOCK);
+    dim3 dimGrid(n_blocks(num_frames, CU2DBLOCK), n_blocks(K, CU2DBLOCK));   // cuda-matrix.cc:987-988
+    emulate_launch(dimGrid, dimBlock, [&] {
+      cudaF_compute_ctc_error(dimGrid, dimBlock, ctc_err.data(), dim_err, alpha, beta, dim_alpha, probs, label_expand.data(), *pzx);
+    });
+  }
+  for (int r = 0; r < T; r++) {                                              // :68-75
+    float* e = &ctc_err[(size_t)r * K];
+    const float* y = &probs[(size_t)r * K];
+    float row_sum = 0.0f;
+    for (int k = 0; k < K; k++) { e[k] *= y[k]; row_sum += e[k]; }
+    for (int k = 0; k < K; k++) diff[(size_t)r * K + k] = e[k] - y[k] * row_sum;
+  }
+  return exp_len_labels;
+}
+
 // Elementwise activation kernels as the CUDA side computes them (cuda-kernels.cu:686-740); used to
 // quantify the CPU-vs-GPU activation-formula difference the survey notes (Appendix A).
 void ref_cuda_sigmoid(float* y, const float* x, int rows, int cols) {

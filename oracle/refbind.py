@@ -150,6 +150,21 @@ def cuda_ctc_eval_parallel(probs: np.ndarray, T: int, S: int, lens, label_ids, l
     return dict(alpha=alpha, beta=beta, pzx=pzx, diff=diff, ctc_err=err, L=L)
 
 
+def cuda_ctc_eval(probs: np.ndarray, label):
+    """The reference's SINGLE-sequence CTC, Ctc::Eval (ctc-loss.cc:28-75) through its one-sequence CUDA kernel bodies:
+    what train-ctc computes per utterance.  probs [T x K], label [U]."""
+    lib = _load()
+    probs = np.ascontiguousarray(probs, np.float32)
+    T, K = probs.shape
+    label = np.ascontiguousarray(label, np.int32)
+    L = 2 * label.size + 1
+    alpha = np.empty((T, L), np.float32); beta = np.empty((T, L), np.float32)
+    pzx = np.empty(1, np.float32); diff = np.empty((T, K), np.float32)
+    rc = lib.ref_cuda_ctc_eval(_p(probs), T, K, _p(label), int(label.size), _p(alpha), _p(beta), _p(pzx), _p(diff))
+    assert rc == L, rc
+    return dict(alpha=alpha, beta=beta, pzx=float(pzx[0]), diff=diff)
+
+
 def cuda_activation(name: str, x: np.ndarray) -> np.ndarray:
     lib = _load()
     x = np.ascontiguousarray(x, np.float32).reshape(1, -1)

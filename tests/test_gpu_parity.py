@@ -192,6 +192,55 @@ def test_sigmoid_and_tanh_layers(gpu, tmp_path):
     assert open(p_bin, "rb").read() == open(ours, "rb").read()
 
 
+def test_single_utterance_against_the_reference_nonparallel_path(gpu, tmp_path):
+    """S = 1 against what the reference's train-ctc runs for one utterance: the NON-parallel <BiLstm> layers (bilstm-layer.h)
+    and Ctc::Eval (ctc-loss.cc:28-75, one-sequence CUDA kernel bodies on the CPU shim) -- not the parallel twins at S = 1.
+    Needs oracle/_ref (built in the authoring container, shipped to the GPU box)."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    from oracle import refbind
+    if not refbind.available():
+        pytest.skip("oracle/_ref not built")
+    import tempfile
+    cfg = synth.config("small_bi"); cfg.update(S=1, T=45)
+    layers = synth.make_model(seed=5, **cfg)
+    batch = synth.make_batch(**{**cfg, "seed": 5})
+    for L in layers:
+        L["type"] = {"BiLstmParallel": "BiLstm"}.get(L["type"], L["type"])
+    path = str(tmp_path / "nonpar.nnet")
+    nnet_io.write_nnet(path, layers, binary=True)
+    ref = refbind.RefNet(path)
+    before = ref.get_params()
+    ref.set_train_options(1.0, 0.0)
+    out_r = ref.propagate(batch.feats)
+    c = refbind.cuda_ctc_eval(out_r, batch.labels[0])
+    in_r = ref.backpropagate(c["diff"], True)
+    grads_r = before.astype(np.float64) - ref.get_params().astype(np.float64)
+    net = Net().Read(path)
+    net.SetTrainOptions(1.0, 0.0)
+    net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats)
+    ctc = Ctc()
+    diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+    in_diff = CuMatrix(batch.T, cfg["D"])
+    net.BackpropagateNoUpdate(diff, in_diff)
+    assert rel_err(out.numpy(), out_r) < TOL
+    assert abs(ctc.pzx[0] - c["pzx"]) < TOL * abs(c["pzx"])
+    assert rel_err(diff.numpy(), c["diff"]) < TOL
+    assert rel_err(in_diff.numpy(), in_r) < TOL
+    # Gradients: every tensor but three.  For the BACKWARD direction's W_m, p_i and p_f the reference's non-parallel layer pairs the
+    # gate gradients of time t with the state of time t - 1 (bilstm-layer.h:838,840-841: YM / YC .RowRange(0, T)), although that
+    # direction's recurrence source is t + 1 -- its own parallel layer uses the t + 1 rows (bilstm-parallel-layer.h:597-600), and so
+    # does this library, which replaces the parallel path (tests/test_oracle_vs_reference.py pins the reference's disagreement
+    # with itself; the S = 1 comparison with the PARALLEL reference is test_odd_shapes_and_single_sequence).
+    odd = ("Wm_bw", "pi_bw", "pf_bw")
+    par = [dict(L, type={"BiLstm": "BiLstmParallel"}.get(L["type"], L["type"])) for L in layers]
+    for (li, name, g), (_, _, w) in zip(split_params(par, net.GetGrads()), split_params(par, grads_r.astype(np.float32))):
+        if name in odd:
+            assert rel_err(g, w) > 1e-2, f"layer {li} {name}: the reference's two layers are expected to disagree here"
+        else:
+            assert rel_err(g, w) < TOL, f"layer {li} {name}"
+
+
 def test_nonparallel_markers_are_kept(gpu, tmp_path):
     """A model in the non-parallel form (<BiLstm> / <Lstm>, what format-to-nonparallel writes for decoding) is read like its
     parallel twin (Net::Read maps both onto the same arithmetic, layer.cc:164-170) and written back under its own markers."""

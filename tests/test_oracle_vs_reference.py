@@ -64,6 +64,41 @@ def test_sigmoid_and_tanh_layers():
     assert rel_err(ora.get_params(), ref.get_params()) < 1e-5
 
 
+def test_single_sequence_reference_path_equals_its_parallel_path():
+    """The reference has TWO implementations of everything on the path: the non-parallel <BiLstm> layer + Ctc::Eval that
+    train-ctc uses one utterance at a time (bilstm-layer.h, ctc-loss.cc:28-75, one-sequence kernels cuda-kernels.cu:1332-1640),
+    and the parallel ones this repository replaces.  On one utterance they must agree: it is the S = 1 pin of SURVEY.md 8f-4."""
+    cfg = synth.config("small_bi"); cfg.update(S=1, T=37)
+    layers = synth.make_model(seed=21, **cfg)
+    batch = synth.make_batch(**{**cfg, "seed": 21})
+    nonpar = [dict(L, type={"BiLstmParallel": "BiLstm"}.get(L["type"], L["type"])) for L in layers]
+    par, single = _ref_net(layers), _ref_net(nonpar)
+    par.set_seq_lengths(batch.lens)
+    out_p = par.propagate(batch.feats)
+    out_s = single.propagate(batch.feats)
+    assert rel_err(out_s, out_p) < 1e-6
+    cp = refbind.cuda_ctc_eval_parallel(out_p, batch.T, 1, batch.lens, batch.label_ids, batch.label_off)
+    cs = refbind.cuda_ctc_eval(out_s, batch.labels[0])
+    assert abs(cs["pzx"] - cp["pzx"][0]) <= 1e-5 * abs(cp["pzx"][0])
+    assert rel_err(cs["diff"], cp["diff"]) < 5e-5     # two different kernels of the reference: 1.05e-5 here, fp32 round-off
+    # ... and where they do NOT agree: the weight gradients of the backward direction's recurrent connections.  The non-parallel
+    # layer pairs DGIFO_t with YM / YC of t - 1 (bilstm-layer.h:838,840-841: RowRange(0, T)) although the backward direction's
+    # recurrence source is t + 1; the parallel layer uses t + 1 (bilstm-parallel-layer.h:597-600: RowRange(2S, T*S)).  The path
+    # this repository replaces is the parallel one (and it is the one whose gradient passes a finite-difference check).
+    from tests.util import split_params
+    grads = {}
+    for name, r, o in (("par", par, out_p), ("single", single, out_s)):
+        before = r.get_params()
+        r.set_train_options(1.0, 0.0)
+        r.backpropagate(cp["diff"], False)
+        grads[name] = before.astype(np.float64) - r.get_params().astype(np.float64)
+    for (li, nm, g), (_, _, w) in zip(split_params(layers, grads["single"]), split_params(layers, grads["par"])):
+        if nm in ("Wm_bw", "pi_bw", "pf_bw"):
+            assert rel_err(g, w) > 1e-2, (li, nm)
+        else:
+            assert rel_err(g, w) < 1e-5, (li, nm)
+
+
 def test_ctc_restatement_on_random_lattices():
     rng = np.random.default_rng(5)
     for S, T, K, U in [(2, 9, 4, 3), (4, 40, 12, 9), (3, 120, 46, 30)]:
