@@ -61,6 +61,14 @@ __global__ __launch_bounds__(256) void feat_stage_kernel(StageDev st, const floa
                                                         float* __restrict__ dst, const long* __restrict__ off_out,
                                                         const int* __restrict__ fr_out, int Dout, const float* __restrict__ cmvn) {
 #pragma clang fp contract(off)   // hipcc contracts a * b + c into one fma by default; __fmul_rn / __fadd_rn do not help (header inlines built with that default)
+  // the delta windows (at most 9 orders x 33-wide steps: 1161 floats) sit in LDS: the tap loop then has no dependent global load
+  // in front of every tap, and the taps' feature loads are independent of each other
+  __shared__ float s_sc[1200];
+  if (st.kind == EESEN_FEAT_DELTAS) {
+    const int nsc = (st.a + 1) + st.b * st.a * (st.a + 1);
+    for (int i = threadIdx.x; i < nsc; i += blockDim.x) s_sc[i] = scales[i];
+    __syncthreads();
+  }
   const int s = blockIdx.y;
   const int Ti = fr_in[s], To = fr_out[s];
   const float* x = src + off_in[s];
@@ -82,14 +90,12 @@ __global__ __launch_bounds__(256) void feat_stage_kernel(StageDev st, const floa
     } else {                                               // DeltaFeatures::Process, feat/feature-functions.cc:252-266
       const int o = c / Din, d = c % Din;
       const int max_off = o * st.b;
-      const float* sc = scales + o + st.b * o * (o - 1);   // windows of orders 0..o-1 hold 1 + 2kW entries each
+      const float* sc = s_sc + o + st.b * o * (o - 1);     // windows of orders 0..o-1 hold 1 + 2kW entries each
       v = 0.f;
       for (int j = -max_off; j <= max_off; ++j) {
         const float w = sc[j + max_off];
-        if (w != 0.f) {
-          const float prod = w * x[(long)clampi(t + j, Ti - 1) * Din + d];
-          v = v + prod;
-        }
+        const float prod = w * x[(long)clampi(t + j, Ti - 1) * Din + d];
+        v = w != 0.f ? v + prod : v;                         // a zero tap is SKIPPED by the reference (:263), not added
       }
     }
     y[i] = v;
@@ -387,7 +393,7 @@ struct Feeder {
       float* dst = k % 2 ? sl.packed.p : sl.packed2.p;
       long biggest = 0;
       for (int s = 0; s < S; ++s) biggest = std::max(biggest, (long)fr_h[(size_t)(k + 1) * S + s] * dims[k + 1]);
-      const int bx = (int)std::min<long>(std::max<long>(cdivl(biggest, 256), 1), 64);
+      const int bx = (int)std::min<long>(std::max<long>(cdivl(biggest, 256), 1), 2048);   // one element per thread: the stage is latency-bound otherwise
       const StageDev sd{pipe[k].kind, pipe[k].a, pipe[k].b};
       hipLaunchKernelGGL(feat_stage_kernel, dim3(bx, S), dim3(256), 0, copy, sd, scales_d.p ? scales_d.p + pipe[k].scale_off : nullptr, src,
                          sl.offs_d.p + (size_t)k * S, sl.frs_d.p + (size_t)k * S, dims[k], dst, sl.offs_d.p + (size_t)(k + 1) * S,
