@@ -337,6 +337,174 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, TWO sequence tiles per workgroup (time-multiplexed): for batches whose tiles need more workgroups than can be
+// co-resident (S = 64 at H = 1024: BASELINE config 5).  Instead of one cooperative launch per window of 32 sequences, run
+// one after the other, every workgroup holds its 16 * NT gate rows of W_m once and steps TWO independent chains -- sequence
+// tile 2g and 2g + 1 -- alternately: A_t, B_t, A_{t+1}, ...  While chain A's step is being published and acknowledged by the
+// peers (the 1.1 us no workgroup can shorten), this workgroup computes chain B's step, so by the time it polls for A again
+// the peers are through: the hand-off latency of one chain hides behind the arithmetic of the other.  Same arithmetic, same
+// order per chain as lstm_fwd_persistent_kernel<CPW, 1, NT>: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int CPW, int NT, bool XCHG>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_mux_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
+                                                                          int spin_limit, Role R) {
+  constexpr int ST = 16, UB = 4 * NT, RW = 16 * NT + 4, Q = 2;
+  __shared__ __attribute__((aligned(16))) float red[NW][ST][RW];
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bg = R.seq_group(blockIdx.x);
+  const int u0 = bx * UB;
+  const int nzall = (S + ST - 1) / ST;
+  const unsigned nblk = R.nblk;
+  const int li = lane & 15, kq = lane >> 4;
+  float b[NT][CPW][8];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + n * 16 + li) * H;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, b[n][c]);
+  }
+  const int es = tid / UB, eu = tid % UB;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  if (tid < ST * UB) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+  }
+  const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
+  // per chain
+  int zt[Q], s_e[Q], len[Q];
+  bool e_ok[Q];
+  float cprev[Q];
+  float4 gx[Q];
+  unsigned* my_cnt[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    zt[q] = bg * Q + q;
+    s_e[q] = zt[q] * ST + es;
+    e_ok[q] = tid < ST * UB && zt[q] < nzall && s_e[q] < S;
+    len[q] = e_ok[q] ? L.lens[s_e[q]] : 0;
+    cprev[q] = 0.f;
+    gx[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e_ok[q]) gx[q] = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e[q]) * ldG + gcol);
+    my_cnt[q] = cnt + (size_t)(dir * nzall + zt[q]) * kShards * kShardStride;
+  }
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(XCHG ? L.X : L.Y);
+  const int nch = (H + 31) / 32;
+  const unsigned xblk = (unsigned)nch * 512u * 4u;
+  bool polled = false;   // uniform: the slot about to start has already been found ready
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (zt[q] >= nzall) continue;   // odd number of tiles: the last workgroup group steps one chain only (uniform per workgroup)
+      f32x4 acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (step > 0) {
+        // readiness of this slot was established by the poller wave during the PREVIOUS slot's cell phase (below); only the very
+        // first polled slot (step 1, chain 0 when chain 1 does not exist) has to poll here
+        if (!polled) {
+          if (wave == EESEN_POLL_WAVE) {
+            const bool go = wait_counters<0>(my_cnt[q], nblk, (unsigned)step, err, spin_limit, lane);
+            if (lane == 0) s_go = go ? 1 : 0;
+          }
+          __syncthreads();
+          if (!s_go) return;
+        }
+        float a[CPW][8];
+        const int s0 = zt[q] * ST;
+        if constexpr (XCHG) {
+          const unsigned xb = ((unsigned)(tp * L.ndir + dir) * (unsigned)nzall + (unsigned)zt[q]) * xblk;
+          constexpr unsigned kOob = 0x80000000u;
+          const bool rok = s0 + li < S;
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const int ch = wave + c * NW;
+            const unsigned o0 = xb + (unsigned)((ch * 2 * 4 + kq) * 64 + li * 4) * 4u;
+            const bool ok = rok && ch < nch;
+            const f32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rY, ok ? o0 : kOob, 0, 0);
+            const f32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rY, ok ? o0 + 4u * 64u * 4u : kOob, 0, 0);
+            a[c][0] = lo[0]; a[c][1] = lo[1]; a[c][2] = lo[2]; a[c][3] = lo[3];
+            a[c][4] = hi[0]; a[c][5] = hi[1]; a[c][6] = hi[2]; a[c][7] = hi[3];
+          }
+        } else {
+          const unsigned ybase = (unsigned)(((size_t)(tp + 1) * S * ldY + dir * H) * 4);
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const int k = (wave + c * NW) * 32 + kq * 8;
+            const int sa = s0 + li;
+            ld8_sc1(rY, ybase + (unsigned)(((size_t)sa * ldY + k) * 4), k, H, sa < S, a[c]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
+      __syncthreads();
+      if (e_ok[q]) {
+        float4 pre = gx[q];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
+          pre.x += v.x; pre.y += v.y; pre.z += v.z; pre.w += v.w;
+        }
+        float g = tanhf_(pre.x);
+        float i = sigmoidf_(pre.y + p_i * cprev[q]);
+        float f = sigmoidf_(pre.z + p_f * cprev[q]);
+        float c = g * i + cprev[q] * f;
+        float h = tanhf_(c);
+        float o = sigmoidf_(pre.w + p_o * c);
+        float m = h * o;
+        if (t >= len[q]) { g = i = f = o = c = m = 0.f; }
+        *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e[q]) * ldG + gcol) = make_float4(g, i, f, o);
+        const size_t o1 = (size_t)((t + 1) * S + s_e[q]) * ldY + dir * H + u0 + eu;
+        L.C[o1] = c;
+        __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (XCHG) {
+          const int k = u0 + eu;
+          const size_t xo = ((size_t)(t * L.ndir + dir) * nzall + zt[q]) * ((size_t)nch * 512) +
+                            (size_t)(((k >> 5) * 2 + ((k & 7) >> 2)) * 4 + ((k & 31) >> 3)) * 64 + es * 4 + (k & 3);
+          __hip_atomic_store(L.X + xo, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cprev[q] = c;
+      }
+      // While waves 0-1 finish the cell and drain their stores, the poller wave (idle otherwise) waits for the NEXT slot's
+      // inputs -- the other chain, whose publish by the peers lies one whole slot back: that slot then starts without a poll.
+      polled = false;
+      {
+        const int nq = q + 1 < Q && zt[Q - 1] < nzall ? q + 1 : 0;       // next slot: the other chain (or this one again)
+        const int nstep = nq > q ? step : step + 1;
+        if (nstep > 0 && nstep < T && !(nq == q)) {                        // same chain next: its inputs depend on OUR publish below
+          if (wave == EESEN_POLL_WAVE) {
+            const bool go = wait_counters<0>(my_cnt[nq], nblk, (unsigned)nstep, err, spin_limit, lane);
+            if (lane == 0) s_go = go ? 1 : 0;
+          }
+          polled = true;
+        }
+      }
+      if (tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (polled && !s_go) return;
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt[q] + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok[q] && step + 1 < T)
+        gx[q] = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e[q]) * ldG + gcol);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: grid (ceil(H/16), ndir, ceil(S/16)), 512 threads -- the decomposition of lstm_bwd_step_kernel
 // ------------------------------------------------------------------------------------------------
 template <int CPW, int ST, bool DROP>  // ST = sequences per workgroup (16, or 8: half-filled MFMA rows but half the DG_next fetch per CU)
@@ -624,6 +792,25 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
   const int nwin = lstm_fwd_persistent_windows(L0);
   if (nwin == 0) return false;
   if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
+  // Two windows of the wide tile: one launch that time-multiplexes the two sequence tiles of every workgroup instead
+  // (lstm_fwd_persistent_mux_kernel).  EESEN_FWD_MUX=0: the two launches, one after the other.
+  static const bool mux_env = !(getenv("EESEN_FWD_MUX") && atoi(getenv("EESEN_FWD_MUX")) == 0);
+  if (mux_env && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
+    const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
+    const bool xchg = L0.X != nullptr && (size_t)L0.T * L0.ndir * nz * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31);
+    dim3 grid(L0.H / 16, L0.ndir, ng), block(NW * 64);
+    const bool fit = xchg ? fits(lstm_fwd_persistent_mux_kernel<4, 4, true>, grid, NW * 64) : fits(lstm_fwd_persistent_mux_kernel<4, 4, false>, grid, NW * 64);
+    if (fit && (size_t)L0.ndir * nz * kShards * kShardStride <= (size_t)kCtlHalf) {
+      LstmLayerDev L = L0;
+      L.s_begin = 0; L.s_count = 0;
+      const dim3 grid1(grid.x * grid.y * grid.z);
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * nz * kShards * kShardStride, st));
+      if (xchg) coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, true>, grid1, block, L, cnt, err, spin_limit, role);
+      else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
+      return true;
+    }
+  }
   for (int w = 0; w < nwin; ++w) {
     LstmLayerDev L = L0;
     L.s_count = L0.S / nwin;
