@@ -145,19 +145,20 @@ def _rdv(rank, world, port, q):
     q.put((rank, rc, buf.raw == bytes(range(128))))
 
 
-def test_library_tcp_rendezvous_hands_the_id_to_every_rank():
-    """eesen_comm_exchange (the hand-out of the RCCL unique id, include/eesen_hip.h) between three processes; the late
-    starter is rank 0, so the others exercise their connect-retry loop."""
+@pytest.mark.parametrize("world", [3, 8])
+def test_library_tcp_rendezvous_hands_the_id_to_every_rank(world):
+    """eesen_comm_exchange (the hand-out of the RCCL unique id, include/eesen_hip.h) between `world` processes -- 8 is the node
+    the scaling bench runs on; the late starter is rank 0, so the others exercise their connect-retry loop."""
     import multiprocessing as mp
     import time
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rdv, args=(r, 3, port, q)) for r in (1, 2)]
+    procs = [ctx.Process(target=_rdv, args=(r, world, port, q)) for r in range(1, world)]
     for p in procs: p.start()
     time.sleep(0.5)
-    p0 = ctx.Process(target=_rdv, args=(0, 3, port, q)); p0.start(); procs.append(p0)
-    got = sorted(q.get(timeout=60) for _ in range(3))
+    p0 = ctx.Process(target=_rdv, args=(0, world, port, q)); p0.start(); procs.append(p0)
+    got = sorted(q.get(timeout=90) for _ in range(world))
     for p in procs:
         p.join(timeout=30); assert p.exitcode == 0
-    assert got == [(0, 0, True), (1, 0, True), (2, 0, True)]
+    assert got == [(r, 0, True) for r in range(world)]
