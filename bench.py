@@ -391,9 +391,11 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
-                    "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step hand-off chain "
-                             "(L1 miss queue + three dependent fabric round trips, DESIGN.md section 4) and is measured while the "
-                             "launch shares the chip with the overlapped GEMMs; whole_step is the step's total FLOPs over its time"),
+                    "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step chain -- 1.8 us of "
+                             "MFMA (half of it on the padding rows of the 8-sequence tile), a 64 KB operand fetch through one CU's L1 and "
+                             "the hand-off (counter-increment flight + poll round trip + drain of the write-through stores), DESIGN.md "
+                             "sections 4 and 10 -- and is measured while the launch shares the chip with the overlapped GEMMs (alone: "
+                             "~4.1 ms per launch); whole_step is the step's total FLOPs over its time"),
                     "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                    "flops_per_frame": fpf},
                     "other_kernels": {n: {"achieved": v["achieved"], "frac": v["achieved"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": v["avg_us"]}
