@@ -22,8 +22,9 @@
 // shares its first line with the previous block, which caches it one step early.
 // A workgroup can run at most one step ahead of the slowest one of its (direction, sequence-tile) group, and step t
 // writes row block t while laggards still read row block t-1, so there is no write-after-read hazard.
-// All workgroups must be co-resident: the host launches cooperatively after an occupancy check with margin and
-// otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an error word instead of hanging.
+// All workgroups must be co-resident: the host launches only after an occupancy check with margin (see coop_launch for why the
+// launch itself is an ordinary one) and otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an
+// error word instead of hanging.
 //
 // Arithmetic is that of lstm.hip (same cell equations, K split over the 8 waves the same way): the forward pass is
 // bit-identical to the per-step path; the backward pass differs in the last bits (FMA contraction, and the full-line operand
@@ -720,6 +721,16 @@ bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE la
 
 template <class K, class... Args>
 void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) {
+  // Ordinary launch by default: hipLaunchCooperativeKernel (EESEN_COOP_LAUNCH=1) costs ~40 us more per launch (its dedicated
+  // queue), 0.3 ms per cfg2 step over eight launches, and guarantees nothing that fits() has not checked already -- the runtime
+  // does not gang-schedule a cooperative grid either (the side-stream GEMMs co-run with it), it only refuses grids above the
+  // occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at
+  // once are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp), exactly as before.
+  static const bool coop = getenv("EESEN_COOP_LAUNCH") && atoi(getenv("EESEN_COOP_LAUNCH")) != 0;
+  if (!coop) {
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+    return;
+  }
   void* argv[] = {(void*)&args...};
   EESEN_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, 0, st));
 }
