@@ -86,6 +86,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 #ifndef EESEN_NO_SYNC
 #define EESEN_NO_SYNC 0
 #endif
+// EESEN_BWD_4X4 (default 1): the 8-sequence backward tile multiplies with v_mfma_f32_4x4x1_16B_f32 and the A-operand BROADCAST of
+// that instruction (CBSZ = 2, ABID) instead of v_mfma_f32_16x16x4_f32 with half of its rows padding -- see the kernel.
+#ifndef EESEN_BWD_4X4
+#define EESEN_BWD_4X4 1
+#endif
 #ifndef EESEN_BWD_FULL_LINES
 #define EESEN_BWD_FULL_LINES 1
 #endif
@@ -513,7 +518,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
                                                                       unsigned* err, int spin_limit, unsigned long long* trace,
                                                                       Role R, int chunk) {
-  __shared__ float red[NW][16][17];
+  constexpr bool X44 = ST == 8 && EESEN_BWD_4X4 && CPW <= 8;
+  // X44 at CPW = 8: the B operand is 128 registers per lane (W_m^T is replicated over the two sequence halves), and with them
+  // the kernel would need ~200 VGPRs -- two of its waves and one wave of a side-stream GEMM (84 + 64 accumulator registers) no
+  // longer fit a SIMD's 512.  The last LDSB chunks' B values live in LDS instead (16 KB per chunk and workgroup) and are read
+  // back every step, 4 ds_read_b128 per chunk, under the operand fetch.
+#ifndef EESEN_BWD_LDSB
+#define EESEN_BWD_LDSB 2
+#endif
+  constexpr int LDSB = X44 && CPW == 8 ? EESEN_BWD_LDSB : 0, REGB = X44 ? CPW - LDSB : 1;
+  __shared__ __attribute__((aligned(16))) float4 bl[LDSB ? LDSB : 1][4][LDSB ? NW * 64 : 1];   // [chunk][ABID][thread]
+  __shared__ float red[NW][16][17];   // X44: [wave][k class (2) x sequence (8)][unit]
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -535,8 +550,34 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 
   const int li = lane & 15, kq = lane >> 4;
   const int sa = s0 + li, ub = u0 + li;
-  float b[CPW][8];  // this wave's part of the workgroup's 16 rows of W_m^T, resident for the whole layer pass
-  {
+  // X44: the 64 lanes are 16 blocks of 4 -- group g = lane >> 4 = (sequence half rb, k class ks), unit quad cb = (lane >> 2) & 3,
+  // x = lane & 3.  One v_mfma_f32_4x4x1_16B_f32 multiplies, per block, a 4-vector of A (4 sequences, ONE k) with a 4-vector of B
+  // (ONE k, 4 units) into a 4 x 4 tile: 16 blocks = 2 sequence halves x 4 unit quads x 2 k classes = the 8 x 16 outputs of the
+  // workgroup for TWO k values, no padding rows, at the same 64 flops per cycle as the 16x16x4 form -- half the MFMA time.
+  // The A vector of a block depends on (rb, ks) only, not on cb: CBSZ = 2 makes the four blocks of a group share the A lanes of
+  // block ABID, so ONE operand register serves FOUR instructions (ABID = 0..3) and nothing is replicated: lane (rb, ks, cb', x)
+  // loads 16 bytes of sequence rb*4 + x at k = chunk + (ks*4 + cb')*4 -- a whole 128-byte line per sequence and chunk, each
+  // requested once -- and instruction (chunk, r, cb') takes component r with ABID = cb': it covers k = chunk + ks*16 + cb'*4 + r
+  // in class ks.  B (resident): lane (rb, ks, cb, x) holds W_m^T[unit cb*4 + x][that k], 16 consecutive floats per chunk.
+  const int g4 = lane >> 4, rb4 = g4 >> 1, ks4 = g4 & 1, cb4 = (lane >> 2) & 3, x4 = lane & 3;
+  float bw[REGB][4][4];   // [chunk][component r][ABID cb']
+  if constexpr (X44) {
+    const int ub4 = u0 + cb4 * 4 + x4;
+    const float* Br = L.WmT + ((size_t)dir * H + min(ub4, H - 1)) * K4;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      const int k0 = (wave + c * NW) * 32 + ks4 * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ub4 < H && k0 + q * 4 < K4) v = *reinterpret_cast<const float4*>(Br + k0 + q * 4);
+        if (c < REGB) { bw[c][0][q] = v.x; bw[c][1][q] = v.y; bw[c][2][q] = v.z; bw[c][3][q] = v.w; }
+        else bl[c - REGB][q][tid] = v;
+      }
+    }
+  }
+  float b[X44 ? 1 : CPW][8];  // this wave's part of the workgroup's 16 rows of W_m^T, resident for the whole layer pass
+  if constexpr (!X44) {
     const float* Br = L.WmT + ((size_t)dir * H + ub) * K4;
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
@@ -604,7 +645,63 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       EESEN_STAMP(1);
       const int tnb = tn * S - tbS;
       const size_t arow = ((size_t)(tnb + sa) * ldG + (size_t)dir * K4) * 4;  // byte offset of this lane's DG_next row in block tn
-      if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
+      if constexpr (X44) {
+        const unsigned arow4 = (unsigned)(((size_t)(tnb + s0 + rb4 * 4 + x4) * ldG + (size_t)dir * K4) * 4);
+        const bool rok = s0 + rb4 * 4 + x4 < s_end;
+        // FOUR chunks of operands in flight (16 registers): chunk c + 4 is requested into chunk c's registers as soon as its 16
+        // MFMAs have been issued -- with all eight in flight the kernel needs 222 VGPRs, and two of its waves plus one wave of a
+        // side-stream GEMM (88) no longer fit a SIMD's 512
+#ifndef EESEN_BWD_INF
+#define EESEN_BWD_INF 4
+#endif
+        constexpr int INF = CPW < EESEN_BWD_INF ? CPW : EESEN_BWD_INF;
+        auto fetch = [&](int c) {
+          const int k = (wave + c * NW) * 32 + (ks4 * 4 + cb4) * 4;
+          return __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow4 + (unsigned)k * 4u : 0x80000000u, 0,
+                                                       EESEN_SC1_LOADS ? kSc1 : 0);
+        };
+        f32x4 a4[INF];
+#pragma unroll
+        for (int c = 0; c < INF; ++c) a4[c] = fetch(c);
+        __builtin_amdgcn_sched_barrier(0);  // these loads are in flight BEFORE the first MFMA
+        f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // two accumulators: dependent MFMAs two issues apart
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const f32x4 cur = a4[c % INF];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {   // ABID 2h and 2h + 1
+            float w0[4], w1[4];
+            if (c < REGB) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { w0[r] = bw[c < REGB ? c : 0][r][2 * h]; w1[r] = bw[c < REGB ? c : 0][r][2 * h + 1]; }
+            } else {   // this chunk's B from LDS, two ABID vectors at a time
+              int lt = tid;
+              asm volatile("" : "+v"(lt));   // opaque per step: the reads are loop-invariant, and hoisted they would be registers again
+              const float4 v0 = bl[c < REGB ? 0 : c - REGB][2 * h][lt], v1 = bl[c < REGB ? 0 : c - REGB][2 * h + 1][lt];
+              w0[0] = v0.x; w0[1] = v0.y; w0[2] = v0.z; w0[3] = v0.w;
+              w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (h == 0) {
+                ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur[r], w0[r], ac[0], 2, 0, 0);
+                ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur[r], w1[r], ac[1], 2, 1, 0);
+              } else {
+                ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur[r], w0[r], ac[0], 2, 2, 0);
+                ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur[r], w1[r], ac[1], 2, 3, 0);
+              }
+            }
+          }
+          if (c + INF < CPW) {
+            __builtin_amdgcn_sched_barrier(0);
+            a4[c % INF] = fetch(c + INF);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // D of block (rb, ks, cb): vgpr i, lane x -> out[sequence rb*4 + i][unit cb*4 + x], partial sum of k class ks
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc0[i] = ac[0][i] + ac[1][i];
+      } else if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
         // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
         // load: lane (li, kq) reads 16 bytes of sequence li & 7 at segment (li >> 3) * 4 + kq of the 128-byte chunk -- one
         // request per line and ONE load instruction per chunk instead of two half-empty ones that each touch every line (the
@@ -658,14 +755,19 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         }
       }
     }
+    if constexpr (X44) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
+      for (int i = 0; i < 4; ++i) red[wave][ks4 * 8 + rb4 * 4 + i][cb4 * 4 + x4] = acc0[i];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][li] = acc0[r] + acc1[r];
+    }
     __syncthreads();
     EESEN_STAMP(2);
     if (e_ok) {
       float dm = dy;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) dm += red[w][es][eu];
+      for (int w = 0; w < NW; ++w) dm += X44 ? red[w][es][eu] + red[w][8 + es][eu] : red[w][es][eu];
       const float g = gt.x, i = gt.y, f = gt.z, o = gt.w;
       const float h = tanhf_(c_t);
       const float dh = (1.f - h * h) * (dm * o);
