@@ -810,6 +810,160 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, 4 sequences x 32 units per workgroup (EESEN_BWD_Q4, default): the 4x4x1 MFMA with CBSZ = 3.
+// With the padding rows gone (see X44 in lstm_bwd_persistent_kernel) the step is bound by the operand FETCH: 64 KB of DG_next per
+// workgroup for 8 sequences.  The 16-block MFMA does not care how the 128 outputs of a workgroup are shaped, so here they are
+// 4 sequences x 32 units: blocks = 8 unit quads x 2 k classes, ALL EIGHT blocks of a k class share the A lanes of block ABID
+// (CBSZ = 3, one operand register serves eight instructions), the fetch is 32 KB per workgroup and step -- half --, W_m^T is
+// not replicated at all (32 units x 256 k per wave = 128 registers per lane, the last quarter in LDS as in X44), and the grid is
+// still one workgroup per CU (H/32 x ndir x S/4 = 256 at cfg2).  Lane l: k class ks = l >> 5, block ab = (l >> 2) & 7, x = l & 3.
+//   A: lane (ks, ab, x) loads 16 bytes of sequence x at k = pair*64 + (ks*8 + ab)*4: per sequence and load two whole lines;
+//   instruction (pair, r, ABID) takes component r: class ks covers k = pair*64 + ks*32 + ABID*4 + r;
+//   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
+// Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
+// ------------------------------------------------------------------------------------------------
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
+                                                                         float* __restrict__ DG, unsigned* cnt, unsigned* err,
+                                                                         int spin_limit, Role R) {
+  constexpr int ST = 4, UW = 32, P = CPW / 2;         // sequences, units per workgroup; (load, 64-float) pairs per wave
+  constexpr int LDSP = CPW == 8 ? 1 : 0, REGP = P - LDSP;   // pairs whose B values live in LDS / registers
+  __shared__ __attribute__((aligned(16))) float4 bl[LDSP ? LDSP : 1][8][LDSP ? NW * 64 : 1];   // [pair][ABID][thread]
+  __shared__ float red[NW][8][UW + 1];               // [wave][k class (2) x sequence (4)][unit]
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int u0 = bx * UW, s0 = bz * ST;
+  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
+  const unsigned nblk = R.nblk;
+  const int ks = lane >> 5, ab = (lane >> 2) & 7, x = lane & 3;
+  float bw[REGP ? REGP : 1][4][8];   // [pair][component r][ABID]
+  {
+    const int ub = u0 + ab * 4 + x;
+    const float* Br = L.WmT + ((size_t)dir * H + min(ub, H - 1)) * K4;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int k0 = (wave + p * NW) * 64 + ks * 32;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ub < H && k0 + q * 4 < K4) v = *reinterpret_cast<const float4*>(Br + k0 + q * 4);
+        if (p < REGP) { bw[p < REGP ? p : 0][0][q] = v.x; bw[p < REGP ? p : 0][1][q] = v.y; bw[p < REGP ? p : 0][2][q] = v.z; bw[p < REGP ? p : 0][3][q] = v.w; }
+        else bl[p < REGP ? 0 : p - REGP][q][tid] = v;
+      }
+    }
+  }
+  const int es = tid >> 5, eu = tid & 31;
+  const int s_e = s0 + es, u_e = u0 + eu;
+  const bool e_ok = tid < ST * UW && s_e < S && u_e < H;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
+  const size_t gcol = (size_t)dir * K4 + u_e * 4;
+  const size_t ycol = (size_t)dir * H + u_e;
+  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dy = 0.f, c_t = 0.f, c_p = 0.f;
+  {
+    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
+    if (e_ok) {
+      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
+      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
+      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
+      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
+  __syncthreads();   // bl is complete
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (step > 0) {
+      if (wave == EESEN_POLL_WAVE) {
+        const bool go = wait_counters<EESEN_POLL_DELAY_BWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      const unsigned arow = (unsigned)(((size_t)(tn * S + s0 + x) * ldG + (size_t)dir * K4) * 4);
+      const bool rok = s0 + x < S;
+      f32x4 a4[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int k = (wave + p * NW) * 64 + (ks * 8 + ab) * 4;
+        a4[p] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow + (unsigned)k * 4u : 0x80000000u, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {   // ABID 2h and 2h + 1
+          float w0[4], w1[4];
+          if (p < REGP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { w0[r] = bw[p < REGP ? p : 0][r][2 * h]; w1[r] = bw[p < REGP ? p : 0][r][2 * h + 1]; }
+          } else {
+            int lt = tid;
+            asm volatile("" : "+v"(lt));   // opaque per step (see X44)
+            const float4 v0 = bl[p < REGP ? 0 : p - REGP][2 * h][lt], v1 = bl[p < REGP ? 0 : p - REGP][2 * h + 1][lt];
+            w0[0] = v0.x; w0[1] = v0.y; w0[2] = v0.z; w0[3] = v0.w;
+            w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (h == 0)      { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 0, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 1, 0); }
+            else if (h == 1) { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 2, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 3, 0); }
+            else if (h == 2) { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 4, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 5, 0); }
+            else             { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 6, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 7, 0); }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][ab * 4 + x] = ac[0][i] + ac[1][i];
+    __syncthreads();
+    if (e_ok) {
+      float dm = dy;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dm += red[w][es][eu] + red[w][4 + es][eu];
+      const float g = gt.x, i = gt.y, f = gt.z, o = gt.w;
+      const float h = tanhf_(c_t);
+      const float dh = (1.f - h * h) * (dm * o);
+      float dob = o * (1.f - o) * (dm * h);
+      const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
+      float df = f * (1.f - f) * (dc * c_p);
+      float di = i * (1.f - i) * (dc * g);
+      float dg = (1.f - g * g) * (dc * i);
+      float carry = dc * f;
+      if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
+      const f32x4 out = {dg, di, df, dob};
+      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4), 0, kSc1);
+      dcf = carry; dn_i = di; dn_f = df;
+    }
+    if (step + 1 < T) {
+      if (tid < ST * UW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      }
+    }
+  }
+}
+
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
@@ -1003,6 +1157,28 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   if (max_blocks < 3) return false;
   int chunk = (int)std::min<long>(L0.T, max_blocks - 1);
   if (chunk < L0.T) { int p2 = 1; while (p2 * 2 <= chunk) p2 *= 2; chunk = p2; }   // a power of two keeps `step % chunk` cheap
+  // The 4-sequence x 32-unit tile (lstm_bwd_persistent_q4_kernel): wherever the 8-sequence tile would be taken and the shape allows
+  const bool q4_env = !(getenv("EESEN_BWD_Q4") && atoi(getenv("EESEN_BWD_Q4")) == 0);   // read per call: tests flip it
+  if (q4_env && stile == 8 && !L0.drop_mode && L0.H % 128 == 0 && L0.H / 64 <= 8 && L0.S % 4 == 0 && chunk >= L0.T && !l2_local()) {   // (the L2-local experiment lives in the 8-sequence kernel)
+    const int cpw = L0.H / 64;   // 2, 4 or 8
+    dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
+    const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
+    bool fit = false;
+    if (cpw == 8) fit = fits(lstm_bwd_persistent_q4_kernel<8>, grid, NW * 64);
+    else if (cpw == 4) fit = fits(lstm_bwd_persistent_q4_kernel<4>, grid, NW * 64);
+    else if (cpw == 2) fit = fits(lstm_bwd_persistent_q4_kernel<2>, grid, NW * 64);
+    if (fit && cwords <= (size_t)kCtlHalf) {
+      LstmLayerDev L = L0;
+      L.s_begin = 0; L.s_count = 0;
+      const dim3 grid1(grid.x * grid.y * grid.z);
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
+      if (cpw == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
+      else if (cpw == 4) coop_launch(st, lstm_bwd_persistent_q4_kernel<4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
+      else coop_launch(st, lstm_bwd_persistent_q4_kernel<2>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
+      return true;
+    }
+  }
   auto launch = [&](const LstmLayerDev& L, bool dry) -> bool {
     const int Sw = L.s_count ? L.s_count : L.S;
     dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(Sw, stile)), block(NW * 64);

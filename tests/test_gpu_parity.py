@@ -383,6 +383,7 @@ def test_l2_local_handoff_option(gpu, monkeypatch):
     cfg = synth.config("cfg2"); cfg.update(T=40, layers=2)      # S = 32, bidirectional, 8-sequence tiles: 8 groups = 8 XCDs
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
     res = {}
+    monkeypatch.setenv("EESEN_BWD_Q4", "0")      # the census lives in the 8-sequence backward kernel, not in the 4 x 32 tile
     for mode in ("0", "1"):
         monkeypatch.setenv("EESEN_L2_LOCAL", mode)
         net = Net.from_layers(layers); ctc = Ctc()

@@ -34,5 +34,6 @@ int main() {
   hipLaunchKernelGGL((probe<0, 0>), dim3(1), dim3(64), 0, 0, da, db, dd); show("cbsz=0 abid=0: D[lane][vgpr] / B[lane] = the A value used");
   hipLaunchKernelGGL((probe<2, 0>), dim3(1), dim3(64), 0, 0, da, db, dd); show("cbsz=2 abid=0");
   hipLaunchKernelGGL((probe<2, 3>), dim3(1), dim3(64), 0, 0, da, db, dd); show("cbsz=2 abid=3");
+  hipLaunchKernelGGL((probe<3, 5>), dim3(1), dim3(64), 0, 0, da, db, dd); show("cbsz=3 abid=5");
   return 0;
 }
