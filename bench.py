@@ -370,9 +370,13 @@ def main():
         if persistent:
             n_rec, rec_flops = nl * K, rec_flops * T
         kn = "persistent_kernel" if persistent else "step_kernel"
+        # the backward pass takes the 4-sequence x 32-unit tile where lstm_bwd_persistent (lstm_persistent.hip) does: the 8-sequence
+        # tile would be chosen (16-sequence tiles leave half the CUs idle), H a multiple of 128 up to 512, whole 4-sequence tiles
+        q4 = (persistent and H % 128 == 0 and H <= 512 and S % 4 == 0 and S > 8 and 2 * ((H + 15) // 16) * nd * ((S + 15) // 16) <= 256
+              and os.environ.get("EESEN_BWD_Q4", "1") != "0")
         kern = {
             "lstm_fwd_" + kn: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops),
-            "lstm_bwd_" + kn: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops),
+            ("lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn): dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops),
             "gemm_f32_mfma_kernel(input->gates)": dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops),
         }
         for k in kern.values():
@@ -391,11 +395,11 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
-                    "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step chain -- 1.8 us of "
-                             "MFMA (half of it on the padding rows of the 8-sequence tile), a 64 KB operand fetch through one CU's L1 and "
-                             "the hand-off (counter-increment flight + poll round trip + drain of the write-through stores), DESIGN.md "
-                             "sections 4 and 10 -- and is measured while the launch shares the chip with the overlapped GEMMs (alone: "
-                             "~4.1 ms per launch); whole_step is the step's total FLOPs over its time"),
+                    "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step chain -- a 32 KB "
+                             "operand fetch through one CU's L1 beside 0.9 us of MFMA (4 x 32 tile on v_mfma_f32_4x4x1_16B_f32 with the "
+                             "A-operand broadcast), the cell update, and the hand-off (counter-increment flight + poll round trip + drain "
+                             "of the write-through stores), DESIGN.md sections 4, 9 and 10 -- and is measured while the launch shares the "
+                             "chip with the overlapped GEMMs (alone: ~3.1 ms per launch); whole_step is the step's total FLOPs over its time"),
                     "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                    "flops_per_frame": fpf},
                     "other_kernels": {n: {"achieved": v["achieved"], "frac": v["achieved"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": v["avg_us"]}
