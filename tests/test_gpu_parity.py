@@ -313,7 +313,9 @@ def test_error_behaviour(gpu, tmp_path):
 
 @pytest.mark.parametrize("cfg_name,over", [("small_bi", {}), ("small_uni", {}), ("cfg1", {}), ("small_bi", dict(S=37, T=33, H=40)),
                                            ("cfg2", dict(T=50, layers=2)), ("cfg4", dict(T=12, layers=1)),
-                                           ("cfg2", dict(T=16, layers=1, H=768)), ("cfg2", dict(T=12, layers=2, H=1024))])
+                                           ("cfg2", dict(T=16, layers=1, H=768)), ("cfg2", dict(T=12, layers=2, H=1024)),
+                                           ("cfg2", dict(T=24, layers=2, H=256)), ("cfg2", dict(T=24, layers=1, H=128)),    # 4 x 32 backward tile, 4 / 2 chunks per wave
+                                           ("cfg2", dict(T=20, layers=1, H=256, S=12)), ("cfg2", dict(T=20, layers=1, S=30))])  # ragged last tiles / S % 4 != 0
 def test_persistent_recurrence_matches_step_kernels(gpu, cfg_name, over, monkeypatch):
     """lstm_persistent.hip (one cooperative launch per layer pass, W_m resident in registers, in-kernel hand-off of
     m_t / DG_t) against the one-launch-per-step kernels: same MFMA and reduction order, so the forward pass is bit
