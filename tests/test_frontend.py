@@ -155,3 +155,41 @@ def test_raw_reader_drops_what_the_reference_tools_drop(tmp_path):
         raw = dict(utts)[k]
         assert u.shape == (len(range(1, raw.shape[0], 3)), raw.shape[1]) and np.array_equal(u.raw, raw)
         assert np.array_equal(u.cmvn, ofe.cmvn_norm(stats[k.split("_")[0]], True))
+
+
+REFUSED = [
+    "scp:feats.scp", "ark:feats.ark",
+    "ark:apply-cmvn --skip-dims=0:1 scp:c.scp scp:f.scp ark:- |",
+    "ark:apply-cmvn scp:c.scp scp:f.scp ark:- | paste-feats ark:- scp:x.scp ark:- |",
+    "ark:add-deltas --truncate=13 scp:f.scp ark:- |",
+    "ark:apply-cmvn scp:c.scp scp:f.scp ark:- | add-deltas --truncate=13 ark:- ark:- |",
+    "ark:apply-cmvn --norm-vars=true --norm-means=false scp:c.scp scp:f.scp ark:- |",
+    "ark:apply-cmvn scp:c.scp scp:f.scp ark:- | subsample-feats --n=0 ark:- ark:- |",
+    "ark:apply-cmvn scp:c.scp scp:f.scp ark:- | splice-feats --left-context=-1 ark:- ark:- |",
+    "ark:apply-cmvn scp:c.scp scp:f.scp ark:- | add-deltas --delta-window=0 ark:- ark:- |",
+]
+
+
+def test_native_parser_agrees_with_the_python_one(tmp_path):
+    """csrc/tools/feat_pipeline.h (what the native trainer / extractor use) and eesen_amd/frontend.py must recognise exactly the
+    same pipelines: a small g++ harness prints the C++ parse of every line."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "parse_pipeline")
+    subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(root, "tests", "native", "parse_pipeline.cc"), "-o", exe,
+                    "-L" + os.path.join(root, "eesen_amd", "lib"), "-leesen_hip", "-Wl,-rpath," + os.path.join(root, "eesen_amd", "lib"),
+                    "-Wl,--allow-shlib-undefined"], check=True)
+    lines = sorted(RECIPE_LINES) + REFUSED + [
+        "ark:copy-feats scp:f.scp ark:- | splice-feats --left_context=2 ark:- ark:- | subsample-feats --n=-2 ark:- ark:- | add-deltas --delta-order=1 --delta-window=3 ark:- ark:- |",
+        "ark,s,cs:/opt/kaldi/bin/apply-cmvn --norm-vars=T --utt2spk=ark:u2s 'scp:c m.scp' scp:f.scp ark:- |",
+    ]
+    out = subprocess.run([exe] + lines, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == len(lines)
+    for line, got in zip(lines, out):
+        p = fe.parse_feature_pipeline(line)
+        want = "NONE" if p is None else "|".join([p.source, p.cmvn or "", p.utt2spk or "", str(int(p.norm_vars)),
+                                                   ",".join(f"{k}:{a}:{b}" for k, a, b in p.stages)])
+        assert got == want, (line, got, want)
