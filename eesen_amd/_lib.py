@@ -70,6 +70,11 @@ SIGNATURES = {
     "eesen_net_allreduce_grads": (_i, [_vp, _vp]),
     "eesen_net_backpropagate_zero": (_i, [_vp]),
     "eesen_net_bucket_order": (_i, [_vp, _pi, _i, _pi]),
+    "eesen_net_live_ranks": (_i, [_vp, _pi]),
+    "eesen_net_layer_marker": (_i, [_vp, _i, C.c_char_p, _i]),
+    "eesen_net_tensor_moments": (_i, [_vp, _i, _i, _pd, _i, _pi]),
+    "eesen_ctc_set_guard": (_i, [_vp, _vp]),
+    "eesen_ctc_dropped": (_i, [_vp, _pl]),
     "eesen_ctc_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "eesen_ctc_destroy": (_i, [_vp]),
     "eesen_ctc_eval_parallel": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),

@@ -329,6 +329,36 @@ class Net:
         """This rank has no minibatch this step (others do): zero gradient through the same collectives; then Update()."""
         check(self.lib.eesen_net_backpropagate_zero(self.h))
 
+    def LiveRanks(self) -> int:
+        """How many ranks had a minibatch in the step issued last (the liveness word that rides with the top layer's gradient
+        bucket).  For a rank in the zero-gradient protocol: 0 = every rank is out of data.  Blocks until that bucket has arrived."""
+        n = C.c_int()
+        check(self.lib.eesen_net_live_ranks(self.h, C.byref(n)))
+        return n.value
+
+    def LayerMarker(self, idx: int) -> str:
+        buf = C.create_string_buffer(64)
+        check(self.lib.eesen_net_layer_marker(self.h, idx, buf, 64))
+        return buf.value.decode()
+
+    def TensorMoments(self, which: int, layer: int) -> np.ndarray:
+        """[n_tensors x 6] = (min, max, mean, variance, skewness, kurtosis) per tensor of `layer`, in the order of the reference
+        layer's Info(); which: 0 parameters, 1 momentum buffers (*_corr_), 2 adaptive accumulators."""
+        n = C.c_int()
+        check(self.lib.eesen_net_tensor_moments(self.h, which, layer, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 6), np.float64)
+        if n.value:
+            check(self.lib.eesen_net_tensor_moments(self.h, which, layer, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+        return out
+
+    def Info(self) -> str:
+        """Net::Info (net.cc:336-354): topology + MomentStatistics of every parameter tensor."""
+        return _net_info(self, 0)
+
+    def InfoGradient(self) -> str:
+        """Net::InfoGradient (net.cc:356-366): MomentStatistics of every momentum buffer (*_corr_)."""
+        return _net_info(self, 1)
+
     def BucketOrder(self) -> List[int]:
         buf = (C.c_int * 64)()
         n = C.c_int()
@@ -363,6 +393,44 @@ class Net:
         out = np.zeros(6, np.float32)
         check(self.lib.eesen_net_get_phase_times(self.h, _np_ptr(out)))
         return dict(zip(["input_gemm", "recurrence_fwd", "affine_softmax", "recurrence_bwd", "grad_gemm", "update"], out.tolist()))
+
+
+_LSTM_TENSORS = ["wei_gifo_x", "wei_gifo_m", "bias", "phole_i_c", "phole_f_c", "phole_o_c"]
+
+
+def _g(v: float) -> str:
+    return f"{v:g}"     # what operator<< prints for a float by default (6 significant digits)
+
+
+def _net_info(net: "Net", which: int) -> str:
+    """The strings of Net::Info / Net::InfoGradient (net.cc:336-366) with the per-layer parts of bilstm-layer.h:496-560,
+    lstm-layer.h:175-196, affine-trans-layer.h:145-159."""
+    layers = net.layers()
+    out = []
+    if which == 0:
+        out += [f"num-layers {len(layers)}", f"input-dim {net.InputDim()}", f"output-dim {net.OutputDim()}",
+                f"number-of-parameters {_g(net.NumParams() / 1e6)} millions"]
+    else:
+        out.append("### Gradient stats :")
+    for i, L in enumerate(layers):
+        m = net.TensorMoments(which, i)
+        stats = [f" ( min {_g(r[0])}, max {_g(r[1])}, mean {_g(r[2])}, variance {_g(r[3])}, skewness {_g(r[4])}, kurtosis {_g(r[5])} ) "
+                 for r in m]
+        suf = "" if which == 0 else "corr_"
+        body = ""
+        if L["type"] in ("BiLstmParallel", "LstmParallel"):
+            dirs = ["_fw_", "_bw_"] if L["type"] == "BiLstmParallel" else ["_"]
+            names = [f"{t}{d}{suf}" for d in dirs for t in _LSTM_TENSORS]
+            body = "    " + "".join(f"\n  {nm}  {st}" for nm, st in zip(names, stats))
+        elif L["type"] == "AffineTransform":
+            names = ["linearity", "bias"] if which == 0 else ["linearity_corr_", "bias_corr_"]
+            body = "".join(f"\n  {nm}{st}" for nm, st in zip(names, stats))
+        marker = net.LayerMarker(i)
+        if which == 0:
+            out.append(f"layer {i + 1} : {marker}, input-dim {L['input_dim']}, output-dim {L['output_dim']}, {body}")
+        else:
+            out.append(f"Layer {i + 1} : {marker}, {body}")
+    return "\n".join(out) + "\n"
 
 
 class Ctc:
@@ -444,6 +512,16 @@ class Ctc:
         b = np.empty((rows, L.value), np.float32)
         check(self.lib.eesen_ctc_get_alpha_beta(self.h, _np_ptr(a), _np_ptr(b), C.byref(L)))
         return a, b
+
+    def SetGuard(self, net: Optional[Net]):
+        """Drop minibatches computed from a timed-out persistent forward pass of `net` from the statistics (eesen_ctc_set_guard)."""
+        check(self.lib.eesen_ctc_set_guard(self.h, net.h if net is not None else None))
+        self._guard = net
+
+    def Dropped(self) -> int:
+        n = C.c_long()
+        check(self.lib.eesen_ctc_dropped(self.h, C.byref(n)))
+        return n.value
 
     def SetSequenceOutFile(self, path: Optional[str]):
         """--sequence-out-file (train-ctc-parallel.cc:53-54,134-137): ErrorRateMSeq appends `utt | label frame prob | ...` lines."""

@@ -103,6 +103,19 @@ int eesen_net_layer_info(eesen_net_t* net, int idx, int* kind, int* in_dim, int*
     if (max_grad) *max_grad = L.max_grad;
   });
 }
+int eesen_net_layer_marker(eesen_net_t* net, int idx, char* buf, int cap) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(buf);
+    EESEN_REQUIRE(idx >= 0 && idx < (int)net->layers.size() && cap > 0, EESEN_ERR_INVALID, "layer index out of range");
+    std::snprintf(buf, (size_t)cap, "%s", net->layers[idx].marker());
+  });
+}
+int eesen_net_tensor_moments(eesen_net_t* net, int which, int layer, double* out6_host, int cap_tensors, int* n_tensors) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(n_tensors);
+    *n_tensors = net->tensor_moments(which, layer, out6_host, cap_tensors);
+  });
+}
 int eesen_net_input_dim(eesen_net_t* net, int* dim) {
   return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.front().din; });
 }
@@ -237,6 +250,16 @@ int eesen_ctc_set_sequence_out_file(eesen_ctc_t* ctc, const char* path) {
     ctc->seq_out = path ? path : "";
     if (!ctc->seq_out.empty()) std::remove(ctc->seq_out.c_str());  // train-ctc-parallel.cc:134-137
   });
+}
+int eesen_ctc_set_guard(eesen_ctc_t* ctc, eesen_net_t* net) {
+  return guard([&] {
+    REQ_PTR(ctc);
+    ctc->flush();
+    ctc->guard = net && net->ctl.p ? net->ctl.p + kCtlWords - 1 : nullptr;
+  });
+}
+int eesen_ctc_dropped(eesen_ctc_t* ctc, long* minibatches) {
+  return guard([&] { REQ_PTR(ctc); REQ_PTR(minibatches); ctc->flush(); *minibatches = ctc->dropped; });
 }
 int eesen_ctc_set_profiling(eesen_ctc_t* ctc, int mode) {
   return guard([&] { REQ_PTR(ctc); ctc->timer.enable(mode == 2); ctc->timer.set_accumulate(mode == 2); });

@@ -11,6 +11,19 @@
 //
 // RCCL is loaded with dlopen on first use: a single-GPU process never maps it, and the library keeps loading on boxes
 // without it.  Rendezvous of the 128-byte ncclUniqueId is a plain TCP hand-out by rank 0 (no MPI, no torch).
+//
+// Two things the reference's file protocol had and a collective does not get for free:
+//   * jobs with DIFFERENT numbers of minibatches (communicator.h:104-112: a sub-job "gives up if the main job finishes first").
+//     Here a rank that is out of data keeps stepping with a zero gradient (Net::backpropagate_zero) and one float rides with
+//     the top layer's gradient bucket: 1 from every rank that had a minibatch, 0 from the others.  Its sum tells a draining
+//     rank whether anybody is still training (Net::live_ranks), and the update kernels read it ON THE DEVICE: a round in
+//     which no rank was live -- the closing round all ranks take together -- does not touch the model.  No per-step host
+//     round trip is needed for any of this.
+//   * a peer that DIES.  The reference's job 1 would poll for a file forever; a collective kernel would spin forever.  Every
+//     collective is followed by an event that a watchdog thread of the communicator watches: one that has not completed
+//     EESEN_COMM_TIMEOUT_S (default 600) seconds after it was issued makes the watchdog call ncclCommAbort -- the kernels see
+//     the abort flag and leave, every host wait returns -- and every later call on the communicator or a net attached to it
+//     fails with EESEN_ERR_COMM.
 #include <arpa/inet.h>
 #include <dlfcn.h>
 #include <netdb.h>
@@ -19,8 +32,12 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include <rccl/rccl.h>
@@ -38,6 +55,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -60,6 +78,7 @@ RcclApi& rccl() {
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.dl, "ncclCommAbort"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
   return api;
@@ -113,8 +132,22 @@ void comm_exchange(const char* addr, int port, int rank, int world, char* buf, i
     sockaddr_in sa{};
     sa.sin_family = AF_INET;
     sa.sin_port = htons((uint16_t)port);
+    // listen on the interface the peers were told to reach (--comm-addr / MASTER_ADDR), not on every one; a name that does not
+    // resolve to a local address (a load-balancer name, 0.0.0.0) falls back to all interfaces
     sa.sin_addr.s_addr = htonl(INADDR_ANY);
-    if (::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0)
+    bool bound = false;
+    if (addr && *addr) {
+      addrinfo hints{}, *res = nullptr;
+      hints.ai_family = AF_INET;
+      hints.ai_socktype = SOCK_STREAM;
+      if (getaddrinfo(addr, nullptr, &hints, &res) == 0 && res) {
+        sockaddr_in sb = sa;
+        sb.sin_addr = reinterpret_cast<sockaddr_in*>(res->ai_addr)->sin_addr;
+        bound = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&sb), sizeof(sb)) == 0;
+      }
+      if (res) freeaddrinfo(res);
+    }
+    if (!bound && ::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0)
       throw Error(EESEN_ERR_IO, "rendezvous: cannot bind port " + std::to_string(port) + ": " + strerror(errno));
     EESEN_REQUIRE(::listen(ls.fd, world) == 0, EESEN_ERR_IO, "rendezvous: listen() failed");
     std::vector<char> served(world, 0);
@@ -139,7 +172,14 @@ void comm_exchange(const char* addr, int port, int rank, int world, char* buf, i
         continue;  // a stray connection: ignore it
       }
       if (hello[0] != magic || hello[1] == 0 || hello[1] >= (unsigned)world || served[hello[1]]) continue;
-      send_all(c.fd, buf, (size_t)n);
+      try {
+        send_all(c.fd, buf, (size_t)n);
+        unsigned ack = 0;   // the peer confirms it HAS the blob: a connection that died on the way is not counted as served
+        recv_all(c.fd, reinterpret_cast<char*>(&ack), sizeof(ack));
+        if (ack != magic) continue;
+      } catch (const Error&) {
+        continue;  // a half-open or stray peer: it may connect again
+      }
       served[hello[1]] = 1;
       --left;
     }
@@ -161,6 +201,7 @@ void comm_exchange(const char* addr, int port, int rank, int world, char* buf, i
         try {
           send_all(c.fd, reinterpret_cast<const char*>(hello), sizeof(hello));
           recv_all(c.fd, buf, (size_t)n);
+          send_all(c.fd, reinterpret_cast<const char*>(&magic), sizeof(magic));
           freeaddrinfo(res);
           return;
         } catch (const Error& e) {
@@ -187,6 +228,18 @@ struct Comm {
   double* scratch_h = nullptr;  // pinned
   static constexpr int kScratch = 64;
 
+  // watchdog (see the head of this file)
+  struct Pending { hipEvent_t ev; double t0; };
+  std::thread wd;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Pending> pending;
+  std::vector<hipEvent_t> free_ev;
+  bool stop = false;
+  std::atomic<bool> dead{false};
+  std::string dead_msg;
+  double timeout_s = 600.0;
+
   Comm(int dev, const char* id128, int rank_, int world_) : device(dev), rank(rank_), world(world_) {
     EESEN_REQUIRE(world >= 1 && rank >= 0 && rank < world, EESEN_ERR_INVALID, "communicator: bad rank / world size");
     int n = 0;
@@ -201,33 +254,104 @@ struct Comm {
     EESEN_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
     EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch_d), kScratch * sizeof(double)));
     EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&scratch_h), kScratch * sizeof(double), hipHostMallocDefault));
+    if (const char* e = getenv("EESEN_COMM_TIMEOUT_S")) timeout_s = std::max(0.05, atof(e));
+    wd = std::thread([this] { watch(); });
   }
   ~Comm() {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (wd.joinable()) wd.join();
     (void)hipSetDevice(device);
     if (st) (void)hipStreamSynchronize(st);
     if (comm) (void)rccl().CommDestroy(comm);
+    for (auto& p : pending) (void)hipEventDestroy(p.ev);
+    for (auto e : free_ev) (void)hipEventDestroy(e);
     if (scratch_d) (void)hipFree(scratch_d);
     if (scratch_h) (void)hipHostFree(scratch_h);
     if (st) (void)hipStreamDestroy(st);
   }
+  void check_alive() const {
+    if (dead.load(std::memory_order_acquire)) throw Error(EESEN_ERR_COMM, dead_msg);
+  }
+  // an event behind the collective just enqueued on `on`: the watchdog sees when it completes
+  void track(hipStream_t on) {
+    hipEvent_t ev = nullptr;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (!free_ev.empty()) { ev = free_ev.back(); free_ev.pop_back(); }
+    }
+    if (!ev) EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    EESEN_HIP_CHECK(hipEventRecord(ev, on));
+    {
+      std::lock_guard<std::mutex> g(mu);
+      pending.push_back({ev, now_s()});
+    }
+  }
+  void watch() {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(mu);
+    while (!stop) {
+      cv.wait_for(lk, std::chrono::milliseconds(timeout_s < 5 ? 10 : 100));
+      while (!pending.empty()) {
+        const Pending p = pending.front();
+        lk.unlock();
+        const hipError_t e = hipEventQuery(p.ev);
+        lk.lock();
+        if (e == hipSuccess) {
+          pending.pop_front();
+          free_ev.push_back(p.ev);
+          continue;
+        }
+        if (now_s() - p.t0 > timeout_s && !dead.load()) {
+          dead_msg = "data-parallel exchange: a collective issued " + std::to_string((int)(now_s() - p.t0)) + " s ago has not completed on rank " +
+                     std::to_string(rank) + " of " + std::to_string(world) + " (a peer died or stalled; EESEN_COMM_TIMEOUT_S = " +
+                     std::to_string((int)timeout_s) + "): communicator aborted";
+          fprintf(stderr, "ERROR (eesen_hip) %s\n", dead_msg.c_str());
+          if (!rccl().CommAbort) {  // nothing can release the spinning kernels: better a dead process than a hung job
+            fprintf(stderr, "ERROR (eesen_hip) this RCCL has no ncclCommAbort: exiting\n");
+            std::_Exit(70);
+          }
+          dead.store(true, std::memory_order_release);
+          ncclComm_t c = comm;
+          comm = nullptr;  // ncclCommAbort frees it
+          lk.unlock();
+          (void)rccl().CommAbort(c);
+          lk.lock();
+        }
+        break;
+      }
+    }
+  }
   // in place, sum, fp32, enqueued on `on`
   void allreduce_f32(float* buf, size_t n, hipStream_t on) {
     if (n == 0) return;
+    check_alive();
     EESEN_NCCL_CHECK(rccl().AllReduce(buf, buf, n, ncclFloat32, ncclSum, comm, on));
+    track(on);
   }
   // host scalars: sum (op 0) or max (op 1) over the ranks; blocks until done
   void allreduce_host(double* v, int n, int op) {
     EESEN_REQUIRE(n >= 0 && n <= kScratch, EESEN_ERR_INVALID, "at most 64 scalars per call");
     if (n == 0) return;
+    check_alive();
     EESEN_HIP_CHECK(hipSetDevice(device));
     std::memcpy(scratch_h, v, n * sizeof(double));
     EESEN_HIP_CHECK(hipMemcpyAsync(scratch_d, scratch_h, n * sizeof(double), hipMemcpyHostToDevice, st));
     EESEN_NCCL_CHECK(rccl().AllReduce(scratch_d, scratch_d, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, comm, st));
+    track(st);
     EESEN_HIP_CHECK(hipMemcpyAsync(scratch_h, scratch_d, n * sizeof(double), hipMemcpyDeviceToHost, st));
-    EESEN_HIP_CHECK(hipStreamSynchronize(st));
+    EESEN_HIP_CHECK(hipStreamSynchronize(st));  // returns when the collective has run -- or when the watchdog has aborted it
+    check_alive();
     std::memcpy(v, scratch_h, n * sizeof(double));
   }
 };
+
+void comm_check_alive(const Comm* c) {
+  if (c) c->check_alive();
+}
 
 // ---- Net side: per-layer buckets -------------------------------------------------------------------------------------
 void Net::set_comm(Comm* c) {
@@ -252,6 +376,14 @@ void Net::set_comm(Comm* c) {
   bucket_pending.assign(layers.size(), 0);
 }
 
+// The liveness word sits right behind the LAST trainable layer's block of the gradient buffer (which is the first bucket a
+// backward pass issues), so it travels with that bucket at no cost.
+int Net::top_trainable() const {
+  for (int li = (int)layers.size() - 1; li >= 0; --li)
+    if (layers[li].p_n) return li;
+  return -1;
+}
+
 // layer li's fresh gradients are complete once everything enqueued on `producer` so far has run: sum them over the ranks
 // on the communicator's stream; update() makes the compute stream wait for exactly this bucket
 void Net::bucket_allreduce(int li, hipStream_t producer) {
@@ -259,7 +391,8 @@ void Net::bucket_allreduce(int li, hipStream_t producer) {
   bucket_log.push_back(li);
   EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], producer));
   EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_ready[li], 0));
-  comm->allreduce_f32(fresh.p + layers[li].p_off, layers[li].p_n, comm->st);
+  const bool top = li == top_trainable();  // its block ends at P: the liveness word (4 floats of padding) rides along
+  comm->allreduce_f32(fresh.p + layers[li].p_off, layers[li].p_n + (top ? kLiveWords : 0), comm->st);
   EESEN_HIP_CHECK(hipEventRecord(ev_bucket[li], comm->st));
   bucket_pending[li] = 1;
 }
@@ -269,15 +402,33 @@ void Net::wait_buckets_host() {
   bool any = false;
   for (char p : bucket_pending) any |= p != 0;
   if (any) EESEN_HIP_CHECK(hipStreamSynchronize(comm->st));
+  comm->check_alive();
 }
 
-// a rank that has no minibatch this step: zero gradient, same collectives in the same (top-down) order
+// a rank that has no minibatch this step: zero gradient, liveness 0, same collectives in the same (top-down) order
 void Net::backpropagate_zero() {
   EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  comm_check_alive(comm);
   EESEN_HIP_CHECK(hipSetDevice(device));
-  if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, P * sizeof(float), st));
+  if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, (P + kLiveWords) * sizeof(float), st));
   bucket_log.clear();
   for (int li = (int)layers.size() - 1; li >= 0; --li) bucket_allreduce(li, st);
+}
+
+// How many ranks had a minibatch in the step whose top bucket was issued last (the sum of the liveness words).  For a
+// rank in the zero-gradient protocol: 0 = every rank is out of data, stop.  Blocks until that bucket has arrived.
+int Net::live_ranks() {
+  EESEN_REQUIRE(finalized && comm, EESEN_ERR_STATE, "live_ranks needs an attached communicator");
+  comm->check_alive();
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  const int top = top_trainable();
+  EESEN_REQUIRE(top >= 0, EESEN_ERR_STATE, "the net has no trainable layer");
+  if (bucket_pending[top]) EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_bucket[top], 0));  // update() has not waited for it yet
+  if (!live_pin) EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&live_pin), sizeof(float), hipHostMallocDefault));
+  EESEN_HIP_CHECK(hipMemcpyAsync(live_pin, fresh.p + P, sizeof(float), hipMemcpyDeviceToHost, st));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  comm->check_alive();
+  return (int)(*live_pin + 0.5f);
 }
 
 void Net::allreduce_grads(Comm* c) {
@@ -338,6 +489,9 @@ int eesen_net_allreduce_grads(eesen_net_t* net, eesen_comm_t* comm) {
 }
 int eesen_net_backpropagate_zero(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->backpropagate_zero(); });
+}
+int eesen_net_live_ranks(eesen_net_t* net, int* live) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(live); *live = net->live_ranks(); });
 }
 int eesen_net_bucket_order(eesen_net_t* net, int* layers_out, int cap, int* n) {
   return guard([&] {

@@ -52,10 +52,17 @@ void Ctc::flush_pzx(PendingPzx& q) {
   EESEN_HIP_CHECK(hipEventSynchronize(q.pin.ev));
   q.pin.busy = false;
   const float* pz = static_cast<const float*>(q.pin.p);
+  q.active = false;
+  if (reinterpret_cast<const unsigned*>(pz)[q.S] != 0) {  // computed from a timed-out forward pass (see Ctc::guard): not a statistic
+    sequences -= q.S;
+    frames -= q.nframes;
+    if (dropped++ == 0 || dropped % 100 == 0)
+      fprintf(stderr, "WARNING (eesen_hip) CTC statistics of a minibatch computed from a timed-out forward pass were dropped (%ld so far)\n", dropped);
+    return;
+  }
   double sum = 0;
   for (int s = 0; s < q.S; ++s) sum += pz[s];
   obj_sum += sum;  // ctc-loss.cc:171-177
-  q.active = false;
 }
 
 void Ctc::flush() {
@@ -145,16 +152,20 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   // the values now waits for them; otherwise they join the objective sum when the next call needs the slot or the statistics.
   PendingPzx& q = ppzx[ppzx_idx++ & 1];
   flush_pzx(q);
-  float* pz = static_cast<float*>(pin_reserve(q.pin, (size_t)S * sizeof(float)));
+  float* pz = static_cast<float*>(pin_reserve(q.pin, (size_t)(S + 1) * sizeof(float)));
   EESEN_HIP_CHECK(hipMemcpyAsync(pz, pzx_d.p, S * sizeof(float), hipMemcpyDeviceToHost, st));
+  reinterpret_cast<unsigned*>(pz)[S] = 0;   // the guard word's value when these ln p were computed
+  if (guard) EESEN_HIP_CHECK(hipMemcpyAsync(pz + S, guard, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   EESEN_HIP_CHECK(hipEventRecord(q.pin.ev, st));
   q.pin.busy = true; q.S = S; q.active = true;
+  q.nframes = 0;
+  for (int s = 0; s < S; ++s) q.nframes += frame_num_utt[s];
+  frames += q.nframes;
+  sequences += S;
   if (pzx_host) {
     flush();  // keeps the accumulation order of the calls
     for (int s = 0; s < S; ++s) pzx_host[s] = pz[s];
   }
-  for (int s = 0; s < S; ++s) frames += frame_num_utt[s];
-  sequences += S;
   last_lens.assign(frame_num_utt, frame_num_utt + S);
   last_T = T; last_S = S; last_Lpad = Lpad; last_Lprime = Lprime;
 }
@@ -216,6 +227,13 @@ void Ctc::flush_err(PendingErr& q, int* num_err, int* num_ref) {
   const int* ids = static_cast<const int*>(q.pin.p);
   const int S = q.S;
   int err = 0, ref = 0;
+  if (q.guarded && ids[(size_t)q.rows] != 0) {  // decoded from a timed-out forward pass (see Ctc::guard): not a statistic
+    if (q.with_probs) { EESEN_HIP_CHECK(hipEventSynchronize(q.probs.ev)); q.probs.busy = false; }
+    if (num_err) *num_err = 0;
+    if (num_ref) *num_ref = 0;
+    q.active = false;
+    return;
+  }
   std::vector<int> hyp, frm;
   std::ofstream output;
   if (q.with_probs) {
@@ -263,8 +281,11 @@ void Ctc::error_rate_mseq(const int* frame_num_utt, int S, const float* net_out,
   PendingErr& q = perr[perr_idx++ & 1];
   flush_err(q, nullptr, nullptr);
   row_argmax(st, net_out, ld, rows, K, ids_d.p);  // FindRowMaxId, ctc-loss.cc:238-239
-  int* pinned = static_cast<int*>(pin_reserve(q.pin, (size_t)rows * sizeof(int)));
+  int* pinned = static_cast<int*>(pin_reserve(q.pin, ((size_t)rows + 1) * sizeof(int)));
   EESEN_HIP_CHECK(hipMemcpyAsync(pinned, ids_d.p, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, st));
+  pinned[rows] = 0;
+  q.rows = rows; q.guarded = guard != nullptr;
+  if (guard) EESEN_HIP_CHECK(hipMemcpyAsync(pinned + rows, guard, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   EESEN_HIP_CHECK(hipEventRecord(q.pin.ev, st));
   q.pin.busy = true; q.S = S; q.K = K; q.active = true;
   q.with_probs = !seq_out.empty();

@@ -135,11 +135,17 @@ void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* id
 // ---------------------------------------------------------------------------------------- optim.hip
 // corr = mmt*corr + fresh; clip to +-max_grad when max_grad > 0; param -= lr_coef*corr
 // skip (may be null): device word; when non-zero at execution time the update is a no-op (see optim.hip)
+// live (may be null): device float; when ZERO at execution time the update is a no-op (data-parallel closing round, comm.cpp)
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
-                float max_grad, const unsigned* skip = nullptr);
+                float max_grad, const unsigned* skip = nullptr, const float* live = nullptr);
 // Adagrad (rmsprop = false) / RMSProp update of one flat parameter block, see optim.hip
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
-                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip = nullptr);
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip = nullptr,
+                     const float* live = nullptr);
+// Moments of a [rows x cols] region (leading dimension ld) of a flat buffer, as MomentStatistics prints them
+// (/root/reference/src/net/utils-functions.h:50-82): out6 = {min, max, mean, variance, skewness, kurtosis}, doubles on the
+// device; two passes (min / max / sum, then the central power sums), fp64 accumulation.  ws: >= 8 doubles of scratch.
+void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws);
 // dst[c][r] = src[r][c]  (rows x cols -> cols x rows), dense
 void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst);
 // dst[r][0..cols) = src[r][0..cols) with different leading dimensions

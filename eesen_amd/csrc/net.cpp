@@ -16,7 +16,6 @@
 
 namespace eesen {
 
-constexpr size_t kCtlWords = 2 * kCtlHalf + 32;  // counters [0, kCtlHalf) forward, [kCtlHalf, 2 kCtlHalf) backward, last word = error flag
 
 // ------------------------------------------------------------------------------------------ PhaseTimer
 PhaseTimer::~PhaseTimer() {
@@ -57,6 +56,18 @@ long Layer::file_params() const {
   if (is_lstm()) return (long)ndir * ((long)4 * H * din + (long)4 * H * H + 4 * H + 3 * H);  // bilstm-layer.h:991-998
   if (kind == EESEN_LAYER_AFFINE) return (long)dout * din + dout;
   return 0;
+}
+
+const char* Layer::marker() const {
+  switch (kind) {
+    case EESEN_LAYER_BILSTM_PARALLEL: return nonparallel ? "<BiLstm>" : "<BiLstmParallel>";
+    case EESEN_LAYER_LSTM_PARALLEL: return nonparallel ? "<Lstm>" : "<LstmParallel>";
+    case EESEN_LAYER_AFFINE: return "<AffineTransform>";
+    case EESEN_LAYER_SOFTMAX: return "<Softmax>";
+    case EESEN_LAYER_SIGMOID: return "<Sigmoid>";
+    case EESEN_LAYER_TANH: return "<Tanh>";
+  }
+  return "<Unknown>";
 }
 
 // Visits every parameter of a layer as (index in Net::GetParams order, offset in the internal block).
@@ -165,6 +176,7 @@ Net::~Net() {
   }
   if (lens_pin) (void)hipHostFree(lens_pin);
   if (err_pin) (void)hipHostFree(err_pin);
+  if (live_pin) (void)hipHostFree(live_pin);
   if (lens_ev) (void)hipEventDestroy(lens_ev);
   if (err_ev) (void)hipEventDestroy(err_ev);
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
@@ -179,27 +191,40 @@ Net::~Net() {
 
 void Net::sync() {
   EESEN_HIP_CHECK(hipSetDevice(device));
-  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));   // (with a communicator: returns at the latest when its watchdog aborts a lost collective)
   wait_buckets_host();  // gradient buckets still in flight on the communicator's stream
-  check_device_error();
+  comm_check_alive(comm);
+  check_device_error(/*consumer=*/true);
 }
 
-void Net::check_device_error() {
+// The error word of the persistent recurrence kernels.  While it is set every persistent kernel leaves at its first poll, the
+// update kernels skip (optim.hip) and a guarded Ctc drops the minibatch from its statistics (eesen_ctc_set_guard), so nothing
+// computed under it reaches the model or the accuracy: `lost` minibatches -- the one that raised it and those the host had
+// already enqueued behind it -- are not applied.  Without a data-parallel communicator the run continues on the
+// one-launch-per-step kernels; with one, the other ranks HAVE applied their steps, the ranks would diverge: that stays fatal.
+// consumer = the caller is about to READ something the last Propagate produced (get_output, Synchronize before a host copy,
+// the inference and cross-validation paths): that forward pass is then re-run on the per-step kernels before returning, so a
+// timed-out Propagate never hands out garbage with status OK.
+void Net::check_device_error(bool consumer) {
   if (!ctl.p) return;
   unsigned e = 0;
   EESEN_HIP_CHECK(hipMemcpy(&e, ctl.p + kCtlWords - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (e) {
-    // The step that raised the word was not applied (the update kernels skip on it).  Without a data-parallel communicator the
-    // run simply continues on the one-launch-per-step kernels -- one minibatch is lost, the model is intact; with one, the
-    // other ranks HAVE applied their step, so the ranks would diverge: that stays fatal.
+  if (!e) { steps_since_clean = 0; return; }
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  EESEN_HIP_CHECK(hipMemset(ctl.p + kCtlWords - 1, 0, sizeof(unsigned)));
+  persistent = 0; gate_fwd = false; overlap = false;
+  ++recoveries;
+  if (comm) throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
+                                       "resident?) in a data-parallel run; rerun with EESEN_PERSISTENT=0");
+  const int lost = std::max(1, steps_since_clean);
+  steps_since_clean = 0;
+  const bool rerun = consumer && propagated && input.p && rows > 0;
+  fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
+                  "%d minibatch(es) in flight were NOT applied%s; continuing with the one-launch-per-step kernels\n", lost,
+          rerun ? " and the last forward pass is re-run" : "");
+  if (rerun) {
+    forward_pass();
     EESEN_HIP_CHECK(hipStreamSynchronize(st));
-    EESEN_HIP_CHECK(hipMemset(ctl.p + kCtlWords - 1, 0, sizeof(unsigned)));
-    persistent = 0; gate_fwd = false; overlap = false;
-    ++recoveries;
-    if (comm) throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
-                                         "resident?) in a data-parallel run; rerun with EESEN_PERSISTENT=0");
-    fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
-                    "the minibatch in flight was NOT applied; continuing with the one-launch-per-step kernels\n");
   }
 }
 
@@ -218,7 +243,8 @@ void Net::arm_device_error_poll() {
 void Net::poll_device_error() {
   if (!err_armed || hipEventQuery(err_ev) != hipSuccess) return;  // not there yet: the next poll or sync() will see it
   err_armed = false;
-  if (*err_pin) check_device_error();  // re-reads, resets and throws
+  if (*err_pin) check_device_error(/*consumer=*/false);  // re-reads the word, resets it and falls back (fatal under a communicator)
+  else steps_since_clean = 0;
 }
 
 void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
@@ -277,10 +303,10 @@ void Net::finalize() {
   }
   P = off;
   if (P) {
-    params.reserve(P); corr.reserve(P); fresh.reserve(P);
+    params.reserve(P); corr.reserve(P); fresh.reserve(P + kLiveWords);   // + the data-parallel liveness word (comm.cpp)
     EESEN_HIP_CHECK(hipMemsetAsync(params.p, 0, P * sizeof(float), st));
     EESEN_HIP_CHECK(hipMemsetAsync(corr.p, 0, P * sizeof(float), st));
-    EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, P * sizeof(float), st));
+    EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, (P + kLiveWords) * sizeof(float), st));
   }
   // Side-stream gradient GEMMs pay only while the backward recurrence leaves register room for a GEMM workgroup next to
   // it; the 16x16 tile of wide layers (H > 512: 256 VGPRs x 2 waves per SIMD) does not, and a GEMM that started before the
@@ -312,6 +338,40 @@ void Net::refresh_derived() {
       for (int dir = 0; dir < L.ndir; ++dir)
         transpose2d(st, params.p + L.p_off + L.off_wm + (size_t)dir * 4 * L.H * L.H, 4 * L.H, L.H,
                     L.WmT.p + (size_t)dir * L.H * 4 * L.H);
+}
+
+int Net::tensor_moments(int which, int layer, double* out6_host, int cap_tensors) {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size(), EESEN_ERR_INVALID, "layer index out of range");
+  EESEN_REQUIRE(which >= 0 && which <= 2, EESEN_ERR_INVALID, "which: 0 parameters, 1 momentum buffers, 2 accumulators");
+  const Layer& L = layers[layer];
+  struct Region { size_t off; long rows; int cols; long ld; };
+  std::vector<Region> reg;
+  if (L.is_lstm()) {
+    const int H = L.H, D = L.din, D4 = pad4(D);
+    for (int dir = 0; dir < L.ndir; ++dir) {
+      reg.push_back({L.off_wx + (size_t)dir * 4 * H * D4, 4L * H, D, D4});
+      reg.push_back({L.off_wm + (size_t)dir * 4 * H * H, 4L * H, H, H});
+      reg.push_back({L.off_bias + (size_t)dir * 4 * H, 1, 4 * H, 4L * H});
+      for (int g = 0; g < 3; ++g) reg.push_back({L.off_peep + ((size_t)dir * 3 + g) * H, 1, H, H});
+    }
+  } else if (L.kind == EESEN_LAYER_AFFINE) {
+    reg.push_back({L.off_w, L.dout, L.din, pad4(L.din)});
+    reg.push_back({L.off_b, 1, L.dout, L.dout});
+  }
+  const int n = (int)reg.size();
+  if (!out6_host || n == 0) return n;
+  EESEN_REQUIRE(cap_tensors >= n, EESEN_ERR_INVALID, "moments buffer too small");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  if (which == 2) init_accu();
+  sync();
+  const float* base = (which == 0 ? params.p : which == 1 ? corr.p : accu.p) + L.p_off;
+  DevBuf<double> d;
+  d.reserve((size_t)n * 6 + 8);
+  for (int i = 0; i < n; ++i) eesen::tensor_moments(st, base + reg[i].off, reg[i].rows, reg[i].cols, reg[i].ld, d.p + (size_t)i * 6, d.p + (size_t)n * 6);
+  EESEN_HIP_CHECK(hipStreamSynchronize(st));
+  EESEN_HIP_CHECK(hipMemcpy(out6_host, d.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  return n;
 }
 
 static void upload_flat(Net& net, DevBuf<float>& dst, const float* host, long n) {
@@ -500,8 +560,14 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
   if (input.reserve((size_t)rows * D4) || D4 != D) EESEN_HIP_CHECK(hipMemsetAsync(input.p, 0, (size_t)rows * D4 * sizeof(float), st));
   EESEN_HIP_CHECK(hipMemcpy2DAsync(input.p, (size_t)D4 * sizeof(float), in, (size_t)ld * sizeof(float), (size_t)D * sizeof(float),
                                    rows, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  forward_pass();
+}
+
+// the layer chain of Net::Propagate on the input already in HBM (also the re-run after a timed-out persistent kernel)
+void Net::forward_pass() {
   const float* x = input.p;
-  int ldx = D4;
+  int ldx = pad4(layers[0].din);
+  ++steps_since_clean;
   info_fwd_persistent = info_lstm_layers = 0;
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
@@ -640,6 +706,10 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   bool side_pending[2] = {false, false};
   bucket_log.clear();
   info_bwd_persistent = 0;
+  if (comm) {  // this rank has a minibatch: liveness 1 rides with the top layer's gradient bucket (comm.cpp)
+    comm_check_alive(comm);
+    EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fresh.p + P), 0x3f800000, 1, st));
+  }
 
   // backpropagate_buf_[L] = out_diff (net.cc:96), into a buffer whose rows are 16-byte aligned
   const int Kout = layers.back().dout;
@@ -762,6 +832,8 @@ void Net::update() {
   // kernels read the word ON THE DEVICE and do nothing then, so a failed step never reaches the parameters; the host notices
   // at its next poll and continues on the per-step kernels (check_device_error).
   const unsigned* skip = persistent ? ctl.p + kCtlWords - 1 : nullptr;
+  const float* live = comm ? fresh.p + P : nullptr;   // 0 after the all-reduce: no rank had a minibatch -- the closing round, a no-op
+  comm_check_alive(comm);
   { const int ti_ = timer.begin(st, 5);
   // top-down, the order in which Backpropagate completed (and all-reduced) the layers' gradients
   for (int li = (int)layers.size() - 1; li >= 0; --li) {
@@ -772,11 +844,11 @@ void Net::update() {
         bucket_pending[li] = 0;
       }
       if (rule == 0) {
-        sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad, skip);
+        sgd_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, (long)L.p_n, mmt, lr * L.coef, L.max_grad, skip, live);
       } else {  // the adaptive rules do not apply learn_rate_coef (bilstm-layer.h:865-869 multiplies only in the SGD branch)
         init_accu();
         adaptive_update(st, params.p + L.p_off, corr.p + L.p_off, fresh.p + L.p_off, accu.p + L.p_off, (long)L.p_n, mmt, lr,
-                        L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2, skip);
+                        L.max_grad, ada_eps, rms_rho, rms_one_minus_rho, rule == 2, skip, live);
       }
     }
   }

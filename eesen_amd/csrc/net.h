@@ -8,6 +8,7 @@
 namespace eesen {
 
 inline int pad4(int x) { return (x + 3) & ~3; }
+constexpr size_t kCtlWords = 2 * kCtlHalf + 32;  // counters [0, kCtlHalf) forward, [kCtlHalf, 2 kCtlHalf) backward, last word = error flag
 
 struct Layer {
   int kind = 0, din = 0, dout = 0;
@@ -45,6 +46,7 @@ struct Layer {
   bool is_activation() const { return kind == EESEN_LAYER_SIGMOID || kind == EESEN_LAYER_TANH; }
   bool trainable() const { return is_lstm() || kind == EESEN_LAYER_AFFINE; }
   long file_params() const;
+  const char* marker() const;  // Layer::TypeToMarker (layer.cc:37-46, 68-79): the token the model file carries for this layer
 };
 
 class PhaseTimer {
@@ -67,6 +69,8 @@ class PhaseTimer {
 };
 
 struct Comm;  // comm.cpp: RCCL communicator (one rank per GPU)
+void comm_check_alive(const Comm* c);  // throws EESEN_ERR_COMM once the communicator's watchdog has aborted it (null: no-op)
+constexpr size_t kLiveWords = 4;       // floats behind the gradient buffer: [0] = the data-parallel liveness word (comm.cpp)
 
 struct Net {
   int device = 0;
@@ -106,7 +110,8 @@ struct Net {
   int spin_limit = 400000;
   int recoveries = 0;         // times a timed-out persistent kernel made the net fall back to the per-step kernels
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
-  void check_device_error();
+  void check_device_error(bool consumer);
+  int steps_since_clean = 0;  // Propagates enqueued since the error word was last seen clear
   // set_seq_lengths does not drain the stream: the lengths go through a pinned staging word-array (the previous copy has
   // long completed; waiting for it bounds the host's run-ahead to one step), and the persistent kernels' error word is
   // polled through an asynchronous copy enqueued behind every Propagate / Update (full check in sync()).
@@ -134,7 +139,10 @@ struct Net {
   std::vector<hipEvent_t> ev_ready, ev_bucket;
   std::vector<char> bucket_pending;
   std::vector<int> bucket_log;                // layer order of the last Backpropagate's buckets (tests)
+  float* live_pin = nullptr;                  // pinned landing slot of the liveness word
   void set_comm(Comm* c);
+  int top_trainable() const;
+  int live_ranks();
   void bucket_allreduce(int li, hipStream_t producer);
   void wait_buckets_host();
   void backpropagate_zero();
@@ -149,9 +157,14 @@ struct Net {
   void get_flat(const DevBuf<float>& buf, float* host, long n);  // params or fresh grads in Net::GetParams order
   void set_seq_lengths(const int* lens, int S);
   void propagate(const float* in, int rows, int ld, bool is_device);
+  void forward_pass();
   void backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi);
   void update();
   void refresh_derived();  // W_m^T copies
+  // MomentStatistics (utils-functions.h:50-82) of the tensors of one layer in the reference's Info() / InfoGradient() order
+  // (bilstm-layer.h:496-560, lstm-layer.h:175-196, affine-trans-layer.h:145-159).  which: 0 parameters, 1 the momentum
+  // buffers (*_corr_), 2 the adaptive accumulators (*_corr_accu; zeros until an adaptive rule ran).  Returns the tensor count.
+  int tensor_moments(int which, int layer, double* out6_host, int cap_tensors);
   void read(const std::string& path);
   void write(const std::string& path, bool binary);
   void sync();
@@ -180,8 +193,13 @@ struct Ctc {
   };
   Pin stage[2];                // label expansion + class position lists (H2D)
   unsigned stage_idx = 0;
-  struct PendingPzx { Pin pin; int S = 0; bool active = false; } ppzx[2];
-  struct PendingErr { Pin pin, probs; int S = 0, K = 0; bool active = false, with_probs = false; std::vector<int> frames, ids, off; } perr[2];
+  struct PendingPzx { Pin pin; int S = 0; long nframes = 0; bool active = false; } ppzx[2];
+  struct PendingErr { Pin pin, probs; int S = 0, K = 0, rows = 0; bool active = false, with_probs = false, guarded = false; std::vector<int> frames, ids, off; } perr[2];
+  // eesen_ctc_set_guard: the error word of the Net whose outputs this Ctc evaluates.  Its value travels back with every
+  // minibatch's ln p / decoded ids; a minibatch computed while it was set (a timed-out persistent forward pass: garbage
+  // activations) is DROPPED from the statistics instead of being folded into the objective and TOKEN_ACCURACY.
+  const unsigned* guard = nullptr;
+  long dropped = 0;
   std::string seq_out;         // --sequence-out-file of the trainer (ctc-loss.cc:247-250,282-291): decoded sequences are appended here
   unsigned ppzx_idx = 0, perr_idx = 0;
   void* pin_reserve(Pin& pin, size_t bytes);  // waits for the slot's last use, grows it, returns the host pointer

@@ -14,10 +14,14 @@ namespace {
 
 __global__ __launch_bounds__(256) void sgd_update_kernel(float* __restrict__ param, float* __restrict__ corr,
                                                          const float* __restrict__ fresh, long n, float mmt,
-                                                         float lr_coef, float max_grad, const unsigned* __restrict__ skip) {
+                                                         float lr_coef, float max_grad, const unsigned* __restrict__ skip,
+                                                         const float* __restrict__ live) {
   // `skip`: the error word of the persistent recurrence kernels.  If one of them gave up waiting for a peer in THIS step, the
   // gradients are garbage: leave parameters and momentum untouched (the host then drops to the per-step kernels, net.cpp).
+  // `live`: the data-parallel liveness word (summed over the ranks with the top layer's gradient bucket, comm.cpp): 0 means
+  // NO rank had a minibatch this step -- the closing round of the zero-gradient protocol, which must not move the model.
   if (skip && *skip) return;
+  if (live && *live == 0.f) return;
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -50,8 +54,9 @@ __global__ __launch_bounds__(256) void adaptive_update_kernel(float* __restrict_
                                                               const float* __restrict__ fresh, float* __restrict__ accu,
                                                               long n, float mmt, float lr, float max_grad, float eps,
                                                               float rho, float one_minus_rho, int rmsprop,
-                                                              const unsigned* __restrict__ skip) {
+                                                              const unsigned* __restrict__ skip, const float* __restrict__ live) {
   if (skip && *skip) return;   // see sgd_update_kernel
+  if (live && *live == 0.f) return;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float c = mmt * corr[i] + fresh[i];
@@ -97,19 +102,19 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ s
 }  // namespace
 
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
-                float max_grad, const unsigned* skip) {
+                float max_grad, const unsigned* skip, const float* live) {
   if (n <= 0) return;
   const int blocks = (int)std::min<long>(cdivl(n / 4 + 1, 256), 2048);
-  hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad, skip);
+  hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad, skip, live);
   check_launch("sgd_update");
 }
 
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
-                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip) {
+                     float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip, const float* live) {
   if (n <= 0) return;
   const int blocks = (int)std::min<long>(cdivl(n, 256), 4096);
   hipLaunchKernelGGL(adaptive_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, accu, n, mmt, lr, max_grad, eps,
-                     rho, one_minus_rho, rmsprop ? 1 : 0, skip);
+                     rho, one_minus_rho, rmsprop ? 1 : 0, skip, live);
   check_launch("adaptive_update");
 }
 
@@ -212,6 +217,52 @@ void mul_elements(hipStream_t st, const float* a, int lda, const float* m, int l
   const int blocks = (int)std::min<long>(cdivl(rows * cols, 256), 256L * 16);
   hipLaunchKernelGGL(mul_elements_kernel, dim3(blocks), dim3(256), 0, st, a, lda, m, ldm, out, ldo, rows, cols);
   check_launch("mul_elements");
+}
+
+// ---- Net::Info / Net::InfoGradient (net.cc:336-385): MomentStatistics of one tensor (utils-functions.h:50-82) -------------
+namespace {
+// One 1024-thread workgroup per tensor and pass (the statistics are printed once, when training ends): pass 0 leaves
+// {min, max, sum} in ws[0..2], pass 1 the central power sums and the six printed figures in out6.
+template <int PASS>
+__global__ __launch_bounds__(1024) void tensor_moments_kernel(const float* __restrict__ base, long rows, int cols, long ld,
+                                                              double* __restrict__ out6, double* __restrict__ ws) {
+  __shared__ double red[4][16];
+  const long n = rows * cols;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a = PASS == 0 ? 1e300 : 0.0, b = PASS == 0 ? -1e300 : 0.0, c = 0.0, d = 0.0;
+  const double mean = PASS == 1 ? ws[2] / (double)n : 0.0;
+  for (long i = tid; i < n; i += 1024) {
+    const double v = (double)base[(i / cols) * ld + (i % cols)];
+    if (PASS == 0) { a = fmin(a, v); b = fmax(b, v); c += v; }
+    else { const double e = v - mean, e2 = e * e; a += e2; b += e2 * e; c += e2 * e2; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double a2 = __shfl_down(a, off), b2 = __shfl_down(b, off), c2 = __shfl_down(c, off);
+    if (PASS == 0) { a = fmin(a, a2); b = fmax(b, b2); c += c2; }
+    else { a += a2; b += b2; c += c2; }
+  }
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; red[3][wave] = d; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) {
+      if (PASS == 0) { a = fmin(a, red[0][w]); b = fmax(b, red[1][w]); c += red[2][w]; }
+      else { a += red[0][w]; b += red[1][w]; c += red[2][w]; }
+    }
+    if (PASS == 0) { ws[0] = a; ws[1] = b; ws[2] = c; }
+    else {
+      const double var = a / (double)n;
+      out6[0] = ws[0]; out6[1] = ws[1]; out6[2] = mean; out6[3] = var;
+      out6[4] = b / pow(var, 1.5) / (double)n;          // skewness
+      out6[5] = c / (var * var) / (double)n - 3.0;      // kurtosis
+    }
+  }
+}
+}  // namespace
+
+void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws) {
+  hipLaunchKernelGGL(tensor_moments_kernel<0>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws);
+  hipLaunchKernelGGL(tensor_moments_kernel<1>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws);
+  check_launch("tensor_moments");
 }
 
 }  // namespace eesen

@@ -30,6 +30,7 @@ class InStream {
     if (n == "-") { is_ = &std::cin; return; }
     if (!n.empty() && n.back() == '|') {
       n.pop_back();
+      cmd_ = n;
       pipe_ = popen(n.c_str(), "r");
       if (!pipe_) throw std::runtime_error("cannot run '" + n + "'");
       buf_.reset(new __gnu_cxx::stdio_filebuf<char>(pipe_, std::ios::in | std::ios::binary));
@@ -42,13 +43,28 @@ class InStream {
     if (!*f) throw std::runtime_error("cannot open " + n);
     is_ = f;
   }
+  // A filter that failed leaves a TRUNCATED table behind an ordinary end-of-file (the reference warns, util/kaldi-io.cc
+  // PipeInputImpl::Close; the Python reader raises): say so as soon as the stream is closed.
   ~InStream() {
     own_.reset(); buf_.reset();
-    if (pipe_) pclose(pipe_);
+    if (pipe_) {
+      const int st = pclose(pipe_);
+      if (st != 0) std::cerr << "WARNING (kaldi_tables) pipe '" << cmd_ << "' ended with status " << st << ": the table may be truncated" << std::endl;
+    }
+  }
+  // to be called once the reader has hit end-of-file on a pipe it must be able to trust (feature and label tables of a trainer)
+  void CloseChecked() {
+    own_.reset(); buf_.reset();
+    if (pipe_) {
+      const int st = pclose(pipe_);
+      pipe_ = nullptr;
+      if (st != 0) throw std::runtime_error("pipe '" + cmd_ + "' ended with status " + std::to_string(st) + ": the table it produced is truncated");
+    }
   }
   InStream(const InStream&) = delete;
   std::istream& get() { return *is_; }
  private:
+  std::string cmd_;
   std::istream* is_ = nullptr;
   std::unique_ptr<std::istream> own_;
   std::unique_ptr<__gnu_cxx::stdio_filebuf<char>> buf_;
@@ -75,7 +91,10 @@ class OutStream {
   ~OutStream() {
     if (os_) os_->flush();
     own_.reset(); buf_.reset();
-    if (pipe_) pclose(pipe_);
+    if (pipe_) {
+      const int st = pclose(pipe_);
+      if (st != 0) std::cerr << "WARNING (kaldi_tables) output pipe ended with status " << st << std::endl;
+    }
   }
   OutStream(const OutStream&) = delete;
   std::ostream& get() { return *os_; }
@@ -213,25 +232,33 @@ class FeatureReader {
   const std::string& Key() const { return key_; }
   Mat& Value() { return val_; }
   void Next() {
+    if (done_) return;
     if (sp_.kind == "ark") {
       key_ = read_key(f_);
-      if (key_.empty()) { done_ = true; return; }
+      if (key_.empty()) { done_ = true; in_.CloseChecked(); return; }
       val_ = read_matrix(f_);
       return;
     }
     std::string line;
     while (std::getline(f_, line)) {
-      std::istringstream ls(line);
-      std::string loc;
-      if (!(ls >> key_ >> loc)) continue;
+      // `key<whitespace>rest-of-line` (util/kaldi-table.cc ReadScriptFile): the entry is everything behind the first run of
+      // whitespace that follows the key -- NOT the first occurrence of its first word, which may sit inside the key itself
+      const size_t k0 = line.find_first_not_of(" \t");
+      if (k0 == std::string::npos) continue;
+      const size_t k1 = line.find_first_of(" \t", k0);
+      if (k1 == std::string::npos) continue;
+      const size_t r0 = line.find_first_not_of(" \t", k1);
+      if (r0 == std::string::npos) continue;
+      key_ = line.substr(k0, k1 - k0);
+      const std::string whole = line.substr(r0);
+      std::string loc = whole.substr(0, whole.find_first_of(" \t"));
       std::streamoff off = 0;
       const size_t c = loc.rfind(':');
       if (c != std::string::npos && c + 1 < loc.size() && loc.find_first_not_of("0123456789", c + 1) == std::string::npos) {
         off = std::stoll(loc.substr(c + 1));
         loc = loc.substr(0, c);
       }
-      const size_t rest = line.find(loc);   // a script entry may itself be a command: `key cmd args |`
-      const std::string whole = rest == std::string::npos ? loc : line.substr(rest);
+      // a script entry may itself be a command: `key cmd args |`
       if (!whole.empty() && whole.find_last_not_of(" \t") != std::string::npos && whole[whole.find_last_not_of(" \t")] == '|') {
         InStream a(whole);
         val_ = read_matrix(a.get());
@@ -265,6 +292,7 @@ inline std::map<std::string, std::vector<int32_t>> read_targets(const std::strin
     if (k.empty()) break;
     t[k] = read_int_vector(f);
   }
+  in.CloseChecked();   // `ark:gunzip -c labels.tr.gz|` that failed must not leave the trainer with half the transcripts
   return t;
 }
 

@@ -9,14 +9,20 @@
 // process per GPU.  Instead of the reference's file-based model averaging every --utts-per-avg utterances (:208-235,
 // src/net/communicator.h) the jobs form an RCCL communicator (rank = J-1; job 1 hands out the id over TCP on
 // --comm-addr / --comm-port, default $MASTER_ADDR and $EESEN_COMM_PORT | $MASTER_PORT+17 | 29517) and sum their
-// gradients every minibatch (eesen_net_set_comm: per-layer buckets under the backward pass).  Data: a feature
-// rspecifier containing the literal JOB is each job's own list (JOB -> J, as queue.pl substitutes it); otherwise all
-// jobs read the same list and job J trains minibatches J-1, J-1+N, ... .  Jobs that run out of minibatches keep stepping
-// with a zero gradient until all are done.  Job 1 writes the model and prints the merged TOKEN_ACCURACY.
+// gradients every minibatch (eesen_net_set_comm: per-layer buckets under the backward pass).  Data: as in the reference,
+// the feature rspecifier a job receives IS that job's shard -- the recipes launch `JOB=1:$nj ... --job-id=JOB
+// scp:feats_tr.JOB.scp`, queue.pl / run.pl substitute JOB before the process starts, and prep_scps.sh has dealt the list
+// (train_ctc_parallel_h.sh:96,141-143) -- so nothing is sharded further.  For launchers that hand every rank the SAME
+// command line: a `JOB` that stands alone (not part of a longer word) is replaced by the job id here, and
+// --shard-shared-list=true makes job J train minibatches J-1, J-1+N, ... of a list all jobs read.  Jobs may hold different
+// numbers of minibatches: one that runs out keeps stepping with a zero gradient until every job is out of data (the
+// liveness word of eesen_net_live_ranks; no host round trip per step).  Job 1 writes the model and prints the merged
+// TOKEN_ACCURACY.
 //
 // Tables: `ark:file`, `ark,t:file`, `scp:file` for the features (float matrices: binary FM, text, compressed CM / CM2 --
 // src/cpucompute/matrix.cc:968-994, compressed-matrix.cc:437-520) and the labels (int32 vectors, binary or text --
 // src/util/kaldi-holder-inl.h:190-260).
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -33,6 +39,7 @@
 #include <vector>
 
 #include "../../../include/eesen_hip.h"
+#include "../../../include/eesen_hip_info.h"
 #include "kaldi_tables.h"
 #include "feat_pipeline.h"
 
@@ -54,7 +61,7 @@ std::string fmt_g(double v) {  // what operator<< prints for a float/double by d
 // ---------------------------------------------------------------------------------------------------- options
 struct Options {  // train-ctc-parallel.cc:45-80, NetTrainOptions train-opts.h:29-62
   float learn_rate = 0.008f, momentum = 0.f, adagrad_epsilon = 1e-6f, rms_prop_rho = 0.9f;
-  bool binary = true, cross_validate = false;
+  bool binary = true, cross_validate = false, shard_shared_list = false;
   int num_sequence = 5, report_step = 100, num_jobs = 1, job_id = 1, utts_per_avg = 500, verbose = 0, device = -1;
   int comm_port = 0, comm_timeout = 300;
   double frame_limit = 100000;
@@ -93,6 +100,7 @@ Options parse_options(int argc, char** argv) {
     else if (k == "comm-addr") o.comm_addr = v;
     else if (k == "comm-port") o.comm_port = std::stoi(v);
     else if (k == "comm-timeout") o.comm_timeout = std::stoi(v);
+    else if (k == "shard-shared-list") o.shard_shared_list = parse_bool(v);
     else throw std::runtime_error("unknown option --" + k);
   }
   return o;
@@ -122,9 +130,21 @@ int main(int argc, char** argv) {
     std::string feature_rspecifier = o.args[0];
     const std::string targets_rspecifier = o.args[1], model_filename = o.args[2];
     const std::string target_model_filename = o.cross_validate ? "" : o.args[3];
-    bool own_list = false;   // the rspecifier names this job's own shard (JOB substituted, as queue.pl does)
-    for (size_t at; (at = feature_rspecifier.find("JOB")) != std::string::npos; own_list = true)
-      feature_rspecifier.replace(at, 3, std::to_string(o.job_id));
+    // The list a job receives is its own shard (reference semantics).  A launcher that cannot substitute JOB itself may leave
+    // it to us -- only with several jobs, and only a JOB that stands alone (`feats.JOB.scp`, not `exp/JOBS/` or `$JOBNAME`).
+    if (world > 1) {
+      auto word = [](char c) { return std::isalnum((unsigned char)c) || c == '_'; };
+      bool rewritten = false;
+      for (size_t at = 0; (at = feature_rspecifier.find("JOB", at)) != std::string::npos;) {
+        const bool alone = (at == 0 || !word(feature_rspecifier[at - 1])) && (at + 3 >= feature_rspecifier.size() || !word(feature_rspecifier[at + 3]));
+        if (!alone) { at += 3; continue; }
+        feature_rspecifier.replace(at, 3, std::to_string(o.job_id));
+        rewritten = true;
+      }
+      if (rewritten) log_line("LOG", "feature rspecifier of job " + std::to_string(o.job_id) + ": " + feature_rspecifier);
+      if (rewritten && o.shard_shared_list) throw std::runtime_error("--shard-shared-list with a per-job (JOB) feature list");
+    }
+    const bool own_list = !o.shard_shared_list;
     const int device = o.device >= 0 ? o.device : (getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : (world > 1 ? rank : 0));
 
     eesen_net_t* net = nullptr;
@@ -149,6 +169,7 @@ int main(int argc, char** argv) {
       if (!o.cross_validate) ck(eesen_net_set_comm(net, comm));
     }
     ck(eesen_ctc_create(device, nullptr, &ctc));
+    ck(eesen_ctc_set_guard(ctc, net));   // a minibatch computed from a timed-out forward pass never reaches the statistics
     ck(eesen_feeder_create(device, nullptr, 2, &feeder));
     if (!o.sequence_out_file.empty()) {                                                // :134-137
       log_line("LOG", "Sequences will be written to " + o.sequence_out_file + " in order from feature file");
@@ -253,17 +274,21 @@ int main(int argc, char** argv) {
     long diff_cap = 0;
     double obj_prog = 0, err_prog = 0, ref_prog = 0;
     long seq_since_report = 0;
+    long zero_steps = 0;
     for (;;) {
-      if (comm) {  // jobs may hold different numbers of minibatches: all keep stepping until every one is out of data
-        double flag = have ? 1.0 : 0.0;
-        ck(eesen_comm_allreduce_host(comm, &flag, 1, 0));
-        if (flag == 0.0) break;
-        if (!have) {
-          if (!o.cross_validate) { ck(eesen_net_backpropagate_zero(net)); ck(eesen_net_update(net)); }
-          continue;
-        }
-      } else if (!have) {
-        break;
+      if (!have) {
+        // Jobs may hold different numbers of minibatches.  One that is out of data keeps stepping with a zero gradient through
+        // the same collectives until NO job had a minibatch in a step (the liveness word that rides with the top layer's
+        // bucket); that closing round, which all jobs take together, leaves the model untouched.  Cross-validation exchanges
+        // nothing, so every job simply finishes.
+        if (!comm || o.cross_validate) break;
+        int live = 0;
+        ck(eesen_net_backpropagate_zero(net));
+        ck(eesen_net_update(net));
+        ck(eesen_net_live_ranks(net, &live));
+        if (live == 0) break;
+        ++zero_steps;
+        continue;
       }
       const int S = (int)cur.mats.size();
       float* feats = nullptr;
@@ -305,14 +330,21 @@ int main(int argc, char** argv) {
       std::swap(cur, nxt);
     }
     for (const auto& w : warnings) log_line("WARNING", w);
+    if (zero_steps) log_line("LOG", "job " + std::to_string(o.job_id) + " ran out of minibatches " + std::to_string(zero_steps) + " step(s) before the last job");
     ck(eesen_net_synchronize(net));
+    if (!o.cross_validate) {                                                            // :236-240
+      log_line("LOG", eesen_hip::NetInfo(net, 0));
+      log_line("LOG", eesen_hip::NetInfo(net, 1, o.opt_algorithm != "SGD"));
+    }
     if (!o.cross_validate && rank == 0) ck(eesen_net_write(net, target_model_filename.c_str(), o.binary ? 1 : 0));   // :244-246 (all ranks hold the same model)
     const double el = std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     log_line("LOG", "Done " + std::to_string(num_done) + " files, " + std::to_string(num_no_tgt_mat) + " with no targets, " +
                         std::to_string(num_other_error) + " with other errors. [" + (o.cross_validate ? "CROSS-VALIDATION" : "TRAINING") + ", " +
                         fmt_g(el / 60) + " min, fps" + fmt_g(total_frames / el) + "]");              // :247-252
-    double obj; long seqs, frames, e, r;
+    double obj; long seqs, frames, e, r, dropped = 0;
     ck(eesen_ctc_stats(ctc, &obj, &seqs, &frames, &e, &r));
+    ck(eesen_ctc_dropped(ctc, &dropped));
+    if (dropped) log_line("WARNING", std::to_string(dropped) + " minibatch(es) were computed from a timed-out forward pass and are not in the statistics");
     if (comm) {  // comm_touch_done (communicator.h:121-170): job 1 merges the jobs' Errors / Refs and reports the total
       double tot[2] = {(double)e, (double)r};
       ck(eesen_comm_allreduce_host(comm, tot, 2, 0));

@@ -93,10 +93,15 @@ def shard_minibatches(batches, rank: int, world: int):
             yield b
 
 
-def job_rspecifier(rspecifier: str, rank: int) -> str:
-    """Kaldi's queue scripts substitute the literal JOB in per-job arguments (`JOB=1:$nj ... feats.JOB.scp`,
-    /root/reference/asr_egs/wsj/steps/train_ctc_parallel_h.sh); do the same for a rank (job id = rank + 1)."""
-    return rspecifier.replace("JOB", str(rank + 1))
+def job_rspecifier(rspecifier: str, rank: int, world: int = 2) -> str:
+    """Kaldi's queue scripts substitute the literal JOB in per-job arguments BEFORE the process starts (`JOB=1:$nj ...
+    feats_tr.JOB.scp`, /root/reference/asr_egs/wsj/steps/train_ctc_parallel_h.sh:96,141-143), so a trainer normally never
+    sees it.  For launchers that hand every rank the same command line the trainers substitute it themselves -- only with
+    several jobs, and only a JOB that stands alone (`feats.JOB.scp`; not `exp/JOBS/x` or `$JOBNAME`); job id = rank + 1."""
+    import re
+    if world <= 1:
+        return rspecifier
+    return re.sub(r"(?<![A-Za-z0-9_])JOB(?![A-Za-z0-9_])", str(rank + 1), rspecifier)
 
 
 def allreduce_stats(values, group=None, device=None):

@@ -11,10 +11,14 @@ Multi-GPU: one process per GPU -- either `--num-jobs=N --job-id=J` (J = 1..N, as
 train_ctc_parallel_h.sh) or a launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run).  Instead of
 the reference's file-based model averaging every --utts-per-avg utterances (src/net/communicator.h) the ranks form an
 RCCL communicator inside libeesen_hip.so (no torch in the process) and sum their FRESH gradients every minibatch, one
-bucket per layer under the backward pass.  Data: a feature rspecifier containing the literal JOB is each rank's own
-list (JOB -> rank + 1, as queue.pl substitutes it); otherwise all ranks read the same list and rank r trains
-minibatches r, r + N, ... (eesen_amd.parallel.shard_minibatches).  Ranks that run out of minibatches keep stepping with
-a zero gradient until every rank is done.  Rank 0 writes the model and prints the merged TOKEN_ACCURACY.
+bucket per layer under the backward pass.  Data: as in the reference, the feature rspecifier a job receives IS that job's
+shard (the recipes launch `JOB=1:$nj ... --job-id=JOB scp:feats_tr.JOB.scp`, queue.pl substitutes JOB before the process
+starts, prep_scps.sh has dealt the list: train_ctc_parallel_h.sh:96,141-143) -- nothing is sharded further.  For launchers
+that hand every rank the SAME command line: a JOB that stands alone is replaced by the job id here, and
+--shard-shared-list=true makes rank r train minibatches r, r + N, ... of a list all ranks read
+(eesen_amd.parallel.shard_minibatches).  Ranks may hold different numbers of minibatches: one that runs out keeps stepping
+with a zero gradient until every rank is out of data (Net.LiveRanks; no host round trip per step).  Rank 0 writes the model
+and prints the merged TOKEN_ACCURACY.
 """
 from __future__ import annotations
 
@@ -86,6 +90,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--comm-addr", default="", help="rendezvous address of job 1 (default $MASTER_ADDR or 127.0.0.1)")
     ap.add_argument("--comm-port", type=int, default=0, help="rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)")
     ap.add_argument("--comm-timeout", type=int, default=300)
+    ap.add_argument("--shard-shared-list", type=_bool, default=False,
+                    help="all jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it "
+                         "(default: the list is this job's own shard, as in the reference)")
     ap.add_argument("args", nargs="*")
     return ap
 
@@ -132,6 +139,7 @@ def main(argv=None) -> int:
                 net.SetDropoutSeed(777 + rank)     # every rank its own masks
                 net.SetComm(comm)                  # per-layer gradient buckets, summed under the backward pass
         ctc = Ctc(dev)
+        ctc.SetGuard(net)      # a minibatch computed from a timed-out forward pass never reaches the statistics
         if o.sequence_out_file:                                                       # :134-137
             log(f"Sequences will be written to {o.sequence_out_file} in order from feature file")
             ctc.SetSequenceOutFile(o.sequence_out_file)
@@ -144,18 +152,23 @@ def main(argv=None) -> int:
         last = dict(obj_sum=0.0, err_tokens=0, ref_tokens=0)
         # the reader thread parses the archives; padding + interleave + H2D of batch n+1 run on the device feeder's own
         # stream while batch n trains (the reference pads on the host and copies synchronously, train-ctc-parallel.cc:186-198)
-        own_list = "JOB" in feature_rspecifier
+        mine = job_rspecifier(feature_rspecifier, rank, world)
+        if mine != feature_rspecifier:
+            log(f"feature rspecifier of job {rank + 1}: {mine}")
+            if o.shard_shared_list:
+                raise EesenError(-1, "--shard-shared-list with a per-job (JOB) feature list")
+        feature_rspecifier = mine
         feeder = Feeder(dev, slots=2)
         # a feature rspecifier that is a pipe of the reference's own filters (apply-cmvn | splice-feats | subsample-feats |
         # add-deltas, train_ctc_parallel.sh:95-110): read the raw table here and run the filters on the device
-        pipe = frontend.parse_feature_pipeline(job_rspecifier(feature_rspecifier, rank)) if not os.environ.get("EESEN_HOST_FEATURE_PIPES") else None
+        pipe = frontend.parse_feature_pipeline(feature_rspecifier) if not os.environ.get("EESEN_HOST_FEATURE_PIPES") else None
         if pipe is not None:
             feeder.set_pipeline(pipe.stages)
             table = frontend.read_raw(pipe, warn=lambda m: log(m, "WARNING"))
         else:
-            table = kaldi_io.read_mat_table(job_rspecifier(feature_rspecifier, rank))
+            table = kaldi_io.read_mat_table(feature_rspecifier)
         groups = assemble(table, targets, o.num_sequence, o.frame_limit, feat_dim, stats, interleaved=False)
-        if world > 1 and not own_list:
+        if world > 1 and o.shard_shared_list:
             groups = shard_minibatches(groups, rank, world)
         batches = _prefetch(groups)
 
@@ -165,18 +178,22 @@ def main(argv=None) -> int:
 
         diff = None
         staged = stage()
+        zero_steps = 0
         while True:
             mb, slot = staged
-            if comm is not None:     # ranks may hold different numbers of minibatches: keep stepping until all are done
-                if comm.allreduce([1.0 if mb is not None else 0.0])[0] == 0:
+            if mb is None:
+                # Ranks may hold different numbers of minibatches.  One that is out of data keeps stepping with a zero gradient
+                # through the same collectives until NO rank had a minibatch in a step (the liveness word that rides with the
+                # top layer's bucket); that closing round, which all ranks take together, leaves the model untouched.
+                # Cross-validation exchanges nothing: every rank simply finishes.
+                if comm is None or o.cross_validate:
                     break
-                if mb is None:       # out of data while others are not: zero gradient through the same collectives
-                    if not o.cross_validate:
-                        net.BackpropagateZero()
-                        net.Update()
-                    continue
-            elif mb is None:
-                break
+                net.BackpropagateZero()
+                net.Update()
+                if net.LiveRanks() == 0:
+                    break
+                zero_steps += 1
+                continue
             net.SetSeqLengths(mb.lens)
             net_out = net.Propagate(feeder.acquire(slot))
             feeder.release(slot)
@@ -200,7 +217,14 @@ def main(argv=None) -> int:
                 last = st; seq_since_report = 0
         for w in stats.warnings:
             log(w, "WARNING")
+        if zero_steps:
+            log(f"job {rank + 1} ran out of minibatches {zero_steps} step(s) before the last job")
         net.Synchronize()
+        if not o.cross_validate:                                                      # :236-240
+            log(net.Info())
+            log(net.InfoGradient())
+        if ctc.Dropped():
+            log(f"{ctc.Dropped()} minibatch(es) were computed from a timed-out forward pass and are not in the statistics", "WARNING")
         if not o.cross_validate and rank == 0:
             net.Write(target_model_filename, o.binary)
         el = max(time.time() - t0, 1e-9)

@@ -29,6 +29,7 @@ extern "C" {
 #define EESEN_ERR_HIP -2       /* a HIP runtime call or kernel launch failed                        */
 #define EESEN_ERR_STATE -3     /* call sequence violated (e.g. Backpropagate before Propagate)      */
 #define EESEN_ERR_IO -4        /* model file could not be read / written / parsed                   */
+#define EESEN_ERR_COMM -5      /* the data-parallel exchange was aborted: a peer died or stalled    */
 
 /* Layer kinds: the markers of src/net/layer.cc:37-46 that are on the hot path. */
 #define EESEN_LAYER_AFFINE 1          /* <AffineTransform>  src/net/affine-trans-layer.h           */
@@ -84,6 +85,17 @@ int eesen_net_write(eesen_net_t* net, const char* path, int binary);
 int eesen_net_num_layers(eesen_net_t* net, int* n);
 int eesen_net_layer_info(eesen_net_t* net, int idx, int* kind, int* in_dim, int* out_dim,
                          float* learn_rate_coef, float* max_grad);
+/* Layer::TypeToMarker (src/net/layer.cc:68-79): the marker token of layer idx as its model file carries it
+ * ("<BiLstmParallel>", "<BiLstm>", "<AffineTransform>", ...), NUL-terminated into buf[cap]. */
+int eesen_net_layer_marker(eesen_net_t* net, int idx, char* buf, int cap);
+/* What Net::Info / Net::InfoGradient print per tensor (src/net/net.cc:336-385 through MomentStatistics,
+ * src/net/utils-functions.h:50-82): {min, max, mean, variance, skewness, kurtosis} of each tensor of `layer`, in the order
+ * of the layer's own Info() (bilstm-layer.h:496-560: W_x, W_m, bias, p_i, p_f, p_o forward, then backward; lstm-layer.h:175-196;
+ * affine-trans-layer.h:145-159: linearity, bias).  which: 0 = the parameters (Info), 1 = the momentum buffers *_corr_
+ * (InfoGradient), 2 = the Adagrad / RMSProp accumulators *_corr_accu.  Computed on the device (two reduction passes per
+ * tensor, fp64 accumulation).  out6_host: [cap_tensors x 6] doubles or NULL (count only); *n_tensors = tensors of the layer
+ * (0 for layers without parameters).  Synchronises. */
+int eesen_net_tensor_moments(eesen_net_t* net, int which, int layer, double* out6_host, int cap_tensors, int* n_tensors);
 int eesen_net_input_dim(eesen_net_t* net, int* dim);   /* Net::InputDim  net.cc:139-142 */
 int eesen_net_output_dim(eesen_net_t* net, int* dim);  /* Net::OutputDim net.cc:134-137 */
 int eesen_net_num_params(eesen_net_t* net, long* n);   /* Net::NumParams net.cc:163-172 */
@@ -189,9 +201,20 @@ int eesen_net_set_comm(eesen_net_t* net, eesen_comm_t* comm);
 /* The same exchange as ONE all-reduce of the whole gradient buffer on the Net's stream, for hosts that keep the
  * communicator detached: call between eesen_net_backpropagate and eesen_net_update. */
 int eesen_net_allreduce_grads(eesen_net_t* net, eesen_comm_t* comm);
-/* For a rank that has run out of minibatches while others have not: zero gradient, the attached communicator's
- * per-layer all-reduces in the order a real Backpropagate issues them; follow with eesen_net_update. */
+/* Jobs with different numbers of minibatches (the reference's sub-jobs simply stop when job 1 has finished,
+ * src/net/communicator.h:104-112): a rank that has run out of minibatches while others have not keeps stepping with
+ *   eesen_net_backpropagate_zero (zero gradient, the attached communicator's per-layer all-reduces in the order a real
+ *   Backpropagate issues them) + eesen_net_update + eesen_net_live_ranks
+ * until live_ranks reports 0.  One float rides with the top layer's gradient bucket: 1 from every rank whose step was a real
+ * eesen_net_backpropagate, 0 from the others; *live is its sum over the ranks for the last step issued (blocks until that
+ * bucket has arrived).  A step in which NO rank was live -- the closing round, which all ranks take together -- leaves the
+ * model untouched (the update kernels read the word on the device), so N ranks with uneven shards still equal one process
+ * on the union of their minibatches.  Ranks that still train never need to ask. */
 int eesen_net_backpropagate_zero(eesen_net_t* net);
+int eesen_net_live_ranks(eesen_net_t* net, int* live);
+/* A peer that dies leaves the others' collectives spinning.  Every communicator runs a watchdog: a collective that has not
+ * completed EESEN_COMM_TIMEOUT_S (default 600) seconds after it was issued is aborted (ncclCommAbort), every blocked wait
+ * returns, and every later call on the communicator or a net attached to it fails with EESEN_ERR_COMM. */
 /* Debug / test accessor: the layer indices whose buckets the last Backpropagate issued, in issue order. */
 int eesen_net_bucket_order(eesen_net_t* net, int* layers_out, int cap, int* n);
 /* hipDeviceSynchronize of `device` (bench.py brackets its timed region with it). */
@@ -223,6 +246,13 @@ int eesen_ctc_error_rate_mseq(eesen_ctc_t* ctc, const int* frame_num_utt, int S,
  * `utt | <label> <frame> <probability> | ...` for the greedy-decoded sequence.  The file is removed first, as the
  * reference's trainer does; NULL or "" switches the output off. */
 int eesen_ctc_set_sequence_out_file(eesen_ctc_t* ctc, const char* path);
+/* Guard the statistics against a timed-out forward pass.  A cooperative recurrence kernel whose bounded spin gave up leaves
+ * garbage activations and raises a device word (eesen_net_recurrence_info); the Net recovers on its own, but a minibatch the
+ * host had already handed to the Ctc would fold a garbage ln p and garbage decodes into the objective and TOKEN_ACCURACY.  With
+ * a guard the word's value travels back with every minibatch's results, and a minibatch computed while it was set is dropped
+ * from ALL running totals (eesen_ctc_dropped counts them; one WARNING on stderr).  net == NULL removes the guard. */
+int eesen_ctc_set_guard(eesen_ctc_t* ctc, eesen_net_t* net);
+int eesen_ctc_dropped(eesen_ctc_t* ctc, long* minibatches);
 /* Running totals: Ctc::NumErrorTokens/NumRefTokens (ctc-loss.h:58-59) and the sums behind
  * Ctc::Report (ctc-loss.cc:300-308): obj = sum of ln p, sequences, frames. */
 int eesen_ctc_stats(eesen_ctc_t* ctc, double* obj_sum, long* sequences, long* frames, long* err_tokens,

@@ -29,18 +29,70 @@
 #include "net/train-opts.h"        /* the reference's NetTrainOptions (src/net/train-opts.h:29-62) */
 #include "util/kaldi-io.h"
 
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
 #include "eesen_hip.h"
+#include "eesen_hip_info.h"
 
 namespace eesen {
 
 inline void HipCheck(int rc) {  /* KALDI_ERR: message + std::runtime_error (src/base/kaldi-error.cc:168-182) */
   if (rc != EESEN_OK) throw std::runtime_error(std::string("eesen_hip: ") + eesen_last_error());
 }
-inline int HipDevice() {  /* CuDevice::SelectGpuId (src/gpucompute/cuda-device.cc:73-140): EESEN_DEVICE, else LOCAL_RANK, else 0 */
+
+/* Which job of how many this process is.  A launcher may say so through RANK / WORLD_SIZE (torch.distributed.run, bench.py);
+ * the recipes say it on the trainer's own command line, `--num-jobs=$nj --job-id=JOB` (train_ctc_parallel_h.sh:141-143, JOB
+ * substituted by queue.pl), which train-ctc-parallel.cc parses into locals this seam never sees before the first minibatch --
+ * so the command line is read here as well (/proc/self/cmdline).  rank = job id - 1. */
+struct SeamJob {
+  int rank, world;
+  SeamJob() : rank(0), world(1) {
+    const char* ws = std::getenv("WORLD_SIZE");
+    const char* rk = std::getenv("RANK");
+    if (ws && rk && std::atoi(ws) > 1) { world = std::atoi(ws); rank = std::atoi(rk); return; }
+    std::ifstream f("/proc/self/cmdline", std::ios::binary);
+    std::string arg;
+    int nj = 1, id = 1;
+    while (std::getline(f, arg, '\0')) {
+      if (arg.compare(0, 11, "--num-jobs=") == 0) nj = std::atoi(arg.c_str() + 11);
+      else if (arg.compare(0, 9, "--job-id=") == 0) id = std::atoi(arg.c_str() + 9);
+    }
+    if (nj > 1 && id >= 1 && id <= nj) { world = nj; rank = id - 1; }
+  }
+};
+inline const SeamJob& Job() { static const SeamJob j; return j; }
+
+inline int HipDevice() {  /* CuDevice::SelectGpuId (src/gpucompute/cuda-device.cc:73-140): EESEN_DEVICE, else LOCAL_RANK, else job id - 1 */
   const char* e = std::getenv("EESEN_DEVICE");
   if (!e) e = std::getenv("LOCAL_RANK");
-  return e ? std::atoi(e) : 0;
+  if (e) return std::atoi(e);
+  int n = 0;
+  if (Job().world > 1 && eesen_device_count(&n) == EESEN_OK && n > 0) return Job().rank % n;
+  return 0;
 }
+
+/* The one communicator of the process (a job = one rank), created on first need: by Net::SetTrainMode when training, by
+ * comm_touch_done when cross-validating (which exchanges nothing but the final counts). */
+struct SeamComm {
+  eesen_comm_t* comm;
+  eesen_net_t* net;   /* the training net the communicator is attached to (NULL: none) */
+  SeamComm() : comm(NULL), net(NULL) {}
+  ~SeamComm() { if (comm) eesen_comm_destroy(comm); }
+  eesen_comm_t* Get() {
+    if (!comm && Job().world > 1) {
+      const char* addr = std::getenv("MASTER_ADDR");
+      const char* cp = std::getenv("EESEN_COMM_PORT");
+      const char* mp = std::getenv("MASTER_PORT");
+      const int port = cp ? std::atoi(cp) : (mp ? std::atoi(mp) + 17 : 29517);
+      HipCheck(eesen_comm_create_tcp(HipDevice(), addr ? addr : "127.0.0.1", port, Job().rank, Job().world, 300, &comm));
+    }
+    return comm;
+  }
+};
+inline SeamComm& TheComm() { static SeamComm c; return c; }
+inline eesen_net_t*& LastNet() { static eesen_net_t* n = NULL; return n; }  /* the process's Net (the trainers hold exactly one) */
 
 /* CuMatrixBase / CuMatrix (src/gpucompute/cuda-matrix.h:39-447): {data, MatrixDim{rows, cols, stride}}.  A CuMatrix built
  * from a host Matrix keeps the HOST pointer (eesen_net_propagate uploads it itself, as the reference's constructor would);
@@ -110,14 +162,22 @@ class CuMatrix : public CuMatrixBase<Real> {
 /* eesen::Net (src/net/net.h:37-175) for <BiLstmParallel> / <LstmParallel> / <AffineTransform> / <Softmax> stacks */
 class Net {
  public:
-  Net() : h_(NULL), comm_(NULL) { HipCheck(eesen_net_create(HipDevice(), NULL, &h_)); }
+  Net() : h_(NULL), attached_(false) { HipCheck(eesen_net_create(HipDevice(), NULL, &h_)); LastNet() = h_; }
   ~Net() {
-    if (comm_) { eesen_net_set_comm(h_, NULL); }
+    if (LastNet() == h_) LastNet() = NULL;
+    if (attached_) { eesen_net_set_comm(h_, NULL); TheComm().net = NULL; }
     if (h_) eesen_net_destroy(h_);
-    if (comm_) eesen_comm_destroy(comm_);
   }
   void Read(const std::string& file) { HipCheck(eesen_net_read(h_, file.c_str())); }                         /* net.cc:279-309 */
-  void Write(const std::string& file, bool binary) const { HipCheck(eesen_net_write(h_, file.c_str(), binary)); }  /* net.cc:325-334 */
+  /* net.cc:325-334.  With several jobs EVERY job of the reference trainer writes the target model (train-ctc-parallel.cc:244-246);
+   * behind this seam they hold identical models, so each writes its own temporary file and renames it over the target */
+  void Write(const std::string& file, bool binary) const {
+    if (Job().world <= 1) { HipCheck(eesen_net_write(h_, file.c_str(), binary)); return; }
+    std::ostringstream tmp;
+    tmp << file << ".job" << Job().rank + 1 << ".$$";
+    HipCheck(eesen_net_write(h_, tmp.str().c_str(), binary));
+    if (std::rename(tmp.str().c_str(), file.c_str()) != 0) throw std::runtime_error("eesen_hip: cannot rename " + tmp.str() + " to " + file);
+  }
   void SetTrainOptions(const NetTrainOptions& o) {                                                          /* net.h:147-153 */
     HipCheck(eesen_net_set_train_options(h_, o.learn_rate, o.momentum));
     HipCheck(eesen_net_set_adaptive_options(h_, o.adagrad_epsilon, o.rmsprop_rho));
@@ -125,18 +185,13 @@ class Net {
   void SetUpdateAlgorithm(std::string opt) { HipCheck(eesen_net_set_update_algorithm(h_, opt.c_str())); }   /* net.cc:481-497 */
   void SetTrainMode() {                                                                                     /* net.cc:405-412 */
     HipCheck(eesen_net_set_train_mode(h_, 1));
-    /* one process per GPU under a launcher that exports RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT: join the RCCL communicator;
-     * from here on Backpropagate sums the gradients over the ranks (replaces comm_avg_weights, communicator.h:39-119) */
-    const char* ws = std::getenv("WORLD_SIZE");
-    const char* rk = std::getenv("RANK");
-    if (!comm_ && ws && rk && std::atoi(ws) > 1) {
-      const char* addr = std::getenv("MASTER_ADDR");
-      const char* cp = std::getenv("EESEN_COMM_PORT");
-      const char* mp = std::getenv("MASTER_PORT");
-      const int port = cp ? std::atoi(cp) : (mp ? std::atoi(mp) + 17 : 29517);
-      HipCheck(eesen_comm_create_tcp(HipDevice(), addr ? addr : "127.0.0.1", port, std::atoi(rk), std::atoi(ws), 300, &comm_));
-      HipCheck(eesen_net_set_dropout_seed(h_, 777ull + (unsigned long long)std::atoi(rk)));
-      HipCheck(eesen_net_set_comm(h_, comm_));
+    /* one job of several (SeamJob): join the RCCL communicator; from here on Backpropagate sums the gradients over the jobs
+     * (replaces comm_avg_weights, communicator.h:39-119) */
+    if (!attached_ && Job().world > 1) {
+      HipCheck(eesen_net_set_dropout_seed(h_, 777ull + (unsigned long long)Job().rank));
+      HipCheck(eesen_net_set_comm(h_, TheComm().Get()));
+      attached_ = true;
+      TheComm().net = h_;
     }
   }
   void SetTestMode() { HipCheck(eesen_net_set_train_mode(h_, 0)); }                                         /* net.cc:396-403 */
@@ -160,28 +215,17 @@ class Net {
     HipCheck(eesen_net_backpropagate(h_, out_diff.Data(), out_diff.Stride(), in_diff ? in_diff->Data() : NULL, in_diff ? in_diff->Stride() : 0));
     HipCheck(eesen_net_update(h_));
   }
-  std::string Info() const {  /* net.cc:336-354: one line per layer */
-    std::ostringstream os;
-    int n = 0;
-    HipCheck(eesen_net_num_layers(h_, &n));
-    os << "num-layers " << n << "\ninput-dim " << InputDim() << "\noutput-dim " << OutputDim() << "\nnumber-of-parameters "
-       << NumParams() / 1e6 << " millions\n";
-    for (int i = 0; i < n; ++i) {
-      int kind = 0, di = 0, dd = 0; float c = 0, g = 0;
-      HipCheck(eesen_net_layer_info(h_, i, &kind, &di, &dd, &c, &g));
-      os << "layer " << i + 1 << " : kind " << kind << ", input-dim " << di << ", output-dim " << dd << ", learn-rate-coef " << c
-         << ", max-grad " << g << "\n";
-    }
-    return os.str();
-  }
-  std::string InfoGradient() const { return "(gradient statistics are not collected on the HIP path)\n"; }  /* net.cc:356-385 */
+  /* net.cc:336-366: topology, layer markers and the MomentStatistics of every parameter tensor / momentum buffer (device-side
+   * reductions, eesen_net_tensor_moments; strings arranged by eesen_hip_info.h) */
+  std::string Info() const { return eesen_hip::NetInfo(h_, 0); }
+  std::string InfoGradient() const { return eesen_hip::NetInfo(h_, 1); }
   eesen_net_t* Handle() { return h_; }
 
  private:
   Net(const Net&);
   Net& operator=(const Net&);
   eesen_net_t* h_;
-  eesen_comm_t* comm_;
+  bool attached_;
 };
 
 /* eesen::Ctc (src/net/ctc-loss.h:29-90), the multi-sequence entry points */
@@ -197,6 +241,7 @@ class Ctc {
                     std::vector<std::vector<int32> >& label, CuMatrix<BaseFloat>* diff) {
     const int S = (int)frame_num_utt.size();
     Csr(label, S);
+    if (!guarded_ && LastNet()) { HipCheck(eesen_ctc_set_guard(h_, LastNet())); guarded_ = true; }  /* a timed-out forward pass never reaches the statistics */
     diff->Resize(net_out.NumRows(), net_out.NumCols());
     HipCheck(eesen_ctc_eval_parallel(h_, frame_num_utt.data(), S, net_out.Data(), net_out.NumRows(), net_out.NumCols(), net_out.Stride(),
                                      ids_.data(), off_.data(), diff->Data(), diff->Stride(), NULL));
@@ -242,26 +287,57 @@ class Ctc {
   long err_last_, ref_last_;
   std::vector<int> ids_, off_;
   std::string seq_out_;
+  bool guarded_ = false;
 };
 
 /* src/net/communicator.h: the multi-job mode of the reference trainer (--num-jobs / --job-id / --utts-per-avg) averages MODELS
  * through files.  Behind this seam a job is one rank of an RCCL communicator that sums GRADIENTS every minibatch inside
- * eesen_net_backpropagate (eesen_net_set_comm): the ranks hold identical models at every step, so "averaging" is the identity,
- * and the error counts are merged through the communicator.  The ranks must see the same number of minibatches (the native
- * eesen_amd/bin/train-ctc-parallel also handles uneven shards). */
-inline std::string comm_done_filename(const std::string& base, int job_id) {  /* communicator.h:29-33 */
+ * eesen_net_backpropagate (eesen_net_set_comm): the jobs hold identical models at every step, so "averaging" is the identity.
+ * What is left of the protocol happens where the reference trainer calls comm_touch_done, once, after its loop
+ * (train-ctc-parallel.cc:226-232):
+ *   * jobs with FEWER minibatches than others (the recipes' per-job lists are only approximately even, prep_scps.sh:37-76;
+ *     the reference lets a sub-job "give up if the main job finishes first", communicator.h:104-112) keep stepping here with a
+ *     zero gradient through the same collectives until no job had a minibatch in a step (eesen_net_live_ranks); the closing
+ *     round leaves the model untouched, so the result equals one process on the union of the minibatches;
+ *   * the jobs' error / reference token counts are summed over the communicator (the done-files of communicator.h:121-170)
+ *     and job 1 prints the `TOTAL TOKEN_ACCURACY` line the recipes grep in its log (train_ctc_parallel_h.sh:147,171). */
+inline std::string comm_done_filename(const std::string& base, int job_id) {  /* communicator.h:29-31 */
   std::ostringstream os;
-  os << base << ".job" << job_id << ".done";
+  os << base << ".done.job" << job_id;
   return os.str();
 }
-inline std::string comm_avg_model_name(const std::string& base, int count) {  /* communicator.h:35-37 */
+inline std::string comm_avg_model_name(const std::string& base, int count) {  /* communicator.h:33-35 */
   std::ostringstream os;
   os << base << ".avg" << count;
   return os.str();
 }
 inline void comm_avg_weights(Net&, const int&, const int&, const int&, const std::string&, const std::string&) {}  /* communicator.h:39-119 */
-inline void comm_touch_done(Ctc& ctc, const int& job_id, const int&, const std::string&) {                        /* communicator.h:121-170 */
-  KALDI_LOG << "job " << job_id << ": Errors " << ctc.NumErrorTokens() << " Refs " << ctc.NumRefTokens();
+inline void comm_touch_done(Ctc& ctc, const int& job_id, const int& num_jobs, const std::string& base_done_filename) {  /* communicator.h:121-170 */
+  KALDI_LOG << "Writing done file for job" << job_id;
+  {  /* :125-129: the file itself, for whoever looks at the experiment directory */
+    std::ofstream out(comm_done_filename(base_done_filename, job_id).c_str());
+    out << "Errors " << ctc.NumErrorTokens() << " Refs " << ctc.NumRefTokens();
+  }
+  if (num_jobs <= 1 || Job().world <= 1) return;
+  eesen_comm_t* comm = TheComm().Get();
+  if (TheComm().net) {  /* a training job: out of minibatches, others may not be */
+    long zero_steps = 0;
+    for (;;) {
+      int live = 0;
+      HipCheck(eesen_net_backpropagate_zero(TheComm().net));
+      HipCheck(eesen_net_update(TheComm().net));
+      HipCheck(eesen_net_live_ranks(TheComm().net, &live));
+      if (live == 0) break;
+      ++zero_steps;
+    }
+    if (zero_steps) KALDI_LOG << "job " << job_id << " ran out of minibatches " << zero_steps << " step(s) before the last job";
+  }
+  double tot[2] = {(double)ctc.NumErrorTokens(), (double)ctc.NumRefTokens()};
+  HipCheck(eesen_comm_allreduce_host(comm, tot, 2, 0));
+  if (job_id == 1) {  /* :132, :168 */
+    KALDI_LOG << "Collecting stats from " << num_jobs << " done files";
+    KALDI_LOG << "\nTOTAL TOKEN_ACCURACY >> " << 100.0 * (1.0 - tot[0] / tot[1]) << "% <<";
+  }
 }
 
 }  // namespace eesen

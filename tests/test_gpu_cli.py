@@ -209,3 +209,100 @@ def test_reference_trainer_source_compiled_against_the_seam(gpu, tmp_path):
     r2 = subprocess.run([exe] + cv, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-1500:], r2.stderr[-1500:])
     assert re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r1.stderr).group(1) == re.search(r"TOKEN_ACCURACY >> ([-0-9.e]+)% <<", r2.stderr).group(1)
+
+
+def test_two_jobs_with_uneven_per_job_lists_through_the_rccl_standin(gpu, tmp_path):
+    """The recipes' multi-job launch (`JOB=1:$nj ... --num-jobs=$nj --job-id=JOB scp:feats_tr.JOB.scp`, train_ctc_parallel_h.sh:
+    96,141-143: queue.pl has substituted JOB before the process starts, so each job receives ITS OWN list and no literal JOB)
+    with two jobs on the one GPU of the box, the library's communicator running over the test stand-in for librccl.so
+    (tests/native/fake_rccl.hip).  The per-job lists are uneven (8 and 5 utterances): job 2 runs out first and follows with
+    zero-gradient steps.  Three hosts -- the native trainer, the Python mirror, and the reference's OWN trainer source behind the
+    seam -- must write the same model, equal to one process stepping through the union of the jobs' minibatches, and job 1 must
+    print the merged `TOTAL TOKEN_ACCURACY` line the recipe greps in its log (:147)."""
+    import socket
+    from tests.test_gpu_multirank import fake_rccl_path, _merge
+    from eesen_amd.api import Net, Ctc
+    exe = os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")
+    seam = os.path.join(ROOT, "oracle", "_ref", "train-ctc-parallel-seam")
+    cfg = synth.config("tiny_bi")
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    feats, labs, scp, lab = _dataset(tmp_path, n=13, D=cfg["D"], K=cfg["K"])
+    lines = open(scp).read().splitlines()
+    shard = {1: lines[0:13:2] + [lines[11]], 2: lines[1:11:2]}           # 8 and 5 utterances, each list still sorted by length
+    shard[1].sort(key=lambda l: [k for k, _ in feats].index(l.split()[0]))
+    for j, ls in shard.items():
+        open(str(tmp_path / f"feats.{j}.scp"), "w").write("\n".join(ls) + "\n")
+    m_in = str(tmp_path / "nnet.init")
+    nnet_io.write_nnet(m_in, layers, binary=True)
+    opts = ["--learn-rate=0.01", "--momentum=0.9", "--num-sequence=2", "--frame-limit=90", "--num-jobs=2"]
+
+    def two_jobs(cmd, out, tag):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, EESEN_RCCL_LIBRARY=fake_rccl_path(), EESEN_PERSISTENT="0", FAKE_RCCL_QUIET="1", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), EESEN_DEVICE="0", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   LD_LIBRARY_PATH=os.path.join(ROOT, "eesen_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        ps = [subprocess.Popen(cmd + opts + [f"--job-id={j}", "scp:" + str(tmp_path / f"feats.{j}.scp"), "ark:" + lab, m_in, out],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT) for j in (1, 2)]
+        errs = [p.communicate(timeout=600)[1] for p in ps]
+        assert [p.returncode for p in ps] == [0, 0], (tag, errs[0][-2500:], errs[1][-2500:])
+        return errs
+
+    o_cc, o_py, o_seam = (str(tmp_path / f"{t}.nnet") for t in ("cc", "py", "seam"))
+    e_cc = two_jobs([exe, "--device=0"], o_cc, "native")
+    e_py = two_jobs([sys.executable, "-m", "eesen_amd.train_ctc_parallel", "--device=0"], o_py, "python")
+    total = lambda err: re.search(r"TOTAL TOKEN_ACCURACY >> ([-0-9.e]+)% <<", err)
+    assert total(e_cc[0]) and not total(e_cc[1]) and total(e_py[0]) and not total(e_py[1])       # job 1 reports the merged line, once
+    assert total(e_cc[0]).group(1) == total(e_py[0]).group(1)
+    assert open(o_cc, "rb").read() == open(o_py, "rb").read()
+    assert "ran out of minibatches" in e_cc[1] and "ran out of minibatches" not in e_cc[0]
+    # the reference's own Info() / InfoGradient() log (train-ctc-parallel.cc:236-240): layer markers and per-tensor moments
+    assert "layer 1 : <BiLstmParallel>, input-dim" in e_cc[0] and "wei_gifo_x_fw_  " in e_cc[0] and "### Gradient stats :" in e_cc[0]
+    assert re.search(r"linearity_corr_ \( min [-0-9.e+]+, max [-0-9.e+]+, mean ", e_cc[0])
+    if os.path.exists(seam):
+        e_seam = two_jobs([seam], o_seam, "seam")
+        assert open(o_seam, "rb").read() == open(o_cc, "rb").read()
+        assert total(e_seam[0]) and not total(e_seam[1])
+        assert abs(float(total(e_seam[0]).group(1)) - float(total(e_cc[0]).group(1))) < 1e-4
+        assert "layer 1 : <BiLstmParallel>, input-dim" in e_seam[0] and "### Gradient stats :" in e_seam[0]
+    # one process on the union: step k = the k-th minibatches of the two lists together
+    groups = {j: list(assemble(((l.split()[0], dict(feats)[l.split()[0]]) for l in shard[j]), labs, 2, 90, cfg["D"])) for j in (1, 2)}
+    os.environ["EESEN_PERSISTENT"] = "0"
+    try:
+        net = Net.from_layers(layers)
+    finally:
+        del os.environ["EESEN_PERSISTENT"]
+    net.SetTrainOptions(0.01, 0.9)
+    ctc = Ctc()
+    errs_tot = refs_tot = 0
+    for k in range(max(len(g) for g in groups.values())):
+        mb = _merge([synth.Batch(feats=g[k].feats, lens=g[k].lens, labels=g[k].labels, T=g[k].T, S=g[k].S) for g in groups.values() if k < len(g)])
+        net.SetSeqLengths(mb.lens)
+        o = net.Propagate(mb.feats)
+        d = ctc.EvalParallel(mb.lens, o, mb.labels)
+        e, n = ctc.ErrorRateMSeq(mb.lens, o, mb.labels); errs_tot += e; refs_tot += n
+        net.Backpropagate(d)
+    assert len(groups[1]) > len(groups[2])
+    assert rel_err(nnet_io.flatten_params(nnet_io.read_nnet(o_cc)), net.GetParams()) < 1e-5
+    assert abs(float(total(e_cc[0]).group(1)) - 100.0 * (1.0 - errs_tot / refs_tot)) < 1e-3
+
+
+def test_shared_list_dealing_is_opt_in(gpu, tmp_path):
+    """Without --shard-shared-list a job trains EVERY minibatch of the list it was handed (reference semantics: the list is the
+    job's shard), with it job J trains minibatches J-1, J-1+N, ... -- checked through the utterance counts of a one-job-of-two
+    cross-validation run (which exchanges nothing)."""
+    import socket
+    from tests.test_gpu_multirank import fake_rccl_path
+    exe = os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")
+    cfg = synth.config("tiny_bi")
+    feats, labs, scp, lab = _dataset(tmp_path, n=12, D=cfg["D"], K=cfg["K"])
+    m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(**cfg), binary=True)
+    for extra, want in (([], (12, 12)), (["--shard-shared-list=true"], (6, 6))):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, EESEN_RCCL_LIBRARY=fake_rccl_path(), EESEN_PERSISTENT="0", FAKE_RCCL_QUIET="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        ps = [subprocess.Popen([exe, "--device=0", "--cross-validate=true", "--num-sequence=2", "--num-jobs=2", f"--job-id={j}"] + extra +
+                               ["scp:" + scp, "ark:" + lab, m_in], env=env, stderr=subprocess.PIPE, text=True) for j in (1, 2)]
+        errs = [p.communicate(timeout=600)[1] for p in ps]
+        assert [p.returncode for p in ps] == [0, 0], errs
+        got = tuple(int(re.search(r"Done (\d+) files", e).group(1)) for e in errs)
+        assert got == want, (extra, got)

@@ -173,3 +173,41 @@ def test_pipe_and_stdin_specifiers(tmp_path):
     assert open(out, "rb").read() == open(ark, "rb").read()
     with pytest.raises(kaldi_io.KaldiIOError):
         list(kaldi_io.read_mat_table("ark:false |"))
+
+
+def _read_tables(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "read_tables")
+    subprocess.run(["g++", "-O1", "-std=c++17", os.path.join(root, "tests", "native", "read_tables.cc"), "-o", exe], check=True)
+    return exe
+
+
+def test_native_table_reader_scp_entries_and_failing_pipes(tmp_path):
+    """eesen_amd/csrc/tools/kaldi_tables.h: an scp entry is everything behind the key -- also when its first
+    word occurs inside the key (`cat_utt1 cat f |`) --, and a table pipe that ends with a non-zero status is an error, not a
+    silently truncated table."""
+    import subprocess
+    from eesen_amd import kaldi_io
+    exe = _read_tables(tmp_path)
+    rng = np.random.default_rng(3)
+    mats = [("cat_utt1", rng.standard_normal((5, 4)).astype(np.float32)), ("utt2", rng.standard_normal((7, 4)).astype(np.float32))]
+    ark, scp = str(tmp_path / "f.ark"), str(tmp_path / "f.scp")
+    kaldi_io.write_mat_ark(ark, mats, scp_path=scp)
+    one = str(tmp_path / "one.ark"); kaldi_io.write_mat_ark(one, mats[:1])
+    # entry 1: a command whose first word is a prefix of the key; entry 2: path:offset
+    off = open(scp).read().splitlines()[1].split()[1]
+    cmd_scp = str(tmp_path / "cmd.scp")
+    open(cmd_scp, "w").write(f"cat_utt1 cat {one} | tail -c +10 |\nutt2\t{off}\n")   # (skips `cat_utt1 ` = 9 bytes: the bare matrix)
+    r = subprocess.run([exe, "feats", "scp:" + cmd_scp], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["cat_utt1", "5", "4", "utt2", "7", "4"], (r.stdout, r.stderr)
+    r = subprocess.run([exe, "feats", f"ark:cat {ark} |"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["cat_utt1", "5", "4", "utt2", "7", "4"]
+    # a filter that dies after its first utterance: the reference warns, the Python reader raises; the native reader must not pass it off
+    r = subprocess.run([exe, "feats", f"ark:cat {one}; exit 7 |"], capture_output=True, text=True)
+    assert r.returncode == 3 and "truncated" in r.stderr, (r.returncode, r.stderr)
+    lab = str(tmp_path / "l.ark"); kaldi_io.write_vec_int_ark(lab, [("a", np.arange(3, dtype=np.int32)), ("b", np.arange(5, dtype=np.int32))])
+    r = subprocess.run([exe, "labels", f"ark:cat {lab} |"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["a", "3", "b", "5"]
+    r = subprocess.run([exe, "labels", f"ark:cat {lab}; false |"], capture_output=True, text=True)
+    assert r.returncode == 3 and "truncated" in r.stderr

@@ -132,6 +132,50 @@ def test_minibatch_sharding_is_a_partition_and_job_substitution():
         for i in range(len(batches)):
             assert batches[i] in parts[minibatch_owner(i, world)]
     assert job_rspecifier("scp:feats.JOB.scp", 2) == "scp:feats.3.scp" and job_rspecifier("ark:x.ark", 5) == "ark:x.ark"
+    # only a JOB that stands alone, and only with several jobs (a path or a command that merely CONTAINS the letters is left alone)
+    assert job_rspecifier("scp:exp/JOBS/feats.scp", 2) == "scp:exp/JOBS/feats.scp"
+    assert job_rspecifier("ark:cat $JOBDIR/f.JOB.ark |", 0) == "ark:cat $JOBDIR/f.1.ark |"
+    assert job_rspecifier("scp:feats.JOB.scp", 0, world=1) == "scp:feats.JOB.scp"
+
+
+def test_python_trainer_treats_its_list_as_its_own_shard(monkeypatch, tmp_path):
+    """queue.pl substitutes JOB before the trainer starts, so a job sees `feats_tr.3.scp --job-id=3` and no
+    literal JOB: that list is the job's shard and must be trained IN FULL; dealing minibatches of a shared list is opt-in."""
+    import inspect
+    from eesen_amd import train_ctc_parallel as t
+    src = inspect.getsource(t.main)
+    assert "if world > 1 and o.shard_shared_list:" in src and '"JOB" in feature_rspecifier' not in src
+    o = t.build_parser().parse_args(["--num-jobs=4", "--job-id=3", "scp:feats_tr.3.scp", "ark:l", "m", "o"])
+    assert o.shard_shared_list is False
+    assert t.build_parser().parse_args(["--shard-shared-list=true", "a", "b", "c", "d"]).shard_shared_list is True
+
+
+def test_rendezvous_survives_stray_and_half_open_peers():
+    """A port scanner or a peer that hangs up in the middle of the hand-out must not take the rendezvous down."""
+    import multiprocessing as mp
+    import struct
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    p0 = ctx.Process(target=_rdv, args=(0, 2, port, q)); p0.start()
+    time.sleep(0.5)
+    for payload in (b"GET / HTTP/1.0\r\n\r\n", struct.pack("<II", 0x45534e31, 1)):     # garbage; a valid hello from "rank 1" that hangs up at once
+        for _ in range(50):
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=2)
+                break
+            except OSError:
+                time.sleep(0.1)
+        c.sendall(payload)
+        c.shutdown(socket.SHUT_RDWR) if payload.startswith(b"GET") else None
+        c.close()
+    p1 = ctx.Process(target=_rdv, args=(1, 2, port, q)); p1.start()
+    got = sorted(q.get(timeout=60) for _ in range(2))
+    for p in (p0, p1):
+        p.join(timeout=30); assert p.exitcode == 0
+    # the half-open "rank 1" never confirmed the blob, so it does not count as served: the real rank 1 still gets it
+    assert got == [(0, 0, True), (1, 0, True)]
 
 
 def _rdv(rank, world, port, q):
