@@ -169,6 +169,102 @@ def frontend_leg(dev: int, S: int = 32, T: int = 1000, D: int = 40, iters: int =
     return out
 
 
+def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_bf16: bool = False) -> dict:
+    """Not the headline: one of the other single-GPU BASELINE.json configurations (configs[3] = cfg4: 5x1024 BiLSTM + 512-d
+    projections; configs[4] = cfg5: 6x1024, S = 64 per GPU, T = 3000), the same loop body, `steps` timed steps, so that the driver's
+    record holds a driver-timed number for every configuration."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config(name)
+    layers = synth.make_model(max_grad=50.0, **cfg)
+    batch = synth.make_batch(**cfg)
+    net = Net.from_layers(layers, device=dev)
+    net.SetTrainOptions(4e-5, 0.9)
+    net.SetForwardPrecision(forward_bf16)
+    ctc = Ctc(device=dev)
+    ctc.SetGuard(net)
+    feats = CuMatrix.from_numpy(batch.feats, dev)
+    diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
+
+    def step():
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(feats)
+        ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
+        ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)
+        net.Backpropagate(diff)
+    for _ in range(warmup):
+        step()
+    net.Synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    net.Synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    info = net.RecurrenceInfo()
+    fpf = flops_per_frame(cfg)
+    frames = float(batch.T * batch.S)
+    nd = 2 if cfg["kind"].startswith("BiLstm") else 1
+    return {"workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
+                        f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "frames_per_s": frames / dt,
+            "dtype": "bf16-fwd/f32" if forward_bf16 else "f32",
+            "whole_step_tflops": fpf * frames / dt / 1e12, "whole_step_frac_of_f32_mfma_peak": fpf * frames / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
+            "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
+
+
+def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120) -> dict:
+    """Not the headline: the reference's OWN recipe shape -- 4 x 320 BiLSTM on 120-d features (40 fbanks + deltas), ~45 phone
+    targets, --num-sequence 10 (20 as the second point) --frame-num-limit 25000, utterances of a length-sorted list with WSJ-like
+    durations (asr_egs/wsj/run_ctc_phn.sh:65-85, steps/train_ctc_parallel.sh:13-21) -- through the trainer's own path: greedy
+    grouping, device feeder (every minibatch has its own T and S), Propagate / CTC / Backpropagate.  H = 320 is not a multiple of
+    128, so the backward pass cannot take the 4 x 32 tile: this leg measures the fallbacks instead of assuming them."""
+    from eesen_amd.api import Net, Ctc, CuMatrix, Feeder
+    from eesen_amd.batching import assemble
+    cfg = dict(kind="BiLstmParallel", layers=4, H=320, D=120, K=46)
+    rng = np.random.default_rng(777)
+    lens = np.sort(np.clip(rng.gamma(6.0, 130.0, size=n_utts), 150, 1600).astype(int))        # ~7.8 s mean, sorted as the recipes do
+    utts = [(f"utt{i:04d}", rng.standard_normal((int(n), cfg["D"])).astype(np.float32)) for i, n in enumerate(lens)]
+    labs = {k: rng.integers(1, cfg["K"], size=max(1, m.shape[0] // 10)).astype(np.int32) for k, m in utts}
+    groups = list(assemble(iter(utts), labs, num_sequence, 25000, cfg["D"], interleaved=False))
+    net = Net.from_layers(synth.make_model(max_grad=50.0, **cfg), device=dev)
+    net.SetTrainOptions(4e-5, 0.9)
+    ctc = Ctc(device=dev)
+    ctc.SetGuard(net)
+    feeder = Feeder(dev, slots=2)
+    diffs = {}
+
+    def epoch():
+        pers = [0, 0, 0]
+        slot = feeder.submit(groups[0].mats)
+        for i, mb in enumerate(groups):
+            net.SetSeqLengths(mb.lens)
+            out = net.Propagate(feeder.acquire(slot))
+            feeder.release(slot)
+            if out.rows not in diffs:
+                diffs[out.rows] = CuMatrix(out.rows, cfg["K"], dev, zero=False)
+            d = diffs[out.rows]
+            ctc.EvalParallel(mb.lens, out, mb.labels, d, want_pzx=False)
+            ctc.ErrorRateMSeq(mb.lens, out, mb.labels, deferred=True)
+            net.Backpropagate(d)
+            if i + 1 < len(groups):
+                slot = feeder.submit(groups[i + 1].mats)
+            info = net.RecurrenceInfo()
+            pers[0] += info["fwd_persistent"]; pers[1] += info["bwd_persistent"]; pers[2] += info["lstm_layers"]
+        net.Synchronize()
+        return pers
+    epoch()                                   # warm-up: allocations, every distinct shape once
+    t0 = time.perf_counter()
+    pers = epoch()
+    dt = time.perf_counter() - t0
+    padded = float(sum(g.T * g.S for g in groups)); real = float(sum(int(g.lens.sum()) for g in groups))
+    fpf = flops_per_frame(cfg)
+    return {"workload": f"4x320 BiLSTM, D=120, K=46, --num-sequence {num_sequence} --frame-num-limit 25000, {n_utts} length-sorted utterances "
+                        f"of {int(lens.min())}-{int(lens.max())} frames in {len(groups)} minibatches (S = {min(g.S for g in groups)}-{max(g.S for g in groups)})",
+            "minibatches": len(groups), "ms_per_minibatch": 1e3 * dt / len(groups), "padded_frames_per_s": padded / dt, "real_frames_per_s": real / dt,
+            "whole_step_tflops": fpf * padded / dt / 1e12, "flops_per_frame": fpf,
+            "persistent_layer_passes": {"fwd": pers[0], "bwd": pers[1], "of": pers[2]}, "recoveries": net.recoveries}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +272,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (cfg4 / cfg5 / the recipe shape, a few timed steps each)")
     ap.add_argument("--main-only", action="store_true",
-                    help="profiling runs: skip the secondary legs (f32-MFMA-GEMM comparison, PCIe-inclusive loop, standalone GEMM, CPU baseline)")
+                    help="profiling runs: skip the secondary legs (f32-MFMA-GEMM comparison, PCIe-inclusive loop, standalone GEMM, CPU baseline, config.secondary)")
     ap.add_argument("--T", type=int, default=0, help="override T_max (debug)")
     ap.add_argument("--H", type=int, default=0, help="override cells per direction (debug)")
     ap.add_argument("--S", type=int, default=0, help="override utterances per GPU (debug)")
@@ -301,6 +398,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    spans = net.PhaseSpans()           # every timed span of the K steps, in record order (before PhaseTimes clears them)
     phases = net.PhaseTimes()
     ctc_ph = ctc.PhaseTimes()
     ctc.SetProfiling(False)
@@ -374,35 +472,68 @@ def main():
         # tile would be chosen (16-sequence tiles leave half the CUs idle), H a multiple of 128 up to 512, whole 4-sequence tiles
         q4 = (persistent and H % 128 == 0 and H <= 512 and S % 4 == 0 and S > 8 and 2 * ((H + 15) // 16) * nd * ((S + 15) // 16) <= 256
               and os.environ.get("EESEN_BWD_Q4", "1") != "0")
+        split = os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1")
+        bf16_fwd = args.forward_precision == "bf16"
+        # the main-stream input->gates GEMMs take the 256 x 256-tile flavour when the shape holds >= 16 whole big tiles (gemm.hip)
+        # (layer 1's K = 40 is not a multiple of 16 and takes the 128 x 128 flavour; the name is that of the layers that dominate)
+        big = not bf16_fwd and (T * S) % 256 == 0 and (nd * 4 * H) % 256 == 0 and ((T * S) // 256) * ((nd * 4 * H) // 256) >= 16
+        gemm_name = ("gemm_f32_mfma_kernel" if not split and not bf16_fwd else
+                     ("gemm_f32_split_bf16_big_kernel" if big else "gemm_f32_split_bf16_kernel")) + "(input->gates)"
+        bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn
         kern = {
-            "lstm_fwd_" + kn: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops),
-            ("lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn): dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops),
-            "gemm_f32_mfma_kernel(input->gates)": dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops),
+            "lstm_fwd_" + kn: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
+            bwd_name: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
+            gemm_name: dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops, pipe="f32" if (not split and not bf16_fwd) else "bf16"),
         }
         for k in kern.values():
             k["avg_us"] = 1e6 * k["total_s"] / k["launches"]
-            k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12
+            k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12      # fp32-equivalent (algorithmic) TFLOP/s
+            # what the matrix pipe EXECUTES: the split GEMM runs six bf16 products per fp32 product (one with bf16-rounded forward operands)
+            k["executed"] = k["achieved"] * (1 if k["pipe"] == "f32" else (1 if bf16_fwd else 6))
+            k["peak"] = PEAK_F32_MFMA_TFLOPS if k["pipe"] == "f32" else PEAK_BF16_MFMA_TFLOPS
+            k["frac"] = k["executed"] / k["peak"]                                     # never above 1: executed flops over that pipe's peak
         dom = max(kern, key=lambda n: kern[n]["total_s"])
-        # HBM traffic per launch of the dominant kernel, from the committed PMC pass (rocprofv3 --pmc cannot run inside this
-        # process); only quoted when the workload is the one the counters were collected on
-        traffic = None
+        # HBM traffic per launch and matrix-pipe occupancy of the dominant kernel, from the committed PMC passes (rocprofv3 --pmc cannot
+        # run inside this process); only quoted when the workload is the one the counters were collected on
+        traffic = mfma_busy = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt["config"] == {"config": args.config, "T": T, "S": S} and not (args.H or args.layers):
                 traffic = pt["bytes_per_launch"].get(dom)
+                mfma_busy = pt.get("mfma_busy", {}).get(dom)
         except Exception:
             pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": kern[dom]["achieved"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        # The launch that runs ALONE on the chip: in the backward pass the top LSTM layer's recurrence starts when no side-stream
+        # GEMM is in flight (the weight-gradient GEMMs of a layer start behind its recurrence), the others share the chip with the
+        # layer above's gradient GEMMs.  Spans of one phase arrive in launch order: top layer first, every step.
+        alone = None
+        try:
+            ph_name = "recurrence_bwd" if dom.startswith("lstm_bwd") else ("recurrence_fwd" if dom.startswith("lstm_fwd") else None)
+            if ph_name and persistent:
+                sp = [sec for name, sec in spans if name == ph_name]
+                if len(sp) == nl * K:
+                    first = sp[0::nl] if ph_name == "recurrence_bwd" else sp[0::nl]
+                    us = 1e6 * float(np.mean(first))
+                    alone = {"avg_launch_us": us, "achieved": kern[dom]["flops"] / (us * 1e-6) / 1e12,
+                             "frac": kern[dom]["flops"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                             "which": ("the top layer's launch of every step: no side-stream GEMM is in flight beside it" if ph_name == "recurrence_bwd"
+                                       else "the lowest layer's launch of every step")}
+        except Exception:
+            pass
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["executed"], "peak": kern[dom]["peak"],
+                    "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": traffic, "mfma_busy": mfma_busy, "alone": alone,
                     "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
                     "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step chain -- a 32 KB "
                              "operand fetch through one CU's L1 beside 0.9 us of MFMA (4 x 32 tile on v_mfma_f32_4x4x1_16B_f32 with the "
                              "A-operand broadcast), the cell update, and the hand-off (counter-increment flight + poll round trip + drain "
                              "of the write-through stores), DESIGN.md sections 4, 9 and 10 -- and is measured while the launch shares the "
-                             "chip with the overlapped GEMMs (alone: ~3.1 ms per launch); whole_step is the step's total FLOPs over its time"),
+                             "chip with the overlapped GEMMs (`alone`: the launch that does not); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES over "
+                             "the kernel's SIMD-cycles from the committed PMC pass; whole_step is the step's total FLOPs over its time"),
                     "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   "flops_per_frame": fpf},
-                    "other_kernels": {n: {"achieved": v["achieved"], "frac": v["achieved"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": v["avg_us"]}
+                                   "flops_per_frame": fpf,
+                                   "note": "fp32-equivalent FLOPs over the fp32-MFMA peak; 74 % of them execute on the bf16 pipe (split GEMMs), see config.f32_mfma_gemm_only for the all-f32 step"},
+                    "other_kernels": {n: ({"achieved_fp32_equivalent": v["achieved"], "executed": v["executed"], "pipe": v["pipe"], "peak": v["peak"],
+                                           "frac": v["frac"], "avg_launch_us": v["avg_us"]})
                                       for n, v in kern.items() if n != dom}}
         # The gate GEMM alone (same kernel, same shape, HIP events around 5 back-to-back launches): inside the step its launches
         # are GATED on the recurrence's arrival counters and run under it, so their in-step duration says nothing about the
@@ -483,6 +614,18 @@ def main():
                 line["frontend"] = frontend_leg(dev)
             except Exception as e:  # never takes the headline down
                 line["frontend"] = {"error": str(e)}
+        if world == 1 and not args.main_only and not args.no_secondary and args.config == "cfg2" and not (args.T or args.H or args.S or args.layers):
+            # the other single-GPU BASELINE configurations and the reference's own recipe shape, driver-timed in the same run
+            del net, feats_dev, diff
+            sec = {}
+            for name, fn in (("cfg4", lambda: secondary_leg("cfg4", dev)), ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, forward_bf16=True)),
+                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=3, warmup=1)),
+                             ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20))):
+                try:
+                    sec[name] = fn()
+                except Exception as e:  # noqa: BLE001
+                    sec[name] = {"error": str(e)}
+            line["config"]["secondary"] = sec
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi:
         all_reduce([0.0])

@@ -56,6 +56,7 @@ SIGNATURES = {
     "eesen_net_synchronize": (_i, [_vp]),
     "eesen_net_set_profiling": (_i, [_vp, _i]),
     "eesen_net_get_phase_times": (_i, [_vp, _vp]),
+    "eesen_net_get_phase_spans": (_i, [_vp, _pi, _pf, _i, _pi]),
     "eesen_device_synchronize": (_i, [_i]),
     "eesen_set_gemm_mode": (_i, [_i]),
     "eesen_get_gemm_mode": (_i, [_pi]),

@@ -389,6 +389,15 @@ class Net:
         """HIP-event phase timers: per step (read after every step), or accumulated over several steps until PhaseTimes()."""
         check(self.lib.eesen_net_set_profiling(self.h, 2 if (on and accumulate) else int(bool(on))))
 
+    def PhaseSpans(self):
+        """[(phase name, seconds)] of every timed span since the last PhaseTimes(), in record order (call before PhaseTimes)."""
+        names = ["input_gemm", "recurrence_fwd", "affine_softmax", "recurrence_bwd", "grad_gemm", "update"]
+        n = C.c_int()
+        check(self.lib.eesen_net_get_phase_spans(self.h, None, None, 0, C.byref(n)))
+        ph, se = (C.c_int * max(n.value, 1))(), (C.c_float * max(n.value, 1))()
+        check(self.lib.eesen_net_get_phase_spans(self.h, ph, se, n.value, C.byref(n)))
+        return [(names[ph[i]] if 0 <= ph[i] < 6 else str(ph[i]), float(se[i])) for i in range(n.value)]
+
     def PhaseTimes(self) -> dict:
         out = np.zeros(6, np.float32)
         check(self.lib.eesen_net_get_phase_times(self.h, _np_ptr(out)))

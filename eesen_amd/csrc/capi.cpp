@@ -204,6 +204,9 @@ int eesen_net_synchronize(eesen_net_t* net) {
 int eesen_net_set_profiling(eesen_net_t* net, int on) {
   return guard([&] { REQ_PTR(net); net->timer.enable(on != 0); net->timer.set_accumulate(on == 2); });
 }
+int eesen_net_get_phase_spans(eesen_net_t* net, int* phases, float* seconds, int cap, int* n) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(n); *n = net->timer.spans(phases, seconds, cap); });
+}
 int eesen_net_get_phase_times(eesen_net_t* net, float* out6) {
   return guard([&] { REQ_PTR(net); REQ_PTR(out6); net->timer.collect(out6, 6); });
 }

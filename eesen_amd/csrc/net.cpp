@@ -51,6 +51,17 @@ void PhaseTimer::collect(float* out, int nphase) {
   if (accumulate_) used_ = 0;
 }
 
+int PhaseTimer::spans(int* phases, float* secs, int cap) {
+  for (size_t i = 0; i < used_ && (int)i < cap; ++i) {
+    EESEN_HIP_CHECK(hipEventSynchronize(spans_[i].b));
+    float ms = 0.f;
+    EESEN_HIP_CHECK(hipEventElapsedTime(&ms, spans_[i].a, spans_[i].b));
+    if (phases) phases[i] = spans_[i].phase;
+    if (secs) secs[i] = ms * 1e-3f;
+  }
+  return (int)used_;
+}
+
 // ------------------------------------------------------------------------------------------ Layer
 long Layer::file_params() const {
   if (is_lstm()) return (long)ndir * ((long)4 * H * din + (long)4 * H * H + 4 * H + 3 * H);  // bilstm-layer.h:991-998
@@ -177,6 +188,7 @@ Net::~Net() {
   if (lens_pin) (void)hipHostFree(lens_pin);
   if (err_pin) (void)hipHostFree(err_pin);
   if (live_pin) (void)hipHostFree(live_pin);
+  for (auto& h : in_stage) { if (h.p) (void)hipHostFree(h.p); if (h.ev) (void)hipEventDestroy(h.ev); }
   if (lens_ev) (void)hipEventDestroy(lens_ev);
   if (err_ev) (void)hipEventDestroy(err_ev);
   if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
@@ -558,8 +570,30 @@ void Net::propagate(const float* in, int nrows, int ld, bool is_device) {
 
   // input -> device, rows padded to a multiple of 4 floats (GEMM operand alignment)
   if (input.reserve((size_t)rows * D4) || D4 != D) EESEN_HIP_CHECK(hipMemsetAsync(input.p, 0, (size_t)rows * D4 * sizeof(float), st));
-  EESEN_HIP_CHECK(hipMemcpy2DAsync(input.p, (size_t)D4 * sizeof(float), in, (size_t)ld * sizeof(float), (size_t)D * sizeof(float),
-                                   rows, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  if (is_device) {
+    EESEN_HIP_CHECK(hipMemcpy2DAsync(input.p, (size_t)D4 * sizeof(float), in, (size_t)ld * sizeof(float), (size_t)D * sizeof(float), rows,
+                                     hipMemcpyDeviceToDevice, st));
+  } else {
+    // A HOST matrix is the caller's to free or overwrite the moment this call returns (the reference's CuMatrix constructor copies
+    // synchronously, train-ctc-parallel.cc:198, and its trainer rebuilds feat_mat_host every minibatch): it is copied into one of
+    // two pinned staging slots here and now, and travels from there on the stream.  (An asynchronous copy straight from pageable
+    // memory may still be in flight when the caller reuses the buffer -- seen as run-to-run differences when two jobs share a GPU.)
+    HostStage& hs = in_stage[in_stage_idx++ & 1];
+    const size_t bytes = (size_t)rows * D * sizeof(float);
+    if (!hs.ev) EESEN_HIP_CHECK(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+    if (hs.busy) { EESEN_HIP_CHECK(hipEventSynchronize(hs.ev)); hs.busy = false; }   // two Propagates ago
+    if (bytes > hs.cap) {
+      if (hs.p) EESEN_HIP_CHECK(hipHostFree(hs.p));
+      hs.p = nullptr;
+      hs.cap = bytes + bytes / 4;
+      EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hs.p), hs.cap, hipHostMallocDefault));
+    }
+    for (int r = 0; r < rows; ++r) std::memcpy(hs.p + (size_t)r * D, in + (size_t)r * ld, (size_t)D * sizeof(float));
+    EESEN_HIP_CHECK(hipMemcpy2DAsync(input.p, (size_t)D4 * sizeof(float), hs.p, (size_t)D * sizeof(float), (size_t)D * sizeof(float), rows,
+                                     hipMemcpyHostToDevice, st));
+    EESEN_HIP_CHECK(hipEventRecord(hs.ev, st));
+    hs.busy = true;
+  }
   forward_pass();
 }
 

@@ -61,6 +61,7 @@ class PhaseTimer {
   int begin(hipStream_t st, int phase);  // returns a span index (-1 when disabled)
   void end(hipStream_t st, int idx);
   void collect(float* out, int nphase);  // seconds per phase; synchronises on the recorded events
+  int spans(int* phases, float* secs, int cap);  // every recorded span in record order (phase, seconds); does not clear
  private:
   struct Span { hipEvent_t a, b; int phase; };
   std::vector<Span> spans_;
@@ -94,6 +95,8 @@ struct Net {
   int T = 0, S = 0, rows = 0;
   bool propagated = false;
   DevBuf<float> input;  // [rows x pad4(din0)]
+  struct HostStage { float* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } in_stage[2];  // pinned staging of HOST inputs
+  unsigned in_stage_idx = 0;
   const float* out_ptr = nullptr;
   int out_cols = 0, out_ld = 0;
   // backward scratch

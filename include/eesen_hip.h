@@ -169,6 +169,11 @@ int eesen_net_synchronize(eesen_net_t* net);
  * since the last eesen_net_get_phase_times, so a multi-step region needs no host synchronisation per step. */
 int eesen_net_set_profiling(eesen_net_t* net, int on);
 int eesen_net_get_phase_times(eesen_net_t* net, float* out6);
+/* The individual timed spans behind those sums, in the order they were recorded: phases[i] (index as above) and seconds[i]
+ * of span i, up to `cap`; *n = spans recorded since the last eesen_net_get_phase_times.  One span per kernel group of a
+ * layer (e.g. one per layer and step for the recurrences, top layer first in the backward pass), so a caller can separate
+ * the launch that runs alone on the chip from those that share it with side-stream work.  Call BEFORE get_phase_times. */
+int eesen_net_get_phase_spans(eesen_net_t* net, int* phases, float* seconds, int cap, int* n);
 
 /* ---- data-parallel exchange: one process per GPU, RCCL over xGMI ------------------------------------------------------
  * Replaces the reference's multi-job mode (--num-jobs / --job-id / --utts-per-avg, src/netbin/train-ctc-parallel.cc:208-235):

@@ -29,7 +29,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "full_cfg2": ("cfg2", {}),
     "full_cfg4_layer": ("cfg4", dict(layers=1, proj=0)),     # one 1024-cell BiLSTM layer at T=1000: the wide persistent tiles
+    # BASELINE.json configs[3]: 5 x 1024 BiLSTM with 512-d <AffineTransform> projections between the layers
+    # (asr_egs/wsj/utils/model_topo.py:99-128), K = 51, S = 32, T = 1000 -- exactly what bench.py's cfg4 leg times
+    "full_cfg4": ("cfg4", {}),
+    # BASELINE.json configs[4] at its 1000-frame length bucket: 6 x 1024 BiLSTM, S = 64 utterances per GPU (two sequence windows
+    # of the wide backward tile, the time-multiplexed forward kernel), K = 51
+    "full_cfg5_b1000": ("cfg5", dict(T=1000)),
 }
+# cases whose reference step is too long to repeat inside the default GPU suite: the committed fixture (made by this script from
+# the reference) is the arbiter unless EESEN_FULLSIZE_LIVE=1
+FIXTURE_FIRST = {"full_cfg5_b1000"}
 
 
 def case(name: str):
@@ -84,6 +93,21 @@ def compact(layers, r: dict) -> dict:
                 diff_absmax=np.array(np.max(np.abs(r["diff"]))), in_diff_absmax=np.array(np.max(np.abs(r["in_diff"]))))
 
 
+def reference_floors(layers, batch, r: dict) -> dict:
+    """What the reference's OWN fp32 CTC round-off does to the reference's results, measured by evaluating the CTC in fp64 on the
+    reference's probabilities (oracle/eesen_oracle.c, f64 build) and backpropagating THAT through the reference: the distance
+    of its fp32 `diff` to the fp64 one, and per gradient tensor (and for in_diff) the shift.  These are the floors below which
+    no fp32 implementation with a different summation order can be expected to agree with the reference end to end; the
+    fixture carries them so that the bars of the test are the same with and without the library on the box."""
+    from oracle import net as onet
+    from tests.util import rel_err, split_params
+    arb = onet.ctc_eval_parallel(r["net_out"], batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off, "f64")
+    r64 = reference_step(layers, batch, diff_override=arb["diff"])
+    fl = [rel_err(a, b) for (_, _, a), (_, _, b) in zip(split_params(layers, r["grads"]), split_params(layers, r64["grads"]))]
+    return dict(floor_diff=np.array(rel_err(r["diff"], arb["diff"])), floor_grads=np.array(fl),
+                floor_in_diff=np.array(rel_err(r["in_diff"], r64["in_diff"])), diff64_rows=arb["diff"][::ROW_STRIDE].astype(np.float32))
+
+
 def main():
     from oracle import refbind
     assert refbind.build_if_possible(), "oracle/_ref could not be built (needs /root/reference)"
@@ -93,8 +117,12 @@ def main():
         t0 = time.time()
         r = reference_step(layers, batch)
         c = compact(layers, r)
+        t1 = time.time()
+        c.update(reference_floors(layers, batch, r))
         np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **c)
-        print(f"{name}: reference step {time.time() - t0:.1f} s, sum ln p = {r['pzx'].astype(np.float64).sum():.4f}, errors {r['errors']}")
+        print(f"{name}: reference step {t1 - t0:.1f} s (+ {time.time() - t1:.1f} s for the fp64-CTC floors), sum ln p = "
+              f"{r['pzx'].astype(np.float64).sum():.4f}, errors {r['errors']}, floors: diff {float(c['floor_diff']):.2e}, "
+              f"gradient tensors up to {float(c['floor_grads'].max()):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -261,7 +261,7 @@ def test_two_jobs_with_uneven_per_job_lists_through_the_rccl_standin(gpu, tmp_pa
     assert re.search(r"linearity_corr_ \( min [-0-9.e+]+, max [-0-9.e+]+, mean ", e_cc[0])
     if os.path.exists(seam):
         e_seam = two_jobs([seam], o_seam, "seam")
-        assert open(o_seam, "rb").read() == open(o_cc, "rb").read()
+        assert open(o_seam, "rb").read() == open(o_cc, "rb").read(), rel_err(nnet_io.flatten_params(nnet_io.read_nnet(o_seam)), nnet_io.flatten_params(nnet_io.read_nnet(o_cc)))
         assert total(e_seam[0]) and not total(e_seam[1])
         assert abs(float(total(e_seam[0]).group(1)) - float(total(e_cc[0]).group(1))) < 1e-4
         assert "layer 1 : <BiLstmParallel>, input-dim" in e_seam[0] and "### Gradient stats :" in e_seam[0]
@@ -306,3 +306,21 @@ def test_shared_list_dealing_is_opt_in(gpu, tmp_path):
         assert [p.returncode for p in ps] == [0, 0], errs
         got = tuple(int(re.search(r"Done (\d+) files", e).group(1)) for e in errs)
         assert got == want, (extra, got)
+
+
+def test_seam2_layer_adaptor_inside_the_reference_net(gpu, tmp_path):
+    """Seam 2, COMPILED: oracle/_ref/seam2_check links the reference's own Net / Layer code (CPU mode)
+    with include/eesen_hip_layer.h, swaps every <BiLstmParallel> of a model for HipBiLstmParallel -- the reference's layer class
+    with PropagateFnc / BackpropagateFnc / Update running in libeesen_hip.so -- and compares two momentum steps (outputs,
+    in_diff, updated parameters, model file round trip) with the unmodified reference net on the same inputs."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "seam2_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/seam2_check is built where /root/reference exists (make -C oracle/ref_build seam2)")
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(max_grad=0.5, learn_rate_coef=0.7, **cfg)
+    model = str(tmp_path / "m.nnet")
+    nnet_io.write_nnet(model, layers, binary=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "eesen_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""), OPENBLAS_NUM_THREADS="8")
+    r = subprocess.run([exe, model, "8", "30", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SEAM2 OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "BiLstmParallel layers running in libeesen_hip.so: 2" in r.stdout
