@@ -69,6 +69,9 @@ struct LstmLayerDev {
   // whole batch needs more workgroups than can be co-resident (S = 64 at H = 1024: BASELINE config 5) run as several
   // launches, one window each -- the sequences are independent chains.  s_count = 0 means all S.
   int s_begin = 0, s_count = 0;
+  // partial-sum exchange space of the K-split backward kernel for wide layers (lstm_bwd_ksplit_px_floats; null: not offered)
+  float* PX = nullptr;
+  size_t px_floats = 0;
 };
 // EESEN_NO_DROPOUT (build flag, A/B only): compiles the recurrent-dropout branches out of the recurrence kernels
 #ifdef EESEN_NO_DROPOUT
@@ -100,6 +103,7 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
 // sequence windows (= cooperative launches) the persistent forward pass of this layer takes: 1 for every shape whose
 // workgroups are co-resident at once, 2+ for S = 64 at H = 1024, 0 when no persistent tile fits (per-step kernels then)
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
+size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

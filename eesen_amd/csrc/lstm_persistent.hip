@@ -81,6 +81,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 #ifndef EESEN_POLL_SLEEP
 #define EESEN_POLL_SLEEP 1
 #endif
+#ifndef EESEN_POLL_DELAY_SIB   // first-poll delay of the K-split backward kernel's sibling hand-off (4 peers in lockstep)
+#define EESEN_POLL_DELAY_SIB 8
+#endif
 // EESEN_NO_SYNC=1: TIMING-ONLY experiment (results are garbage): no arrival counters, no drain, no publish -- the floor a
 // hand-off without separate synchronisation traffic (e.g. readiness carried by the payload) could approach.
 #ifndef EESEN_NO_SYNC
@@ -964,6 +967,190 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward for WIDE layers (H = 1024: BASELINE configs 4 and 5), K split four ways (EESEN_BWD_KSPLIT, default on).
+// The 16 x 16 tile of lstm_bwd_persistent_kernel fetches ALL 4H gate gradients of its 16 sequences every step -- 256 KB per
+// workgroup, the same 256 KB in each of the 64 unit groups of a (direction, sequence tile): 64 MB per step through the L1s of
+// the chip at ~34 GB/s per CU is 7 of the step's 9.4 us, beside 3.4 us of MFMA.  Here a workgroup multiplies only ONE QUARTER
+// of K (the gate gradients of 256 of the 1024 units) into partial sums for FOUR times as many units (64 instead of 16): the
+// same 256 KB of W_m^T in its registers, the same MFMA count, a QUARTER of the fetch (64 KB, hidden under the MFMA chain).  The
+// four workgroups that share a 64-unit block then exchange their partial sums -- each writes the three 16 x 16 blocks its
+// siblings own (3 KB, write-through, a fresh row of the exchange space every step so no line is ever re-read) and reads the
+// three it needs -- and each finishes the cell update of its own 16 units as before.  A second, small hand-off (4 peers) buys
+// 192 KB of fetch per step.  Measured (cfg4 / cfg5, same box): backward recurrences 46.5 -> 38.9 ms / 333 -> 280 ms.
+//   roles: unit block uu = bx / 4 (64 units), K quarter ku = bx % 4; cell units = uu*64 + ku*16 .. +16
+//   hand-off 1 (DG_t): a consumer of quarter ku needs only the 16 producers whose cell units lie in that quarter's 256 units
+//   hand-off 2 (partials): counter per (group, uu), 4 increments per step
+// Shapes: H % 256 == 0, 16-sequence tiles, no dropout.  Same cell arithmetic; the d_m sum is formed in a different order
+// (as every backward variant here: parity tests, not bit equality, hold it).
+// ------------------------------------------------------------------------------------------------
+template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * NW)
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
+                                                                             float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
+                                                                             unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk) {
+  constexpr int KU = 4, ST = 16, UW = 64, NT = 4;
+  __shared__ float red[NW][ST][UW + 1];
+  __shared__ float own[ST][17];
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H, KQ = K4 / KU;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int uu = bx / KU, ku = bx % KU;
+  const int um0 = uu * UW, uc0 = um0 + ku * 16;            // units of the MFMA outputs / of the cell update
+  const int s0 = L.s_begin + bz * ST;
+  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);
+  const int g = dir * R.nz + bz, ngroups = R.ndir * R.nz, nub = H / UW;
+  const unsigned nprod = (unsigned)(H / KU / 16);          // producers of one K quarter
+  unsigned* wait_cnt = cnt + (size_t)(g * KU + ku) * kShards * kShardStride;
+  unsigned* pub_cnt = cnt + (size_t)(g * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
+  unsigned* sib_cnt = cnt2 + (size_t)(g * nub + uu) * kShardStride;
+
+  const int li = lane & 15, kq = lane >> 4;
+  const int sa = s0 + li;
+  // this wave's part of W_m^T: 64 unit rows x its CPW chunks of the K quarter, resident for the whole layer pass
+  float b[NT][CPW][8];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float* Br = L.WmT + ((size_t)dir * H + um0 + n * 16 + li) * K4 + (size_t)ku * KQ;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, KQ, true, b[n][c]);
+  }
+  const int es = tid >> 4, eu = tid & 15;
+  const int s_e = s0 + es, u_e = uc0 + eu;
+  const bool e_ok = tid < ST * 16 && s_e < s_end;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
+  const size_t gcol = (size_t)dir * K4 + u_e * 4;
+  const size_t ycol = (size_t)dir * H + u_e;
+  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dy = 0.f, c_t = 0.f, c_p = 0.f;
+  {
+    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
+    if (e_ok) {
+      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
+      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
+      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
+      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
+    }
+  }
+  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
+  int tbS = 0;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    if (chunk < T && step % chunk == 0) {
+      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
+      tbS = tb * S;
+      rDG = make_rsrc(DG + (size_t)tbS * ldG);
+    }
+    float dm_in = 0.f;
+    if (step > 0) {
+      if (wave == EESEN_POLL_WAVE) {
+        const bool go = wait_counters<EESEN_POLL_DELAY_BWD>(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      f32x4 acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
+      float a[CPW][8];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int k = (wave + c * NW) * 32 + kq * 8;
+        ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+      // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
+      __syncthreads();
+      // partial sums of this K quarter for the 64 units: the own 16 stay in LDS, the other three blocks go to their owners
+      float* px = PX + ((size_t)((size_t)step * ngroups + g) * nub + uu) * (KU * KU * 256);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int o = tid + h * (NW * 64), sq = o >> 6, uc = o & 63, dst = uc >> 4;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
+        if (dst == ku) own[sq][uc & 15] = v;
+        else __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave stored: drain the write-through stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(sib_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == EESEN_POLL_WAVE) {   // the three siblings: they finish their MFMA chains at about the same time
+        bool go = true;
+        if (lane == 0) {
+          go = false;
+          __builtin_amdgcn_s_sleep(EESEN_POLL_DELAY_SIB);
+          for (int spins = 0; spins < spin_limit; ++spins) {
+            if (__hip_atomic_load(sib_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
+            if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
+          }
+          if (!go) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_go = go ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (!s_go) return;
+      if (e_ok) {
+        dm_in = own[es][eu];
+#pragma unroll
+        for (int src = 0; src < KU; ++src)
+          if (src != ku) dm_in += px[(size_t)(ku * KU + src) * 256 + es * 16 + eu];
+      }
+    }
+    if (e_ok) {
+      const float dm = dy + dm_in;
+      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
+      const float h = tanhf_(c_t);
+      const float dh = (1.f - h * h) * (dm * o);
+      float dob = o * (1.f - o) * (dm * h);
+      const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
+      float df = f * (1.f - f) * (dc * c_p);
+      float di = i * (1.f - i) * (dc * g_);
+      float dg = (1.f - g_ * g_) * (dc * i);
+      float carry = dc * f;
+      if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
+      const f32x4 out = {dg, di, df, dob};
+      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4), 0, kSc1);
+      dcf = carry; dn_i = di; dn_f = df;
+    }
+    if (step + 1 < T) {
+      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {  // next step's operands, issued after the publish
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      }
+    }
+  }
+}
+
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
@@ -1136,6 +1323,22 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
   return pick_windows(L.S, 16 * ft.mt, fits_with);
 }
 
+// Floats of partial-sum exchange space the K-split backward kernel needs for this layer shape (16 KB per step, (direction,
+// 16-sequence tile) group and 64-unit block: 16 blocks of 16 x 16); 0 = the kernel does not apply (narrow layers take the 4 x 32
+// tile, dropout layers and odd shapes the generic one).  EESEN_BWD_KSPLIT=0 switches it off.
+size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
+  const char* e = getenv("EESEN_BWD_KSPLIT");
+  if (e && atoi(e) == 0) return 0;
+  if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
+  if (2 * blocks16 <= ncu && L.S > 8) return 0;   // the 8-sequence / 4 x 32 tiles are taken there
+  // the largest window the launcher may pick is the whole batch
+  return (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096;
+}
+
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace) {
   const int nch = (4 * L0.H + 31) / 32;
@@ -1176,6 +1379,42 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       if (cpw == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
       else if (cpw == 4) coop_launch(st, lstm_bwd_persistent_q4_kernel<4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
       else coop_launch(st, lstm_bwd_persistent_q4_kernel<2>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
+      return true;
+    }
+  }
+  // Wide layers: K split four ways (lstm_bwd_persistent_ksplit_kernel) wherever the 16-sequence tile would be taken and the caller
+  // handed over the partial-sum exchange buffer (lstm_bwd_ksplit_px_floats)
+  if (stile == 16 && L0.PX && lstm_bwd_ksplit_px_floats(L0) && L0.px_floats >= lstm_bwd_ksplit_px_floats(L0)) {
+    const int cpw = (4 * L0.H / 4) / (32 * NW);
+    auto kfits = [&](int Sw) {
+      dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(Sw, 16));
+      const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L0.H / 64) * kShardStride;
+      if (c1 + c2 > (size_t)kCtlHalf) return false;
+      switch (cpw) {
+        case 4: return fits(lstm_bwd_persistent_ksplit_kernel<4>, grid, NW * 64);
+        case 3: return fits(lstm_bwd_persistent_ksplit_kernel<3>, grid, NW * 64);
+        case 2: return fits(lstm_bwd_persistent_ksplit_kernel<2>, grid, NW * 64);
+        default: return false;
+      }
+    };
+    const int nwin = pick_windows(L0.S, 16, kfits);
+    if (nwin > 0 && (nwin == 1 || ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
+      for (int w = 0; w < nwin; ++w) {
+        LstmLayerDev L = L0;
+        L.s_count = L0.S / nwin;
+        L.s_begin = w * L.s_count;
+        dim3 grid(L.H / 64 * 4, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
+        const dim3 grid1(grid.x * grid.y * grid.z);
+        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L.H / 64) * kShardStride;
+        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
+        unsigned* cnt2 = cnt + c1;
+        switch (cpw) {
+          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
+          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
+          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
+        }
+      }
       return true;
     }
   }

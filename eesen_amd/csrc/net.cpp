@@ -788,7 +788,11 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       bucket_allreduce(li, st);
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
-      const LstmLayerDev v = lstm_view(*this, L);
+      LstmLayerDev v = lstm_view(*this, L);
+      if (persistent) {  // wide layers: partial-sum exchange space of the K-split backward kernel (shared by the layers: their passes are serial)
+        const size_t need = lstm_bwd_ksplit_px_floats(v);
+        if (need) { bwd_px.reserve(need); v.PX = bwd_px.p; v.px_floats = bwd_px.cap; }
+      }
       EESEN_REQUIRE(in_train || !L.has_dropout(), EESEN_ERR_STATE, "Can't backpropagate a dropout layer in test mode (bilstm-parallel-layer.h:425)");
       if (L.cur_fwd_drop) mul_elements(st, d, ld_d, L.fmask.p, ldY, d, ld_d, rows, ldY);  // out_diff_drop, :892-896
       // Gate-gradient buffers alternate between LSTM layers: while this layer's weight-gradient GEMMs (side stream)

@@ -101,6 +101,7 @@ struct Net {
   int out_cols = 0, out_ld = 0;
   // backward scratch
   DevBuf<float> DGb[2], DCF, dA, dB, ws, ws2;
+  DevBuf<float> bwd_px;       // partial-sum exchange space of the K-split backward kernel (wide layers)
   hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;
