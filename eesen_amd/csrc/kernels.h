@@ -72,7 +72,11 @@ struct LstmLayerDev {
   // partial-sum exchange space of the K-split backward kernel for wide layers (lstm_bwd_ksplit_px_floats; null: not offered)
   float* PX = nullptr;
   size_t px_floats = 0;
+  // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns (poll_delay2: the K-split backward
+  // kernel's sibling hand-off); set by the host from the measured increment flight of the device (handoff_flight_ns)
+  int poll_delay = 0, poll_delay2 = 0;
 };
+float handoff_flight_ns();
 // EESEN_NO_DROPOUT (build flag, A/B only): compiles the recurrent-dropout branches out of the recurrence kernels
 #ifdef EESEN_NO_DROPOUT
 #define EESEN_DROP_MODE(L) 0

@@ -69,20 +69,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 #ifndef EESEN_POLL_WAVE
 #define EESEN_POLL_WAVE 7
 #endif
-#ifndef EESEN_POLL_DELAY
-#define EESEN_POLL_DELAY -1
-#endif
-#ifndef EESEN_POLL_DELAY_FWD
-#define EESEN_POLL_DELAY_FWD (EESEN_POLL_DELAY >= 0 ? EESEN_POLL_DELAY : 20)
-#endif
-#ifndef EESEN_POLL_DELAY_BWD
-#define EESEN_POLL_DELAY_BWD (EESEN_POLL_DELAY >= 0 ? EESEN_POLL_DELAY : 14)
-#endif
 #ifndef EESEN_POLL_SLEEP
 #define EESEN_POLL_SLEEP 1
-#endif
-#ifndef EESEN_POLL_DELAY_SIB   // first-poll delay of the K-split backward kernel's sibling hand-off (4 peers in lockstep)
-#define EESEN_POLL_DELAY_SIB 8
 #endif
 // EESEN_NO_SYNC=1: TIMING-ONLY experiment (results are garbage): no arrival counters, no drain, no publish -- the floor a
 // hand-off without separate synchronisation traffic (e.g. readiness carried by the payload) could approach.
@@ -143,11 +131,28 @@ struct Role {
 // Arrival counters are sharded 8 ways (shard = unit group & 7, one 128-byte line each) so that the increments of a
 // step do not serialise on one address.  Lanes 0-7 of wave 0 each poll one shard until it reaches its own target
 // (workgroups in that shard x steps).  Returns false (and raises *err) when the bound is hit or a peer gave up.
-template <int DELAY>
-__device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit,
-                                              int lane) {
+//
+// The first-poll delay.  A poll issued before the peers' increments have landed costs a whole extra round trip AND slows the
+// very increments it waits for; one issued late is pure waiting.  Round 2 found the optimum by hand as s_sleep constants (20
+// forward, 14 backward: about ONE increment flight) for one clock and one box of the pool.  It is a hardware latency, so it is
+// now MEASURED: when a Net is created, a two-workgroup ping-pong (handoff_flight_ns below) times the flight of an agent-scope
+// increment between two CUs of this device against the constant-rate wall clock, and each wait's delay is that flight times a
+// dimensionless factor (net.cpp) -- passed to the kernels in wall-clock ticks and waited for on the wall clock, so neither the
+// measurement nor the wait depends on where DVFS has the shader clock at the time.  What was tried instead and
+// measured: controllers that steer the delay from first-poll misses.  Per workgroup they are unstable (a workgroup that
+// lengthens its delay publishes late, its peers' polls then miss and lengthen theirs: the delays ran to the limit, cfg2 forward
+// pass 12.3 -> 23.3 ms); with one common delay steered from the grid's miss rate they run away as well, because the workgroups
+// that finish their step early miss at ANY delay (the step is paced by the slowest one, for which the right delay is exactly the
+// flight).  The flight is the quantity to know; the miss rate says nothing about it.
+// waits `ticks` of the constant-rate wall clock (wall_clock64: 100 MHz, 10 ns): independent of where DVFS has the shader clock
+__device__ __forceinline__ void sleep_ticks(int ticks) {
+  if (ticks <= 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while ((long long)(wall_clock64() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsigned step, unsigned* err, int spin_limit, int lane, int delay) {
   const unsigned mine = lane < kShards ? ((nblk - lane + kShards - 1) / kShards) * step : 0u;
-  if constexpr (DELAY > 0) __builtin_amdgcn_s_sleep(DELAY);  // nobody can have arrived yet: the peers are still in their own step
+  sleep_ticks(delay);  // nobody can have arrived yet: the peers are still in their own step
   for (int spins = 0; spins < spin_limit; ++spins) {
     bool ok = true;
     if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
@@ -159,6 +164,22 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
   }
   if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
+}
+
+// Two workgroups (two CUs) hand a counter back and forth `rounds` times with the same agent-scope relaxed atomics the hand-off
+// uses; out[0] = wall-clock ticks (10 ns) of the whole exchange.  One round = two flights (A's store becomes visible to B's poll, B's to A's).
+__global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, unsigned long long* out, int rounds) {
+  if (threadIdx.x != 0) return;
+  unsigned* mine = flags + (blockIdx.x == 0 ? 0 : 32);
+  unsigned* theirs = flags + (blockIdx.x == 0 ? 32 : 0);
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 1; i <= rounds; ++i) {
+    if (blockIdx.x == 0) __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spins = 0; spins < (1 << 22); ++spins)
+      if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)i) break;
+    if (blockIdx.x != 0) __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
 }
 
 // XCD census.  When the (direction, sequence-tile) groups number exactly 8 and the role map is XCD-aware, group g is
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = EESEN_NO_SYNC ? true : wait_counters<EESEN_POLL_DELAY_FWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        const bool go = EESEN_NO_SYNC ? true : wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_mux_kernel(LstmLa
         // first polled slot (step 1, chain 0 when chain 1 does not exist) has to poll here
         if (!polled) {
           if (wave == EESEN_POLL_WAVE) {
-            const bool go = wait_counters<0>(my_cnt[q], nblk, (unsigned)step, err, spin_limit, lane);
+            const bool go = wait_counters(my_cnt[q], nblk, (unsigned)step, err, spin_limit, lane, 0);
             if (lane == 0) s_go = go ? 1 : 0;
           }
           __syncthreads();
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_mux_kernel(LstmLa
         const int nstep = nq > q ? step : step + 1;
         if (nstep > 0 && nstep < T && !(nq == q)) {                        // same chain next: its inputs depend on OUR publish below
           if (wave == EESEN_POLL_WAVE) {
-            const bool go = wait_counters<0>(my_cnt[nq], nblk, (unsigned)nstep, err, spin_limit, lane);
+            const bool go = wait_counters(my_cnt[nq], nblk, (unsigned)nstep, err, spin_limit, lane, 0);
             if (lane == 0) s_go = go ? 1 : 0;
           }
           polled = true;
@@ -640,7 +661,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = EESEN_NO_SYNC ? true : wait_counters<EESEN_POLL_DELAY_BWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        const bool go = EESEN_NO_SYNC ? true : wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -892,7 +913,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters<EESEN_POLL_DELAY_BWD>(my_cnt, nblk, (unsigned)step, err, spin_limit, lane);
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -1055,7 +1076,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
     float dm_in = 0.f;
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters<EESEN_POLL_DELAY_BWD>(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane);
+        const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -1101,7 +1122,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
         bool go = true;
         if (lane == 0) {
           go = false;
-          __builtin_amdgcn_s_sleep(EESEN_POLL_DELAY_SIB);
+          sleep_ticks(L.poll_delay2);
           for (int spins = 0; spins < spin_limit; ++spins) {
             if (__hip_atomic_load(sib_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
             if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -1179,6 +1200,33 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 }
 
 }  // namespace
+
+// One-way flight of an agent-scope increment between two CUs of the current device, in nanoseconds (measured once per device and
+// process, ~3 ms: 2000 round trips, the median of five runs).  The first-poll delays of the recurrence kernels are multiples of it.
+float handoff_flight_ns() {
+  static float cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0.f;
+  if (cache[dev] > 0.f) return cache[dev];
+  unsigned* flags = nullptr;
+  unsigned long long* out = nullptr;
+  EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&flags), 64 * sizeof(unsigned)));
+  EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&out), sizeof(unsigned long long)));
+  const int rounds = 2000;
+  double ns[5];
+  for (int rep = 0; rep < 5; ++rep) {
+    EESEN_HIP_CHECK(hipMemset(flags, 0, 64 * sizeof(unsigned)));
+    hipLaunchKernelGGL(handoff_pingpong_kernel, dim3(2), dim3(64), 0, nullptr, flags, out, rounds);
+    unsigned long long ticks = 0;
+    EESEN_HIP_CHECK(hipMemcpy(&ticks, out, sizeof(ticks), hipMemcpyDeviceToHost));
+    ns[rep] = 10.0 * (double)ticks / (2.0 * rounds);
+  }
+  std::sort(ns, ns + 5);
+  (void)hipFree(flags);
+  (void)hipFree(out);
+  cache[dev] = (float)ns[2];
+  return cache[dev];
+}
 
 static int xcd_map() {  // read per launch (a few ns): tests flip these between nets of one process
   const char* e = getenv("EESEN_XCD_MAP");

@@ -192,7 +192,10 @@ def _check(name, persistent, record, expect_all_persistent=True):
     assert rep["net_out_valid"] < TOL
     floor_g = rep.get("reference_grads_fp32ctc_vs_fp64ctc", {})
     for k, v in rep["grads"].items():
-        assert v < max(TOL, 3.0 * floor_g.get(k, 0.0)) and v < 3 * TOL, f"gradient tensor {k}: {v} (reference's own fp32-CTC floor {floor_g.get(k)})"
+        # within 1e-4, or within 3x the distance the reference's OWN fp32 CTC round-off moves that tensor; and never beyond 3e-4 unless
+        # the reference's own floor for the tensor lies above that (the 5- and 6-layer 1024-cell stacks: floors up to 1.7e-3)
+        fl = floor_g.get(k, 0.0)
+        assert v < max(TOL, 3.0 * fl) and v < max(3 * TOL, fl), f"gradient tensor {k}: {v} (reference's own fp32-CTC floor {fl})"
     d = rep["diff"]
     if ref is not None:
         floor = d["reference_fp32_vs_fp64_on_reference_probs"]          # what the reference's own fp32 CTC arithmetic achieves
