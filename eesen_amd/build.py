@@ -15,8 +15,8 @@ CSRC = os.path.join(_DIR, "csrc")
 LIBDIR = os.path.join(_DIR, "lib")
 LIB = os.path.join(LIBDIR, "libeesen_hip.so")
 SOURCES = ["gemm.hip", "lstm.hip", "lstm_persistent.hip", "ctc.hip", "optim.hip", "feeder.hip", "net.cpp", "ctc_host.cpp", "nnet_format.cpp", "capi.cpp", "comm.cpp"]
-HEADERS = ["common.h", "guard.h", "kernels.h", "net.h", "handles.h", os.path.join("..", "..", "include", "eesen_hip.h")]
-FLAGS = (["-DEESEN_POLL_NOSLEEP"] if os.environ.get("EESEN_BUILD_NOSLEEP") else []) + (os.environ.get("EESEN_BUILD_DEFS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+HEADERS = ["common.h", "guard.h", "kernels.h", "net.h", "handles.h", "tuning.h", os.path.join("..", "..", "include", "eesen_hip.h")]
+FLAGS = (os.environ.get("EESEN_BUILD_DEFS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 BINDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin")

@@ -362,7 +362,7 @@ void Net::set_comm(Comm* c) {
   // RCCL's kernels share the CUs with the cooperative recurrence kernels: a workgroup of the latter may have to wait for an
   // all-reduce block to retire before it becomes resident.  That always ends (the collectives never depend on later compute),
   // so give the bounded spins ten times the room instead of treating it as a lost peer.
-  if (c && !getenv("EESEN_SPIN_LIMIT")) spin_limit = std::max(spin_limit, 4000000);
+  if (c && !tn.spin_limit_set) spin_limit = std::max(spin_limit, 4000000);
   if (c && ev_ready.size() < layers.size()) {
     EESEN_HIP_CHECK(hipSetDevice(device));
     const size_t old = ev_ready.size();

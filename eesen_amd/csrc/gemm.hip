@@ -24,13 +24,9 @@
 namespace eesen {
 namespace {
 
-#ifndef EESEN_GEMM_PRIO
-#define EESEN_GEMM_PRIO 0
-#endif
-#ifndef EESEN_GEMM_BK
-#define EESEN_GEMM_BK 16  // measured on MI355X: BK=32 is -8 % on the k-contiguous shapes (97 vs 107 TF), +3 % on the tall-K transposed ones
-#endif
-constexpr int BM = 128, BN = 128, BK = EESEN_GEMM_BK, LDP = 4;
+// BK = 16: measured on MI355X, BK = 32 is -8 % on the k-contiguous shapes (97 vs 107 TF), +3 % on the tall-K transposed ones.
+// (Raising the wave priority around the MFMA block, s_setprio 1-3: within noise.)
+constexpr int BM = 128, BN = 128, BK = 16, LDP = 4;
 constexpr int NLD = BM * BK / 4 / 256;        // float4 loads per thread per operand tile
 constexpr int KQ_BITS = BK == 16 ? 2 : 3;     // log2(BK / 4): float4 per k-contiguous row
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -262,9 +258,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
     // keep the prefetch ABOVE the MFMA block: without the guards' branches hipcc sinks these loads to just before the
     // LDS stores, which serialises HBM latency with the matrix pipe (measured: 93 -> 66 TF on the tall-K shapes)
     __builtin_amdgcn_sched_barrier(0);
-#if EESEN_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(EESEN_GEMM_PRIO);
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int kr = 2 * kk + lk;
@@ -277,9 +270,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float (*As)[BK][B
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-#if EESEN_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (kt + 1 < nk) {
       store_tile<A_KC>(As[cur ^ 1], tid, ra);
       store_tile<B_KC>(Bs[cur ^ 1], tid, rb);
@@ -322,9 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
 // LDS: per operand and stage 3 planes (hi, mid, lo) x 2 k-halves x 128 rows x 8 bf16 (16 B): lane l of an MFMA reads row
 // l & 31, k-half l >> 5 with ONE conflict-free ds_read_b128 (consecutive rows are consecutive 16-byte slots); the k-halves
 // are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
-#ifndef EESEN_SPLIT_MINW
-#define EESEN_SPLIT_MINW 3   // measured (profiles/r02_gemm_variants.md): 171 -> 178 TF with two tiles of prefetch, 189 with three workgroups per CU
-#endif
+constexpr int kSplitMinW = 3;   // workgroups per CU of the 128 x 128 split kernel; measured: 171 -> 178 TF with two tiles of prefetch, 189 with three workgroups per CU
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Geometry of one split-kernel flavour.  TM x TN output tile, WGM x WGN waves, each wave (TM/WGM) x (TN/WGN) = BMW x BNW MFMA
@@ -635,60 +623,16 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
 }
 
 template <bool A_KC, bool B_KC, bool GUARD>
-__global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_bf16_kernel(GemmParams p) {
   gemm_split_body<GeoSmall, A_KC, B_KC, GUARD, false>(p);
 }
-__global__ __launch_bounds__(256, EESEN_SPLIT_MINW) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_bf16_gated_kernel(GemmParams p) {
   gemm_split_body<GeoSmall, true, true, false, true>(p);
 }
 // 256 x 256 tiles, eight waves: unguarded shapes only (every tile interior, whole k-tiles; the host checks)
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_f32_split_bf16_big_kernel(GemmParams p) {
   gemm_split_body<GeoBig, A_KC, B_KC, false, false>(p);
-}
-
-// Interference probes (EESEN_GEMM_SYNTH=1|2|3, side-stream launches only; results are garbage, timing experiments only):
-// a stand-in with the GEMM's grid, occupancy and pacing that exercises ONE resource -- 1: the matrix pipe (32 MFMAs per
-// k-tile on registers, no memory), 2: the global-load path (the GEMM's tile loads, then sleeps for the MFMA time),
-// 3: LDS (the GEMM's LDS stores + reads, then sleeps).  Used to find what a co-running GEMM takes from the recurrence.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_synth_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BM + LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + LDP];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int tile = blockIdx.x, m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-  const int kbeg = blockIdx.y * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk), nk = (kend - kbeg + BK - 1) / BK;
-  f32x16 acc[2][2];
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float keep = 0.f;
-  float4 ra[NLD], rb[NLD];
-  for (int i = 0; i < NLD; ++i) ra[i] = rb[i] = make_float4(1.f, 2.f, 3.f, 4.f);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (MODE == 1) {
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const float a0 = (float)lane, b0 = (float)kk;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[1][1], 0, 0, 0);
-      }
-    } else if (MODE == 2) {
-      load_tile<false, true>(p.A, p.lda, p.M, m0, kbeg + kt * BK, kend, tid, ra);
-      load_tile<false, true>(p.B, p.ldb, p.N, n0, kbeg + kt * BK, kend, tid, rb);
-      for (int i = 0; i < NLD; ++i) keep += ra[i].x + rb[i].w;
-      __builtin_amdgcn_s_sleep(32);  // ~2048 cycles: the k-tile's MFMA time
-    } else {
-      store_tile<false>(As[kt & 1], tid, ra);
-      store_tile<false>(Bs[kt & 1], tid, rb);
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < BK; ++kk) keep += As[kt & 1][kk][lane] + As[kt & 1][kk][64 + lane] + Bs[kt & 1][kk][lane] + Bs[kt & 1][kk][64 + lane];
-      __builtin_amdgcn_s_sleep(32);
-    }
-  }
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-  if (keep == 12345.678f) p.C[0] = keep;  // never true: keeps the work alive
 }
 
 // C = alpha * sum_s ws[s] + beta * C + bias
@@ -722,9 +666,8 @@ void set_gemm_mode(int mode) { g_gemm_mode = mode; }
 // Row-group height of the XCD-aware tile map (0 = plain row-major) and the grid it needs.  Groups of 8 tile-rows once
 // every XCD gets at least two of them; fewer rows per group for short grids so that all eight XCDs still get work.
 static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
-  static const int mode = getenv("EESEN_GEMM_XCD") ? atoi(getenv("EESEN_GEMM_XCD")) : 8;  // 0 disables, else the group height
-  if (mode <= 0 || tiles_m < 8) return 0;
-  int gm = mode;
+  if (tiles_m < 8) return 0;
+  int gm = 8;
   while (gm > 1 && cdiv(tiles_m, gm) < 16) gm >>= 1;
   const long groups = cdiv(tiles_m, gm), rounds = cdivl(groups, 8);
   const long gx = rounds * 8 * gm * tiles_n;
@@ -739,8 +682,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
-  static const int synth = getenv("EESEN_GEMM_SYNTH") ? atoi(getenv("EESEN_GEMM_SYNTH")) : 0;
-  const bool use_split = (gemm_mode() == 1 || bf16_operands) && !synth;
+  const bool use_split = gemm_mode() == 1 || bf16_operands;
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -749,8 +691,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   p.nprod = bf16_operands ? 1 : 6;
   // The 256 x 256 flavour of the split kernel: main-stream GEMMs (no occupancy cap requested) of shapes made of whole big tiles.
   // A side-stream GEMM has to fit beside a 512-thread recurrence workgroup (<= 168 VGPRs x one wave per SIMD): small flavour.
-  static const int big_env = getenv("EESEN_GEMM_BIG") ? atoi(getenv("EESEN_GEMM_BIG")) : 1;
-  const bool big = use_split && big_env && !bf16_operands && extra_lds_bytes == 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 &&
+  const bool big = use_split && !bf16_operands && extra_lds_bytes == 0 && M % 256 == 0 && N % 256 == 0 && K % 16 == 0 &&
                    (long)(M / 256) * (N / 256) >= 16;
   const int TB = big ? 256 : BM;
   p.bm = p.bn = TB;
@@ -760,8 +701,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   const long tiles = (long)tiles_m * tiles_n;
   // split-K only when the tile grid cannot fill the chip and K is long enough to amortise the reduce pass
   int splits = 1;
-  static const int target_env = getenv("EESEN_GEMM_TARGET_BLOCKS") ? atoi(getenv("EESEN_GEMM_TARGET_BLOCKS")) : 1024;  // >= 4 workgroups per CU (measured: tall-K W_x gradient 92 -> 110 TF)
-  const int target = big ? 256 : target_env;   // the big flavour runs one workgroup per CU
+  const int target = big ? 256 : 1024;   // >= 4 workgroups per CU (measured: tall-K W_x gradient 92 -> 110 TF); the big flavour runs one per CU
   if (ws && tiles < target && K >= 2048) {
     splits = (int)std::min<long>((target + tiles - 1) / tiles, K / 1024);
     splits = std::max(1, std::min(splits, 64));
@@ -775,7 +715,6 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   if (splits > 1) p.C = ws;
   unsigned gx = 0;
   p.gm = xcd_group_rows(tiles_m, tiles_n, &gx);
-  if (synth) p.gm = 0;
   dim3 grid(p.gm ? gx : (unsigned)tiles, (unsigned)splits), block(big ? 512 : 256);
   // measured on MI355X: the branch-free loads win only when both operands are k-contiguous (111 vs 107 TF); with an
   // m/n-contiguous operand the guarded code is faster (NN 107 vs 100 TF, tall-K TN 93 vs 67 TF), so it stays guarded
@@ -806,12 +745,6 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     else if (!a_kc && b_kc) EESEN_SPLIT_LAUNCH(false, true);
     else EESEN_SPLIT_LAUNCH(false, false);
 #undef EESEN_SPLIT_LAUNCH
-  } else if (synth && extra_lds_bytes > 0 && !a_kc && !b_kc) {  // interference probe instead of the side-stream weight-gradient GEMM
-    static bool warned = false;
-    if (!warned) { fprintf(stderr, "eesen_hip: EESEN_GEMM_SYNTH=%d -- weight gradients are NOT computed (timing probe)\n", synth); warned = true; }
-    if (synth == 1) hipLaunchKernelGGL(gemm_synth_kernel<1>, grid, block, extra_lds_bytes, st, p);
-    else if (synth == 2) hipLaunchKernelGGL(gemm_synth_kernel<2>, grid, block, extra_lds_bytes, st, p);
-    else hipLaunchKernelGGL(gemm_synth_kernel<3>, grid, block, extra_lds_bytes, st, p);
   } else if (a_kc && b_kc) EESEN_GEMM_LAUNCH(true, true);
   else if (a_kc && !b_kc) EESEN_GEMM_LAUNCH(true, false);
   else if (!a_kc && b_kc) EESEN_GEMM_LAUNCH(false, true);
@@ -845,7 +778,7 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // becoming resident.  26 KB of unused dynamic LDS on top of the 33 KB static makes at most two of these workgroups
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
-  static const int gate_lds = (getenv("EESEN_GATE_LDS_KB") ? atoi(getenv("EESEN_GATE_LDS_KB")) : 26) * 1024;
+  constexpr int gate_lds = 26 * 1024;
   if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmall::STAGE), st, p);
   else hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");

@@ -75,14 +75,11 @@ struct LstmLayerDev {
   // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns (poll_delay2: the K-split backward
   // kernel's sibling hand-off); set by the host from the measured increment flight of the device (handoff_flight_ns)
   int poll_delay = 0, poll_delay2 = 0;
+  // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
+  // K-split backward tiles
+  int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1;
 };
 float handoff_flight_ns();
-// EESEN_NO_DROPOUT (build flag, A/B only): compiles the recurrent-dropout branches out of the recurrence kernels
-#ifdef EESEN_NO_DROPOUT
-#define EESEN_DROP_MODE(L) 0
-#else
-#define EESEN_DROP_MODE(L) ((L).drop_mode)
-#endif
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
 // One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.

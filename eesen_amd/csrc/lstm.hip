@@ -48,7 +48,7 @@ __device__ __forceinline__ void ld8(const float* __restrict__ row, int k, int km
 // ------------------------------------------------------------------------------------------------
 // forward step
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int PROBE = 0>  // CPW k-chunks (of 32) per wave: every operand load of the step is in flight before the first MFMA. PROBE != 0: timing probes only (EESEN_STEP_PROBE)
+template <int CPW>  // CPW k-chunks (of 32) per wave: every operand load of the step is in flight before the first MFMA
 __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, int step) {
   __shared__ __attribute__((aligned(16))) float red[NW][32][20];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,15 +88,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
     for (int c = 0; c < CPW; ++c) {
       const int ch = cb + c * NW;
       const int k = ch * 32 + kq * 8;  // k >= H for ch >= nch: ld8 then returns zeros
-      ld8(A0, k, H, sa0 < S && !(PROBE & 2), a0[c]);
-      ld8(A1, k, H, sa1 < S && !(PROBE & 2), a1[c]);
-      ld8(Wr, k, H, !(PROBE & 1), b[c]);
+      ld8(A0, k, H, sa0 < S, a0[c]);
+      ld8(A1, k, H, sa1 < S, a1[c]);
+      ld8(Wr, k, H, true, b[c]);
     }
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (PROBE & 4) { acc0[0] += a0[c][j] * b[c][j]; acc1[0] += a1[c][j] * b[c][j]; continue; }
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c][j], b[c][j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c][j], b[c][j], acc1, 0, 0, 0);
       }
@@ -125,9 +124,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
   float i = sigmoidf_(pre.y + p_i * cprev);
   float f = sigmoidf_(pre.z + p_f * cprev);
   float c = g * i + cprev * f;
-  if (EESEN_DROP_MODE(L)) {  // recurrent dropout (:266-272): the mask multiplies g*i (no-memory-loss) or the whole new cell (RNNDrop)
+  if (L.drop_mode) {  // recurrent dropout (:266-272): the mask multiplies g*i (no-memory-loss) or the whole new cell (RNNDrop)
     const float mk = L.rmask[(size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu];
-    c = EESEN_DROP_MODE(L) == 1 ? mk * (g * i) + cprev * f : mk * (g * i + cprev * f);
+    c = L.drop_mode == 1 ? mk * (g * i) + cprev * f : mk * (g * i + cprev * f);
   }
   float h = tanhf_(c);
   float o = sigmoidf_(pre.w + p_o * c);
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(LstmLayerDev L, 
 // ------------------------------------------------------------------------------------------------
 // backward step
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int PROBE = 0>
+template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, int step, const float* __restrict__ dY,
                                                                 int lddy, float* __restrict__ DG,
                                                                 float* __restrict__ DCF) {
@@ -195,14 +194,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (cb + c * NW) * 32 + kq * 8;  // beyond K4: zeros
-        ld8(Ar, k, K4, a_ok && !(PROBE & 2), a[c]);
-        ld8(Br, k, K4, b_ok && !(PROBE & 1), b[c]);
+        ld8(Ar, k, K4, a_ok, a[c]);
+        ld8(Br, k, K4, b_ok, b[c]);
       }
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-          if (PROBE & 4) { acc0[0] += a[c][j] * b[c][j] + a[c][j + 1] * b[c][j + 1]; continue; }
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[c][j], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j + 1], b[c][j + 1], acc1, 0, 0, 0);
         }
@@ -232,9 +230,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(LstmLayerDev L, 
   float dc = dh + dcf + dgn.y * p_i + dgn.z * p_f + dob * p_o;
   // recurrent dropout (:700-725): d_i, d_g see d_c times the mask; with RNNDrop so do d_f and the carry to the next step
   float dcm = dc, dcx = dc;
-  if (EESEN_DROP_MODE(L)) {
+  if (L.drop_mode) {
     dcm = dc * L.rmask[cofs];
-    if (EESEN_DROP_MODE(L) == 2) dcx = dcm;
+    if (L.drop_mode == 2) dcx = dcm;
   }
   float df = f * (1.f - f) * (dcx * c_p);
   float di = i * (1.f - i) * (dcm * g);
@@ -331,18 +329,7 @@ void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step) {
   dim3 grid(L.H / 4, L.ndir, cdiv(L.S, 32)), block(NW * 64);
   switch (std::min(4, pick_cpw((L.H + 31) / 32))) {
     case 1: hipLaunchKernelGGL(lstm_fwd_step_kernel<1>, grid, block, 0, st, L, step); break;
-    case 2: {
-      static const int probe = getenv("EESEN_STEP_PROBE") ? atoi(getenv("EESEN_STEP_PROBE")) : 0;  // timing probes (wrong results!)
-      switch (probe) {
-        case 1: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 1>), grid, block, 0, st, L, step); break;
-        case 2: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 2>), grid, block, 0, st, L, step); break;
-        case 3: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 3>), grid, block, 0, st, L, step); break;
-        case 4: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 4>), grid, block, 0, st, L, step); break;
-        case 7: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 7>), grid, block, 0, st, L, step); break;
-        default: hipLaunchKernelGGL((lstm_fwd_step_kernel<2, 0>), grid, block, 0, st, L, step); break;
-      }
-      break;
-    }
+    case 2: hipLaunchKernelGGL(lstm_fwd_step_kernel<2>, grid, block, 0, st, L, step); break;
     default: hipLaunchKernelGGL(lstm_fwd_step_kernel<4>, grid, block, 0, st, L, step); break;
   }
 }
@@ -350,24 +337,8 @@ void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step) {
 void lstm_bwd_step(hipStream_t st, const LstmLayerDev& L, int step, const float* dY, int lddy, float* DG, float* DCF) {
   dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(L.S, 16)), block(NW * 64);
   // measured on MI355X at H = 512: 2 chunks in flight per wave (77 VGPRs) beat 8 (190 VGPRs): 10.0 vs 10.9 us per step
-  static const int cap = getenv("EESEN_BWD_CPW") ? atoi(getenv("EESEN_BWD_CPW")) : 2;
-  switch (std::min(cap, pick_cpw((4 * L.H + 31) / 32))) {
-    case 1: hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-    case 2: {
-      static const int probe = getenv("EESEN_BSTEP_PROBE") ? atoi(getenv("EESEN_BSTEP_PROBE")) : 0;  // timing probes (wrong results!)
-      switch (probe) {
-        case 1: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 1>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-        case 2: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 2>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-        case 3: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 3>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-        case 4: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 4>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-        case 7: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 7>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-        default: hipLaunchKernelGGL((lstm_bwd_step_kernel<2, 0>), grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-      }
-      break;
-    }
-    case 4: hipLaunchKernelGGL(lstm_bwd_step_kernel<4>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-    default: hipLaunchKernelGGL(lstm_bwd_step_kernel<8>, grid, block, 0, st, L, step, dY, lddy, DG, DCF); break;
-  }
+  if (pick_cpw((4 * L.H + 31) / 32) <= 1) hipLaunchKernelGGL(lstm_bwd_step_kernel<1>, grid, block, 0, st, L, step, dY, lddy, DG, DCF);
+  else hipLaunchKernelGGL(lstm_bwd_step_kernel<2>, grid, block, 0, st, L, step, dY, lddy, DG, DCF);
 }
 
 size_t lstm_bias_peep_ws_floats(int T, int S, int H, int ndir) { return (size_t)RED_RB * ndir * H * 7; }

@@ -14,7 +14,7 @@
 //   consumer: 8 lanes of ONE wave (wave 7, after a first-poll delay; see EESEN_POLL_WAVE below) poll the 8 shards (relaxed,
 //             agent scope, s_sleep between polls, BOUNDED spin) ->
 //             workgroup barrier -> every wave reads the payload with plain loads of lines nobody has read before (see below;
-//             EESEN_SC1_LOADS=1 builds the L1-bypassing variant, measured slower).
+//             L1-bypassing sc1 loads were measured slower).
 // Workgroup roles are laid out so that, with the observed block -> XCD round-robin, the workgroups of one group share an L2
 // (struct Role); that only changes how much crosses the fabric, never correctness.
 // Every step writes row blocks that no one has read before in this launch, so no cache can hold a stale copy -- PROVIDED
@@ -42,9 +42,7 @@ constexpr int kSc1 = 16;  // cache-policy bit of the raw-buffer builtins: sc1 = 
 // per-step critical path; the error (~2e-7 relative) is three orders below the parity bar
 // __frcp_rn compiles to the IEEE division sequence (v_div_scale / v_rcp / 3 fma / v_div_fmas / v_div_fixup, ~10 dependent
 // instructions); v_rcp_f32 alone is 1 ulp -- three orders below the parity bar, and the cell update is on the per-step critical path
-#ifndef EESEN_RCP
 #define EESEN_RCP(x) __builtin_amdgcn_rcpf(x)
-#endif
 __device__ __forceinline__ float sigmoidf_(float x) { return EESEN_RCP(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * EESEN_RCP(1.f + __expf(2.f * x)); }
 
@@ -52,7 +50,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
 // 8 consecutive floats at row[k..k+7] (k, kmax multiples of 4) through the sc1 path; zeros outside
-// EESEN_SC1_LOADS=1 (build flag): consumers read the handed-off rows with sc1 (L1-bypassing) loads.  Measured on MI355X
+// Tried: consumers reading the handed-off rows with sc1 (L1-bypassing) loads.  Measured on MI355X
 // this makes every workgroup pull its own copy through the Infinity Fabric (16 MB per backward step, ~27 GB/s per CU).
 // Default: plain loads.  They are safe HERE because (i) every step reads row blocks that were never read before in this
 // launch, so neither the CU's L1 nor the XCD's L2 can hold an older copy, (ii) the producers' sc1 stores write through
@@ -66,34 +64,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
 // than that (forward 16.6 ms): 256 eager pollers crowd the counter lines and delay the very increments they wait for.  So the
 // first poll is DELAYED by about the time the peers' increments need to land (s_sleep 20 = 1280 cycles forward, 14 backward:
 // flat optimum 16-24 / 12-16; 12 forward or 8 backward give the gain away, 48 costs 10 %), and then usually succeeds at once.
-#ifndef EESEN_POLL_WAVE
-#define EESEN_POLL_WAVE 7
-#endif
-#ifndef EESEN_POLL_SLEEP
-#define EESEN_POLL_SLEEP 1
-#endif
-// EESEN_NO_SYNC=1: TIMING-ONLY experiment (results are garbage): no arrival counters, no drain, no publish -- the floor a
-// hand-off without separate synchronisation traffic (e.g. readiness carried by the payload) could approach.
-#ifndef EESEN_NO_SYNC
-#define EESEN_NO_SYNC 0
-#endif
-// EESEN_BWD_4X4 (default 1): the 8-sequence backward tile multiplies with v_mfma_f32_4x4x1_16B_f32 and the A-operand BROADCAST of
-// that instruction (CBSZ = 2, ABID) instead of v_mfma_f32_16x16x4_f32 with half of its rows padding -- see the kernel.
-#ifndef EESEN_BWD_4X4
-#define EESEN_BWD_4X4 1
-#endif
-#ifndef EESEN_BWD_FULL_LINES
-#define EESEN_BWD_FULL_LINES 1
-#endif
-#ifndef EESEN_SC1_LOADS
-#define EESEN_SC1_LOADS 0
-#endif
+constexpr int EESEN_POLL_WAVE = 7;   // the polling wave (see above)
+constexpr int EESEN_POLL_SLEEP = 1;  // s_sleep between polls (0 ... 16: flat)
 // Branch-free on purpose: a lane that has nothing to read points its offset past the descriptor's num_records and the
 // buffer unit returns zeros.  With predicated loads (`if (ok) load`) the compiler cannot count outstanding loads and puts
 // one `s_waitcnt vmcnt(0)` in front of the whole MFMA chain, which serialised operand fetch (~1.9 us per backward step)
 // and MFMA (~1.7 us); straight-line loads get per-chunk `vmcnt(n)` waits and the two overlap.
 __device__ __forceinline__ void ld8_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int k, int kmax, bool ok, float (&v)[8]) {
-  constexpr int pol = EESEN_SC1_LOADS ? kSc1 : 0;
+  constexpr int pol = 0;   // plain loads (see above); sc1 loads were measured slower
   constexpr unsigned kOob = 0x80000000u;  // >= num_records (0x7fffffff): reads as zero
   const unsigned oa = (ok && k < kmax) ? byte_off : kOob;
   const unsigned ob = (ok && k + 4 < kmax) ? byte_off + 16 : kOob;
@@ -121,7 +99,6 @@ __device__ __forceinline__ void ld8_plain(const float* __restrict__ row, int k, 
 // protocol does not depend on the placement.
 struct Role {
   int nblk, ndir, nz, xcd;
-  int census;  // 1: take the XCD census and use the L2-local hand-off when every group sits behind one L2
   __device__ __forceinline__ int combo(int b) const { return xcd ? b % (ndir * nz) : b / nblk; }
   __device__ __forceinline__ int unit_group(int b) const { return xcd ? b / (ndir * nz) : b % nblk; }
   __device__ __forceinline__ int dir(int b) const { return combo(b) % ndir; }
@@ -158,9 +135,7 @@ __device__ __forceinline__ bool wait_counters(unsigned* cnt, unsigned nblk, unsi
     if (lane < kShards) ok = __hip_atomic_load(cnt + lane * kShardStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mine;
     if (__all(ok)) return true;
     if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-#ifndef EESEN_POLL_NOSLEEP
     __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
-#endif
   }
   if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
@@ -180,26 +155,6 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
     if (blockIdx.x != 0) __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
-}
-
-// XCD census.  When the (direction, sequence-tile) groups number exactly 8 and the role map is XCD-aware, group g is
-// MEANT to run on XCD g -- then all of a group's hand-offs can stay inside that XCD's L2 (the coherence point of its 32
-// CUs): plain stores that keep the line in L2, L2-executed counter increments, no trip through the fabric.  Placement is
-// not a contract, so it is CHECKED, per launch: every workgroup reads HW_REG_XCC_ID, votes with an agent-scope atomic,
-// waits (bounded) for all votes, and the L2-local protocol is used only if EVERY workgroup sits where the map assumes;
-// otherwise all of them use the placement-independent write-through protocol.  Returns 1 (local), 0 (global), -1 (error).
-__device__ __forceinline__ int xcd_census(unsigned* word, unsigned nwg, unsigned* err, int spin_limit) {
-  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
-  const unsigned good = xcc == (blockIdx.x & 7u) ? 1u : 0u;
-  __hip_atomic_fetch_add(word, 1u + (good << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int spins = 0; spins < spin_limit; ++spins) {
-    const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((v & 0xffffu) == nwg) return (v >> 16) == nwg ? 1 : 0;
-    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return -1;
 }
 
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
@@ -270,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {  // m_{tp} complete? (step 0 reads the zero boundary: nothing to wait for, nothing to multiply)
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = EESEN_NO_SYNC ? true : wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -356,10 +311,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
     }
     EESEN_STAMP(3);
     {  // published after EVERY step: the last one is what a gated GEMM of the next layer waits for
-      if (!EESEN_NO_SYNC && tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (ST * UB is a multiple of 64)
+      if (tid < ST * UB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (ST * UB is a multiple of 64)
       __syncthreads();                                                 // (also fences `red` for the next step)
       EESEN_STAMP(4);
-      if (!EESEN_NO_SYNC && tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok && step + 1 < T)  // next step's gate pre-activations: issued AFTER the publish so the drain never waits for HBM
         gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
     }
@@ -542,15 +497,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
                                                                       int lddy, float* __restrict__ DG, unsigned* cnt,
                                                                       unsigned* err, int spin_limit, unsigned long long* trace,
                                                                       Role R, int chunk) {
-  constexpr bool X44 = ST == 8 && EESEN_BWD_4X4 && CPW <= 8;
+  constexpr bool X44 = ST == 8 && CPW <= 8;
   // X44 at CPW = 8: the B operand is 128 registers per lane (W_m^T is replicated over the two sequence halves), and with them
   // the kernel would need ~200 VGPRs -- two of its waves and one wave of a side-stream GEMM (84 + 64 accumulator registers) no
   // longer fit a SIMD's 512.  The last LDSB chunks' B values live in LDS instead (16 KB per chunk and workgroup) and are read
   // back every step, 4 ds_read_b128 per chunk, under the operand fetch.
-#ifndef EESEN_BWD_LDSB
-#define EESEN_BWD_LDSB 2
-#endif
-  constexpr int LDSB = X44 && CPW == 8 ? EESEN_BWD_LDSB : 0, REGB = X44 ? CPW - LDSB : 1;
+  constexpr int LDSB = X44 && CPW == 8 ? 2 : 0, REGB = X44 ? CPW - LDSB : 1;
   __shared__ __attribute__((aligned(16))) float4 bl[LDSB ? LDSB : 1][4][LDSB ? NW * 64 : 1];   // [chunk][ABID][thread]
   __shared__ float red[NW][16][17];   // X44: [wave][k class (2) x sequence (8)][unit]
   __shared__ int s_go;
@@ -563,14 +515,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
   const int s_end = L.s_begin + (L.s_count ? L.s_count : S);   // sequence window of this launch
   unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
   const unsigned nblk = R.nblk;
-
-  // L2-local hand-off (see xcd_census): decided once per launch, identically by every workgroup
-  if (tid == 0) s_go = R.census ? xcd_census(cnt + (size_t)R.ndir * R.nz * kShards * kShardStride, gridDim.x, err, spin_limit) : 0;
-  __syncthreads();
-  const int local = s_go;
-  if (local < 0) return;
-  if (trace && tid == 0 && blockIdx.x == 0) trace[639] = (unsigned long long)local;
-  __syncthreads();
 
   const int li = lane & 15, kq = lane >> 4;
   const int sa = s0 + li, ub = u0 + li;
@@ -606,7 +550,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       const int k0 = (wave + c * NW) * 32;
-      if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {  // k order of the full-line operand fetch below: j < 4 -> k0 + 4kq + j, j >= 4 -> k0 + 16 + 4kq + (j - 4)
+      if constexpr (ST == 8) {  // k order of the full-line operand fetch below: j < 4 -> k0 + 4kq + j, j >= 4 -> k0 + 16 + 4kq + (j - 4)
         float lo[8], hi[8];
         ld8_plain(Br, k0 + kq * 4, K4, ub < H, lo);       // only lo[0..3] / hi[0..3] are used
         ld8_plain(Br, k0 + 16 + kq * 4, K4, ub < H, hi);
@@ -661,7 +605,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
     EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
-        const bool go = EESEN_NO_SYNC ? true : wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
         if (lane == 0) s_go = go ? 1 : 0;
       }
       __syncthreads();
@@ -675,14 +619,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         // FOUR chunks of operands in flight (16 registers): chunk c + 4 is requested into chunk c's registers as soon as its 16
         // MFMAs have been issued -- with all eight in flight the kernel needs 222 VGPRs, and two of its waves plus one wave of a
         // side-stream GEMM (88) no longer fit a SIMD's 512
-#ifndef EESEN_BWD_INF
-#define EESEN_BWD_INF 4
-#endif
-        constexpr int INF = CPW < EESEN_BWD_INF ? CPW : EESEN_BWD_INF;
+        constexpr int INF = CPW < 4 ? CPW : 4;
         auto fetch = [&](int c) {
           const int k = (wave + c * NW) * 32 + (ks4 * 4 + cb4) * 4;
           return __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow4 + (unsigned)k * 4u : 0x80000000u, 0,
-                                                       EESEN_SC1_LOADS ? kSc1 : 0);
+                                                       0);
         };
         f32x4 a4[INF];
 #pragma unroll
@@ -725,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         // D of block (rb, ks, cb): vgpr i, lane x -> out[sequence rb*4 + i][unit cb*4 + x], partial sum of k class ks
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc0[i] = ac[0][i] + ac[1][i];
-      } else if constexpr (ST == 8 && EESEN_BWD_FULL_LINES) {
+      } else if constexpr (ST == 8) {
         // Full-line fetch.  Only MFMA rows 0-7 carry sequences, so the lanes of rows 8-15 would idle.  Instead all 64 lanes
         // load: lane (li, kq) reads 16 bytes of sequence li & 7 at segment (li >> 3) * 4 + kq of the 128-byte chunk -- one
         // request per line and ONE load instruction per chunk instead of two half-empty ones that each touch every line (the
@@ -740,7 +681,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
         for (int c = 0; c < CPW; ++c) {
           const int k = (wave + c * NW) * 32 + seg * 4;
           a4[c] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow8 + (unsigned)k * 4u : 0x80000000u, 0,
-                                                        EESEN_SC1_LOADS ? kSc1 : 0);
+                                                        0);
         }
         __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
 #pragma unroll
@@ -809,19 +750,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
       if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
       const f32x4 out = {dg, di, df, dob};
       const unsigned ooff = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
-      if (local) __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, 0);  // stays in this XCD's L2, where all readers are
-      else __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
+      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, ooff, 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
     EESEN_STAMP(3);
     if (step + 1 < T) {
-      if (!EESEN_NO_SYNC && tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       EESEN_STAMP(4);
-      if (!EESEN_NO_SYNC && tid == 0) {
-        unsigned* c = my_cnt + (bx & (kShards - 1)) * kShardStride;
-        if (local) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // executes in the XCD's L2
-        else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (e_ok) {  // next step's operands, issued after the publish
         const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
@@ -1183,20 +1121,14 @@ bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE la
   return (long)grid.x * grid.y * grid.z <= cap;
 }
 
+// The persistent grids are launched as ORDINARY kernels: hipLaunchCooperativeKernel costs ~40 us more per launch (its dedicated
+// queue; 0.3 ms per cfg2 step over eight launches, measured) and guarantees nothing that fits() has not checked already -- the
+// runtime does not gang-schedule a cooperative grid either (the side-stream GEMMs co-run with it), it only refuses grids above the
+// occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at once
+// are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp).
 template <class K, class... Args>
 void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) {
-  // Ordinary launch by default: hipLaunchCooperativeKernel (EESEN_COOP_LAUNCH=1) costs ~40 us more per launch (its dedicated
-  // queue), 0.3 ms per cfg2 step over eight launches, and guarantees nothing that fits() has not checked already -- the runtime
-  // does not gang-schedule a cooperative grid either (the side-stream GEMMs co-run with it), it only refuses grids above the
-  // occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at
-  // once are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp), exactly as before.
-  static const bool coop = getenv("EESEN_COOP_LAUNCH") && atoi(getenv("EESEN_COOP_LAUNCH")) != 0;
-  if (!coop) {
-    hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
-    return;
-  }
-  void* argv[] = {(void*)&args...};
-  EESEN_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, 0, st));
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
 }
 
 }  // namespace
@@ -1228,16 +1160,6 @@ float handoff_flight_ns() {
   return cache[dev];
 }
 
-static int xcd_map() {  // read per launch (a few ns): tests flip these between nets of one process
-  const char* e = getenv("EESEN_XCD_MAP");
-  return e ? atoi(e) : 1;
-}
-
-static int l2_local() {  // measured neutral (55.1 vs 55.0 ms/step): opt-in
-  const char* e = getenv("EESEN_L2_LOCAL");
-  return e ? atoi(e) : 0;
-}
-
 // ctl: [0 .. 2*ndir*nz) arrival counters (fwd then bwd use disjoint halves via `ctl_off`), last word = error flag
 // Forward tile (sequences x hidden units per workgroup), chosen so that every CU gets ONE workgroup where the shape allows:
 //   32 x 4  <MT=2, NT=1>: the decomposition of lstm_fwd_step_kernel (any H)
@@ -1246,13 +1168,11 @@ static int l2_local() {  // measured neutral (55.1 vs 55.0 ms/step): opt-in
 //                         (256 KB at H = 1024) live in the registers of one workgroup
 struct FwdTile { int mt, nt; };
 static FwdTile fwd_tile(const LstmLayerDev& L) {
-  static const int force_tile = getenv("EESEN_FWD_SEQ_TILE") ? atoi(getenv("EESEN_FWD_SEQ_TILE")) : 0;
   const int need = ((L.H + 31) / 32 + NW - 1) / NW;
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  if (force_tile == 32) return {2, 1};
-  const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || force_tile == 16);
+  const bool t16_ok = L.H % 8 == 0 && L.S > 16;
   if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > ncu)) return {1, 4};
   if (t16_ok && need <= 2) return {1, 2};
   return {2, 1};
@@ -1295,9 +1215,8 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
   if (nwin == 0) return false;
   if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
   // Two windows of the wide tile: one launch that time-multiplexes the two sequence tiles of every workgroup instead
-  // (lstm_fwd_persistent_mux_kernel).  EESEN_FWD_MUX=0: the two launches, one after the other.
-  static const bool mux_env = !(getenv("EESEN_FWD_MUX") && atoi(getenv("EESEN_FWD_MUX")) == 0);
-  if (mux_env && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
+  // (lstm_fwd_persistent_mux_kernel).  LstmLayerDev::fwd_mux = 0 (EESEN_FWD_MUX=0): the two launches, one after the other.
+  if (L0.fwd_mux && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
     const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
     const bool xchg = L0.X != nullptr && (size_t)L0.T * L0.ndir * nz * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31);
     dim3 grid(L0.H / 16, L0.ndir, ng), block(NW * 64);
@@ -1306,7 +1225,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
       LstmLayerDev L = L0;
       L.s_begin = 0; L.s_count = 0;
       const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * nz * kShards * kShardStride, st));
       if (xchg) coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, true>, grid1, block, L, cnt, err, spin_limit, role);
       else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
@@ -1319,7 +1238,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
     L.s_begin = w * L.s_count;
     dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.s_count, 16 * ft.mt)), block(NW * 64);
     const dim3 grid1(grid.x * grid.y * grid.z);
-    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
     if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
     EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
     if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
@@ -1373,10 +1292,9 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
 
 // Floats of partial-sum exchange space the K-split backward kernel needs for this layer shape (16 KB per step, (direction,
 // 16-sequence tile) group and 64-unit block: 16 blocks of 16 x 16); 0 = the kernel does not apply (narrow layers take the 4 x 32
-// tile, dropout layers and odd shapes the generic one).  EESEN_BWD_KSPLIT=0 switches it off.
+// tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
-  const char* e = getenv("EESEN_BWD_KSPLIT");
-  if (e && atoi(e) == 0) return 0;
+  if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
@@ -1399,9 +1317,8 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  static const int force_st = getenv("EESEN_BWD_SEQ_TILE") ? atoi(getenv("EESEN_BWD_SEQ_TILE")) : 0;
   const long blocks16 = (long)cdiv(L0.H, 16) * L0.ndir * cdiv(L0.S, 16);
-  const int stile = force_st ? force_st : (2 * blocks16 <= ncu && L0.S > 8 ? 8 : 16);
+  const int stile = 2 * blocks16 <= ncu && L0.S > 8 ? 8 : 16;
   // 32-bit buffer offsets: the kernel re-bases its DG resource every `chunk` steps; a chunk touches chunk + 1 row blocks
   const size_t blk_bytes = (size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float);
   const long max_blocks = (long)((((size_t)1 << 31) - 1) / blk_bytes);
@@ -1409,8 +1326,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   int chunk = (int)std::min<long>(L0.T, max_blocks - 1);
   if (chunk < L0.T) { int p2 = 1; while (p2 * 2 <= chunk) p2 *= 2; chunk = p2; }   // a power of two keeps `step % chunk` cheap
   // The 4-sequence x 32-unit tile (lstm_bwd_persistent_q4_kernel): wherever the 8-sequence tile would be taken and the shape allows
-  const bool q4_env = !(getenv("EESEN_BWD_Q4") && atoi(getenv("EESEN_BWD_Q4")) == 0);   // read per call: tests flip it
-  if (q4_env && stile == 8 && !L0.drop_mode && L0.H % 128 == 0 && L0.H / 64 <= 8 && L0.S % 4 == 0 && chunk >= L0.T && !l2_local()) {   // (the L2-local experiment lives in the 8-sequence kernel)
+  if (L0.bwd_q4 && stile == 8 && !L0.drop_mode && L0.H % 128 == 0 && L0.H / 64 <= 8 && L0.S % 4 == 0 && chunk >= L0.T) {
     const int cpw = L0.H / 64;   // 2, 4 or 8
     dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
@@ -1422,7 +1338,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       LstmLayerDev L = L0;
       L.s_begin = 0; L.s_count = 0;
       const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
       if (cpw == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
       else if (cpw == 4) coop_launch(st, lstm_bwd_persistent_q4_kernel<4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
@@ -1453,7 +1369,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         L.s_begin = w * L.s_count;
         dim3 grid(L.H / 64 * 4, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
         const dim3 grid1(grid.x * grid.y * grid.z);
-        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), 0};
+        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
         const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L.H / 64) * kShardStride;
         EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
         unsigned* cnt2 = cnt + c1;
@@ -1470,10 +1386,9 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     const int Sw = L.s_count ? L.s_count : L.S;
     dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(Sw, stile)), block(NW * 64);
     const dim3 grid1(grid.x * grid.y * grid.z);
-    const int ngroups = (int)(grid.y * grid.z);
-    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, xcd_map(), xcd_map() && l2_local() && ngroups == 8 && grid1.x < 65536};
-    if ((size_t)grid.y * grid.z * kShards * kShardStride + 32 > (size_t)kCtlHalf) return false;
-    if (!dry) EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride + 32), st));  // + census word
+    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L.xcd_map};
+    if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
+    if (!dry) EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride), st));
 #define EESEN_BP2(CPW, STV)                                                                                       \
   do {                                                                                                            \
     if (L.drop_mode) {                                                                                            \

@@ -129,36 +129,24 @@ Net::Net(int dev, void* stream) : device(dev) {
   // recurrence kernels of the main stream are dispatched first
   int lo = 0, hi = 0;
   EESEN_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  const int side_cus = getenv("EESEN_SIDE_CUS") ? atoi(getenv("EESEN_SIDE_CUS")) : 0;
-  if (side_cus > 0) {  // confine the side stream to a subset of the CUs (bit i of the mask = CU i)
-    hipDeviceProp_t prop;
-    EESEN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    const int ncu = prop.multiProcessorCount;
-    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-    const int stride = getenv("EESEN_SIDE_STRIDE") ? atoi(getenv("EESEN_SIDE_STRIDE")) : 1;
-    for (int k = 0, c = 0; k < side_cus && c < ncu; ++k, c += stride) mask[c / 32] |= 1u << (c % 32);
-    EESEN_HIP_CHECK(hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()));
-  } else {
-    EESEN_HIP_CHECK(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
-  }
+  EESEN_HIP_CHECK(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_rec, hipEventDisableTiming));
   for (auto& e : ev_grad) EESEN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_reset, hipEventDisableTiming));
   EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_gate_done, hipEventDisableTiming));
-  // The next layer's input GEMM runs UNDER this layer's forward recurrence, gated tile by tile on the recurrence's
-  // arrival counters (gemm_f32_nt_gated).  Measured on MI355X (cfg2), bit-identical results: with the 32x4 forward tiles
-  // it lost (74.7 vs 73.0 ms/step: the hand-off chain slowed more than the 7 ms of GEMM it hid; wave priority did not
-  // help); with the 16x8 tiles and capped side-stream occupancy it wins: 62.0 -> 60.0 ms/step.
-  // With the bf16-split GEMM (1.7x faster) the gated GEMM no longer pays: the spinning tiles cost the recurrence more than the
-  // 1.5 ms of GEMM per layer they hide (measured, cfg2: 50.5 ms/step gated, 48.9 not).  Default: gate only in f32 mode.
-  gate_fwd = getenv("EESEN_GATE_FWD") ? atoi(getenv("EESEN_GATE_FWD")) != 0 : gemm_mode() == 0;
-  if (getenv("EESEN_PERSISTENT")) persistent = atoi(getenv("EESEN_PERSISTENT"));
-  // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on MI355X, cfg2: with the
-  // one-launch-per-step recurrence it is neutral (105.1 vs 104.9 ms/step: the step kernels slow down by what the
-  // GEMMs gain); with the persistent recurrence, whose workgroups mostly wait on hand-offs, it pays: 78.3 -> 73.0 ms.
-  overlap = getenv("EESEN_OVERLAP") ? atoi(getenv("EESEN_OVERLAP")) != 0 : persistent != 0;
-  if (getenv("EESEN_SPIN_LIMIT")) spin_limit = atoi(getenv("EESEN_SPIN_LIMIT"));
-  if (getenv("EESEN_TRACE") && atoi(getenv("EESEN_TRACE"))) {
+  tn = Tuning::from_env();   // every switch: tuning.h
+  persistent = tn.persistent;
+  // The next layer's input GEMM can run UNDER this layer's forward recurrence, gated tile by tile on the recurrence's arrival
+  // counters (gemm_f32_nt_gated, bit-identical results).  Measured on cfg2: with the f32-MFMA GEMMs it pays (62.0 -> 60.0 ms per
+  // step); with the 1.7x faster bf16-split GEMMs the spinning tiles cost the recurrence more than the 1.5 ms of GEMM per layer
+  // they hide (50.5 ms gated, 48.9 not).  Default: gate only in f32 mode.
+  gate_fwd = tn.gate_fwd >= 0 ? tn.gate_fwd != 0 : gemm_mode() == 0;
+  // Weight-gradient GEMMs under the next layer's recurrence (side stream).  Measured on cfg2: with the one-launch-per-step
+  // recurrence it is neutral (105.1 vs 104.9 ms per step); with the persistent recurrence, whose workgroups mostly wait on
+  // hand-offs, it pays (78.3 -> 73.0 ms at the time).
+  overlap = tn.overlap >= 0 ? tn.overlap != 0 : persistent != 0;
+  spin_limit = tn.spin_limit;
+  if (tn.trace) {
     trace.reserve(1280);
     EESEN_HIP_CHECK(hipMemset(trace.p, 0, 1280 * sizeof(unsigned long long)));
   }
@@ -176,11 +164,11 @@ Net::Net(int dev, void* stream) : device(dev) {
     flight_ns = handoff_flight_ns();
     auto ticks = [&](float factor) { return std::min(300, std::max(0, (int)std::lround(factor * flight_ns / 10.f))); };
     delay_fwd = ticks(kFactorFwd); delay_bwd = ticks(kFactorBwd); delay_sib = ticks(kFactorSib);
-    if (const char* e = getenv("EESEN_POLL_NS")) {
+    if (const char* e = tn.poll_ns) {
       int a = -1, b2 = -1, c = -1;
       if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3) { delay_fwd = a / 10; delay_bwd = b2 / 10; delay_sib = c / 10; }
     }
-    if (getenv("EESEN_PRINT_FLIGHT"))
+    if (tn.print_flight)
       fprintf(stderr, "eesen_hip: increment flight %.0f ns; first-poll delays forward %d0, backward %d0, sibling %d0 ns\n", flight_ns, delay_fwd,
               delay_bwd, delay_sib);
   }
@@ -204,7 +192,6 @@ Net::~Net() {
         }
         if (n) fprintf(stderr, "EESEN_TRACE %s: wait %.0f | A-load+MFMA+reduce %.0f | epilogue %.0f | drain+barrier %.0f | publish->next %.0f ticks/step (%d steps)\n",
                        pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
-        if (pass) fprintf(stderr, "EESEN_TRACE bwd hand-off: %s\n", h[640 + 639] ? "L2-local (XCD census passed)" : "write-through");
       }
   }
   if (lens_pin) (void)hipHostFree(lens_pin);
@@ -345,7 +332,7 @@ void Net::finalize() {
   // Side-stream gradient GEMMs pay only while the backward recurrence leaves register room for a GEMM workgroup next to
   // it; the 16x16 tile of wide layers (H > 512: 256 VGPRs x 2 waves per SIMD) does not, and a GEMM that started before the
   // cooperative launch then only delays it (measured on cfg4: 141 ms overlapped, 138 ms not).  EESEN_OVERLAP overrides.
-  if (!getenv("EESEN_OVERLAP"))
+  if (tn.overlap < 0)
     for (const Layer& L : layers)
       if (L.is_lstm() && L.H > 512) overlap = false;
   finalized = true;
@@ -481,6 +468,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.lens = net.lens_d.p;
   d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
   d.drop_mode = L.cur_drop_mode;
+  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit;
   return d;
 }
 
@@ -634,10 +622,8 @@ void Net::forward_pass() {
       const size_t state = (size_t)(T + 2) * S * ldY;
       L.C.reserve(state);
       L.Y.reserve(state);
-      {  // exchange copy of Y for the persistent forward kernel (EESEN_FWD_XCHG=0: off)
-        static const bool xchg = !(getenv("EESEN_FWD_XCHG") && atoi(getenv("EESEN_FWD_XCHG")) == 0);
-        if (xchg && persistent && H % 32 == 0) L.X.reserve((size_t)T * nd * ((S + 15) / 16) * (size_t)(H / 32) * 512);
-      }
+      // exchange copy of Y in the persistent forward kernel's fetch order (LstmLayerDev::X)
+      if (persistent && H % 32 == 0) L.X.reserve((size_t)T * nd * ((S + 15) / 16) * (size_t)(H / 32) * 512);
       // boundary row blocks t = -1 and t = T (bilstm-parallel-layer.h:393-394)
       const size_t blk = (size_t)S * ldY * sizeof(float);
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p, 0, blk, st));
@@ -841,9 +827,8 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
                  nullptr, nullptr, 0);
         timer.end(st, ti_);
         // The input-gradient GEMM is on the critical path (the next-lower recurrence waits for it), the weight-gradient GEMMs
-        // are not: they start behind it instead of beside it (EESEN_SIDE_AFTER_INDIFF=0: beside it, as before)
-        static const bool side_after = !(getenv("EESEN_SIDE_AFTER_INDIFF") && atoi(getenv("EESEN_SIDE_AFTER_INDIFF")) == 0);
-        if (side_after) EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
+        // are not: they start behind it instead of beside it (measured: step 44.15 -> 42.97 ms)
+        EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
       }
       // Everything that only feeds the parameter gradients leaves the critical path: it runs on the side stream,
       // under the next layer's (latency-bound, mostly idle-chip) recurrence.
@@ -854,7 +839,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       // with one per CU the side stream itself became the critical path (12 ms of gradient GEMMs per layer against 9 ms of
       // recurrence + input-gradient GEMM); before the recurrence kernels overlapped fetch and MFMA the ranking was the reverse.
       // (with the bf16-split GEMM: one per CU -- 47.6 vs 48.9 ms/step; the gradient GEMMs are short enough not to become the critical path)
-      const int side_lds_env = (getenv("EESEN_SIDE_LDS_KB") ? atoi(getenv("EESEN_SIDE_LDS_KB")) : (gemm_mode() == 1 ? 48 : 32)) * 1024;
+      const int side_lds_env = (tn.side_lds_kb >= 0 ? tn.side_lds_kb : (gemm_mode() == 1 ? 48 : 32)) * 1024;
       bool lstm_below = false;   // the cap protects the NEXT-LOWER recurrence's cooperative launch: the lowest LSTM layer's
       for (int lj = 0; lj < li; ++lj) lstm_below |= layers[lj].is_lstm();   // gradient GEMMs have the chip to themselves
       const int side_lds = overlap && lstm_below ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "tuning.h"
 
 namespace eesen {
 
@@ -109,7 +110,8 @@ struct Net {
   bool gate_fwd = true;
   bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1): forward GEMMs on bf16-rounded operands (BASELINE config 4)
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
-  int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels
+  Tuning tn;                  // every run-time switch, read from the environment when the Net is created (tuning.h)
+  int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels; also cleared by a recovery
   int info_fwd_persistent = 0, info_bwd_persistent = 0, info_lstm_layers = 0;   // of the last Propagate / Backpropagate (tests)
   int spin_limit = 400000;
   float flight_ns = 0.f;      // measured increment flight between two CUs of this device

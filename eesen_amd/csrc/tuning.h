@@ -1,0 +1,71 @@
+// tuning.h -- EVERY run-time switch of libeesen_hip.so, in one place.
+//
+// The product path has no tuning to do: all defaults below are what bench.py measures.  The switches exist for three reasons --
+// (i) fallbacks a deployment may need, (ii) A/B arms of the parity tests (a kernel against its slower twin), (iii) diagnostics --
+// and are read from the environment ONCE PER NET, when it is created (tests create a fresh Net per arm).  Everything else that
+// rounds 1 and 2 carried as experiment knobs (CU-masked side streams, cooperative launches, poll-wave / sleep / shard-count
+// variants, the L2-local hand-off, synthetic interference GEMMs, timing probes, ...) has been measured, written up in DESIGN.md
+// section 9 and REMOVED from the code.
+//
+//   variable                default  meaning
+//   ---- fallbacks ---------------------------------------------------------------------------------------------------------
+//   EESEN_PERSISTENT        1        0: one launch per recurrence step (lstm.hip) instead of one persistent launch per layer pass
+//   EESEN_OVERLAP           auto     weight-gradient GEMMs on a side stream under the next recurrence (auto: on with persistent
+//                                    kernels)
+//   EESEN_SPIN_LIMIT        400000   bound of the in-kernel hand-off spins (x10 with a communicator attached); 0 in tests forces a time-out
+//   EESEN_GEMM_MODE         split    f32: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain) instead of the 3-way bf16 split
+//   EESEN_HOST_FEATURE_PIPES unset   (trainers) run recognised feature pipes as host processes instead of on the device
+//   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
+//   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
+//   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
+//   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
+//   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
+//   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
+//   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 split / 32 f32)
+//   ---- diagnostics -------------------------------------------------------------------------------------------------------
+//   EESEN_TRACE             0        1: in-kernel s_memtime timeline of workgroup 0, printed when the Net is destroyed
+//   EESEN_PRINT_FLIGHT      unset    print the measured increment flight and the derived first-poll delays
+//   EESEN_POLL_NS           unset    "fwd,bwd,sibling": first-poll delays in ns instead of the derived ones
+//   ---- data-parallel exchange (comm.cpp) ----------------------------------------------------------------------------------
+//   EESEN_RCCL_LIBRARY      librccl.so.1   library to dlopen for the nccl* entry points (tests: the stand-in)
+//   EESEN_COMM_TIMEOUT_S    600      watchdog: seconds after which an unfinished collective aborts the communicator
+//   EESEN_COMM_PORT         MASTER_PORT+17  rendezvous port of the hosts that create the communicator from the environment
+#pragma once
+#include <cstdlib>
+
+namespace eesen {
+
+struct Tuning {
+  int persistent = 1;
+  int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
+  int spin_limit = 400000;
+  bool spin_limit_set = false;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, xcd_map = 1;
+  int trace = 0;
+  bool print_flight = false;
+  const char* poll_ns = nullptr;
+
+  static Tuning from_env() {
+    Tuning t;
+    auto num = [](const char* name, int dflt) {
+      const char* e = getenv(name);
+      return e && *e ? atoi(e) : dflt;
+    };
+    t.persistent = num("EESEN_PERSISTENT", 1);
+    t.overlap = num("EESEN_OVERLAP", -1);
+    t.gate_fwd = num("EESEN_GATE_FWD", -1);
+    t.side_lds_kb = num("EESEN_SIDE_LDS_KB", -1);
+    t.spin_limit_set = getenv("EESEN_SPIN_LIMIT") != nullptr;
+    t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
+    t.bwd_q4 = num("EESEN_BWD_Q4", 1);
+    t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
+    t.fwd_mux = num("EESEN_FWD_MUX", 1);
+    t.xcd_map = num("EESEN_XCD_MAP", 1);
+    t.trace = num("EESEN_TRACE", 0);
+    t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;
+    t.poll_ns = getenv("EESEN_POLL_NS");
+    return t;
+  }
+};
+
+}  // namespace eesen

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build a variant of libeesen_hip.so with extra -D flags on selected sources, for A/B runs on the GPU box.
 
-  python scripts/build_variant.py NAME "-DEESEN_POLL_SLEEP=4" [source.hip ...]   (default source: lstm_persistent.hip)
+  python scripts/build_variant.py NAME "-DSOME_EXPERIMENT=1" [source.hip ...]   (default source: lstm_persistent.hip)
   EESEN_HIP_LIBRARY=eesen_amd/lib/variants/libeesen_hip_NAME.so python bench.py ...
 
 Objects of the other sources are taken from the regular build (python -m eesen_amd.build).

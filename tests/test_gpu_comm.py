@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from eesen_amd import synth
+from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -22,6 +23,13 @@ def _steps(net, ctc, batch, n=3):
         net.Update()
         out.append((g, net.GetParams()))
     return out
+
+
+def _steps_reference(layers, batch, n):
+    """n plain steps without any exchange."""
+    from eesen_amd.api import Net, Ctc
+    net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+    return _steps(net, ctc, batch, n)[-1][1]
 
 
 @pytest.fixture(scope="module")
@@ -66,13 +74,26 @@ def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name,
     # reference calls Update per layer (net.cc:98-104)
     trainable = [i for i, L in enumerate(layers) if L["params"]]
     assert nb.BucketOrder() == trainable[::-1]
-    # a rank without a minibatch: zero gradient through the same collectives, momentum still decays the step
+    # a rank without a minibatch: zero gradient through the same collectives.  At world size 1 that is a step in which NO rank
+    # was live -- the closing round of the zero-gradient protocol -- which must not move the model (the liveness word that
+    # rides with the top bucket is 0, the update kernels read it on the device); with a live peer the step would be applied
+    # (tests/test_gpu_multirank.py::test_uneven_shards_zero_gradient_protocol)
     before = nb.GetParams()
     nb.BackpropagateZero()
     assert nb.BucketOrder() == trainable[::-1]
     assert not np.any(nb.GetGrads())
     nb.Update()
-    assert not np.array_equal(before, nb.GetParams())      # momentum 0.9 carries the previous direction on
+    assert nb.LiveRanks() == 0
+    assert np.array_equal(before, nb.GetParams())
+    # ... and the next real step counts this rank again and carries the momentum on as if the closing round had not happened
+    nb.SetSeqLengths(batch.lens)
+    o = nb.Propagate(batch.feats)
+    from eesen_amd.api import Ctc as _Ctc
+    d = _Ctc().EvalParallel(batch.lens, o, batch.labels)
+    nb.BackpropagateNoUpdate(d)
+    nb.Update()
+    assert nb.LiveRanks() == 1
+    assert rel_err(nb.GetParams(), _steps_reference(layers, batch, 4)) < 1e-6
     nb.SetComm(None)
 
 

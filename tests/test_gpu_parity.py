@@ -377,17 +377,16 @@ def test_adaptive_update_rules(gpu, rule, tmp_path):
         net.SetUpdateAlgorithm("Adam")
 
 
-def test_l2_local_handoff_option(gpu, monkeypatch):
-    """EESEN_L2_LOCAL=1 (opt-in): the backward hand-off stays inside the XCD's L2 when the in-kernel HW_REG_XCC_ID census
-    confirms the placement, and falls back to the write-through protocol otherwise -- either way the numbers are those of
-    the default path, run after run."""
+def test_backward_tiles_agree_and_are_deterministic(gpu, monkeypatch):
+    """The 4-sequence x 32-unit backward tile (default where the shape allows) and the 8-sequence tile it replaced
+    (EESEN_BWD_Q4=0: v_mfma_f32_4x4x1 with CBSZ = 2, part of W_m^T in LDS) on the same inputs: each bit-identical run after
+    run (the in-kernel hand-off leaves no room for a race), and equal to each other up to the summation order."""
     from eesen_amd.api import Net, Ctc, CuMatrix
-    cfg = synth.config("cfg2"); cfg.update(T=40, layers=2)      # S = 32, bidirectional, 8-sequence tiles: 8 groups = 8 XCDs
+    cfg = synth.config("cfg2"); cfg.update(T=40, layers=2)      # S = 32, bidirectional
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
     res = {}
-    monkeypatch.setenv("EESEN_BWD_Q4", "0")      # the census lives in the 8-sequence backward kernel, not in the 4 x 32 tile
     for mode in ("0", "1"):
-        monkeypatch.setenv("EESEN_L2_LOCAL", mode)
+        monkeypatch.setenv("EESEN_BWD_Q4", mode)
         net = Net.from_layers(layers); ctc = Ctc()
         runs = []
         for _ in range(4):
@@ -397,11 +396,12 @@ def test_l2_local_handoff_option(gpu, monkeypatch):
             idf = CuMatrix(batch.T * batch.S, cfg["D"])
             net.BackpropagateNoUpdate(diff, idf)
             runs.append((idf.numpy(), net.GetGrads()))
+        assert net.RecurrenceInfo()["bwd_persistent"] == 2
         res[mode] = runs
     for mode in ("0", "1"):
         for r in res[mode]:
-            assert np.array_equal(r[0], res["0"][0][0]) and np.array_equal(r[1], res["0"][0][1])
-
+            assert np.array_equal(r[0], res[mode][0][0]) and np.array_equal(r[1], res[mode][0][1])
+    assert rel_err(res["1"][0][0], res["0"][0][0]) < 1e-5 and rel_err(res["1"][0][1], res["0"][0][1]) < 1e-5
 
 def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, capfd):
     """A hand-off that cannot complete (here: a spin bound of zero polls) must surface at the next synchronisation point --
