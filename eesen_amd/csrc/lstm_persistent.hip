@@ -1110,6 +1110,198 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K-split backward, TWO sequence tiles per workgroup (time-multiplexed): BASELINE config 5 (S = 64 at H = 1024).
+// 64 sequences need 512 K-split workgroups -- two windows of 32, one launch after the other, 2 x 7.8 us per time step.  Here one
+// launch covers all four tiles: a workgroup keeps its W_m^T slice ONCE and steps two independent chains, tile 2g and 2g + 1 of
+// its direction, alternately and in two phases per time step:
+//     MFMA(A) + partials(A) -> MFMA(B) + partials(B) -> cell(A) + publish(A) -> cell(B) + publish(B)
+// so every wait of a chain falls behind the other chain's work: A's sibling partials were sent a whole MFMA chain (3.4 us) before
+// cell(A) asks for them, A's gate gradients were published a cell phase before the next MFMA(A), B's an MFMA chain before
+// MFMA(B).  Same arithmetic per chain as lstm_bwd_persistent_ksplit_kernel (bit-identical results).
+// ------------------------------------------------------------------------------------------------
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
+                                                                                 float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
+                                                                                 unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk) {
+  constexpr int KU = 4, ST = 16, UW = 64, NT = 4, Q = 2;
+  __shared__ float red[NW][ST][UW + 1];
+  __shared__ float own[Q][ST][17];
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H, KQ = K4 / KU;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bg = R.seq_group(blockIdx.x);
+  const int uu = bx / KU, ku = bx % KU;
+  const int um0 = uu * UW, uc0 = um0 + ku * 16;
+  const int nzall = (S + ST - 1) / ST, ngroups = L.ndir * nzall, nub = H / UW;
+  const unsigned nprod = (unsigned)(H / KU / 16);
+  const int li = lane & 15, kq = lane >> 4;
+  float b[NT][CPW][8];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float* Br = L.WmT + ((size_t)dir * H + um0 + n * 16 + li) * K4 + (size_t)ku * KQ;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, KQ, true, b[n][c]);
+  }
+  const int es = tid >> 4, eu = tid & 15;
+  const int u_e = uc0 + eu;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  if (tid < ST * 16) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+  }
+  const size_t gcol = (size_t)dir * K4 + u_e * 4;
+  const size_t ycol = (size_t)dir * H + u_e;
+  // per chain
+  int zt[Q], s0[Q], s_e[Q], len[Q], g[Q];
+  bool live[Q], e_ok[Q];
+  float dcf[Q], dn_i[Q], dn_f[Q], dy[Q], c_t[Q], c_p[Q], dm_in[Q];
+  float4 gt[Q];
+  unsigned *wait_cnt[Q], *pub_cnt[Q], *sib_cnt[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    zt[q] = bg * Q + q;
+    live[q] = zt[q] < nzall;
+    s0[q] = zt[q] * ST;
+    s_e[q] = s0[q] + es;
+    e_ok[q] = live[q] && tid < ST * 16 && s_e[q] < S;
+    g[q] = dir * nzall + (live[q] ? zt[q] : 0);
+    wait_cnt[q] = cnt + (size_t)(g[q] * KU + ku) * kShards * kShardStride;
+    pub_cnt[q] = cnt + (size_t)(g[q] * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
+    sib_cnt[q] = cnt2 + (size_t)(g[q] * nub + uu) * kShardStride;
+    len[q] = e_ok[q] ? L.lens[s_e[q]] : 0;
+    dcf[q] = dn_i[q] = dn_f[q] = dy[q] = c_t[q] = c_p[q] = dm_in[q] = 0.f;
+    gt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
+    if (e_ok[q]) {
+      gt[q] = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e[q]) * ldG + gcol);
+      dy[q] = dY[(size_t)(t0 * S + s_e[q]) * lddy + ycol];
+      c_t[q] = L.C[(size_t)((t0 + 1) * S + s_e[q]) * ldY + ycol];
+      c_p[q] = L.C[(size_t)((tp0 + 1) * S + s_e[q]) * ldY + ycol];
+    }
+  }
+  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
+  int tbS = 0;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    if (chunk < T && step % chunk == 0) {
+      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
+      tbS = tb * S;
+      rDG = make_rsrc(DG + (size_t)tbS * ldG);
+    }
+    // ---- phase 1, both chains: partial sums of this K quarter from the chain's DG_next
+    if (step > 0) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (!live[q]) continue;   // odd number of tiles: the last workgroup group steps one chain only (uniform per workgroup)
+        if (wave == EESEN_POLL_WAVE) {
+          const bool go = wait_counters(wait_cnt[q], nprod, (unsigned)step, err, spin_limit, lane, 0);
+          if (lane == 0) s_go = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_go) return;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int sa = s0[q] + li;
+        const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
+        float a[CPW][8];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const int k = (wave + c * NW) * 32 + kq * 8;
+          ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < S, a[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
+        __syncthreads();
+        float* px = PX + ((size_t)((size_t)step * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int o = tid + h * (NW * 64), sq = o >> 6, uc = o & 63, dst = uc >> 4;
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
+          if (dst == ku) own[q][sq][uc & 15] = v;
+          else __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // (also fences `red` for the other chain)
+        if (tid == 0) __hip_atomic_fetch_add(sib_cnt[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- phase 2, both chains: the siblings' partials, the cell update, publish
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (!live[q]) continue;
+      float dm = dy[q];
+      if (step > 0) {
+        if (wave == EESEN_POLL_WAVE) {
+          bool go = true;
+          if (lane == 0) {
+            go = false;
+            for (int spins = 0; spins < spin_limit; ++spins) {
+              if (__hip_atomic_load(sib_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
+              if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
+            }
+            if (!go) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_go = go ? 1 : 0;
+          }
+        }
+        __syncthreads();
+        if (!s_go) return;
+        if (e_ok[q]) {
+          const float* px = PX + ((size_t)((size_t)step * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
+          dm += own[q][es][eu];
+#pragma unroll
+          for (int src = 0; src < KU; ++src)
+            if (src != ku) dm += px[(size_t)(ku * KU + src) * 256 + es * 16 + eu];
+        }
+      }
+      if (e_ok[q]) {
+        const float g_ = gt[q].x, i = gt[q].y, f = gt[q].z, o = gt[q].w;
+        const float h = tanhf_(c_t[q]);
+        const float dh = (1.f - h * h) * (dm * o);
+        float dob = o * (1.f - o) * (dm * h);
+        const float dc = dh + dcf[q] + dn_i[q] * p_i + dn_f[q] * p_f + dob * p_o;
+        float df = f * (1.f - f) * (dc * c_p[q]);
+        float di = i * (1.f - i) * (dc * g_);
+        float dg = (1.f - g_ * g_) * (dc * i);
+        float carry = dc * f;
+        if (t >= len[q]) { dg = di = df = dob = 0.f; carry = 0.f; }
+        const f32x4 out = {dg, di, df, dob};
+        __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S - tbS + s_e[q]) * ldG + gcol) * 4), 0, kSc1);
+        dcf[q] = carry; dn_i[q] = di; dn_f[q] = df;
+      }
+      if (step + 1 < T) {
+        if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(pub_cnt[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok[q]) {
+          const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+          gt[q] = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e[q]) * ldG + gcol);
+          dy[q] = dY[(size_t)(t2 * S + s_e[q]) * lddy + ycol];
+          c_t[q] = c_p[q];
+          c_p[q] = L.C[(size_t)((tp2 + 1) * S + s_e[q]) * ldY + ycol];
+        }
+      }
+    }
+  }
+}
+
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
@@ -1362,6 +1554,28 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       }
     };
     const int nwin = pick_windows(L0.S, 16, kfits);
+    // Two windows: one launch that time-multiplexes two sequence tiles per workgroup instead (lstm_bwd_persistent_ksplit_mux_kernel;
+    // LstmLayerDev::bwd_mux = 0 / EESEN_BWD_MUX=0: the two launches, one after the other)
+    if (nwin == 2 && L0.bwd_mux && cpw >= 2 && cpw <= 4) {
+      const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
+      dim3 grid(L0.H / 64 * 4, L0.ndir, ng), block(NW * 64);
+      const size_t c1 = (size_t)L0.ndir * nz * 4 * kShards * kShardStride, c2 = (size_t)L0.ndir * nz * (L0.H / 64) * kShardStride;
+      bool fit = c1 + c2 <= (size_t)kCtlHalf;
+      if (fit) fit = cpw == 4 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<4>, grid, NW * 64)
+                   : cpw == 3 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<3>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_mux_kernel<2>, grid, NW * 64);
+      if (fit) {
+        LstmLayerDev L = L0;
+        L.s_begin = 0; L.s_count = 0;
+        const dim3 grid1(grid.x * grid.y * grid.z);
+        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
+        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
+        unsigned* cnt2 = cnt + c1;
+        if (cpw == 4) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
+        else if (cpw == 3) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
+        else coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
+        return true;
+      }
+    }
     if (nwin > 0 && (nwin == 1 || ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
       for (int w = 0; w < nwin; ++w) {
         LstmLayerDev L = L0;
