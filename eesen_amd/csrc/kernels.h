@@ -27,7 +27,7 @@ void set_gemm_mode(int mode);
 #define EESEN_SHARDS 8
 #endif
 constexpr int kShards = EESEN_SHARDS, kShardStride = 32;  // words
-constexpr int kCtlHalf = 1024 * kShards;                  // words of counters per pass (forward / backward): 32 groups
+constexpr int kCtlHalf = 2048 * kShards;                  // words of counters per pass (forward / backward): 64 groups
 
 // "Gated" input->gates GEMM: C = A * B^T + bias where the rows of A are the time-major output [T*S x K] of an LSTM layer
 // whose persistent forward kernel is STILL RUNNING on another stream.  A tile of rows waits until the arrival counters
