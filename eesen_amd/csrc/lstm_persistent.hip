@@ -946,10 +946,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
 template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * NW)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                              float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
-                                                                             unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk) {
+                                                                             unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
   constexpr int KU = 4, ST = 16, UW = 64, NT = 4;
-  __shared__ float red[NW][ST][UW + 1];
-  __shared__ float own[ST][17];
+  __shared__ float red[NW][ST][48 + 1];    // partial sums of the three sibling blocks, per wave
+  __shared__ float red2[NW][ST][16 + 1];   // ... of the own block
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -968,11 +968,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 
   const int li = lane & 15, kq = lane >> 4;
   const int sa = s0 + li;
-  // this wave's part of W_m^T: 64 unit rows x its CPW chunks of the K quarter, resident for the whole layer pass
+  // this wave's part of W_m^T: 64 unit rows x its CPW chunks of the K quarter, resident for the whole layer pass.  Local tile
+  // n = 0..2 are the three SIBLINGS' 16-unit blocks (in order of their ku), n = 3 is this workgroup's own block: the siblings'
+  // partial sums are produced, sent and on their way while the own block's quarter of the MFMA chain still runs.
   float b[NT][CPW][8];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const float* Br = L.WmT + ((size_t)dir * H + um0 + n * 16 + li) * K4 + (size_t)ku * KQ;
+    const int ut = n == 3 ? ku : n + (n >= ku ? 1 : 0);
+    const float* Br = L.WmT + ((size_t)dir * H + um0 + ut * 16 + li) * K4 + (size_t)ku * KQ;
 #pragma unroll
     for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, KQ, true, b[n][c]);
   }
@@ -1012,6 +1015,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       rDG = make_rsrc(DG + (size_t)tbS * ldG);
     }
     float dm_in = 0.f;
+    EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       }
       __syncthreads();
       if (!s_go) return;
+      EESEN_STAMP(1);
       f32x4 acc[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1030,37 +1035,47 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
         ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+      // pass 1: the siblings' three blocks (three accumulators interleaved)
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
       // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int n = 0; n < 3; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
       __syncthreads();
-      // partial sums of this K quarter for the 64 units: the own 16 stay in LDS, the other three blocks go to their owners
       float* px = PX + ((size_t)((size_t)step * ngroups + g) * nub + uu) * (KU * KU * 256);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int o = tid + h * (NW * 64), sq = o >> 6, uc = o & 63, dst = uc >> 4;
-        float v = 0.f;
+        const int o = tid + h * (NW * 64);
+        if (o < ST * 48) {
+          const int sq = o / 48, uc = o % 48, n = uc >> 4, dst = n + (n >= ku ? 1 : 0);
+          float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
-        if (dst == ku) own[sq][uc & 15] = v;
-        else __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
+          __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave stored: drain the write-through stores
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(sib_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wave == EESEN_POLL_WAVE) {   // the three siblings: they finish their MFMA chains at about the same time
+      __builtin_amdgcn_sched_barrier(0);
+      // pass 2: the own block -- its quarter of the MFMA chain runs while the siblings' increments are in flight
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red2[wave][4 * kq + r][li] = acc[3][r];
+      EESEN_STAMP(2);
+      if (wave == EESEN_POLL_WAVE) {   // the three siblings: they run in lockstep with this workgroup
         bool go = true;
         if (lane == 0) {
-          go = false;
-          sleep_ticks(L.poll_delay2);
+          go = false;   // (no first-poll delay: the siblings' increments went out a quarter of an MFMA chain ago)
           for (int spins = 0; spins < spin_limit; ++spins) {
             if (__hip_atomic_load(sib_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
             if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -1072,8 +1087,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       }
       __syncthreads();
       if (!s_go) return;
+      EESEN_STAMP(3);
       if (e_ok) {
-        dm_in = own[es][eu];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dm_in += red2[w][es][eu];
 #pragma unroll
         for (int src = 0; src < KU; ++src)
           if (src != ku) dm_in += px[(size_t)(ku * KU + src) * 256 + es * 16 + eu];
@@ -1098,6 +1115,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
     if (step + 1 < T) {
       if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok) {  // next step's operands, issued after the publish
         const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
@@ -1588,9 +1606,9 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
         unsigned* cnt2 = cnt + c1;
         switch (cpw) {
-          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
-          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
-          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk); break;
+          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
+          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
+          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
         }
       }
       return true;
