@@ -77,7 +77,7 @@ struct LstmLayerDev {
   int poll_delay = 0, poll_delay2 = 0;
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
-  int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1, bwd_half = 1;
+  int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
 };
 float handoff_flight_ns();
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.

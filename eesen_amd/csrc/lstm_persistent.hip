@@ -1320,193 +1320,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K-split backward in HALF-SIZE workgroups: 256 threads, 16 sequences x 32 units x a quarter of K, TWO workgroups per CU.
-// One 512-thread workgroup per CU leaves the matrix pipe idle whenever that workgroup waits -- and the K-split step is
-// 3.4 us of MFMA in 7.5 us (timeline: two hand-offs, three write-through drains, the cell).  Two independent workgroups per
-// CU, from DIFFERENT (direction, sequence tile) chains, hide each other's waiting the way occupancy always does: while one
-// waits for its peers the other has the pipe to itself.  Each holds half the units (32 x 1024 k = 128 registers per lane over
-// four waves) and fetches the same 64 KB per step; the grid doubles to 512 workgroups, which the launcher admits only when the
-// occupancy arithmetic says two fit a CU (<= 256 VGPRs, LDS).  The role map puts workgroups b and b + 256 -- the two that share
-// a CU under the dispatcher's round-robin -- on different sequence tiles, so the two chains on a CU are not in lockstep.
-//   roles: 32-unit block uu = bx / 4, K quarter ku = bx % 4; cell units = uu*32 + ku*8 .. +8 (128 cell threads)
-// ------------------------------------------------------------------------------------------------
-template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * 4)
-__global__ __launch_bounds__(256) void lstm_bwd_persistent_ksplit_half_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
-                                                                              float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
-                                                                              unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk) {
-  constexpr int KU = 4, ST = 16, UW = 32, NT = 2, NWV = 4, CH = CPW < 4 ? CPW : 4, PW = NWV - 1;
-  static_assert(CPW % CH == 0, "whole rounds of operand chunks");
-  __shared__ float red[NWV][ST][UW + 1];
-  __shared__ float own[ST][9];
-  __shared__ int s_go;
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = L.H, S = L.S, T = L.T;
-  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H, KQ = K4 / KU;
-  // roles: with two sequence tiles, the first half of the grid takes tile 0 and the second half tile 1 (see above)
-  int bx, dir, bz;
-  if (R.nz == 2) {
-    const int half = (int)gridDim.x / 2, r = (int)blockIdx.x % half;
-    bz = (int)blockIdx.x / half; dir = r % R.ndir; bx = r / R.ndir;
-  } else {
-    bx = R.unit_group(blockIdx.x); dir = R.dir(blockIdx.x); bz = R.seq_group(blockIdx.x);
-  }
-  const int uu = bx / KU, ku = bx % KU;
-  const int um0 = uu * UW, uc0 = um0 + ku * 8;
-  const int s0 = L.s_begin + bz * ST;
-  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);
-  const int g = dir * R.nz + bz, ngroups = R.ndir * R.nz, nub = H / UW;
-  const unsigned nprod = (unsigned)(H / KU / 8);
-  unsigned* wait_cnt = cnt + (size_t)(g * KU + ku) * kShards * kShardStride;
-  unsigned* pub_cnt = cnt + (size_t)(g * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 8) % (int)nprod) & (kShards - 1)) * kShardStride;
-  unsigned* sib_cnt = cnt2 + (size_t)(g * nub + uu) * kShardStride;
-
-  const int li = lane & 15, kq = lane >> 4;
-  const int sa = s0 + li;
-  float b[NT][CPW][8];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const float* Br = L.WmT + ((size_t)dir * H + um0 + n * 16 + li) * K4 + (size_t)ku * KQ;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) ld8_plain(Br, (wave + c * NWV) * 32 + kq * 8, KQ, true, b[n][c]);
-  }
-  const int es = tid >> 3, eu = tid & 7;
-  const int s_e = s0 + es, u_e = uc0 + eu;
-  const bool e_ok = tid < ST * 8 && s_e < s_end;
-  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
-  int len = 0;
-  if (e_ok) {
-    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
-    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
-    len = L.lens[s_e];
-  }
-  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
-  const size_t gcol = (size_t)dir * K4 + u_e * 4;
-  const size_t ycol = (size_t)dir * H + u_e;
-  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dy = 0.f, c_t = 0.f, c_p = 0.f;
-  {
-    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
-    if (e_ok) {
-      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
-      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
-      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
-      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
-    }
-  }
-  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
-  int tbS = 0;
-
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? T - 1 - step : step;
-    const int tn = dir == 0 ? t + 1 : t - 1;
-    if (chunk < T && step % chunk == 0) {
-      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
-      tbS = tb * S;
-      rDG = make_rsrc(DG + (size_t)tbS * ldG);
-    }
-    float dm_in = 0.f;
-    if (step > 0) {
-      if (wave == PW) {
-        const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
-        if (lane == 0) s_go = go ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_go) return;
-      f32x4 acc[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
-#pragma unroll
-      for (int r0 = 0; r0 < CPW; r0 += CH) {   // CH chunks (32 registers) of operands in flight per round
-        float a[CH][8];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int k = (wave + (r0 + c) * NWV) * 32 + kq * 8;
-          ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][r0 + c][j], acc[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
-      __syncthreads();
-      float* px = PX + ((size_t)((size_t)step * ngroups + g) * nub + uu) * (KU * KU * 128);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int o = tid + h * 256, sq = o >> 5, uc = o & 31, dst = uc >> 3;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) v += red[w][sq][uc];
-        if (dst == ku) own[sq][uc & 7] = v;
-        else __hip_atomic_store(px + (size_t)(dst * KU + ku) * 128 + sq * 8 + (uc & 7), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(sib_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wave == PW) {
-        bool go = true;
-        if (lane == 0) {
-          go = false;
-          sleep_ticks(L.poll_delay2);
-          for (int spins = 0; spins < spin_limit; ++spins) {
-            if (__hip_atomic_load(sib_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
-            if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
-          }
-          if (!go) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_go = go ? 1 : 0;
-        }
-      }
-      __syncthreads();
-      if (!s_go) return;
-      if (e_ok) {
-        dm_in = own[es][eu];
-#pragma unroll
-        for (int src = 0; src < KU; ++src)
-          if (src != ku) dm_in += px[(size_t)(ku * KU + src) * 128 + es * 8 + eu];
-      }
-    }
-    if (e_ok) {
-      const float dm = dy + dm_in;
-      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
-      const float h = tanhf_(c_t);
-      const float dh = (1.f - h * h) * (dm * o);
-      float dob = o * (1.f - o) * (dm * h);
-      const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
-      float df = f * (1.f - f) * (dc * c_p);
-      float di = i * (1.f - i) * (dc * g_);
-      float dg = (1.f - g_ * g_) * (dc * i);
-      float carry = dc * f;
-      if (t >= len) { dg = di = df = dob = 0.f; carry = 0.f; }
-      const f32x4 out = {dg, di, df, dob};
-      __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4), 0, kSc1);
-      dcf = carry; dn_i = di; dn_f = df;
-    }
-    if (step + 1 < T) {
-      if (tid < ST * 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok) {
-        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-        c_t = c_p;
-        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
-      }
-    }
-  }
-}
-
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
@@ -1523,17 +1336,6 @@ bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE la
 // runtime does not gang-schedule a cooperative grid either (the side-stream GEMMs co-run with it), it only refuses grids above the
 // occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at once
 // are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp).
-// grid of 256-thread workgroups that needs TWO per CU: the occupancy query must say at least two, and the grid must not exceed
-// two per CU (no margin to give: the register file is what limits, and that arithmetic is exact)
-template <class K>
-bool fits_two_per_cu(K kernel, dim3 grid, int threads) {
-  int dev = 0, ncu = 0, nb = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) return false;
-  return nb >= 2 && (long)grid.x * grid.y * grid.z <= 2L * ncu;
-}
-
 template <class K, class... Args>
 void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) {
   hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
@@ -1756,25 +1558,6 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   }
   // Wide layers: K split four ways (lstm_bwd_persistent_ksplit_kernel) wherever the 16-sequence tile would be taken and the caller
   // handed over the partial-sum exchange buffer (lstm_bwd_ksplit_px_floats)
-  if (stile == 16 && L0.PX && L0.bwd_half && lstm_bwd_ksplit_px_floats(L0) && L0.px_floats >= lstm_bwd_ksplit_px_floats(L0) && L0.H == 1024) {
-    // half-size workgroups, two per CU (lstm_bwd_persistent_ksplit_half_kernel): windows of 32 sequences (two tiles)
-    const int nwin = L0.S % 32 == 0 ? L0.S / 32 : 0;
-    dim3 grid(L0.H / 32 * 4, L0.ndir, 2), block(256);
-    const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L0.H / 32) * kShardStride;
-    if (nwin >= 1 && c1 + c2 <= (size_t)kCtlHalf && fits_two_per_cu(lstm_bwd_persistent_ksplit_half_kernel<8>, grid, 256) &&
-        (nwin == 1 || ((size_t)32 * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
-      for (int w = 0; w < nwin; ++w) {
-        LstmLayerDev L = L0;
-        L.s_count = 32;
-        L.s_begin = w * 32;
-        const dim3 grid1(grid.x * grid.y * grid.z);
-        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
-        coop_launch(st, lstm_bwd_persistent_ksplit_half_kernel<8>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt + c1, err, spin_limit, role, chunk);
-      }
-      return true;
-    }
-  }
   if (stile == 16 && L0.PX && lstm_bwd_ksplit_px_floats(L0) && L0.px_floats >= lstm_bwd_ksplit_px_floats(L0)) {
     const int cpw = (4 * L0.H / 4) / (32 * NW);
     auto kfits = [&](int Sw) {

@@ -468,7 +468,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.lens = net.lens_d.p;
   d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
   d.drop_mode = L.cur_drop_mode;
-  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux; d.bwd_half = net.tn.bwd_half;
+  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
 

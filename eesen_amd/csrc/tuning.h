@@ -20,7 +20,6 @@
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
-//   EESEN_BWD_HALF          1        0: one 512-thread K-split workgroup per CU instead of two half-size ones (H = 1024)
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 split / 32 f32)
@@ -42,7 +41,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, bwd_half = 1, xcd_map = 1;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -63,7 +62,6 @@ struct Tuning {
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
-    t.bwd_half = num("EESEN_BWD_HALF", 1);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;
