@@ -72,9 +72,9 @@ struct LstmLayerDev {
   // partial-sum exchange space of the K-split backward kernel for wide layers (lstm_bwd_ksplit_px_floats; null: not offered)
   float* PX = nullptr;
   size_t px_floats = 0;
-  // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns (poll_delay2: the K-split backward
-  // kernel's sibling hand-off); set by the host from the measured increment flight of the device (handoff_flight_ns)
-  int poll_delay = 0, poll_delay2 = 0;
+  // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns; set by the host from the measured
+  // increment flight of the device (handoff_flight_ns)
+  int poll_delay = 0;
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;

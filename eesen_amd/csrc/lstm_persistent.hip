@@ -926,6 +926,43 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
   }
 }
 
+// The K-split kernels' partial-sum exchange: a partial sum and the step it belongs to travel in ONE 8-byte word (a single
+// 8-byte store is single-copy atomic), so the consumer polls the DATA: no counter to increment, no drain of the stores before
+// an increment, no second round trip for the data after the counter.  Two slots per word, by step parity: a sibling can be at
+// most one exchange ahead (its step s + 1 exchange needs this workgroup's step s + 1 partials).  The launcher zeroes the space
+// (tag 0 = no step).
+__device__ __forceinline__ void px_put(unsigned long long* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the words of the three siblings (src != ku) for this thread's (sequence, unit): issued early, looked at late (px_take)
+template <int KU>
+__device__ __forceinline__ void px_load(const unsigned long long* px, int ku, int off, unsigned long long (&w)[KU]) {
+#pragma unroll
+  for (int src = 0; src < KU; ++src)
+    w[src] = src == ku ? 0ull : __hip_atomic_load(px + (size_t)(ku * KU + src) * 256 + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// adds the three partial sums (in order of src) once all three words carry this step's tag, re-reading while they do not;
+// false: a sibling never wrote (bounded spin) or another workgroup gave up
+template <int KU>
+__device__ __forceinline__ bool px_take(const unsigned long long* px, int ku, int off, unsigned tag, unsigned* err, int spin_limit,
+                                        unsigned long long (&w)[KU], float& sum) {
+  for (int spins = 0; spins < spin_limit; ++spins) {
+    bool ok = true;
+#pragma unroll
+    for (int src = 0; src < KU; ++src) ok = ok && (src == ku || (unsigned)(w[src] >> 32) == tag);
+    if (ok) {
+#pragma unroll
+      for (int src = 0; src < KU; ++src)
+        if (src != ku) sum += __uint_as_float((unsigned)w[src]);
+      return true;
+    }
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+    px_load<KU>(px, ku, off, w);
+  }
+  return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward for WIDE layers (H = 1024: BASELINE configs 4 and 5), K split four ways (EESEN_BWD_KSPLIT, default on).
 // The 16 x 16 tile of lstm_bwd_persistent_kernel fetches ALL 4H gate gradients of its 16 sequences every step -- 256 KB per
@@ -934,23 +971,25 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
 // of K (the gate gradients of 256 of the 1024 units) into partial sums for FOUR times as many units (64 instead of 16): the
 // same 256 KB of W_m^T in its registers, the same MFMA count, a QUARTER of the fetch (64 KB, hidden under the MFMA chain).  The
 // four workgroups that share a 64-unit block then exchange their partial sums -- each writes the three 16 x 16 blocks its
-// siblings own (3 KB, write-through, a fresh row of the exchange space every step so no line is ever re-read) and reads the
-// three it needs -- and each finishes the cell update of its own 16 units as before.  A second, small hand-off (4 peers) buys
-// 192 KB of fetch per step.  Measured (cfg4 / cfg5, same box): backward recurrences 46.5 -> 38.9 ms / 333 -> 280 ms.
+// siblings own and reads the three it needs -- and each finishes the cell update of its own 16 units as before.  The
+// exchange carries its own flag: every partial sum is an 8-byte word (value, step), polled by the thread that needs it
+// (px_put / px_take above), so there is no counter, no drain before an increment and no second round trip; the words are read
+// speculatively half way through the own block's MFMA pass.  Measured (cfg4 / cfg5, same box): backward recurrences
+// 46.5 -> 38.9 ms / 333 -> 280 ms with a counted exchange; own block last 37.5 ms; tagged words 36 ms.
 //   roles: unit block uu = bx / 4 (64 units), K quarter ku = bx % 4; cell units = uu*64 + ku*16 .. +16
 //   hand-off 1 (DG_t): a consumer of quarter ku needs only the 16 producers whose cell units lie in that quarter's 256 units
-//   hand-off 2 (partials): counter per (group, uu), 4 increments per step
+//   hand-off 2 (partials): tagged words, two slots by step parity (4 MB for S = 32; zeroed by the launcher)
 // Shapes: H % 256 == 0, 16-sequence tiles, no dropout.  Same cell arithmetic; the d_m sum is formed in a different order
 // (as every backward variant here: parity tests, not bit equality, hold it).
 // ------------------------------------------------------------------------------------------------
 template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * NW)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
-                                                                             float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
-                                                                             unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
+                                                                             float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
+                                                                             unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
   constexpr int KU = 4, ST = 16, UW = 64, NT = 4;
   __shared__ float red[NW][ST][48 + 1];    // partial sums of the three sibling blocks, per wave
   __shared__ float red2[NW][ST][16 + 1];   // ... of the own block
-  __shared__ int s_go;
+  __shared__ int s_go, s_fail;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
@@ -964,7 +1003,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
   const unsigned nprod = (unsigned)(H / KU / 16);          // producers of one K quarter
   unsigned* wait_cnt = cnt + (size_t)(g * KU + ku) * kShards * kShardStride;
   unsigned* pub_cnt = cnt + (size_t)(g * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
-  unsigned* sib_cnt = cnt2 + (size_t)(g * nub + uu) * kShardStride;
 
   const int li = lane & 15, kq = lane >> 4;
   const int sa = s0 + li;
@@ -1003,6 +1041,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
     }
   }
+  if (tid == 0) s_fail = 0;   // (the first barrier of step 1 orders it)
   __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
   int tbS = 0;
 
@@ -1048,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
       __syncthreads();
-      float* px = PX + ((size_t)((size_t)step * ngroups + g) * nub + uu) * (KU * KU * 256);
+      unsigned long long* px = PX + ((size_t)((size_t)(step & 1) * ngroups + g) * nub + uu) * (KU * KU * 256);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int o = tid + h * (NW * 64);
@@ -1057,44 +1096,38 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
           float v = 0.f;
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
-          __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          px_put(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, (unsigned)step);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave stored: drain the write-through stores
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(sib_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_sched_barrier(0);
-      // pass 2: the own block -- its quarter of the MFMA chain runs while the siblings' increments are in flight
+      __builtin_amdgcn_sched_barrier(0);   // the stores leave BEFORE pass 2 (nothing waits for them)
+      // pass 2: the own block -- its quarter of the MFMA chain runs while the siblings' partial sums are in flight
 #pragma unroll
-      for (int c = 0; c < CPW; ++c)
+      for (int c = 0; c < CPW / 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
+      // half way through, the siblings' words are read SPECULATIVELY: the siblings run in lockstep, their stores left when this
+      // workgroup's did, and the answer is back by the end of the pass (px_take re-reads in the rare case it was too early)
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long sw[KU] = {};
+      if (e_ok) px_load<KU>(px, ku, es * 16 + eu, sw);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = CPW / 2; c < CPW; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) red2[wave][4 * kq + r][li] = acc[3][r];
       EESEN_STAMP(2);
-      if (wave == EESEN_POLL_WAVE) {   // the three siblings: they run in lockstep with this workgroup
-        bool go = true;
-        if (lane == 0) {
-          go = false;   // (no first-poll delay: the siblings' increments went out a quarter of an MFMA chain ago)
-          for (int spins = 0; spins < spin_limit; ++spins) {
-            if (__hip_atomic_load(sib_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
-            if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
-          }
-          if (!go) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_go = go ? 1 : 0;
-        }
-      }
       __syncthreads();
-      if (!s_go) return;
-      EESEN_STAMP(3);
-      if (e_ok) {
+      if (e_ok) {   // the three siblings' partial sums: they run in lockstep with this workgroup, the words left them a pass ago
 #pragma unroll
         for (int w = 0; w < NW; ++w) dm_in += red2[w][es][eu];
-#pragma unroll
-        for (int src = 0; src < KU; ++src)
-          if (src != ku) dm_in += px[(size_t)(ku * KU + src) * 256 + es * 16 + eu];
+        if (!px_take<KU>(px, ku, es * 16 + eu, (unsigned)step, err, spin_limit, sw, dm_in)) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_fail = 1;
+        }
       }
+      EESEN_STAMP(3);
     }
     if (e_ok) {
       const float dm = dy + dm_in;
@@ -1115,6 +1148,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
     if (step + 1 < T) {
       if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (s_fail) return;
       EESEN_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (e_ok) {  // next step's operands, issued after the publish
@@ -1140,12 +1174,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 // ------------------------------------------------------------------------------------------------
 template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
-                                                                                 float* __restrict__ DG, float* __restrict__ PX, unsigned* cnt,
-                                                                                 unsigned* cnt2, unsigned* err, int spin_limit, Role R, int chunk) {
+                                                                                 float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
+                                                                                 unsigned* err, int spin_limit, Role R, int chunk) {
   constexpr int KU = 4, ST = 16, UW = 64, NT = 4, Q = 2;
   __shared__ float red[NW][ST][UW + 1];
   __shared__ float own[Q][ST][17];
-  __shared__ int s_go;
+  __shared__ int s_go, s_fail;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
@@ -1177,7 +1211,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
   bool live[Q], e_ok[Q];
   float dcf[Q], dn_i[Q], dn_f[Q], dy[Q], c_t[Q], c_p[Q], dm_in[Q];
   float4 gt[Q];
-  unsigned *wait_cnt[Q], *pub_cnt[Q], *sib_cnt[Q];
+  unsigned *wait_cnt[Q], *pub_cnt[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     zt[q] = bg * Q + q;
@@ -1188,7 +1222,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
     g[q] = dir * nzall + (live[q] ? zt[q] : 0);
     wait_cnt[q] = cnt + (size_t)(g[q] * KU + ku) * kShards * kShardStride;
     pub_cnt[q] = cnt + (size_t)(g[q] * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
-    sib_cnt[q] = cnt2 + (size_t)(g[q] * nub + uu) * kShardStride;
     len[q] = e_ok[q] ? L.lens[s_e[q]] : 0;
     dcf[q] = dn_i[q] = dn_f[q] = dy[q] = c_t[q] = c_p[q] = dm_in[q] = 0.f;
     gt[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1200,6 +1233,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
       c_p[q] = L.C[(size_t)((tp0 + 1) * S + s_e[q]) * ldY + ycol];
     }
   }
+  if (tid == 0) s_fail = 0;
   __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
   int tbS = 0;
 
@@ -1212,6 +1246,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
       rDG = make_rsrc(DG + (size_t)tbS * ldG);
     }
     // ---- phase 1, both chains: partial sums of this K quarter from the chain's DG_next
+    unsigned long long sw[Q][KU] = {};
     if (step > 0) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
@@ -1235,7 +1270,19 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < CPW; ++c)
+        for (int c = 0; c < CPW / 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+        // chain A's sibling words, sent before this chain's fetch began, are asked for half way through chain B's MFMA chain:
+        // back long before phase 2 looks at them
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 1 && e_ok[0])
+          px_load<KU>(PX + ((size_t)((size_t)(step & 1) * ngroups + g[0]) * nub + uu) * (KU * KU * 256), ku, es * 16 + eu, sw[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = CPW / 2; c < CPW; ++c)
 #pragma unroll
           for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -1245,7 +1292,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
         __syncthreads();
-        float* px = PX + ((size_t)((size_t)step * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
+        unsigned long long* px = PX + ((size_t)((size_t)(step & 1) * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int o = tid + h * (NW * 64), sq = o >> 6, uc = o & 63, dst = uc >> 4;
@@ -1253,40 +1300,28 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
           if (dst == ku) own[q][sq][uc & 15] = v;
-          else __hip_atomic_store(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else px_put(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, (unsigned)step);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // (also fences `red` for the other chain)
-        if (tid == 0) __hip_atomic_fetch_add(sib_cnt[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // fences `red` for the other chain (the stores are not waited for)
       }
     }
     // ---- phase 2, both chains: the siblings' partials, the cell update, publish
+    if (step > 0) {   // chain B's words (and chain A's where chain B is idle): under chain A's cell update
+      if (live[1] && e_ok[1]) px_load<KU>(PX + ((size_t)((size_t)(step & 1) * ngroups + g[1]) * nub + uu) * (KU * KU * 256), ku, es * 16 + eu, sw[1]);
+      if (!live[1] && e_ok[0]) px_load<KU>(PX + ((size_t)((size_t)(step & 1) * ngroups + g[0]) * nub + uu) * (KU * KU * 256), ku, es * 16 + eu, sw[0]);
+    }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       if (!live[q]) continue;
       float dm = dy[q];
       if (step > 0) {
-        if (wave == EESEN_POLL_WAVE) {
-          bool go = true;
-          if (lane == 0) {
-            go = false;
-            for (int spins = 0; spins < spin_limit; ++spins) {
-              if (__hip_atomic_load(sib_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(KU * step)) { go = true; break; }
-              if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-              __builtin_amdgcn_s_sleep(EESEN_POLL_SLEEP);
-            }
-            if (!go) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_go = go ? 1 : 0;
-          }
-        }
-        __syncthreads();
-        if (!s_go) return;
         if (e_ok[q]) {
-          const float* px = PX + ((size_t)((size_t)step * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
+          const unsigned long long* px = PX + ((size_t)((size_t)(step & 1) * ngroups + g[q]) * nub + uu) * (KU * KU * 256);
           dm += own[q][es][eu];
-#pragma unroll
-          for (int src = 0; src < KU; ++src)
-            if (src != ku) dm += px[(size_t)(ku * KU + src) * 256 + es * 16 + eu];
+          if (!px_take<KU>(px, ku, es * 16 + eu, (unsigned)step, err, spin_limit, sw[q], dm)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_fail = 1;
+          }
         }
       }
       if (e_ok[q]) {
@@ -1307,6 +1342,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
       if (step + 1 < T) {
         if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (s_fail) return;
         if (tid == 0) __hip_atomic_fetch_add(pub_cnt[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e_ok[q]) {
           const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
@@ -1500,8 +1536,9 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
   return pick_windows(L.S, 16 * ft.mt, fits_with);
 }
 
-// Floats of partial-sum exchange space the K-split backward kernel needs for this layer shape (16 KB per step, (direction,
-// 16-sequence tile) group and 64-unit block: 16 blocks of 16 x 16); 0 = the kernel does not apply (narrow layers take the 4 x 32
+// Floats of partial-sum exchange space the K-split backward kernels need for this layer shape: per (direction, 16-sequence tile)
+// group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
+// 0 = the kernel does not apply (narrow layers take the 4 x 32
 // tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
@@ -1512,7 +1549,7 @@ size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
   if (2 * blocks16 <= ncu && L.S > 8) return 0;   // the 8-sequence / 4 x 32 tiles are taken there
   // the largest window the launcher may pick is the whole batch
-  return (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096;
+  return (size_t)2 * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096 * 2;
 }
 
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY, int lddy, float* DG, unsigned* cnt,
@@ -1558,12 +1595,12 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   }
   // Wide layers: K split four ways (lstm_bwd_persistent_ksplit_kernel) wherever the 16-sequence tile would be taken and the caller
   // handed over the partial-sum exchange buffer (lstm_bwd_ksplit_px_floats)
-  if (stile == 16 && L0.PX && lstm_bwd_ksplit_px_floats(L0) && L0.px_floats >= lstm_bwd_ksplit_px_floats(L0)) {
+  if (const size_t px_need = stile == 16 && L0.PX ? lstm_bwd_ksplit_px_floats(L0) : 0; px_need && L0.px_floats >= px_need) {
     const int cpw = (4 * L0.H / 4) / (32 * NW);
     auto kfits = [&](int Sw) {
       dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(Sw, 16));
-      const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L0.H / 64) * kShardStride;
-      if (c1 + c2 > (size_t)kCtlHalf) return false;
+      const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
+      if (c1 > (size_t)kCtlHalf) return false;
       switch (cpw) {
         case 4: return fits(lstm_bwd_persistent_ksplit_kernel<4>, grid, NW * 64);
         case 3: return fits(lstm_bwd_persistent_ksplit_kernel<3>, grid, NW * 64);
@@ -1577,8 +1614,8 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     if (nwin == 2 && L0.bwd_mux && cpw >= 2 && cpw <= 4) {
       const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
       dim3 grid(L0.H / 64 * 4, L0.ndir, ng), block(NW * 64);
-      const size_t c1 = (size_t)L0.ndir * nz * 4 * kShards * kShardStride, c2 = (size_t)L0.ndir * nz * (L0.H / 64) * kShardStride;
-      bool fit = c1 + c2 <= (size_t)kCtlHalf;
+      const size_t c1 = (size_t)L0.ndir * nz * 4 * kShards * kShardStride;
+      bool fit = c1 <= (size_t)kCtlHalf;
       if (fit) fit = cpw == 4 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<4>, grid, NW * 64)
                    : cpw == 3 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<3>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_mux_kernel<2>, grid, NW * 64);
       if (fit) {
@@ -1586,11 +1623,12 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         L.s_begin = 0; L.s_count = 0;
         const dim3 grid1(grid.x * grid.y * grid.z);
         const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
-        unsigned* cnt2 = cnt + c1;
-        if (cpw == 4) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
-        else if (cpw == 3) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
-        else coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk);
+        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
+        EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
+        unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
+        if (cpw == 4) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
+        else if (cpw == 3) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
+        else coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
         return true;
       }
     }
@@ -1602,13 +1640,14 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         dim3 grid(L.H / 64 * 4, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
         const dim3 grid1(grid.x * grid.y * grid.z);
         const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride, c2 = (size_t)grid.y * grid.z * (L.H / 64) * kShardStride;
-        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (c1 + c2), st));
-        unsigned* cnt2 = cnt + c1;
+        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
+        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
+        EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
+        unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
         switch (cpw) {
-          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
-          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
-          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, L.PX, cnt, cnt2, err, spin_limit, role, chunk, trace); break;
+          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
+          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
+          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
         }
       }
       return true;

@@ -155,22 +155,21 @@ Net::Net(int dev, void* stream) : device(dev) {
   // First-poll delays of the recurrence kernels' hand-off waits = the MEASURED flight of an agent-scope increment between two CUs
   // of this device (lstm_persistent.hip: handoff_flight_ns) times a dimensionless factor per wait kind.  The factors restate round
   // 2's hand-tuned optima (s_sleep 20 forward / 14 backward at ~2.1 GHz = 610 / 430 ns, against ~610 ns of flight on those boxes:
-  // "about one flight"; 0.4 for the K-split kernel's sibling hand-off, whose four peers run in lockstep); a chip that clocks or
+  // "about one flight"; the K-split kernel's sibling exchange has no counter to wait on any more); a chip that clocks or
   // routes differently gets proportionally different delays instead of another box's constants.  Measured on a box with
   // derived delays anywhere between 12 and 21 units: the step does not move (39.2-39.3 ms) -- the optimum is flat, the
-  // measurement only has to land in it.  EESEN_POLL_NS="fwd,bwd,sibling" overrides (experiments).
+  // measurement only has to land in it.  EESEN_POLL_NS="fwd,bwd" overrides (experiments).
   {
-    constexpr float kFactorFwd = 1.0f, kFactorBwd = 0.7f, kFactorSib = 0.4f;
+    constexpr float kFactorFwd = 1.0f, kFactorBwd = 0.7f;
     flight_ns = handoff_flight_ns();
     auto ticks = [&](float factor) { return std::min(300, std::max(0, (int)std::lround(factor * flight_ns / 10.f))); };
-    delay_fwd = ticks(kFactorFwd); delay_bwd = ticks(kFactorBwd); delay_sib = ticks(kFactorSib);
+    delay_fwd = ticks(kFactorFwd); delay_bwd = ticks(kFactorBwd);
     if (const char* e = tn.poll_ns) {
-      int a = -1, b2 = -1, c = -1;
-      if (sscanf(e, "%d,%d,%d", &a, &b2, &c) == 3) { delay_fwd = a / 10; delay_bwd = b2 / 10; delay_sib = c / 10; }
+      int a = -1, b2 = -1;
+      if (sscanf(e, "%d,%d", &a, &b2) == 2) { delay_fwd = a / 10; delay_bwd = b2 / 10; }
     }
     if (tn.print_flight)
-      fprintf(stderr, "eesen_hip: increment flight %.0f ns; first-poll delays forward %d0, backward %d0, sibling %d0 ns\n", flight_ns, delay_fwd,
-              delay_bwd, delay_sib);
+      fprintf(stderr, "eesen_hip: increment flight %.0f ns; first-poll delays forward %d0, backward %d0 ns\n", flight_ns, delay_fwd, delay_bwd);
   }
 }
 
@@ -798,7 +797,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
       LstmLayerDev v = lstm_view(*this, L);
-      v.poll_delay = delay_bwd; v.poll_delay2 = delay_sib;
+      v.poll_delay = delay_bwd;
       if (persistent) {  // wide layers: partial-sum exchange space of the K-split backward kernel (shared by the layers: their passes are serial)
         const size_t need = lstm_bwd_ksplit_px_floats(v);
         if (need) { bwd_px.reserve(need); v.PX = bwd_px.p; v.px_floats = bwd_px.cap; }
