@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
   else ctc_sweep<PL, false>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last);
 }
 
-// ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per frame -----
+// ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per 8 frames of an utterance -----
 // gamma_k = log sum_{j: l'_j = k} exp(alpha_j + beta_j).  The reference folds every class serially (thread (frame, k) loops
 // over ALL L' positions).  The blank owns every second lattice position (~(L'+1)/2 = 101 at cfg2), every other class two or
 // three: a class-per-lane fold is one lane grinding through 101 dependent log-add-exps while 63 wait (round 1: 0.19 ms for
@@ -241,6 +241,12 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 // <= 0, so the smallest pattern is the largest value) and a float add of exp(v - max_k).  One wave owns a frame and its LDS
 // slots, and same-address lanes of one LDS atomic are served in lane order, so the sums are reproducible run to run.
 // Only the L'_s positions the utterance has are read (the lattice rows are padded to 64 * PL for the sweep's stores).
+// A wave owns kFramesPerWave CONSECUTIVE frames of ONE utterance (round 3; it used to own one frame): the utterance's label
+// table, lengths and ln p are read once and stay in registers, the lattice rows of the next frame are in flight while this one
+// is folded (rows of one utterance are adjacent in alpha / beta: a wave streams 8 x 2 x L' floats), and the per-wave start-up
+// -- three dependent scalar loads before the first row could even be addressed -- is paid once per 8 frames.  Arithmetic and
+// order per frame are unchanged (bit-identical to the one-frame kernel).
+constexpr int kFramesPerWave = 8;
 template <int MAXP>   // lattice positions per lane: L' <= 64 * MAXP
 __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __restrict__ probs, int ld, int T, int S, int K,
                                                              int Lpad, const int* __restrict__ lens,
@@ -252,65 +258,89 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
                                                              int ldd) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r = blockIdx.x * 4 + w;
-  if (r >= T * S) return;
-  const int t = r / S, s = r % S;
-  float* drow = diff + (size_t)r * ldd;
-  if (t >= lens[s]) {  // ctc_err_ stays zero there (:1613), and so does diff
-    for (int k = lane; k < K; k += 64) drow[k] = 0.f;
-    return;
-  }
+  const int nchunk = (T + kFramesPerWave - 1) / kFramesPerWave;
+  const int wid = blockIdx.x * 4 + w;                       // wave -> (utterance, chunk of frames), utterance fastest
+  if (wid >= nchunk * S) return;
+  const int s = wid % S, t0 = (wid / S) * kFramesPerWave;
+  const int t1 = min(T, t0 + kFramesPerWave);
+  const int len = lens[s], Ls = lablens[s];
+  const float pz = pzx[s];
   unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * K;   // per class: bit pattern of the maximum ...
   float* sm = smem + (size_t)w * 2 * K + K;                                 // ... and sum of exp(v - max); later e_k
-  for (int k = lane; k < K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
-  const float* ar = alpha + ((size_t)s * T + t) * Lpad;
-  const float* br = beta + ((size_t)s * T + t) * Lpad;
-  const int* lx = labx + (size_t)s * Lpad;
-  const int Ls = lablens[s];
-  float v[MAXP];
   int cls[MAXP];
-  float bmax = kLogZero;
-  __builtin_amdgcn_wave_barrier();
+  {
+    const int* lx = labx + (size_t)s * Lpad;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int j = lane + 64 * i;
-    v[i] = kLogZero; cls[i] = 0;
-    if (j < Ls) {
-      v[i] = AddAB(ar[j], br[j]);
-      cls[i] = lx[j];
-      if (cls[i] == 0) bmax = fmaxf(bmax, v[i]);
-      else if (v[i] > kLogZero) atomicMin(&mxb[cls[i]], __builtin_bit_cast(unsigned, v[i]));
+    for (int i = 0; i < MAXP; ++i) {
+      const int j = lane + 64 * i;
+      cls[i] = j < Ls ? lx[j] : 0;
     }
   }
-  __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
-  bmax = wave_max(bmax);
-  float bsum = 0.f;
+  float an[MAXP], bn[MAXP];   // the next frame's lattice rows, in flight
+  auto fetch = [&](int t) {
+    const float* ar = alpha + ((size_t)s * T + t) * Lpad;
+    const float* br = beta + ((size_t)s * T + t) * Lpad;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int j = lane + 64 * i;
-    if (j < Ls && v[i] > kLogZero) {
-      if (cls[i] == 0) bsum += ExpA(SubAB(v[i], bmax));
-      else atomicAdd(&sm[cls[i]], ExpA(SubAB(v[i], __builtin_bit_cast(float, mxb[cls[i]]))));
+    for (int i = 0; i < MAXP; ++i) {
+      const int j = lane + 64 * i;
+      const bool ok = j < Ls && t < len;
+      an[i] = ok ? ar[j] : kLogZero;
+      bn[i] = ok ? br[j] : kLogZero;
     }
+  };
+  fetch(t0);
+  for (int t = t0; t < t1; ++t) {
+    const int r = t * S + s;
+    float* drow = diff + (size_t)r * ldd;
+    float v[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) v[i] = lane + 64 * i < Ls ? AddAB(an[i], bn[i]) : kLogZero;
+    if (t + 1 < t1) fetch(t + 1);
+    if (t >= len) {  // ctc_err_ stays zero there (:1613), and so does diff
+      for (int k = lane; k < K; k += 64) drow[k] = 0.f;
+      continue;
+    }
+    const float* yr = probs + (size_t)r * ld;
+    for (int k = lane; k < K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
+    float bmax = kLogZero;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int j = lane + 64 * i;
+      if (j < Ls) {
+        if (cls[i] == 0) bmax = fmaxf(bmax, v[i]);
+        else if (v[i] > kLogZero) atomicMin(&mxb[cls[i]], __builtin_bit_cast(unsigned, v[i]));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
+    bmax = wave_max(bmax);
+    float bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int j = lane + 64 * i;
+      if (j < Ls && v[i] > kLogZero) {
+        if (cls[i] == 0) bsum += ExpA(SubAB(v[i], bmax));
+        else atomicAdd(&sm[cls[i]], ExpA(SubAB(v[i], __builtin_bit_cast(float, mxb[cls[i]]))));
+      }
+    }
+    bsum = wave_sum(bsum);
+    __builtin_amdgcn_wave_barrier();
+    float rsum = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      float err;
+      if (k == 0) err = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
+      else err = mxb[k] != 0xffffffffu ? __builtin_bit_cast(float, mxb[k]) + logf(sm[k]) : kLogZero;                                   // :1617-1624
+      const float y = yr[k];
+      const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
+      const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
+      sm[k] = e_k;
+      rsum += e_k;
+    }
+    rsum = wave_sum(rsum);                                                                   // ctc-loss.cc:162
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < K; k += 64) drow[k] = sm[k] - yr[k] * rsum;                       // :164-168
+    __builtin_amdgcn_wave_barrier();
   }
-  bsum = wave_sum(bsum);
-  __builtin_amdgcn_wave_barrier();
-  const float* yr = probs + (size_t)r * ld;
-  const float pz = pzx[s];
-  float rsum = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    float err;
-    if (k == 0) err = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
-    else err = mxb[k] != 0xffffffffu ? __builtin_bit_cast(float, mxb[k]) + logf(sm[k]) : kLogZero;                                   // :1617-1624
-    const float y = yr[k];
-    const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
-    const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
-    sm[k] = e_k;
-    rsum += e_k;
-  }
-  rsum = wave_sum(rsum);                                                                   // ctc-loss.cc:162
-  __builtin_amdgcn_wave_barrier();
-  for (int k = lane; k < K; k += 64) drow[k] = sm[k] - yr[k] * rsum;                       // :164-168
 }
 
 // m = (apply_log ? log(m) : m) - prior_scale * log_prior[col]   (net-output-extract.cc:103-112: ApplyLog, then
@@ -396,7 +426,7 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
       EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       granted = smem;
     }
-    hipLaunchKernelGGL(kern, dim3(cdiv(rows, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
+    hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, kFramesPerWave) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
                        beta, pzx, diff, ldd);
   };
   static size_t granted[3] = {0, 0, 0};

@@ -443,6 +443,36 @@ def test_odd_shapes_and_single_sequence(gpu, over):
     assert rel_err(r["grads"], r["ora_grads"]) < TOL
 
 
+@pytest.mark.parametrize("S", [10, 20])
+def test_recipe_shape_on_the_persistent_kernels(gpu, S):
+    """The reference's OWN recipe shape (asr_egs/wsj/run_ctc_phn.sh:65-85, steps/train_ctc_parallel.sh:13-21: 4 x 320 BiLSTM on
+    120-d features, --num-sequence 10 / 20) against the oracle.  H = 320 is a multiple of neither 128 nor 256, S fills neither a
+    16- nor a 32-sequence tile: none of the tiles the BASELINE configurations take applies, and the layer passes must still run
+    on the persistent kernels (bench.py's recipe leg times exactly these)."""
+    over = dict(layers=4, H=320, D=120, K=46, S=S, T=48)
+    cfg = dict(synth.config("small_bi")); cfg.update(over)
+    layers = synth.make_model(max_grad=0.0, **cfg)
+    batch = synth.make_batch(**cfg)
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(1.0, 0.0)
+    o = onet.train_step(ora, batch, "f32")
+    net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0)
+    ctc = Ctc()
+    net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats)
+    diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+    in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
+    net.BackpropagateNoUpdate(diff, in_diff)
+    info = net.RecurrenceInfo()
+    assert info["fwd_persistent"] == info["bwd_persistent"] == info["lstm_layers"] == 4, info
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(out.numpy()[vm], o["net_out"][vm]) < TOL
+    assert rel_err(ctc.pzx, o["pzx"]) < TOL
+    assert rel_err(diff.numpy(), o["diff"]) < TOL
+    assert rel_err(in_diff.numpy(), o["in_diff"]) < TOL
+    for (li, name, g), (_, _, w) in zip(split_params(layers, net.GetGrads()), split_params(layers, ora.fresh_grads_flat().astype(np.float32))):
+        assert rel_err(g, w) < TOL, f"layer {li} {name}: gradient rel err {rel_err(g, w):.2e}"
+
+
 def test_ctc_edge_cases(gpu):
     """Infeasible alignment (fewer frames than the labels need: ln p ~ -1e30 in the reference), a
     one-label utterance, and the expanded-label limit."""
