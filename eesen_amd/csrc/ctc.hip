@@ -241,13 +241,16 @@ __global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restr
 // <= 0, so the smallest pattern is the largest value) and a float add of exp(v - max_k).  One wave owns a frame and its LDS
 // slots, and same-address lanes of one LDS atomic are served in lane order, so the sums are reproducible run to run.
 // Only the L'_s positions the utterance has are read (the lattice rows are padded to 64 * PL for the sweep's stores).
-// A wave owns kFramesPerWave CONSECUTIVE frames of ONE utterance (round 3; it used to own one frame): the utterance's label
-// table, lengths and ln p are read once and stay in registers, the lattice rows of the next frame are in flight while this one
-// is folded (rows of one utterance are adjacent in alpha / beta: a wave streams 8 x 2 x L' floats), and the per-wave start-up
-// -- three dependent scalar loads before the first row could even be addressed -- is paid once per 8 frames.  Arithmetic and
-// order per frame are unchanged (bit-identical to the one-frame kernel).
-constexpr int kFramesPerWave = 8;
-template <int MAXP>   // lattice positions per lane: L' <= 64 * MAXP
+// A wave owns `frames` CONSECUTIVE frames of ONE utterance (round 3; it used to own one frame): the utterance's label table,
+// lengths and ln p are read once and stay in registers, the lattice rows of the next frame are in flight while this one is
+// folded (rows of one utterance are adjacent in alpha / beta), and the per-wave start-up -- three dependent scalar loads before
+// the first row could even be addressed -- is paid once per `frames` frames.
+// A lane owns PAIRS of lattice positions (2p, 2p + 1) = (a blank, a label): with positions dealt out one per lane the even
+// lanes only ever saw blanks and the odd lanes only labels, so every branch of the fold ran with half the wave masked off.
+// The per-position exponentials exp(v - max) (arguments <= 0) are v_exp_f32 (the sweep's argument: ~2 ulp, far below the fp32
+// rounding of the sum they enter); the per-class logarithms and the final exponential keep the library functions.
+// Measured (MI355X): the pass was instruction-bound, not latency-bound -- ~6500 issue cycles per frame at L' = 601.
+template <int MAXP>   // lattice positions per lane: L' <= 64 * MAXP (MAXP even)
 __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __restrict__ probs, int ld, int T, int S, int K,
                                                              int Lpad, const int* __restrict__ lens,
                                                              const int* __restrict__ lablens,
@@ -255,83 +258,98 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
                                                              const float* __restrict__ alpha,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ pzx, float* __restrict__ diff,
-                                                             int ldd) {
+                                                             int ldd, int frames) {
+  static_assert(MAXP % 2 == 0, "pairs of positions");
+  constexpr int NP = MAXP / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int nchunk = (T + kFramesPerWave - 1) / kFramesPerWave;
+  const int nchunk = (T + frames - 1) / frames;
   const int wid = blockIdx.x * 4 + w;                       // wave -> (utterance, chunk of frames), utterance fastest
   if (wid >= nchunk * S) return;
-  const int s = wid % S, t0 = (wid / S) * kFramesPerWave;
-  const int t1 = min(T, t0 + kFramesPerWave);
+  const int s = wid % S, t0 = (wid / S) * frames;
+  const int t1 = min(T, t0 + frames);
   const int len = lens[s], Ls = lablens[s];
   const float pz = pzx[s];
-  unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * K;   // per class: bit pattern of the maximum ...
-  float* sm = smem + (size_t)w * 2 * K + K;                                 // ... and sum of exp(v - max); later e_k
-  int cls[MAXP];
+  unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * (K + 1);   // per class: bit pattern of the maximum ...
+  float* sm = smem + (size_t)w * 2 * (K + 1) + K + 1;                             // ... and sum of exp(v - max); later e_k
+  // class slot of the pair's label position (odd position 2p + 1).  Slot K is a dump: positions beyond the utterance's lattice
+  // (and impossible ones, -1e30) send their LDS atomics there with neutral operands, so the fold below has no branches.
+  int cls[NP];
+  bool isb[NP];   // the "label" is class 0 itself (a target sequence that names the blank): it folds with the blanks
   {
     const int* lx = labx + (size_t)s * Lpad;
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int j = lane + 64 * i;
-      cls[i] = j < Ls ? lx[j] : 0;
+    for (int i = 0; i < NP; ++i) {
+      const int j1 = 2 * (lane + 64 * i) + 1;
+      const int c = j1 < Ls ? lx[j1] : K;
+      isb[i] = c == 0;
+      cls[i] = c == 0 ? K : c;
     }
   }
-  float an[MAXP], bn[MAXP];   // the next frame's lattice rows, in flight
+  float2 an[NP] = {}, bn[NP] = {};   // the next frame's lattice rows, in flight
+  // straight-line loads (a predicated load is a branch per load): positions beyond the lattice read the row's last pair and are
+  // masked afterwards; frames beyond the utterance (uniform per wave) are not read at all
+  const int half = Lpad / 2;
   auto fetch = [&](int t) {
-    const float* ar = alpha + ((size_t)s * T + t) * Lpad;
-    const float* br = beta + ((size_t)s * T + t) * Lpad;
+    if (t >= len) return;
+    const float2* ar = reinterpret_cast<const float2*>(alpha + ((size_t)s * T + t) * Lpad);
+    const float2* br = reinterpret_cast<const float2*>(beta + ((size_t)s * T + t) * Lpad);
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int j = lane + 64 * i;
-      const bool ok = j < Ls && t < len;
-      an[i] = ok ? ar[j] : kLogZero;
-      bn[i] = ok ? br[j] : kLogZero;
+    for (int i = 0; i < NP; ++i) {
+      const int p = min(lane + 64 * i, half - 1);
+      an[i] = ar[p];
+      bn[i] = br[p];
     }
   };
   fetch(t0);
   for (int t = t0; t < t1; ++t) {
     const int r = t * S + s;
     float* drow = diff + (size_t)r * ldd;
-    float v[MAXP];
+    // alpha + beta of the pair's blank / label position.  Plain sums: x + (-1e30) == -1e30 exactly (ulp(1e30) = 7.6e22) and
+    // (-1e30) + (-1e30) < -1e30, and everything below only asks "> -1e30" -- AddAB's cases without its branches.
+    float vb[NP], vl[NP];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) v[i] = lane + 64 * i < Ls ? AddAB(an[i], bn[i]) : kLogZero;
+    for (int i = 0; i < NP; ++i) {
+      vb[i] = 2 * (lane + 64 * i) < Ls ? an[i].x + bn[i].x : kLogZero;
+      vl[i] = 2 * (lane + 64 * i) + 1 < Ls ? an[i].y + bn[i].y : kLogZero;
+    }
     if (t + 1 < t1) fetch(t + 1);
     if (t >= len) {  // ctc_err_ stays zero there (:1613), and so does diff
       for (int k = lane; k < K; k += 64) drow[k] = 0.f;
       continue;
     }
     const float* yr = probs + (size_t)r * ld;
-    for (int k = lane; k < K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
+    for (int k = lane; k <= K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
     float bmax = kLogZero;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int j = lane + 64 * i;
-      if (j < Ls) {
-        if (cls[i] == 0) bmax = fmaxf(bmax, v[i]);
-        else if (v[i] > kLogZero) atomicMin(&mxb[cls[i]], __builtin_bit_cast(unsigned, v[i]));
-      }
+    for (int i = 0; i < NP; ++i) {
+      bmax = fmaxf(bmax, fmaxf(vb[i], isb[i] ? vl[i] : kLogZero));
+      // all values are <= 0, so the smallest bit pattern is the largest value
+      atomicMin(&mxb[cls[i]], vl[i] > kLogZero ? __builtin_bit_cast(unsigned, vl[i]) : 0xffffffffu);
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
     bmax = wave_max(bmax);
     float bsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-      const int j = lane + 64 * i;
-      if (j < Ls && v[i] > kLogZero) {
-        if (cls[i] == 0) bsum += ExpA(SubAB(v[i], bmax));
-        else atomicAdd(&sm[cls[i]], ExpA(SubAB(v[i], __builtin_bit_cast(float, mxb[cls[i]]))));
-      }
+    for (int i = 0; i < NP; ++i) {
+      const float mk = __builtin_bit_cast(float, mxb[cls[i]]);
+      const float eb = vb[i] > kLogZero ? __expf(vb[i] - bmax) : 0.f;
+      const float el = vl[i] > kLogZero ? __expf(vl[i] - (isb[i] ? bmax : mk)) : 0.f;
+      bsum += eb + (isb[i] ? el : 0.f);
+      atomicAdd(&sm[cls[i]], isb[i] ? 0.f : el);
     }
     bsum = wave_sum(bsum);
     __builtin_amdgcn_wave_barrier();
     float rsum = 0.f;
     for (int k = lane; k < K; k += 64) {
       float err;
-      if (k == 0) err = bmax > kLogZero ? bmax + logf(bsum) : kLogZero;
-      else err = mxb[k] != 0xffffffffu ? __builtin_bit_cast(float, mxb[k]) + logf(sm[k]) : kLogZero;                                   // :1617-1624
+      // (hardware log / exp, ~1 ulp of the log2 / exp2 units: 2e-6 absolute on ln y at y = 1e-10, against the 1e-4 bar)
+      if (k == 0) err = bmax > kLogZero ? bmax + __logf(bsum) : kLogZero;
+      else err = mxb[k] != 0xffffffffu ? __builtin_bit_cast(float, mxb[k]) + __logf(sm[k]) : kLogZero;                                 // :1617-1624
       const float y = yr[k];
-      const float val = ExpA(SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * logf(y))));   // :1625
+      const float x = SubAB(err, AddAB(pz, y == 0.f ? kLogZero : 2.f * __logf(y)));
+      const float val = x <= kLogZero ? 0.f : x >= kExpLimit ? kFltMax : __expf(x);          // ExpA, :1625
       const float e_k = (-1.0f * val) * y;                                                  // :1626, ctc-loss.cc:160
       sm[k] = e_k;
       rsum += e_k;
@@ -417,7 +435,9 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
                     const float* pzx, float* diff, int ldd) {
   const int rows = T * S;
   if (rows <= 0) return;
-  const size_t smem = (size_t)4 * 2 * K * sizeof(float);
+  const size_t smem = (size_t)4 * 2 * (K + 1) * sizeof(float);   // per wave: K classes + the dump slot, maxima and sums
+  // frames per wave: 8 where that still leaves >= 8192 waves (32 per CU), fewer for small minibatches
+  const int frames = std::max(1, std::min(8, rows / 8192));
   if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
     EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (8 K floats of LDS per workgroup exceed 160 KB)");
   }
@@ -426,8 +446,8 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
       EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       granted = smem;
     }
-    hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, kFramesPerWave) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
-                       beta, pzx, diff, ldd);
+    hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
+                       beta, pzx, diff, ldd, frames);
   };
   static size_t granted[3] = {0, 0, 0};
   EESEN_REQUIRE(Lpad <= 1024, EESEN_ERR_INVALID, "ctc: expanded label length above 1024");

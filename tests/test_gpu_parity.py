@@ -449,6 +449,8 @@ def test_recipe_shape_on_the_persistent_kernels(gpu, S):
     120-d features, --num-sequence 10 / 20) against the oracle.  H = 320 is a multiple of neither 128 nor 256, S fills neither a
     16- nor a 32-sequence tile: none of the tiles the BASELINE configurations take applies, and the layer passes must still run
     on the persistent kernels (bench.py's recipe leg times exactly these)."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    from oracle import net as onet
     over = dict(layers=4, H=320, D=120, K=46, S=S, T=48)
     cfg = dict(synth.config("small_bi")); cfg.update(over)
     layers = synth.make_model(max_grad=0.0, **cfg)
