@@ -270,20 +270,15 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
   const int t1 = min(T, t0 + frames);
   const int len = lens[s], Ls = lablens[s];
   const float pz = pzx[s];
-  unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * (K + 1);   // per class: bit pattern of the maximum ...
-  float* sm = smem + (size_t)w * 2 * (K + 1) + K + 1;                             // ... and sum of exp(v - max); later e_k
-  // class slot of the pair's label position (odd position 2p + 1).  Slot K is a dump: positions beyond the utterance's lattice
-  // (and impossible ones, -1e30) send their LDS atomics there with neutral operands, so the fold below has no branches.
-  int cls[NP];
-  bool isb[NP];   // the "label" is class 0 itself (a target sequence that names the blank): it folds with the blanks
+  unsigned* mxb = reinterpret_cast<unsigned*>(smem) + (size_t)w * 2 * K;   // per class: bit pattern of the maximum ...
+  float* sm = smem + (size_t)w * 2 * K + K;                             // ... and sum of exp(v - max); later e_k
+  int cls[NP];   // class of the pair's label position (odd position 2p + 1); -1: beyond the utterance's lattice
   {
     const int* lx = labx + (size_t)s * Lpad;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int j1 = 2 * (lane + 64 * i) + 1;
-      const int c = j1 < Ls ? lx[j1] : K;
-      isb[i] = c == 0;
-      cls[i] = c == 0 ? K : c;
+      cls[i] = j1 < Ls ? lx[j1] : -1;
     }
   }
   float2 an[NP] = {}, bn[NP] = {};   // the next frame's lattice rows, in flight
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       vb[i] = 2 * (lane + 64 * i) < Ls ? an[i].x + bn[i].x : kLogZero;
-      vl[i] = 2 * (lane + 64 * i) + 1 < Ls ? an[i].y + bn[i].y : kLogZero;
+      vl[i] = cls[i] >= 0 ? an[i].y + bn[i].y : kLogZero;
     }
     if (t + 1 < t1) fetch(t + 1);
     if (t >= len) {  // ctc_err_ stays zero there (:1613), and so does diff
@@ -319,25 +314,29 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
       continue;
     }
     const float* yr = probs + (size_t)r * ld;
-    for (int k = lane; k <= K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
+    for (int k = lane; k < K; k += 64) { mxb[k] = 0xffffffffu; sm[k] = 0.f; }
     float bmax = kLogZero;
     __builtin_amdgcn_wave_barrier();
+    // (branches on purpose: beyond the lattice whole instructions are skipped, and a branch-free fold through dump slots
+    // measured 1.5x slower -- LDS atomics of all 64 lanes instead of the live ones)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      bmax = fmaxf(bmax, fmaxf(vb[i], isb[i] ? vl[i] : kLogZero));
-      // all values are <= 0, so the smallest bit pattern is the largest value
-      atomicMin(&mxb[cls[i]], vl[i] > kLogZero ? __builtin_bit_cast(unsigned, vl[i]) : 0xffffffffu);
+      bmax = fmaxf(bmax, vb[i]);
+      // all values are <= 0, so the smallest bit pattern is the largest value.  (A target sequence that names class 0 itself
+      // puts a "blank" on an odd position: it folds with the blanks, as the reference's per-class loop would have it.)
+      if (cls[i] == 0) bmax = fmaxf(bmax, vl[i]);
+      else if (vl[i] > kLogZero) atomicMin(&mxb[cls[i]], __builtin_bit_cast(unsigned, vl[i]));
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS ops execute in order; this only pins the compiler's schedule
     bmax = wave_max(bmax);
     float bsum = 0.f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const float mk = __builtin_bit_cast(float, mxb[cls[i]]);
-      const float eb = vb[i] > kLogZero ? __expf(vb[i] - bmax) : 0.f;
-      const float el = vl[i] > kLogZero ? __expf(vl[i] - (isb[i] ? bmax : mk)) : 0.f;
-      bsum += eb + (isb[i] ? el : 0.f);
-      atomicAdd(&sm[cls[i]], isb[i] ? 0.f : el);
+      if (vb[i] > kLogZero) bsum += __expf(vb[i] - bmax);
+      if (vl[i] > kLogZero) {
+        if (cls[i] == 0) bsum += __expf(vl[i] - bmax);
+        else atomicAdd(&sm[cls[i]], __expf(vl[i] - __builtin_bit_cast(float, mxb[cls[i]])));
+      }
     }
     bsum = wave_sum(bsum);
     __builtin_amdgcn_wave_barrier();
@@ -430,14 +429,15 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
   check_launch("ctc_alpha_beta");
 }
 
-void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
+void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, int Lmax, const int* lens,
                     const int* lablens, const int* labx, const float* alpha, const float* beta,
                     const float* pzx, float* diff, int ldd) {
   const int rows = T * S;
   if (rows <= 0) return;
-  const size_t smem = (size_t)4 * 2 * (K + 1) * sizeof(float);   // per wave: K classes + the dump slot, maxima and sums
-  // frames per wave: 8 where that still leaves >= 8192 waves (32 per CU), fewer for small minibatches
-  const int frames = std::max(1, std::min(8, rows / 8192));
+  const size_t smem = (size_t)4 * 2 * K * sizeof(float);
+  // frames per wave: 8 where that still leaves >= 16384 waves (64 per CU: measured, cfg5 0.50 -> 0.37 ms), one for small
+  // minibatches (cfg2's 32 000 frames: 3 per wave measured slower than 1)
+  const int frames = std::max(1, std::min(8, rows / 16384));
   if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
     EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (8 K floats of LDS per workgroup exceed 160 KB)");
   }
@@ -449,11 +449,16 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
     hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
                        beta, pzx, diff, ldd, frames);
   };
-  static size_t granted[3] = {0, 0, 0};
+  static size_t granted[6] = {0, 0, 0, 0, 0, 0};
   EESEN_REQUIRE(Lpad <= 1024, EESEN_ERR_INVALID, "ctc: expanded label length above 1024");
-  if (Lpad <= 256) launch(ctc_error_diff_kernel<4>, granted[0]);
-  else if (Lpad <= 512) launch(ctc_error_diff_kernel<8>, granted[1]);
-  else launch(ctc_error_diff_kernel<16>, granted[2]);
+  // positions per lane: the smallest even count that covers the longest lattice of the minibatch (Lmax = max 2 U_s + 1 <= Lpad)
+  EESEN_REQUIRE(Lmax >= 1 && Lmax <= Lpad, EESEN_ERR_INVALID, "ctc: lattice length outside the padded row");
+  if (Lmax <= 128) launch(ctc_error_diff_kernel<2>, granted[0]);
+  else if (Lmax <= 256) launch(ctc_error_diff_kernel<4>, granted[1]);
+  else if (Lmax <= 384) launch(ctc_error_diff_kernel<6>, granted[2]);
+  else if (Lmax <= 512) launch(ctc_error_diff_kernel<8>, granted[3]);
+  else if (Lmax <= 768) launch(ctc_error_diff_kernel<12>, granted[4]);
+  else launch(ctc_error_diff_kernel<16>, granted[5]);
   check_launch("ctc_error_diff");
 }
 

@@ -145,7 +145,7 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   if (acc) { timer.end(st, sp0); sp1 = timer.begin(st, 1); } else EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
   ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p);  // :136-153
   if (acc) { timer.end(st, sp1); sp2 = timer.begin(st, 2); } else EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
-  ctc_error_diff(st, net_out, ld, T, S, K, Lpad, lens_dd, ll_d, labx_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
+  ctc_error_diff(st, net_out, ld, T, S, K, Lpad, Lprime, lens_dd, ll_d, labx_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
   if (acc) timer.end(st, sp2); else EESEN_HIP_CHECK(hipEventRecord(ev[3], st));
 
   // ln p(z|x) per sequence (ctc-loss.cc:146-153 reads it element by element): back through a pinned slot.  A caller that wants

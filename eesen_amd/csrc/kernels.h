@@ -129,7 +129,7 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
                     const int* lablens, float* alpha, float* beta, float* pzx);
 // diff[t*S+s][k] = y*rowsum(e) - gamma ... (error kernel + softmax Jacobian, ctc-loss.cc:156-168)
 // labx [S x Lpad]: the expanded labels (blank 0 at even positions), lablens [S] = 2 U_s + 1
-void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, const int* lens,
+void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, int Lmax, const int* lens,
                     const int* lablens, const int* labx, const float* alpha, const float* beta,
                     const float* pzx, float* diff, int ldd);
 // in place: m = (apply_log ? log m : m) - prior_scale * log_prior[col]; log_prior may be null (net-output-extract.cc:103-112)
