@@ -75,11 +75,19 @@ struct LstmLayerDev {
   // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns; set by the host from the measured
   // increment flight of the device (handoff_flight_ns)
   int poll_delay = 0;
+  // progress milestone of the forward persistent kernel (null: none): when every workgroup of a (direction, sequence tile) group has
+  // published step `milestone_step`, the group's first workgroup adds 1 to *milestone -- the host starts the next layer's input
+  // GEMM for the frames both directions have finished by then while the recurrence is still running (net.cpp)
+  unsigned* milestone = nullptr;
+  int milestone_step = 0;
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
 };
 float handoff_flight_ns();
+// one wave that returns once *word >= target (bounded; also returns when the recurrence kernels' error word is raised): puts a
+// stream behind a milestone of a kernel that is still running on another stream
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, const unsigned* err);
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
 // One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.

@@ -157,6 +157,15 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
   if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
 }
 
+__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, const unsigned* err) {
+  if (threadIdx.x != 0) return;
+  for (int spins = 0; spins < (1 << 22); ++spins) {   // ~1 us per poll: bounded at seconds
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+    if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
 #define EESEN_STAMP(i) do { if (trace && tid == 0 && blockIdx.x == 0 && step < 127) \
     trace[step * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -231,6 +240,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
+      if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)   // the whole group has published step milestone_step
+        __hip_atomic_fetch_add(L.milestone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned ybase = (unsigned)(((size_t)(tp + 1) * S * ldY + dir * H) * 4);  // < 2 GB, checked on the host
       float a[MT][CPW][8];
       if constexpr (XCHG) {
@@ -1540,6 +1551,11 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
 // group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
 // 0 = the kernel does not apply (narrow layers take the 4 x 32
 // tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, const unsigned* err) {
+  hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err);
+  check_launch("wait_for_word");
+}
+
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;

@@ -614,6 +614,7 @@ void Net::forward_pass() {
   info_fwd_persistent = info_lstm_layers = 0;
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
+  int mid_r0 = 0, mid_r1 = 0;   // rows [mid_r0, mid_r1) of the current layer's input GEMM already ran on the side stream (see plan_mid)
   for (Layer& L : layers) {
     if (L.is_lstm()) {
       const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
@@ -640,6 +641,16 @@ void Net::forward_pass() {
         }
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
         g_gated = false;
+      } else if (mid_r1 > mid_r0) {  // the middle frames are done (or under way) on the side stream: the two ends here
+        const int ti_ = timer.begin(st, 0);
+        const int parts[2][2] = {{0, mid_r0}, {mid_r1, rows}};
+        for (const auto& pr : parts)
+          if (pr[1] > pr[0])
+            gemm_f32(st, true, true, pr[1] - pr[0], ldG, L.din, 1.f, x + (size_t)pr[0] * ldx, ldx, params.p + L.p_off + L.off_wx, pad4(L.din),
+                     0.f, L.G.p + (size_t)pr[0] * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
+        timer.end(st, ti_);
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
+        mid_r0 = mid_r1 = 0;
       } else {
         const int ti_ = timer.begin(st, 0);
         gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
@@ -657,9 +668,28 @@ void Net::forward_pass() {
       const bool plan_gate = persistent && overlap && gate_fwd && !fwd_bf16 && !L.cur_fwd_drop && gate_units <= 8 && nxt && nxt->is_lstm() && T >= 2 && rows >= 128 &&
                              lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1 &&
                              (nxt->ndir * 4 * nxt->H) % 128 == 0 && ldY % 16 == 0 && nd * nz * kShards <= 64;
+      // The MIDDLE of the next layer's input GEMM under the END of this layer's recurrence.  A bidirectional layer has finished frame
+      // t when its forward chain has passed step t and its backward chain step T-1-t: once both have published step m = 3T/4, the
+      // frames [T-1-m, m] -- half of them -- are final, and the next layer's input GEMM for those rows runs on the side stream
+      // while the last quarter of the recurrence (latency-bound: the matrix pipes are ~28 % busy) is still stepping.  The kernel
+      // reports the milestone through a word in HBM (LstmLayerDev::milestone); a one-wave kernel on the side stream waits for it
+      // (wait_for_word), and the main stream sets the word itself behind the recurrence, so the side stream is released even if
+      // the kernel never reports (per-step fallback, a kernel that gave up).  Narrow tiles only: beside the wide tiles (H = 1024)
+      // no GEMM workgroup fits on a CU (section 9), the early part would only queue.  Same GEMM, same rows: results are
+      // bit-identical to the one-launch GEMM (every output row is its own dot products).
+      const int mile_step = (3 * T) / 4;
+      const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
+                            T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
       { const int ti_ = timer.begin(st, 1);
       LstmLayerDev v = lstm_view(*this, L);
       v.poll_delay = delay_fwd;
+      if (plan_mid) {
+        mile.reserve(32);
+        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, sizeof(unsigned), st));
+        EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
+        v.milestone = mile.p;
+        v.milestone_step = mile_step;
+      }
       const bool pers = persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p,
                                                           plan_gate ? ev_gate_reset : nullptr);
       if (!pers)
@@ -680,6 +710,21 @@ void Net::forward_pass() {
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
         g_gated = true;
+      }
+      if (plan_mid) {
+        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p), 0x7fffffff, 1, st));   // released at the latest here
+        const int ldG2 = nxt->ndir * 4 * nxt->H;
+        nxt->G.reserve((size_t)rows * ldG2);
+        mid_r0 = (T - 1 - mile_step) * S;
+        mid_r1 = (mile_step + 1) * S;
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+        wait_for_word(st2, mile.p, (unsigned)(nd * nz), ctl.p + kCtlWords - 1);
+        const int tj_ = timer.begin(st2, 0);
+        gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
+                 params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,
+                 params.p + nxt->p_off + nxt->off_bias, nullptr, 0, 0, fwd_bf16);
+        timer.end(st2, tj_);
+        EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
       } }
       if (L.cur_fwd_drop)  // :414-417: the layer's output, not its recurrent state, is masked
         mul_elements(st, L.Y.p + (size_t)S * ldY, ldY, L.fmask.p, ldY, L.Yd.p, ldY, rows, ldY);

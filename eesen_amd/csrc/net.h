@@ -106,7 +106,8 @@ struct Net {
   hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;
-  hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated input GEMM of the next layer (forward)
+  hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated / early input GEMM of the next layer (forward)
+  DevBuf<unsigned> mile;      // progress milestone of the running forward recurrence (LstmLayerDev::milestone)
   bool gate_fwd = true;
   bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1): forward GEMMs on bf16-rounded operands (BASELINE config 4)
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word

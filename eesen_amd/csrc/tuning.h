@@ -22,6 +22,7 @@
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
+//   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part)
 //   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 split / 32 f32)
 //   ---- diagnostics -------------------------------------------------------------------------------------------------------
 //   EESEN_TRACE             0        1: in-kernel s_memtime timeline of workgroup 0, printed when the Net is destroyed
@@ -41,7 +42,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -55,6 +56,7 @@ struct Tuning {
     t.persistent = num("EESEN_PERSISTENT", 1);
     t.overlap = num("EESEN_OVERLAP", -1);
     t.gate_fwd = num("EESEN_GATE_FWD", -1);
+    t.fwd_mid = num("EESEN_FWD_MID", 1);
     t.side_lds_kb = num("EESEN_SIDE_LDS_KB", -1);
     t.spin_limit_set = getenv("EESEN_SPIN_LIMIT") != nullptr;
     t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
