@@ -75,9 +75,10 @@ struct LstmLayerDev {
   // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns; set by the host from the measured
   // increment flight of the device (handoff_flight_ns)
   int poll_delay = 0;
-  // progress milestone of the forward persistent kernel (null: none): when every workgroup of a (direction, sequence tile) group has
-  // published step `milestone_step`, the group's first workgroup adds 1 to *milestone -- the host starts the next layer's input
-  // GEMM for the frames both directions have finished by then while the recurrence is still running (net.cpp)
+  // progress milestone of the narrow forward persistent kernel (null: none; two words): when every workgroup of a (direction, sequence
+  // tile) group has published step `milestone_step`, the group's first workgroup adds 1 to milestone[0], and the last group sets
+  // milestone[1] -- the host starts the GEMM that consumes this pass's rows for the frames both directions have finished by then
+  // while the recurrence is still running (net.cpp: "the middle first")
   unsigned* milestone = nullptr;
   int milestone_step = 0;
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and

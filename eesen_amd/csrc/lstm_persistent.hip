@@ -166,6 +166,13 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
   }
 }
 
+// LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published
+// step milestone_step; the last of them raises the flag word the host's side stream waits for
+__device__ __forceinline__ void report_milestone(unsigned* ms, unsigned ngroups) {
+  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups)
+    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
 #define EESEN_STAMP(i) do { if (trace && tid == 0 && blockIdx.x == 0 && step < 127) \
     trace[step * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
       if (!s_go) return;
       EESEN_STAMP(1);
       if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)   // the whole group has published step milestone_step
-        __hip_atomic_fetch_add(L.milestone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        report_milestone(L.milestone, (unsigned)(R.ndir * R.nz));
       const unsigned ybase = (unsigned)(((size_t)(tp + 1) * S * ldY + dir * H) * 4);  // < 2 GB, checked on the host
       float a[MT][CPW][8];
       if constexpr (XCHG) {

@@ -677,7 +677,7 @@ void Net::forward_pass() {
       // the kernel never reports (per-step fallback, a kernel that gave up).  Narrow tiles only: beside the wide tiles (H = 1024)
       // no GEMM workgroup fits on a CU (section 9), the early part would only queue.  Same GEMM, same rows: results are
       // bit-identical to the one-launch GEMM (every output row is its own dot products).
-      const int mile_step = (3 * T) / 4;
+      const int mile_step = (3 * T) / 4;   // measured at cfg2, same box: 60 % 39.4, 67 % 38.7, 75 % 38.2, 82 % 38.85, 88 % 38.8, off 39.0 ms
       const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
                             T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
       { const int ti_ = timer.begin(st, 1);
@@ -685,7 +685,7 @@ void Net::forward_pass() {
       v.poll_delay = delay_fwd;
       if (plan_mid) {
         mile.reserve(32);
-        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, sizeof(unsigned), st));
+        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
         v.milestone = mile.p;
         v.milestone_step = mile_step;
@@ -712,13 +712,13 @@ void Net::forward_pass() {
         g_gated = true;
       }
       if (plan_mid) {
-        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p), 0x7fffffff, 1, st));   // released at the latest here
+        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));   // released at the latest here
         const int ldG2 = nxt->ndir * 4 * nxt->H;
         nxt->G.reserve((size_t)rows * ldG2);
         mid_r0 = (T - 1 - mile_step) * S;
         mid_r1 = (mile_step + 1) * S;
         EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
-        wait_for_word(st2, mile.p, (unsigned)(nd * nz), ctl.p + kCtlWords - 1);
+        wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1);
         const int tj_ = timer.begin(st2, 0);
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,
@@ -856,6 +856,9 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_grad[dg_slot], 0));
         side_pending[dg_slot] = false;
       }
+      // ("The middle first" of the forward pass does not pay here: with the input-gradient GEMM's middle rows on a third stream from
+      // step 3T/4 of this recurrence, beside the weight-gradient GEMMs already co-running on the side stream, the cfg2 step went
+      // 38.4 -> 39.4-39.5 ms on the same box -- the recurrence loses more to the third contender than the GEMM's head start gains.)
       { const int ti_ = timer.begin(st, 3);
       if (persistent && lstm_bwd_persistent(st, v, d, ld_d, DGl, ctl.p + kCtlHalf, ctl.p + kCtlWords - 1, spin_limit, trace.p ? trace.p + 640 : nullptr))
         ++info_bwd_persistent;
