@@ -54,6 +54,22 @@ def flops_per_frame(cfg) -> float:
     return total
 
 
+def pipe_bound(cfg, split_gemm: bool = True) -> dict:
+    """The step's flops by matrix pipe and the time the two pipes need for them at their peaks.  Per layer and direction the
+    recurrence kernels execute the forward and the backward recurrent product (16 H^2 per frame) on the fp32 pipe
+    (v_mfma_f32_16x16x4_f32 / 4x4x1); everything else is GEMM: on the bf16 pipe as six bf16 products per fp32 product (the exact
+    3-way split), or on the fp32 pipe in EESEN_GEMM_MODE=f32.  frac = bound / measured time is <= 1 by construction."""
+    nd = 2 if cfg["kind"].startswith("BiLstm") else 1
+    rec = float(cfg["layers"]) * nd * 16.0 * cfg["H"] * cfg["H"]
+    gemm = flops_per_frame(cfg) - rec
+    if split_gemm:
+        sec = rec / (PEAK_F32_MFMA_TFLOPS * 1e12) + 6.0 * gemm / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    else:
+        sec = (rec + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    return {"f32_pipe_flops_per_frame": rec, "gemm_flops_per_frame_fp32_equivalent": gemm,
+            "bf16_pipe_executed_flops_per_frame": 6.0 * gemm if split_gemm else 0.0, "bound_us_per_frame": 1e6 * sec}
+
+
 def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
     """The reference's CPU path (oracle/_ref: src/net + src/cpucompute compiled unmodified; its CUDA-only CTC
     kernels run through the CPU shim) or, when that library is absent, the C port; same model, a bounded
@@ -207,7 +223,8 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
                         f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "frames_per_s": frames / dt,
             "dtype": "bf16-fwd/f32" if forward_bf16 else "f32",
-            "whole_step_tflops": fpf * frames / dt / 1e12, "whole_step_frac_of_f32_mfma_peak": fpf * frames / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
+            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg)["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
 
@@ -261,7 +278,7 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120) -> dict:
     return {"workload": f"4x320 BiLSTM, D=120, K=46, --num-sequence {num_sequence} --frame-num-limit 25000, {n_utts} length-sorted utterances "
                         f"of {int(lens.min())}-{int(lens.max())} frames in {len(groups)} minibatches (S = {min(g.S for g in groups)}-{max(g.S for g in groups)})",
             "minibatches": len(groups), "ms_per_minibatch": 1e3 * dt / len(groups), "padded_frames_per_s": padded / dt, "real_frames_per_s": real / dt,
-            "whole_step_tflops": fpf * padded / dt / 1e12, "flops_per_frame": fpf,
+            "whole_step_tflops_fp32_equivalent": fpf * padded / dt / 1e12, "flops_per_frame": fpf,
             "persistent_layer_passes": {"fwd": pers[0], "bwd": pers[1], "of": pers[2]}, "recoveries": net.recoveries}
 
 
@@ -458,6 +475,7 @@ def main():
         K = args.steps
         value = padded * K / dt
         fpf = flops_per_frame(cfg)
+        pb = pipe_bound(cfg, os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"))
         nd = 2 if cfg["kind"].startswith("BiLstm") else 1
         H, S, T, nl = cfg["H"], batch.S, batch.T, cfg["layers"]
         # per-launch algorithmic work of the three kernels that carry the step (DESIGN.md "kernels")
@@ -529,9 +547,9 @@ def main():
                              "of the write-through stores), DESIGN.md sections 4, 9 and 10 -- and is measured while the launch shares the "
                              "chip with the overlapped GEMMs (`alone`: the launch that does not); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES over "
                              "the kernel's SIMD-cycles from the committed PMC pass; whole_step is the step's total FLOPs over its time"),
-                    "whole_step": {"achieved": fpf * value / world / 1e12, "frac": fpf * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                   "flops_per_frame": fpf,
-                                   "note": "fp32-equivalent FLOPs over the fp32-MFMA peak; 74 % of them execute on the bf16 pipe (split GEMMs), see config.f32_mfma_gemm_only for the all-f32 step"},
+                    "whole_step": {"achieved": fpf * value / world / 1e12, "unit": "TFLOP/s fp32-equivalent", "flops_per_frame": fpf,
+                                   **pb, "frac": pb["bound_us_per_frame"] * 1e-6 * value / world,
+                                   "note": "frac = (recurrence flops / fp32-MFMA peak + 6 x GEMM flops / bf16-MFMA peak) / measured time: the step against BOTH matrix pipes at their peaks, <= 1 by construction (the GEMMs run as six bf16 products per fp32 product); see config.f32_mfma_gemm_only for the all-f32 step"},
                     "other_kernels": {n: ({"achieved_fp32_equivalent": v["achieved"], "executed": v["executed"], "pipe": v["pipe"], "peak": v["peak"],
                                            "frac": v["frac"], "avg_launch_us": v["avg_us"]})
                                       for n, v in kern.items() if n != dom}}
