@@ -157,13 +157,18 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
   if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
 }
 
-__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, const unsigned* err) {
+// (unsigned* err: this kernel may RAISE the error word too)
+__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err) {
   if (threadIdx.x != 0) return;
-  for (int spins = 0; spins < (1 << 22); ++spins) {   // ~1 us per poll: bounded at seconds
+  // ~1 us per poll.  The producer's stream raises the word itself behind the kernel this waits on, so the bound (half an hour)
+  // is only there so that a wedged device cannot hold a wave for ever -- and a wait that does give up must not let the consumer
+  // behind it pass for a success: it raises the error word, and the step is handled like a recurrence kernel that gave up.
+  for (unsigned spins = 0; spins < (1u << 31); ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
     if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     __builtin_amdgcn_s_sleep(32);
   }
+  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published
@@ -1558,7 +1563,7 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
 // group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
 // 0 = the kernel does not apply (narrow layers take the 4 x 32
 // tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
-void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, const unsigned* err) {
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err) {
   hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err);
   check_launch("wait_for_word");
 }

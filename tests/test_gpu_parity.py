@@ -347,6 +347,33 @@ def test_persistent_recurrence_matches_step_kernels(gpu, cfg_name, over, monkeyp
     assert rel_err(res["1"][1], res["0"][1]) < 1e-6
 
 
+@pytest.mark.parametrize("over", [dict(T=200, S=16, H=64, layers=3), dict(T=130, S=20, H=96, layers=2, min_frac=0.3)])
+def test_middle_first_input_gemm_is_bit_identical(gpu, over, monkeypatch):
+    """net.cpp "the middle first": the middle rows of the next layer's input GEMM start on the side stream when both chains of the
+    running forward recurrence have published step 3T/4 (in-kernel milestone, wait_for_word), the two ends follow.  Shapes where
+    the split exists (whole 256-row tiles on both sides of the middle): every run bit-identical to the one-launch GEMM
+    (EESEN_FWD_MID=0) -- a GEMM that started before its rows were final would show up here as run-to-run differences."""
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config("small_bi"); cfg.update(over)
+    assert ((cfg["T"] - 1 - 3 * cfg["T"] // 4) * cfg["S"] + 255) // 256 * 256 < (3 * cfg["T"] // 4 + 1) * cfg["S"] // 256 * 256
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EESEN_FWD_MID", mode)
+        net = Net.from_layers(layers); ctc = Ctc()
+        runs = []
+        for it in range(8):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            runs.append(out.numpy())
+        info = net.RecurrenceInfo()
+        assert info["fwd_persistent"] == info["lstm_layers"] == cfg["layers"]
+        outs[mode] = runs
+    for r in outs["0"] + outs["1"]:
+        assert np.array_equal(r, outs["0"][0])
+
+
 @pytest.mark.parametrize("rule", ["Adagrad", "RMSProp"])
 def test_adaptive_update_rules(gpu, rule, tmp_path):
     """--opt-algorithm Adagrad / RMSProp (trainable-layer.h:65-114): three steps against the oracle, then the
