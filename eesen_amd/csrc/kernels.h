@@ -86,6 +86,9 @@ struct LstmLayerDev {
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
 };
 float handoff_flight_ns();
+// one wave that returns once *word >= target (or when the recurrence kernels' error word is raised; it raises that word itself
+// if it ever gives up): puts a stream behind a milestone of a kernel that is still running on another stream
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err);
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
 // One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.

@@ -157,12 +157,25 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
   if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
 }
 
+// (unsigned* err: this kernel may RAISE the error word too)
+__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err) {
+  if (threadIdx.x != 0) return;
+  // ~1 us per poll.  The producer's stream raises the word itself behind the kernel this waits on, so the bound (half an hour)
+  // is only there so that a wedged device cannot hold a wave for ever -- and a wait that does give up must not let the consumer
+  // behind it pass for a success: it raises the error word, and the step is handled like a recurrence kernel that gave up.
+  for (unsigned spins = 0; spins < (1u << 31); ++spins) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+    if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published
-// step milestone_step; the last of them raises the flag word the host's side stream waits for (signal memory, host-coherent:
-// system scope)
+// step milestone_step; the last of them raises the flag word the host's side stream waits for
 __device__ __forceinline__ void report_milestone(unsigned* ms, unsigned ngroups) {
-  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u == ngroups)
-    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups)
+    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
@@ -1550,6 +1563,11 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
 // group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
 // 0 = the kernel does not apply (narrow layers take the 4 x 32
 // tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err) {
+  hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err);
+  check_launch("wait_for_word");
+}
+
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;

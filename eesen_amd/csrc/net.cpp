@@ -193,7 +193,6 @@ Net::~Net() {
                        pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
       }
   }
-  if (mile) (void)hipFree(mile);
   if (lens_pin) (void)hipHostFree(lens_pin);
   if (err_pin) (void)hipHostFree(err_pin);
   if (live_pin) (void)hipHostFree(live_pin);
@@ -673,47 +672,22 @@ void Net::forward_pass() {
       // t when its forward chain has passed step t and its backward chain step T-1-t: once both have published step m = 3T/4, the
       // frames [T-1-m, m] -- half of them -- are final, and the next layer's input GEMM for those rows runs on the side stream
       // while the last quarter of the recurrence (latency-bound: the matrix pipes are ~28 % busy) is still stepping.  The kernel
-      // reports the milestone through two words of SIGNAL memory (LstmLayerDev::milestone: a count of reporting groups and a flag);
-      // the side stream's COMMAND PROCESSOR waits for the flag (hipStreamWaitValue64 on an hsa signal: no shader spins, so a
-      // tool that serialises kernels -- rocprofv3 --pmc -- cannot dead-lock a waiting kernel against the recurrence it waits
-      // for), and the main stream raises the flag itself behind the recurrence, so the side stream is released even if the
-      // kernel never reports (per-step fallback, a kernel that gave up).  Narrow tiles only: beside the wide tiles (H = 1024)
+      // reports the milestone through a word in HBM (LstmLayerDev::milestone); a one-wave kernel on the side stream waits for it
+      // (wait_for_word), and the main stream sets the word itself behind the recurrence, so the side stream is released even if
+      // the kernel never reports (per-step fallback, a kernel that gave up).  Narrow tiles only: beside the wide tiles (H = 1024)
       // no GEMM workgroup fits on a CU (section 9), the early part would only queue.  Same GEMM, same rows: results are
       // bit-identical to the one-launch GEMM (every output row is its own dot products).
       const int mile_step = (3 * T) / 4;   // measured at cfg2, same box: 60 % 39.4, 67 % 38.7, 75 % 38.2, 82 % 38.85, 88 % 38.8, off 39.0 ms
-      bool plan_mid = persistent && overlap && tn.fwd_mid && mile_ok != 0 && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
-                      T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
-      if (plan_mid && mile_ok < 0) {   // first use: is there a stream wait on this device, and signal memory for it?
-        int can = 0;
-        void* q = nullptr;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
-            hipExtMallocWithFlags(&q, 8, hipMallocSignalMemory) == hipSuccess && q) {
-          mile = static_cast<unsigned*>(q);
-          mile_ok = 1;
-        } else {
-          (void)hipGetLastError();
-          mile_ok = 0;
-          plan_mid = false;
-        }
-      }
-      if (plan_mid) {  // reset, then put the side stream behind the flag (high word of the 8 bytes) BEFORE anything else is committed
-        constexpr uint64_t kFlag = 1ull << 32;
-        if (hipStreamWriteValue64(st, mile, 0, 0) != hipSuccess) { (void)hipGetLastError(); mile_ok = 0; plan_mid = false; }
-        if (plan_mid) {
-          EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
-          EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
-          if (hipStreamWaitValue64(st2, mile, kFlag, hipStreamWaitValueGte, 0xFFFFFFFF00000000ull) != hipSuccess) {
-            (void)hipGetLastError();
-            mile_ok = 0;   // (the side stream holds a harmless event wait)
-            plan_mid = false;
-          }
-        }
-      }
+      const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
+                            T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
       { const int ti_ = timer.begin(st, 1);
       LstmLayerDev v = lstm_view(*this, L);
       v.poll_delay = delay_fwd;
       if (plan_mid) {
-        v.milestone = mile;
+        mile.reserve(32);
+        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
+        EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
+        v.milestone = mile.p;
         v.milestone_step = mile_step;
       }
       const bool pers = persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p,
@@ -738,7 +712,7 @@ void Net::forward_pass() {
         g_gated = true;
       }
       if (plan_mid) {
-        EESEN_HIP_CHECK(hipStreamWriteValue64(st, mile, 1ull << 32, 0));   // released at the latest here
+        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));   // released at the latest here
         const int ldG2 = nxt->ndir * 4 * nxt->H;
         nxt->G.reserve((size_t)rows * ldG2);
         // whole 256-row tiles: the two ends (main stream, critical path) keep the GEMM's 256 x 256 flavour; the middle part takes the
@@ -750,6 +724,8 @@ void Net::forward_pass() {
       }
       if (plan_mid && mid_r1 > mid_r0) {
         const int ldG2 = nxt->ndir * 4 * nxt->H;
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+        wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1);
         const int tj_ = timer.begin(st2, 0);
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,

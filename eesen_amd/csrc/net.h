@@ -107,10 +107,7 @@ struct Net {
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;
   hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated / early input GEMM of the next layer (forward)
-  // progress milestone of the running forward recurrence (LstmLayerDev::milestone): 8 bytes of SIGNAL memory, waited for by the
-  // side stream's command processor (hipStreamWaitValue64), never by a spinning kernel; mile_ok: -1 not tried, 0 unsupported, 1 in use
-  unsigned* mile = nullptr;
-  int mile_ok = -1;
+  DevBuf<unsigned> mile;      // progress milestone of the running forward recurrence (LstmLayerDev::milestone)
   bool gate_fwd = true;
   bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1): forward GEMMs on bf16-rounded operands (BASELINE config 4)
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
