@@ -160,10 +160,14 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
 // (unsigned* err: this kernel may RAISE the error word too)
 __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err) {
   if (threadIdx.x != 0) return;
-  // ~1 us per poll.  The producer's stream raises the word itself behind the kernel this waits on, so the bound (half an hour)
-  // is only there so that a wedged device cannot hold a wave for ever -- and a wait that does give up must not let the consumer
-  // behind it pass for a success: it raises the error word, and the step is handled like a recurrence kernel that gave up.
-  for (unsigned spins = 0; spins < (1u << 31); ++spins) {
+  // ~1 us per poll, bounded at ~2 s: two orders of magnitude above any recurrence this waits on (the producer's stream raises the
+  // word itself behind that kernel).  A wait that does give up must not let the consumer behind it pass for a success: it raises
+  // the error word, and the step is handled like a recurrence kernel that gave up (re-run on the per-step kernels).  The one known
+  // way to get there: a tool that lets only ONE kernel run at a time (rocprofv3 --pmc) and picks this one before the
+  // recurrence -- collect counters with EESEN_FWD_MID=0 (scripts/collect_profiles.sh does).  Tried instead: a command-processor
+  // wait (hipStreamWaitValue64 on signal memory), which cannot dead-lock -- it works, and costs 2.2 ms per cfg2 step (38.5 ->
+  // 40.7-40.9 ms) where this kernel gains 0.85.
+  for (unsigned spins = 0; spins < (1u << 21); ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
     if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     __builtin_amdgcn_s_sleep(32);

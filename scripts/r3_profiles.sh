@@ -5,6 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rm -rf $O/prof_${TAG}_cfg4
 rocprofv3 --kernel-trace -d $O/prof_${TAG}_cfg4 -o ${TAG}cfg4 -- python $R/bench.py --config cfg4 --steps 2 --warmup 1 --main-only > $O/prof_${TAG}_cfg4.log 2>&1
+export EESEN_FWD_MID=0   # (counter passes: see collect_profiles.sh)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $O/pmc_${TAG}_cfg4_SQ -o pmc -- python $R/bench.py --config cfg4 --steps 1 --warmup 1 --main-only > $O/pmc_${TAG}_cfg4_SQ.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${TAG}_cfg4_$c -o pmc -- python $R/bench.py --config cfg4 --steps 1 --warmup 1 --main-only > $O/pmc_${TAG}_cfg4_$c.log 2>&1
