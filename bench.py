@@ -495,8 +495,13 @@ def main():
         # the main-stream input->gates GEMMs take the 256 x 256-tile flavour when the shape holds >= 16 whole big tiles (gemm.hip)
         # (layer 1's K = 40 is not a multiple of 16 and takes the 128 x 128 flavour; the name is that of the layers that dominate)
         big = not bf16_fwd and (T * S) % 256 == 0 and (nd * 4 * H) % 256 == 0 and ((T * S) // 256) * ((nd * 4 * H) // 256) >= 16
+        # "the middle first" (net.cpp): with the persistent kernels every upper layer's input GEMM is three launches -- the middle half
+        # of the rows on the 128 x 128 flavour under the end of the recurrence below, the two ends on the main stream -- and the
+        # figure below is their summed time per layer (the middle part's duration is that of a kernel sharing the chip)
+        mid_first = persistent and nd == 2 and nl > 1 and H <= 512 and os.environ.get("EESEN_FWD_MID", "1") != "0" and os.environ.get("EESEN_OVERLAP", "1") != "0"
         gemm_name = ("gemm_f32_mfma_kernel" if not split and not bf16_fwd else
-                     ("gemm_f32_split_bf16_big_kernel" if big else "gemm_f32_split_bf16_kernel")) + "(input->gates)"
+                     ("gemm_f32_split_bf16_big_kernel" if big else "gemm_f32_split_bf16_kernel")) + \
+                    ("(input->gates: 2 ends + gemm_f32_split_bf16_kernel middle under the recurrence)" if mid_first and split and not bf16_fwd else "(input->gates)")
         bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn
         kern = {
             "lstm_fwd_" + kn: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32"),

@@ -206,3 +206,21 @@ def test_library_tcp_rendezvous_hands_the_id_to_every_rank(world):
     for p in procs:
         p.join(timeout=30); assert p.exitcode == 0
     assert got == [(r, 0, True) for r in range(world)]
+
+
+def test_bench_pipe_bound_keeps_every_fraction_at_or_below_one():
+    """bench.py's whole-step roofline: recurrent products on the fp32 matrix pipe, every other flop as six bf16 products on the
+    bf16 pipe, both at peak (a driver record must never carry a fraction above 1).  The bound is a sum of two times,
+    so no measured step can beat it; the flops it splits must add up to SURVEY.md section 8(d)'s per-frame figure."""
+    import bench
+    from eesen_amd import synth
+    for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
+        cfg = synth.config(name)
+        pb = bench.pipe_bound(cfg)
+        assert pb["f32_pipe_flops_per_frame"] + pb["gemm_flops_per_frame_fp32_equivalent"] == pytest.approx(bench.flops_per_frame(cfg))
+        assert pb["bf16_pipe_executed_flops_per_frame"] == pytest.approx(6 * pb["gemm_flops_per_frame_fp32_equivalent"])
+        lower = pb["f32_pipe_flops_per_frame"] / (bench.PEAK_F32_MFMA_TFLOPS * 1e12) + \
+            pb["bf16_pipe_executed_flops_per_frame"] / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
+        assert pb["bound_us_per_frame"] == pytest.approx(1e6 * lower)
+        # the all-f32 arithmetic (EESEN_GEMM_MODE=f32) is bounded by the fp32 pipe alone, and more tightly
+        assert bench.pipe_bound(cfg, split_gemm=False)["bound_us_per_frame"] > pb["bound_us_per_frame"]
