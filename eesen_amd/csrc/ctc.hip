@@ -34,7 +34,7 @@ __device__ __forceinline__ float ExpA(float a) {
   if (a >= kExpLimit) return kFltMax;
   return expf(a);
 }
-__device__ __forceinline__ float LogAPlusB(float a, float b) {
+[[maybe_unused]] __device__ __forceinline__ float LogAPlusB(float a, float b) {   // (the reference helper the fast form below is held against)
   if (b < a) return AddAB(a, logf(1.f + ExpA(SubAB(b, a))));
   return AddAB(b, logf(1.f + ExpA(SubAB(a, b))));
 }
