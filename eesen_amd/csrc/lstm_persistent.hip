@@ -162,7 +162,8 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
   if (threadIdx.x != 0) return;
   // ~1 us per poll, bounded at ~2 s: two orders of magnitude above any recurrence this waits on (the producer's stream raises the
   // word itself behind that kernel).  A wait that does give up must not let the consumer behind it pass for a success: it raises
-  // the error word, and the step is handled like a recurrence kernel that gave up (re-run on the per-step kernels).  The one known
+  // the error word (value 2), the step is dropped like one whose recurrence kernel gave up, and the host goes on WITHOUT the early
+  // GEMM (the persistent kernels stay).  The one known
   // way to get there: a tool that lets only ONE kernel run at a time (rocprofv3 --pmc) and picks this one before the
   // recurrence -- collect counters with EESEN_FWD_MID=0 (scripts/collect_profiles.sh does).  Tried instead: a command-processor
   // wait (hipStreamWaitValue64 on signal memory), which cannot dead-lock -- it works, and costs 2.2 ms per cfg2 step (38.5 ->
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
     if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     __builtin_amdgcn_s_sleep(32);
   }
-  __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2: "the milestone wait gave up" (net.cpp: check_device_error)
 }
 
 // LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published

@@ -232,16 +232,26 @@ void Net::check_device_error(bool consumer) {
   if (!e) { steps_since_clean = 0; return; }
   EESEN_HIP_CHECK(hipStreamSynchronize(st));
   EESEN_HIP_CHECK(hipMemset(ctl.p + kCtlWords - 1, 0, sizeof(unsigned)));
-  persistent = 0; gate_fwd = false; overlap = false;
+  // 2: only the side stream's wait for a forward milestone gave up (wait_for_word: something lets one kernel run at a time and ran the
+  // waiter before the recurrence it waits for -- a counter-collecting profiler).  The early GEMM may have read unfinished rows:
+  // the step is lost like any other, but the cure is to stop starting GEMMs early, not to give up the persistent kernels.
+  const bool only_waiter = e == 2 && tn.fwd_mid;
+  if (only_waiter) tn.fwd_mid = 0;
+  else { persistent = 0; gate_fwd = false; overlap = false; }
   ++recoveries;
   if (comm) throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
                                        "resident?) in a data-parallel run; rerun with EESEN_PERSISTENT=0");
   const int lost = std::max(1, steps_since_clean);
   steps_since_clean = 0;
   const bool rerun = consumer && propagated && input.p && rows > 0;
-  fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
-                  "%d minibatch(es) in flight were NOT applied%s; continuing with the one-launch-per-step kernels\n", lost,
-          rerun ? " and the last forward pass is re-run" : "");
+  if (only_waiter)
+    fprintf(stderr, "WARNING (eesen_hip) the side stream's wait for a forward-recurrence milestone gave up (kernels serialised by a tool?): "
+                    "%d minibatch(es) in flight were NOT applied%s; continuing without the early input GEMM (EESEN_FWD_MID=0)\n", lost,
+            rerun ? " and the last forward pass is re-run" : "");
+  else
+    fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
+                    "%d minibatch(es) in flight were NOT applied%s; continuing with the one-launch-per-step kernels\n", lost,
+            rerun ? " and the last forward pass is re-run" : "");
   if (rerun) {
     forward_pass();
     EESEN_HIP_CHECK(hipStreamSynchronize(st));
