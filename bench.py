@@ -185,7 +185,7 @@ def frontend_leg(dev: int, S: int = 32, T: int = 1000, D: int = 40, iters: int =
     return out
 
 
-def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_bf16: bool = False) -> dict:
+def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_bf16=False) -> dict:
     """Not the headline: one of the other single-GPU BASELINE.json configurations (configs[3] = cfg4: 5x1024 BiLSTM + 512-d
     projections; configs[4] = cfg5: 6x1024, S = 64 per GPU, T = 3000), the same loop body, `steps` timed steps, so that the driver's
     record holds a driver-timed number for every configuration."""
@@ -195,7 +195,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     batch = synth.make_batch(**cfg)
     net = Net.from_layers(layers, device=dev)
     net.SetTrainOptions(4e-5, 0.9)
-    net.SetForwardPrecision(forward_bf16)
+    net.SetForwardPrecision(int(forward_bf16))    # 1 / True: forward GEMMs + forward recurrence on bf16 operands; 2: the GEMMs only
     ctc = Ctc(device=dev)
     ctc.SetGuard(net)
     feats = CuMatrix.from_numpy(batch.feats, dev)
@@ -222,7 +222,8 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     return {"workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
                         f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "frames_per_s": frames / dt,
-            "dtype": "bf16-fwd/f32" if forward_bf16 else "f32",
+            "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
+            "bf16_recurrence_layers": net.Bf16RecurrenceLayers(),
             "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
             "whole_step_frac_of_pipe_roofline": pipe_bound(cfg)["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
@@ -298,9 +299,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL communicator, per-layer gradient all-reduce) even with one rank (debug)")
-    ap.add_argument("--forward-precision", choices=["f32", "bf16"], default="f32",
-                    help="bf16: BASELINE config 4's variant -- forward GEMM operands rounded to bf16, one bf16 MFMA product, fp32 accumulate; "
-                         "never the headline (reported with dtype bf16-fwd/f32)")
+    ap.add_argument("--forward-precision", choices=["f32", "bf16", "bf16-gemm"], default="f32",
+                    help="bf16: BASELINE config 4's variant -- forward GEMMs and the forward time recurrence on bf16 operands, fp32 accumulate "
+                         "(bf16-gemm: the GEMM operands only, the round-3 variant); never the headline (reported with dtype bf16-fwd/f32)")
     ap.add_argument("--comm", choices=["native", "bulk", "torch"], default="native",
                     help="gradient exchange: native = the library's RCCL communicator, one bucket per layer overlapped with the backward "
                          "pass (default); bulk = the same communicator, one all-reduce after the backward pass; torch = torch.distributed")
@@ -357,7 +358,7 @@ def main():
         n = Net.from_layers(layers, device=dev)
         n.SetTrainOptions(4e-5, 0.9)
         n.SetProfiling(True)
-        n.SetForwardPrecision(args.forward_precision == "bf16")
+        n.SetForwardPrecision({"f32": 0, "bf16": 1, "bf16-gemm": 2}[args.forward_precision])
         if not attach:
             return n
         if comm is not None and args.comm == "native":
@@ -491,7 +492,7 @@ def main():
         q4 = (persistent and H % 128 == 0 and H <= 512 and S % 4 == 0 and S > 8 and 2 * ((H + 15) // 16) * nd * ((S + 15) // 16) <= 256
               and os.environ.get("EESEN_BWD_Q4", "1") != "0")
         split = os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1")
-        bf16_fwd = args.forward_precision == "bf16"
+        bf16_fwd = args.forward_precision != "f32"
         # the main-stream input->gates GEMMs take the 256 x 256-tile flavour when the shape holds >= 16 whole big tiles (gemm.hip)
         # (layer 1's K = 40 is not a multiple of 16 and takes the 128 x 128 flavour; the name is that of the layers that dominate)
         big = not bf16_fwd and (T * S) % 256 == 0 and (nd * 4 * H) % 256 == 0 and ((T * S) // 256) * ((nd * 4 * H) // 256) >= 16

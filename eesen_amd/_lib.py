@@ -52,6 +52,7 @@ SIGNATURES = {
     "eesen_net_get_grads": (_i, [_vp, _vp, _l]),
     "eesen_net_update": (_i, [_vp]),
     "eesen_net_set_forward_precision": (_i, [_vp, _i]),
+    "eesen_net_bf16_recurrence_layers": (_i, [_vp, _vp]),
     "eesen_net_recurrence_info": (_i, [_vp, _pi]),
     "eesen_net_synchronize": (_i, [_vp]),
     "eesen_net_set_profiling": (_i, [_vp, _i]),

@@ -371,9 +371,16 @@ class Net:
         check(self.lib.eesen_net_grad_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def SetForwardPrecision(self, bf16: bool):
-        """BASELINE config 4: forward GEMMs on bf16-rounded operands (one bf16 MFMA product, fp32 accumulate); everything else fp32."""
-        check(self.lib.eesen_net_set_forward_precision(self.h, int(bool(bf16))))
+    def SetForwardPrecision(self, bf16):
+        """BASELINE config 4's bf16 forward (eesen_net_set_forward_precision): True / 1 = forward GEMMs AND the forward time
+        recurrence on bf16 operands with fp32 accumulation; 2 = the GEMMs only; False / 0 = fp32.  Everything else stays fp32."""
+        check(self.lib.eesen_net_set_forward_precision(self.h, int(bf16)))
+
+    def Bf16RecurrenceLayers(self) -> int:
+        """LSTM layers of the last Propagate whose recurrence ran on the bf16 kernel (debug accessor)."""
+        n = C.c_int()
+        check(self.lib.eesen_net_bf16_recurrence_layers(self.h, C.byref(n)))
+        return n.value
 
     def RecurrenceInfo(self) -> dict:
         """Which recurrence kernels the last Propagate / Backpropagate used (debug accessor)."""

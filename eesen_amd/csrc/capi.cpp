@@ -189,7 +189,10 @@ int eesen_net_update(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->update(); });
 }
 int eesen_net_set_forward_precision(eesen_net_t* net, int bf16) {
-  return guard([&] { REQ_PTR(net); net->fwd_bf16 = bf16 != 0; });
+  return guard([&] { REQ_PTR(net); net->fwd_bf16 = bf16 != 0; net->fwd_bf16_rec = bf16 == 1; });
+}
+int eesen_net_bf16_recurrence_layers(eesen_net_t* net, int* layers) {
+  return guard([&] { REQ_PTR(net); REQ_PTR(layers); *layers = net->info_fwd_bf16; });
 }
 int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {  // four ints
   return guard([&] {

@@ -84,6 +84,10 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
+  // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on ONE bf16 plane with
+  // fp32 accumulation (lstm_fwd_persistent_bf16_kernel); X then holds the exchange copy of m as bf16
+  int fwd_bf16 = 0;
+  int fwd_mux2 = 0;   // experiment: narrow layers through the time-multiplexed forward kernel (tuning.h: EESEN_FWD_MUX2)
 };
 float handoff_flight_ns();
 // one wave that returns once *word >= target (or when the recurrence kernels' error word is raised; it raises that word itself
@@ -113,6 +117,8 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
 // sequence windows (= cooperative launches) the persistent forward pass of this layer takes: 1 for every shape whose
 // workgroups are co-resident at once, 2+ for S = 64 at H = 1024, 0 when no persistent tile fits (per-step kernels then)
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
+// true when lstm_fwd_persistent would run this layer's recurrence on the bf16 kernel (L.fwd_bf16 set and the shape allows)
+bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L);
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);

@@ -350,6 +350,162 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, bf16 recurrence (eesen_net_set_forward_precision(1): BASELINE config 4's "bf16 forward / fp32 CTC accumulate").
+// The time loop being replaced is bilstm-parallel-layer.h:112-149,165-204; what changes against lstm_fwd_persistent_kernel is the
+// ARITHMETIC OF THE RECURRENT PRODUCT m_{t-1} W_m^T only: W_m is rounded to nearest-even bf16 once per launch (ONE plane: 16 * CPW
+// registers per lane for the workgroup's 64 gate rows instead of 32 * CPW of fp32), m_t is rounded to bf16 once, where the cell
+// writes it into the exchange buffer (LstmLayerDev::X reinterpreted as bf16: HALF the bytes every consumer fetches per step --
+// the fetch is what bounds the fp32 step), and the products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 4 * CPW
+// instructions of ~17 cycles per wave and step instead of 32 * CPW of 32 cycles.  Gate pre-activations, the cell state c, the
+// peephole terms, the activations and everything the kernel writes for the backward pass (G, C, Y) stay fp32; the backward pass
+// is the fp32 one.  Tile: 16 sequences x 16 units (the wide fp32 tile's geometry, one workgroup per CU at H = 1024, S = 32).
+// Exchange layout (bf16): block of (t, dir, sequence tile) = [32-unit chunk][k quad][16 sequences][8 bf16]: lane (sequence li,
+// quad kq) of chunk ch reads 16 bytes at ((ch * 4 + kq) * 16 + li) * 16 -- the 16 lanes of a quad read 256 contiguous bytes.
+// A and B fragments use the same lane -> k assignment (lane (li, kq) holds k = 32 ch + 8 kq .. + 7), so the contraction is exact
+// whatever the instruction's internal k order.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned rne_bf16(float x) {   // round-to-nearest-even bf16 (gemm.hip: rne_bf16_bits), in the low 16 bits
+  const unsigned b = __float_as_uint(x);
+  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
+                                                                           int spin_limit, unsigned long long* trace, Role R) {
+  constexpr int ST = 16, NT = 4, UB = 16, RW = 16 * NT + 4;
+  __shared__ __attribute__((aligned(16))) float red[NW][ST][RW];
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int u0 = bx * UB, s0 = L.s_begin + bz * ST;
+  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);
+  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
+  const unsigned nblk = R.nblk;
+  const int li = lane & 15, kq = lane >> 4;
+  const int nch = H / 32;
+  // this wave's part of the workgroup's 64 gate rows of W_m, as ONE bf16 plane, resident for the whole layer pass
+  bf16x8_t b[NT][CPW];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + n * 16 + li) * H;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      float w[8];
+      ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, w);
+      f32x4 pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pk[j] = __uint_as_float(rne_bf16(w[2 * j]) | (rne_bf16(w[2 * j + 1]) << 16));
+      b[n][c] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+  }
+  const int es = tid / UB, eu = tid % UB;
+  const int s_e = s0 + es;
+  const bool e_act = tid < ST * UB;            // the four cell waves (all of their lanes take part in the packing shuffles)
+  const bool e_ok = e_act && s_e < s_end;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
+  float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
+  const __amdgpu_buffer_rsrc_t rX = make_rsrc(L.X);
+  const unsigned xblk = (unsigned)nch * 1024u;                                       // bytes per block
+  const int zt = (L.s_begin / ST) + bz;
+  const int nzall = (S + ST - 1) / ST;
+  unsigned char* const xbytes = reinterpret_cast<unsigned char*>(L.X);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    EESEN_STAMP(0);
+    if (step > 0) {
+      if (wave == EESEN_POLL_WAVE) {
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      EESEN_STAMP(1);
+      if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)
+        report_milestone(L.milestone, (unsigned)(R.ndir * R.nz));
+      const unsigned xb = ((unsigned)(tp * L.ndir + dir) * (unsigned)nzall + (unsigned)zt) * xblk;
+      constexpr unsigned kOob = 0x80000000u;
+      const bool rok = s0 + li < s_end;
+      f32x4 a[CPW];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int ch = wave + c * NW;
+        a[c] = __builtin_amdgcn_raw_buffer_load_b128(rX, rok ? xb + (unsigned)(((ch * 4 + kq) * 16 + li) * 16) : kOob, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[c]), b[n][c], acc[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r];
+    __syncthreads();
+    EESEN_STAMP(2);
+    if (e_act) {
+      float4 pre = gx;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
+        pre.x += v.x; pre.y += v.y; pre.z += v.z; pre.w += v.w;
+      }
+      float g = tanhf_(pre.x);
+      float i = sigmoidf_(pre.y + p_i * cprev);
+      float f = sigmoidf_(pre.z + p_f * cprev);
+      float c = g * i + cprev * f;
+      float h = tanhf_(c);
+      float o = sigmoidf_(pre.w + p_o * c);
+      float m = h * o;
+      if (t >= len || !e_ok) { g = i = f = o = c = m = 0.f; }
+      // four adjacent units -> one 8-byte word of the exchange block (a single 8-byte store is single-copy atomic; write-through)
+      unsigned pk = rne_bf16(m);
+      pk |= (unsigned)__shfl_xor((int)pk, 1) << 16;                         // valid in even lanes: (m[eu], m[eu + 1])
+      const unsigned pk2 = (unsigned)__shfl_xor((int)pk, 2);                 // lanes eu % 4 == 0: the pair of (eu + 2, eu + 3)
+      if (e_ok) {
+        *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e) * ldG + gcol) = make_float4(g, i, f, o);
+        const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
+        L.C[o1] = c;
+        __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((eu & 3) == 0) {
+          const int k = u0 + eu;
+          const size_t xo = ((size_t)(t * L.ndir + dir) * nzall + zt) * (size_t)xblk +
+                            (size_t)((((k >> 5) * 4 + ((k & 31) >> 3)) * 16 + es) * 16 + (k & 7) * 2);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(xbytes + xo), (unsigned long long)pk | ((unsigned long long)pk2 << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cprev = c;
+      }
+    }
+    EESEN_STAMP(3);
+    {
+      if (e_act) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      EESEN_STAMP(4);
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok && step + 1 < T)
+        gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward, TWO sequence tiles per workgroup (time-multiplexed): for batches whose tiles need more workgroups than can be
 // co-resident (S = 64 at H = 1024: BASELINE config 5).  Instead of one cooperative launch per window of 32 sequences, run
 // one after the other, every workgroup holds its 16 * NT gate rows of W_m once and steps TWO independent chains -- sequence
@@ -428,6 +584,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_mux_kernel(LstmLa
           __syncthreads();
           if (!s_go) return;
         }
+        if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)   // this chain's group has published step milestone_step
+          report_milestone(L.milestone, (unsigned)(L.ndir * nzall));
         float a[CPW][8];
         const int s0 = zt[q] * ST;
         if constexpr (XCHG) {
@@ -1452,7 +1610,28 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   return {2, 1};
 }
 
+// the bf16 forward recurrence (lstm_fwd_persistent_bf16_kernel) applies: requested, exchange buffer present, whole 256-unit
+// multiples (each of the 8 waves owns CPW = H / 256 chunks of 32 units), no recurrent dropout
+static bool fwd_bf16_ok(const LstmLayerDev& L) {
+  return L.fwd_bf16 && L.X != nullptr && !L.drop_mode && L.H % 256 == 0 && L.H / 256 <= 4 && L.T >= 2 &&
+         (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 1024 < ((size_t)1 << 31);
+}
+static bool fwd_bf16_fits(const LstmLayerDev& L, int Sw) {
+  dim3 grid(L.H / 16, L.ndir, cdiv(Sw, 16));
+  switch (L.H / 256) {
+    case 1: return fits(lstm_fwd_persistent_bf16_kernel<1>, grid, NW * 64);
+    case 2: return fits(lstm_fwd_persistent_bf16_kernel<2>, grid, NW * 64);
+    case 3: return fits(lstm_fwd_persistent_bf16_kernel<3>, grid, NW * 64);
+    default: return fits(lstm_fwd_persistent_bf16_kernel<4>, grid, NW * 64);
+  }
+}
+
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg) {
+  if (fwd_bf16_ok(L)) {
+    *nblk = L.H / 16; *nz = cdiv(L.S, 16);
+    if (units_per_wg) *units_per_wg = 16;
+    return;
+  }
   const FwdTile ft = fwd_tile(L);
   *nblk = L.H / (4 * ft.nt);
   *nz = cdiv(L.S, 16 * ft.mt);
@@ -1473,6 +1652,8 @@ static int pick_windows(int S, int seq_tile, F fits_with) {
 
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
 
+bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return fwd_bf16_ok(L) && lstm_fwd_persistent_windows(L) > 0; }
+
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace, hipEvent_t after_reset) {
   const int nch = (L0.H + 31) / 32;
@@ -1488,6 +1669,25 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
   const int nwin = lstm_fwd_persistent_windows(L0);
   if (nwin == 0) return false;
   if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
+  if (fwd_bf16_ok(L0)) {   // BASELINE config 4's bf16 forward: the recurrent product on one bf16 plane (lstm_fwd_persistent_bf16_kernel)
+    for (int w = 0; w < nwin; ++w) {
+      LstmLayerDev L = L0;
+      L.s_count = L0.S / nwin;
+      L.s_begin = w * L.s_count;
+      dim3 grid(L.H / 16, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
+      const dim3 grid1(grid.x * grid.y * grid.z);
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
+      if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
+      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+      switch (L.H / 256) {
+        case 1: coop_launch(st, lstm_fwd_persistent_bf16_kernel<1>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
+        case 2: coop_launch(st, lstm_fwd_persistent_bf16_kernel<2>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
+        case 3: coop_launch(st, lstm_fwd_persistent_bf16_kernel<3>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
+        default: coop_launch(st, lstm_fwd_persistent_bf16_kernel<4>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
+      }
+    }
+    return true;
+  }
   // Two windows of the wide tile: one launch that time-multiplexes the two sequence tiles of every workgroup instead
   // (lstm_fwd_persistent_mux_kernel).  LstmLayerDev::fwd_mux = 0 (EESEN_FWD_MUX=0): the two launches, one after the other.
   if (L0.fwd_mux && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
@@ -1505,6 +1705,22 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
       else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
       return true;
     }
+  }
+  // EXPERIMENT (EESEN_FWD_MUX2, default 0; DESIGN.md section 9 "two chains per workgroup at cfg2"): the narrow layers through the
+  // time-multiplexed kernel -- 1: 4 units x two 16-sequence tiles per workgroup (same workgroup count as the default tile),
+  // 2: 8 units x two tiles on HALF the workgroups
+  if (L0.fwd_mux2 && nwin == 1 && ft.mt == 1 && ft.nt == 2 && need == 2 && !L0.drop_mode && L0.H % 32 == 0 && L0.X != nullptr &&
+      cdiv(L0.S, 16) == 2 && (size_t)L0.T * L0.ndir * 2 * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31)) {
+    const int nt = L0.fwd_mux2 == 2 ? 2 : 1;
+    dim3 grid(L0.H / (4 * nt), L0.ndir, 1), block(NW * 64);
+    LstmLayerDev L = L0;
+    L.s_begin = 0; L.s_count = 0;
+    const dim3 grid1(grid.x * grid.y * grid.z);
+    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * 2 * kShards * kShardStride, st));
+    if (nt == 2) coop_launch(st, lstm_fwd_persistent_mux_kernel<2, 2, true>, grid1, block, L, cnt, err, spin_limit, role);
+    else coop_launch(st, lstm_fwd_persistent_mux_kernel<2, 1, true>, grid1, block, L, cnt, err, spin_limit, role);
+    return true;
   }
   for (int w = 0; w < nwin; ++w) {
     LstmLayerDev L = L0;
@@ -1549,6 +1765,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
 
 // number of sequence windows the forward pass of this layer takes (0: no persistent tile fits; 1: the whole batch at once)
 int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
+  if (fwd_bf16_ok(L)) return pick_windows(L.S, 16, [&](int Sw) { return fwd_bf16_fits(L, Sw); });
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
   const FwdTile ft = fwd_tile(L);

@@ -477,6 +477,8 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.lens = net.lens_d.p;
   d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
   d.drop_mode = L.cur_drop_mode;
+  d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
+  d.fwd_mux2 = net.tn.fwd_mux2;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
@@ -621,7 +623,7 @@ void Net::forward_pass() {
   const float* x = input.p;
   int ldx = pad4(layers[0].din);
   ++steps_since_clean;
-  info_fwd_persistent = info_lstm_layers = 0;
+  info_fwd_persistent = info_lstm_layers = info_fwd_bf16 = 0;
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
   int mid_r0 = 0, mid_r1 = 0;   // rows [mid_r0, mid_r1) of the current layer's input GEMM already ran on the side stream (see plan_mid)
@@ -705,6 +707,7 @@ void Net::forward_pass() {
       if (!pers)
         for (int step = 0; step < T; ++step) lstm_fwd_step(st, v, step);
       info_fwd_persistent += pers ? 1 : 0;
+      info_fwd_bf16 += pers && lstm_fwd_persistent_is_bf16(v) ? 1 : 0;
       ++info_lstm_layers;
       check_launch("lstm_fwd");
       timer.end(st, ti_);

@@ -109,7 +109,9 @@ struct Net {
   hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated / early input GEMM of the next layer (forward)
   DevBuf<unsigned> mile;      // progress milestone of the running forward recurrence (LstmLayerDev::milestone)
   bool gate_fwd = true;
-  bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1): forward GEMMs on bf16-rounded operands (BASELINE config 4)
+  bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1 | 2): forward GEMMs on bf16-rounded operands (BASELINE config 4)
+  bool fwd_bf16_rec = false;  // ... (1 only): and the forward time recurrence on one bf16 plane of W_m / a bf16 exchange of m_t (lstm_fwd_persistent_bf16_kernel)
+  int info_fwd_bf16 = 0;      // layers of the last Propagate whose recurrence ran on that kernel
   DevBuf<unsigned> ctl;       // arrival counters of the persistent recurrence kernels + [last] error word
   Tuning tn;                  // every run-time switch, read from the environment when the Net is created (tuning.h)
   int persistent = 1;         // EESEN_PERSISTENT=0 forces the one-launch-per-step kernels; also cleared by a recovery

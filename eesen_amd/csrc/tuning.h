@@ -20,6 +20,9 @@
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
+//   EESEN_FWD_MUX2          0        1 | 2: narrow layers (H = 512, S = 32) through the time-multiplexed forward kernel as well -- two
+//                                    16-sequence chains per workgroup, 4 (1) or 8 (2) units; measured slower than one chain per CU
+//                                    (DESIGN.md section 9), kept as the A/B arm
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part)
@@ -42,7 +45,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -64,6 +67,7 @@ struct Tuning {
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
+    t.fwd_mux2 = num("EESEN_FWD_MUX2", 0);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;

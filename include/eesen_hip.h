@@ -148,12 +148,20 @@ int eesen_net_get_grads(eesen_net_t* net, float* host_flat, long n);
  * max_grad > 0; param -= learn_rate*learn_rate_coef*corr. */
 int eesen_net_update(eesen_net_t* net);
 /* BASELINE config 4's "bf16 forward / fp32 CTC accumulate" variant (no counterpart in the reference, whose BaseFloat is float,
- * src/base/kaldi-types.h:26-30): with bf16 != 0 the GEMMs of Propagate (input->gates, affine / projection) round both
- * operands to nearest-even bf16 and run ONE v_mfma_f32_32x32x16_bf16 product with fp32 accumulation; the time recurrence
- * (m_{t-1} W_m), softmax, CTC, the whole backward pass and the update stay fp32.  Default 0.  Tolerance against the fp32
- * path: tests/test_gpu_gemm.py::test_bf16_forward_variant (measured at cfg4 width, profiles/r02_bf16_forward.json: 8e-4 on ln p,
- * 8e-3 on the softmax outputs, ~1e-2 on the gradient tensors). */
-int eesen_net_set_forward_precision(eesen_net_t* net, int bf16);
+ * src/base/kaldi-types.h:26-30).  mode 1: the whole forward pass multiplies in bf16 with fp32 accumulation --
+ *   (a) the GEMMs of Propagate (input->gates, affine / projection) round both operands to nearest-even bf16 and run ONE
+ *       v_mfma_f32_32x32x16_bf16 product;
+ *   (b) the forward TIME RECURRENCE (the loop of src/net/bilstm-parallel-layer.h:112-149,165-204) keeps W_m as one bf16 plane,
+ *       rounds m_t to bf16 once, at the cell write into the kernel's exchange buffer, and forms m_{t-1} W_m^T on
+ *       v_mfma_f32_16x16x32_bf16 (layers with H a multiple of 256 up to 1024 cells per direction, no recurrent dropout; other
+ *       layers keep the fp32 recurrence).  Gate pre-activations, cell state, activations, and everything stored for the
+ *       backward pass stay fp32;
+ * softmax, CTC, the whole backward pass and the update stay fp32.  mode 2: (a) only (the round-3 behaviour; A/B arm).
+ * mode 0 (default): fp32 everywhere.  Distances: tests/test_gpu_gemm.py::test_bf16_forward_variant against this library's fp32
+ * path; against THE REFERENCE at BASELINE config 4's full size: tests/test_gpu_reference_fullsize.py, profiles/parity_cfg4.json. */
+int eesen_net_set_forward_precision(eesen_net_t* net, int mode);
+/* Debug / test accessor: how many LSTM layers of the last Propagate ran their recurrence on the bf16 kernel of (b). */
+int eesen_net_bf16_recurrence_layers(eesen_net_t* net, int* layers);
 /* Debug / test accessor: out4 = {LSTM layers, layers whose forward time loop ran as ONE cooperative launch per sequence
  * window (lstm_persistent.hip), layers whose backward time loop did} for the last Propagate / Backpropagate (the rest
  * took the one-launch-per-step kernels), and the number of recoveries so far.  A recovery: a cooperative recurrence

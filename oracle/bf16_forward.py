@@ -1,0 +1,97 @@
+"""numpy restatement of Net::Propagate with the roundings of BASELINE config 4's "bf16 forward" variant.  TEST INFRASTRUCTURE.
+
+The reference has no bf16 arithmetic (BaseFloat = float, /root/reference/src/base/kaldi-types.h:26-30), so the variant's arbiter
+is the reference's OWN forward equations with the variant's roundings applied at exactly the places include/eesen_hip.h
+(eesen_net_set_forward_precision) names:
+  * (gemm)  every forward GEMM -- x W_x^T of an LSTM layer (bilstm-parallel-layer.h:109-110,163-164), an <AffineTransform>
+            (affine-trans-layer.h:161-166) -- rounds BOTH operands to nearest-even bf16, products and sums in fp32 or wider;
+  * (rec)   the recurrent product m_{t-1} W_m^T (bilstm-parallel-layer.h:116-118,171-173) rounds W_m and m_{t-1} to bf16; the gate
+            pre-activations, the cell state and the activations stay fp32.
+With both switched off this is the plain forward pass and must equal the C oracle / the golden fixtures (tests/test_bf16_forward_oracle.py
+pins it), which is what makes the roundings the only difference.  Cell equations: bilstm-parallel-layer.h:120-148 (g = tanh, i / f with
+the peepholes on c_{t-1}, c = g i + c_{t-1} f, o with the peephole on c_t, m = tanh(c) o).  Padding frames (t >= len_s) carry zero state in
+both directions, as in the HIP library.  Sums are formed in fp64: the order of an fp32 sum is not part of the
+statement, and at the variant's tolerance (1e-4 and up) it does not matter.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def round_bf16(a):
+    """fp32 -> nearest-even bf16 -> fp32 (the bit trick of gemm.hip: rne_bf16_bits; no NaN handling needed here)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def _mm(a, b_t, bf16):
+    """a [n x k] times b_t [m x k] transposed, fp64 accumulation; operands rounded to bf16 on request."""
+    if bf16:
+        a, b_t = round_bf16(a), round_bf16(b_t)
+    return (np.asarray(a, np.float64) @ np.asarray(b_t, np.float64).T).astype(np.float32)
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+
+
+def _lstm_direction(gx, Wm, peep, lens, T, S, H, reverse, bf16_rec, teacher=None):
+    """gx [T, S, 4H] = x W_x^T + bias in the FILE's gate order g | i | f | o; returns m [T, S, H] (zero on padding).
+    teacher [T, S, H]: another implementation's m; when given, step t takes ITS m of the previous step as the recurrent input
+    (the cell state is still carried here), so that a comparison of the two outputs is one step deep everywhere: an m that
+    falls on the other side of a bf16 rounding boundary in one of the two cannot amplify through the chain."""
+    p_i, p_f, p_o = [np.asarray(p, np.float64) for p in peep]
+    m_out = np.zeros((T, S, H), np.float32)
+    Wm_r = round_bf16(Wm) if bf16_rec else np.asarray(Wm, np.float32)
+    for s in range(S):
+        c = np.zeros(H, np.float64)
+        m = np.zeros(H, np.float32)
+        steps = range(int(lens[s]) - 1, -1, -1) if reverse else range(int(lens[s]))
+        for n, t in enumerate(steps):
+            if teacher is not None and n > 0:
+                m = np.asarray(teacher[t + 1 if reverse else t - 1, s], np.float32)
+            mp = round_bf16(m) if bf16_rec else m
+            pre = gx[t, s].astype(np.float64) + (mp.astype(np.float64) @ Wm_r.astype(np.float64).T).astype(np.float32)
+            g = np.tanh(pre[0:H])
+            i = _sig((pre[H:2 * H] + p_i * c).astype(np.float32))
+            f = _sig((pre[2 * H:3 * H] + p_f * c).astype(np.float32))
+            c = g * i + c * f
+            o = _sig((pre[3 * H:4 * H] + p_o * c).astype(np.float32))
+            m = (np.tanh(c) * o).astype(np.float32)
+            m_out[t, s] = m
+    return m_out
+
+
+def forward(layers, feats, lens, T, S, bf16_gemm=False, bf16_rec=False, teacher=None):
+    """layers: eesen_amd.synth.make_model / nnet_io.read_nnet dicts (parameters in the file's order); feats [T*S x D] time-major
+    interleaved.  Returns net_out [T*S x K].  teacher: for a net that is ONE (Bi)LSTM layer, another implementation's output
+    [T*S x ndir*H] to take the recurrent inputs from (see _lstm_direction)."""
+    x = np.asarray(feats, np.float32)
+    assert teacher is None or len(layers) == 1
+    for L in layers:
+        t = L["type"]
+        if t in ("BiLstmParallel", "LstmParallel"):
+            nd = 2 if t == "BiLstmParallel" else 1
+            H = L["output_dim"] // nd
+            outs = []
+            for d in range(nd):
+                Wx, Wm, bias, pi, pf, po = L["params"][6 * d: 6 * d + 6]
+                gx = (_mm(x, Wx, bf16_gemm) + np.asarray(bias, np.float32)).reshape(T, S, 4 * H)
+                tch = None if teacher is None else np.asarray(teacher, np.float32).reshape(T, S, nd * H)[:, :, d * H:(d + 1) * H]
+                outs.append(_lstm_direction(gx, Wm, (pi, pf, po), lens, T, S, H, d == 1, bf16_rec, tch))
+            x = np.concatenate(outs, axis=2).reshape(T * S, nd * H)
+        elif t == "AffineTransform":
+            W, b = L["params"]
+            x = _mm(x, W, bf16_gemm) + np.asarray(b, np.float32)
+        elif t == "Softmax":
+            z = x.astype(np.float64)
+            z = np.exp(z - z.max(axis=1, keepdims=True))
+            x = (z / z.sum(axis=1, keepdims=True)).astype(np.float32)
+        elif t == "Sigmoid":
+            x = _sig(x).astype(np.float32)
+        elif t == "Tanh":
+            x = np.tanh(x.astype(np.float64)).astype(np.float32)
+        else:
+            raise ValueError(t)
+    return x

@@ -156,6 +156,44 @@ int ref_net_backpropagate(void* p, const float* out_diff, int rows, float* in_di
   REF_CATCH(-1)
 }
 
+// The same loop as Net::Backpropagate (net.cc:88-108) -- every layer's own Backpropagate + Update, top down, through the public
+// Layer / TrainableLayer interface -- except that a BiLstm layer's four [(T+2)S x 7H] state buffers are released as soon as the
+// layer is done with them.  Net keeps them all until the next minibatch (bilstm-layer.h:1131-1136), which at BASELINE
+// configs[2]'s global minibatch (S = 256, T = 1000, 4 x 512: 59 GB) or at the 3000-frame bucket of configs[4] does not fit the
+// authoring container's memory.  Arithmetic and order of operations are the reference's; nothing is restated.
+namespace {
+struct BufPeek : public BiLstm {
+  static CuMatrix<BaseFloat> BiLstm::*pf() { return &BufPeek::propagate_buf_fw_; }
+  static CuMatrix<BaseFloat> BiLstm::*pb() { return &BufPeek::propagate_buf_bw_; }
+  static CuMatrix<BaseFloat> BiLstm::*bf() { return &BufPeek::backpropagate_buf_fw_; }
+  static CuMatrix<BaseFloat> BiLstm::*bb() { return &BufPeek::backpropagate_buf_bw_; }
+};
+}  // namespace
+
+int ref_net_backpropagate_lowmem(void* p, const float* out_diff, int rows, float* in_diff) {
+  REF_TRY
+  Net& net = static_cast<RefNet*>(p)->net;
+  const std::vector<CuMatrix<BaseFloat> >& act = net.PropagateBuffer();
+  const int L = net.NumLayers();
+  if ((int)act.size() != L + 1) throw std::runtime_error("ref_net_backpropagate_lowmem: Propagate first");
+  CuMatrix<BaseFloat> d_out, d_in;
+  ToCu(out_diff, rows, net.OutputDim(), &d_out);
+  for (int i = L - 1; i >= 0; i--) {
+    Layer& l = net.GetLayer(i);
+    l.Backpropagate(act[i], act[i + 1], d_out, &d_in);
+    if (l.IsTrainable()) dynamic_cast<TrainableLayer&>(l).Update(act[i], d_out, sgd_update);
+    if (BiLstm* b = dynamic_cast<BiLstm*>(&l)) {
+      (b->*BufPeek::pf()).Resize(0, 0); (b->*BufPeek::pb()).Resize(0, 0);
+      (b->*BufPeek::bf()).Resize(0, 0); (b->*BufPeek::bb()).Resize(0, 0);
+    }
+    d_out.Swap(&d_in);
+    d_in.Resize(0, 0);
+  }
+  if (in_diff) FromCu(d_out, in_diff);
+  return 0;
+  REF_CATCH(-1)
+}
+
 // Copies layer `layer`'s input activation buffer (propagate_buf_[layer]) — layer==NumLayers gives the output.
 int ref_net_get_propagate_buf(void* p, int layer, float* out, int capacity) {
   REF_TRY

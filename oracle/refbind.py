@@ -96,11 +96,13 @@ class RefNet:
         self._ck(self.lib.ref_net_propagate(self.h, _p(feats), feats.shape[0], _p(out)))
         return out
 
-    def backpropagate(self, out_diff: np.ndarray, want_in_diff: bool = True) -> Optional[np.ndarray]:
+    def backpropagate(self, out_diff: np.ndarray, want_in_diff: bool = True, lowmem: bool = False) -> Optional[np.ndarray]:
+        """Net::Backpropagate (net.cc:88-108).  lowmem: the same per-layer Backpropagate + Update loop driven from
+        ref_driver.cc, which releases each BiLstm layer's state buffers once the layer is done (SGD only)."""
         out_diff = np.ascontiguousarray(out_diff, np.float32)
         in_diff = np.empty((out_diff.shape[0], self.din), np.float32) if want_in_diff else None
-        self._ck(self.lib.ref_net_backpropagate(self.h, _p(out_diff), out_diff.shape[0],
-                                                _p(in_diff) if want_in_diff else None))
+        fn = self.lib.ref_net_backpropagate_lowmem if lowmem else self.lib.ref_net_backpropagate
+        self._ck(fn(self.h, _p(out_diff), out_diff.shape[0], _p(in_diff) if want_in_diff else None))
         return in_diff
 
     def write(self, path: str, binary: bool):

@@ -8,6 +8,22 @@ def rel_err(a, b, eps=1e-12):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), eps)) if a.size else 0.0
 
 
+def err_metrics(a, b, rel_floor=1e-3, eps=1e-300):
+    """Three views of the same difference (the max-norm ratio alone is the most forgiving metric for tensors that a
+    few large entries dominate):
+      maxnorm  ||a-b||_inf / ||b||_inf            (rel_err above: the bar SURVEY.md section 7 names)
+      l2       ||a-b||_2 / ||b||_2
+      p999     the 99.9th percentile of |a-b| / |b| over the elements with |b| > rel_floor * ||b||_inf
+    b is the reference."""
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    if not a.size:
+        return dict(maxnorm=0.0, l2=0.0, p999=0.0)
+    d = np.abs(a - b); ab = np.abs(b); mx = float(ab.max())
+    sel = ab > rel_floor * mx
+    return dict(maxnorm=float(d.max() / max(mx, eps)), l2=float(np.sqrt(np.square(d).sum()) / max(np.sqrt(np.square(b).sum()), eps)),
+                p999=float(np.percentile(d[sel] / ab[sel], 99.9)) if sel.any() else 0.0)
+
+
 def valid_mask(lens, T, S):
     """[T*S] bool: row t*S+s is a real frame of sequence s."""
     t = np.arange(T)[:, None]
