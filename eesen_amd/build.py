@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for name, src in TOOLS.items():
         exe = os.path.join(BINDIR, name)
         srcp = os.path.join(CSRC, "tools", src)
-        if force or _stale(exe, [srcp, LIB, os.path.join(CSRC, "tools", "kaldi_tables.h"), os.path.join(CSRC, "tools", "feat_pipeline.h"),
+        if force or _stale(exe, [srcp, LIB, os.path.join(CSRC, "tools", "kaldi_tables.h"), os.path.join(CSRC, "tools", "feat_pipeline.h"), os.path.join(CSRC, "tools", "parse_options.h"),
                                  os.path.join(CSRC, "..", "..", "include", "eesen_hip.h"), os.path.join(CSRC, "..", "..", "include", "eesen_hip_info.h")]):
             run([cxx, "-O2", "-std=c++17", "-Wall", srcp, "-o", exe, "-L" + LIBDIR, "-leesen_hip", "-Wl,-rpath," + LIBDIR,
                  "-Wl,-rpath,$ORIGIN/../lib", "-Wl,--allow-shlib-undefined"])

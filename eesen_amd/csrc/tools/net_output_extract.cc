@@ -14,17 +14,13 @@
 #include "../../../include/eesen_hip.h"
 #include "kaldi_tables.h"
 #include "feat_pipeline.h"
+#include "parse_options.h"
 
 namespace {
 using namespace ktab;
 
 void ck(int rc) {
   if (rc != EESEN_OK) throw std::runtime_error(eesen_last_error());
-}
-bool parse_bool(const std::string& v) {
-  std::string l = v;
-  std::transform(l.begin(), l.end(), l.begin(), ::tolower);
-  return l == "true" || l == "t" || l == "1" || l == "yes" || l.empty();
 }
 // ClassPrior::ClassPrior (class-prior.cc:30-77): counts -> floor -> blank scaling -> normalise -> log, with FLT_MAX/2 added
 // for the classes below the cutoff so that they get zero likelihood
@@ -56,25 +52,30 @@ int main(int argc, char** argv) {
     double prior_cutoff = 1e-10, blank_scale = 1.0, frame_limit = 1e5;
     bool apply_log = false;
     int num_sequence = 1, device = 0;
+    std::string use_gpu = "yes";
+    // the reference's ParseOptions conventions (parse_options.h); options and help texts of net-output-extract.cc:39-47 and
+    // ClassPriorOptions::Register (src/net/class-prior.h:46-57), then this tool's own
+    eesen_tools::ParseOptions po(
+        "Perform a forward pass through the network for classification/feature extraction.\n"
+        "\n"
+        "Usage:  net-output-extract [options] <model-in> <feature-rspecifier> <feature-wspecifier>\n"
+        "e.g.: \n"
+        "net-output-extract net ark:features.ark ark:output.ark\n");
+    po.Register("class-frame-counts", &class_frame_counts, "Vector with frame-counts of classes to compute log-priors. (priors are typically "
+                                                           "subtracted from log-posteriors or pre-softmax activations)");
+    po.Register("prior-scale", &prior_scale, "Scaling factor to be applied on class-log-priors");
+    po.Register("prior-cutoff", &prior_cutoff, "Classes with priors lower than cutoff will have 0 likelihood");
+    po.Register("blank-scale", &blank_scale, "Scale probability of class 0 (blank) by this factor");
+    po.Register("apply-log", &apply_log, "Transform network output to logscale");
+    po.Register("use-gpu", &use_gpu, "yes|no|optional (accepted for the recipes' command lines; this tool always runs on the GPU)");
+    po.Register("num-sequence", &num_sequence, "Utterances forwarded together (1 = the reference's one utterance at a time)");
+    po.Register("frame-limit", &frame_limit, "Max number of frames forwarded together");
+    po.Register("device", &device, "GPU index");
+    po.Read(argc, argv);
     std::vector<std::string> args;
-    for (int i = 1; i < argc; ++i) {
-      const std::string a = argv[i];
-      if (a.rfind("--", 0) != 0) { args.push_back(a); continue; }
-      const size_t eq = a.find('=');
-      const std::string k = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2), v = eq == std::string::npos ? "" : a.substr(eq + 1);
-      if (k == "class-frame-counts") class_frame_counts = v;
-      else if (k == "prior-scale") prior_scale = std::stof(v);
-      else if (k == "prior-cutoff") prior_cutoff = std::stod(v);
-      else if (k == "blank-scale") blank_scale = std::stod(v);
-      else if (k == "apply-log") apply_log = parse_bool(v);
-      else if (k == "use-gpu") {}  // always
-      else if (k == "num-sequence") num_sequence = std::stoi(v);
-      else if (k == "frame-limit") frame_limit = std::stod(v);
-      else if (k == "device") device = std::stoi(v);
-      else throw std::runtime_error("unknown option --" + k);
-    }
+    for (int i = 1; i <= po.NumArgs(); ++i) args.push_back(po.GetArg(i));
     if (args.size() != 3) {
-      std::cerr << "Usage: net-output-extract [options] <model-in> <feature-rspecifier> <feature-wspecifier>\n";
+      po.PrintUsage();
       return 1;
     }
     eesen_net_t* net = nullptr;

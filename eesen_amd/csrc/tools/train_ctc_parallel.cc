@@ -42,6 +42,7 @@
 #include "../../../include/eesen_hip_info.h"
 #include "kaldi_tables.h"
 #include "feat_pipeline.h"
+#include "parse_options.h"
 
 namespace {
 using namespace ktab;
@@ -68,41 +69,41 @@ struct Options {  // train-ctc-parallel.cc:45-80, NetTrainOptions train-opts.h:2
   std::string opt_algorithm = "SGD", sequence_out_file, comm_addr;
   std::vector<std::string> args;
 };
-bool parse_bool(const std::string& v) {
-  if (v == "true" || v == "True" || v == "T" || v == "1" || v.empty()) return true;
-  if (v == "false" || v == "False" || v == "F" || v == "0") return false;
-  throw std::runtime_error("bad boolean option value '" + v + "'");
-}
-Options parse_options(int argc, char** argv) {
+const char* kUsage =   // train-ctc-parallel.cc:36-42
+    "Perform one iteration of CTC training by SGD.\n"
+    "The updates are done per-utterance and by processing multiple utterances in parallel.\n"
+    "\n"
+    "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n"
+    "e.g.: \n"
+    "train-ctc-parallel scp:feature.scp ark:labels.ark nnet.init nnet.iter1\n";
+
+// The reference's ParseOptions conventions (tools/parse_options.h): --config=<file>, --print-args, --help, --verbose, `--x=y` before
+// the positional arguments, "Invalid option" + usage + exit code -1 for anything else.  Options and help texts of
+// train-ctc-parallel.cc:44-80 and NetTrainOptions::Register (train-opts.h:45-51), then this tool's own.
+Options parse_options(int argc, char** argv, eesen_tools::ParseOptions* po) {
   Options o;
-  for (int i = 1; i < argc; ++i) {
-    const std::string a = argv[i];
-    if (a.rfind("--", 0) != 0) { o.args.push_back(a); continue; }
-    const size_t eq = a.find('=');
-    const std::string k = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
-    const std::string v = eq == std::string::npos ? "" : a.substr(eq + 1);
-    if (k == "learn-rate") o.learn_rate = std::stof(v);
-    else if (k == "momentum") o.momentum = std::stof(v);
-    else if (k == "adagrad-epsilon") o.adagrad_epsilon = std::stof(v);
-    else if (k == "rms-prop-rho") o.rms_prop_rho = std::stof(v);
-    else if (k == "binary") o.binary = parse_bool(v);
-    else if (k == "cross-validate") o.cross_validate = parse_bool(v);
-    else if (k == "sequence-out-file") o.sequence_out_file = v;
-    else if (k == "num-sequence") o.num_sequence = std::stoi(v);
-    else if (k == "frame-limit") o.frame_limit = std::stod(v);
-    else if (k == "report-step") o.report_step = std::stoi(v);
-    else if (k == "num-jobs") o.num_jobs = std::stoi(v);
-    else if (k == "job-id") o.job_id = std::stoi(v);
-    else if (k == "utts-per-avg") o.utts_per_avg = std::stoi(v);
-    else if (k == "opt-algorithm") o.opt_algorithm = v;
-    else if (k == "verbose") o.verbose = std::stoi(v);
-    else if (k == "device") o.device = std::stoi(v);
-    else if (k == "comm-addr") o.comm_addr = v;
-    else if (k == "comm-port") o.comm_port = std::stoi(v);
-    else if (k == "comm-timeout") o.comm_timeout = std::stoi(v);
-    else if (k == "shard-shared-list") o.shard_shared_list = parse_bool(v);
-    else throw std::runtime_error("unknown option --" + k);
-  }
+  po->Register("learn-rate", &o.learn_rate, "Learning rate");
+  po->Register("momentum", &o.momentum, "Momentum");
+  po->Register("adagrad-epsilon", &o.adagrad_epsilon, "Epsilon for numerical stability for all adaptive optimizers (Adagrad, RMSProp)");
+  po->Register("rms-prop-rho", &o.rms_prop_rho, "Rho parameter for RMSProp");
+  po->Register("binary", &o.binary, "Write model  in binary mode");
+  po->Register("cross-validate", &o.cross_validate, "Perform cross-validation (no backpropagation)");
+  po->Register("sequence-out-file", &o.sequence_out_file, "output file for the generated sequence");
+  po->Register("num-sequence", &o.num_sequence, "Number of sequences processed in parallel");
+  po->Register("frame-limit", &o.frame_limit, "Max number of frames to be processed");
+  po->Register("report-step", &o.report_step, "Step (number of sequences) for status reporting");
+  po->Register("num-jobs", &o.num_jobs, "Number subjobs in multi-GPU mode");
+  po->Register("job-id", &o.job_id, "Subjob id in multi-GPU mode");
+  po->Register("utts-per-avg", &o.utts_per_avg, "Number of utterances to process per average (default is 250)");
+  po->Register("opt-algorithm", &o.opt_algorithm, "Optimization algorithm (SGD|Adagrad|RMSProp)");
+  po->Register("device", &o.device, "GPU index (default: $LOCAL_RANK, else job-id - 1 with several jobs, else 0)");
+  po->Register("comm-addr", &o.comm_addr, "Rendezvous address of job 1 (default $MASTER_ADDR or 127.0.0.1)");
+  po->Register("comm-port", &o.comm_port, "Rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)");
+  po->Register("comm-timeout", &o.comm_timeout, "Seconds to wait for the other jobs at the rendezvous");
+  po->Register("shard-shared-list", &o.shard_shared_list, "All jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it");
+  po->Read(argc, argv);
+  o.verbose = po->Verbose();
+  for (int i = 1; i <= po->NumArgs(); ++i) o.args.push_back(po->GetArg(i));
   return o;
 }
 
@@ -120,9 +121,10 @@ struct Minibatch {
 int main(int argc, char** argv) {
   try {
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite*/ 0);   // dmabuf IPC for RCCL peer access; read when the ROCr runtime initialises
-    const Options o = parse_options(argc, argv);
+    eesen_tools::ParseOptions po(kUsage);
+    const Options o = parse_options(argc, argv, &po);
     if ((int)o.args.size() != 4 - (o.cross_validate ? 1 : 0)) {  // :82-85
-      std::cerr << "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n";
+      po.PrintUsage();
       return 1;
     }
     if (o.num_jobs < 1 || o.job_id < 1 || o.job_id > o.num_jobs) throw std::runtime_error("--job-id must lie in 1..--num-jobs");
@@ -157,6 +159,21 @@ int main(int argc, char** argv) {
                                                  : getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 17 : 29517;
       ck(eesen_comm_create_tcp(device, addr.c_str(), port, rank, world, o.comm_timeout, &comm));
       log_line("LOG", "job " + std::to_string(o.job_id) + " of " + std::to_string(world) + " joined the RCCL communicator on GPU " + std::to_string(device));
+      if (own_list) {
+        // Every job trains the WHOLE list it was given (reference semantics: the recipes hand job J its own feats_tr.J.scp).  A launcher
+        // that hands all ranks the same command line without a JOB to substitute would make N jobs train identical minibatches and
+        // sum N copies of the same gradient -- silently, an N times larger step on duplicated data.  The jobs compare
+        // their rspecifiers: identical on every job = one shared list, refused unless --shard-shared-list=true deals it out.
+        unsigned long long h = 1469598103934665603ull;   // FNV-1a
+        for (unsigned char c : feature_rspecifier) { h ^= c; h *= 1099511628211ull; }
+        const double hv = (double)(h >> 16);             // 48 bits: exact in a double
+        double mm[2] = {hv, -hv};
+        ck(eesen_comm_allreduce_host(comm, mm, 2, /*max*/ 1));
+        if (mm[0] == -mm[1])
+          throw std::runtime_error("all " + std::to_string(world) + " jobs were given the same feature rspecifier '" + feature_rspecifier +
+                                   "': each job trains its whole list, so they would all train the same minibatches.  Hand every job its "
+                                   "own list (feats.JOB.scp: a JOB that stands alone is replaced by the job id) or pass --shard-shared-list=true");
+      }
     }
     ck(eesen_net_create(device, nullptr, &net));
     ck(eesen_net_read(net, model_filename.c_str()));                                   // :111

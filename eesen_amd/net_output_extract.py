@@ -11,7 +11,6 @@ which changes nothing on valid frames because padding is masked in both directio
 """
 from __future__ import annotations
 
-import argparse
 import os
 import sys
 import time
@@ -36,25 +35,32 @@ def class_log_priors(counts_path: str, prior_cutoff: float = 1e-10, blank_scale:
     return pri.astype(np.float32) + mask
 
 
-def _bool(v: str) -> bool:
-    return v.lower() in ("true", "t", "1", "yes")
-
-
 def main(argv=None) -> int:
-    ap = argparse.ArgumentParser(prog="net-output-extract")
-    ap.add_argument("--class-frame-counts", default="")
-    ap.add_argument("--prior-scale", type=float, default=1.0)
-    ap.add_argument("--prior-cutoff", type=float, default=1e-10)
-    ap.add_argument("--blank-scale", type=float, default=1.0)
-    ap.add_argument("--apply-log", type=_bool, default=False)
-    ap.add_argument("--use-gpu", default="yes")
-    ap.add_argument("--num-sequence", type=int, default=1, help="utterances propagated together (extension; 1 = the reference)")
-    ap.add_argument("--frame-limit", type=float, default=1e5)
-    ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("args", nargs="*")
-    o = ap.parse_args(argv)
+    # the reference's ParseOptions conventions (eesen_amd/parse_options.py); options and help texts of net-output-extract.cc:39-47 and
+    # ClassPriorOptions::Register (src/net/class-prior.h:46-57), then this tool's own
+    from eesen_amd.parse_options import ParseOptions, ParseError
+    ap = ParseOptions("Perform a forward pass through the network for classification/feature extraction.\n"
+                      "\n"
+                      "Usage:  net-output-extract [options] <model-in> <feature-rspecifier> <feature-wspecifier>\n"
+                      "e.g.: \n"
+                      "net-output-extract net ark:features.ark ark:output.ark\n", prog="net-output-extract")
+    ap.register("class-frame-counts", "", "Vector with frame-counts of classes to compute log-priors. (priors are typically subtracted from "
+                                          "log-posteriors or pre-softmax activations)")
+    ap.register("prior-scale", 1.0, "Scaling factor to be applied on class-log-priors")
+    ap.register("prior-cutoff", 1e-10, "Classes with priors lower than cutoff will have 0 likelihood")
+    ap.register("blank-scale", 1.0, "Scale probability of class 0 (blank) by this factor")
+    ap.register("apply-log", False, "Transform network output to logscale")
+    ap.register("use-gpu", "yes", "yes|no|optional (accepted for the recipes' command lines; this tool always runs on the GPU)")
+    ap.register("num-sequence", 1, "Utterances forwarded together (1 = the reference's one utterance at a time)")
+    ap.register("frame-limit", 1e5, "Max number of frames forwarded together", kind="double")
+    ap.register("device", 0, "GPU index")
+    try:
+        o = ap.read(argv)
+    except ParseError as e:
+        print(str(e), file=sys.stderr)
+        return 255
     if len(o.args) != 3:
-        ap.print_usage(sys.stderr)
+        ap.print_usage()
         return 1
     model_filename, feature_rspecifier, feature_wspecifier = o.args
     try:

@@ -22,18 +22,9 @@ and prints the merged TOKEN_ACCURACY.
 """
 from __future__ import annotations
 
-import argparse
 import os
 import sys
 import time
-
-
-def _bool(v: str) -> bool:
-    if v.lower() in ("true", "t", "1", "yes"):
-        return True
-    if v.lower() in ("false", "f", "0", "no"):
-        return False
-    raise argparse.ArgumentTypeError(f"bad boolean '{v}'")
 
 
 def log(msg: str, level: str = "LOG"):
@@ -66,43 +57,53 @@ def _prefetch(it, depth: int = 2):
         yield x
 
 
-def build_parser() -> argparse.ArgumentParser:
-    ap = argparse.ArgumentParser(prog="train-ctc-parallel", add_help=True,
-                                 description="Perform one iteration of CTC training by SGD; multiple utterances are processed in parallel.")
-    # NetTrainOptions (src/net/train-opts.h:45-51)
-    ap.add_argument("--learn-rate", type=float, default=0.008)
-    ap.add_argument("--momentum", type=float, default=0.0)
-    ap.add_argument("--adagrad-epsilon", type=float, default=1e-6)
-    ap.add_argument("--rms-prop-rho", type=float, default=0.9)
-    # train-ctc-parallel.cc:48-80
-    ap.add_argument("--binary", type=_bool, default=True, help="Write model in binary mode")
-    ap.add_argument("--cross-validate", type=_bool, default=False, help="Perform cross-validation (no backpropagation)")
-    ap.add_argument("--sequence-out-file", default="")
-    ap.add_argument("--num-sequence", type=int, default=5, help="Number of sequences processed in parallel")
-    ap.add_argument("--frame-limit", type=float, default=100000, help="Max number of frames to be processed")
-    ap.add_argument("--report-step", type=int, default=100, help="Step (number of sequences) for status reporting")
-    ap.add_argument("--num-jobs", type=int, default=1)
-    ap.add_argument("--job-id", type=int, default=1)
-    ap.add_argument("--utts-per-avg", type=int, default=500)
-    ap.add_argument("--opt-algorithm", default="SGD", help="Optimization algorithm (SGD|Adagrad|RMSProp)")
-    ap.add_argument("--verbose", type=int, default=0)
-    ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK, else job-id - 1, else 0)")
-    ap.add_argument("--comm-addr", default="", help="rendezvous address of job 1 (default $MASTER_ADDR or 127.0.0.1)")
-    ap.add_argument("--comm-port", type=int, default=0, help="rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)")
-    ap.add_argument("--comm-timeout", type=int, default=300)
-    ap.add_argument("--shard-shared-list", type=_bool, default=False,
-                    help="all jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it "
-                         "(default: the list is this job's own shard, as in the reference)")
-    ap.add_argument("args", nargs="*")
-    return ap
+USAGE = ("Perform one iteration of CTC training by SGD.\n"
+         "The updates are done per-utterance and by processing multiple utterances in parallel.\n"
+         "\n"
+         "Usage: train-ctc-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n"
+         "e.g.: \n"
+         "train-ctc-parallel scp:feature.scp ark:labels.ark nnet.init nnet.iter1\n")
+
+
+def build_parser():
+    """The reference's ParseOptions conventions (eesen_amd/parse_options.py): --config=<file>, --print-args, --help, --verbose, `--x=y`
+    before the positional arguments.  Options and help texts of train-ctc-parallel.cc:44-80 and NetTrainOptions::Register
+    (src/net/train-opts.h:45-51), then this tool's own."""
+    from eesen_amd.parse_options import ParseOptions
+    po = ParseOptions(USAGE, prog="train-ctc-parallel")
+    po.register("learn-rate", 0.008, "Learning rate")
+    po.register("momentum", 0.0, "Momentum")
+    po.register("adagrad-epsilon", 1e-6, "Epsilon for numerical stability for all adaptive optimizers (Adagrad, RMSProp)")
+    po.register("rms-prop-rho", 0.9, "Rho parameter for RMSProp")
+    po.register("binary", True, "Write model  in binary mode")
+    po.register("cross-validate", False, "Perform cross-validation (no backpropagation)")
+    po.register("sequence-out-file", "", "output file for the generated sequence")
+    po.register("num-sequence", 5, "Number of sequences processed in parallel")
+    po.register("frame-limit", 100000.0, "Max number of frames to be processed", kind="double")
+    po.register("report-step", 100, "Step (number of sequences) for status reporting")
+    po.register("num-jobs", 1, "Number subjobs in multi-GPU mode")
+    po.register("job-id", 1, "Subjob id in multi-GPU mode")
+    po.register("utts-per-avg", 500, "Number of utterances to process per average (default is 250)")
+    po.register("opt-algorithm", "SGD", "Optimization algorithm (SGD|Adagrad|RMSProp)")
+    po.register("device", -1, "GPU index (default: $LOCAL_RANK, else job-id - 1 with several jobs, else 0)")
+    po.register("comm-addr", "", "Rendezvous address of job 1 (default $MASTER_ADDR or 127.0.0.1)")
+    po.register("comm-port", 0, "Rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)")
+    po.register("comm-timeout", 300, "Seconds to wait for the other jobs at the rendezvous")
+    po.register("shard-shared-list", False, "All jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it")
+    return po
 
 
 def main(argv=None) -> int:
+    from eesen_amd.parse_options import ParseError
     ap = build_parser()
-    o = ap.parse_args(argv)
+    try:
+        o = ap.read(argv)
+    except ParseError as e:      # KALDI_ERR -> main's catch: message, -1 (train-ctc-parallel.cc:259-263)
+        print(str(e), file=sys.stderr)
+        return 255
     n_expected = 3 if o.cross_validate else 4
     if len(o.args) != n_expected:
-        ap.print_usage(sys.stderr)
+        ap.print_usage()
         return 1
     feature_rspecifier, targets_rspecifier, model_filename = o.args[:3]
     target_model_filename = None if o.cross_validate else o.args[3]
@@ -121,7 +122,7 @@ def main(argv=None) -> int:
         else:
             world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", str(rank if world > 1 else 0)))
-        dev = o.device if o.device is not None else local
+        dev = o.device if o.device >= 0 else local
         comm = None
         if world > 1:
             port = o.comm_port or int(os.environ.get("EESEN_COMM_PORT", 0)) or int(os.environ.get("MASTER_PORT", "29500")) + 17
@@ -158,6 +159,16 @@ def main(argv=None) -> int:
             if o.shard_shared_list:
                 raise EesenError(-1, "--shard-shared-list with a per-job (JOB) feature list")
         feature_rspecifier = mine
+        if comm is not None and not o.shard_shared_list:
+            # every job trains the WHOLE list it was given; the same list on every job would be N copies of the same gradient, silently
+            # (ADVICE r3): the jobs compare their rspecifiers and refuse a shared one unless --shard-shared-list=true deals it out
+            import zlib
+            hv = float(zlib.crc32(feature_rspecifier.encode()) * 65536 + (zlib.adler32(feature_rspecifier.encode()) & 0xFFFF))
+            mx = comm.allreduce([hv, -hv], op=1)
+            if mx[0] == -mx[1]:
+                raise EesenError(-1, f"all {world} jobs were given the same feature rspecifier '{feature_rspecifier}': each job trains its "
+                                     "whole list, so they would all train the same minibatches.  Hand every job its own list (feats.JOB.scp: a "
+                                     "JOB that stands alone is replaced by the job id) or pass --shard-shared-list=true")
         feeder = Feeder(dev, slots=2)
         # a feature rspecifier that is a pipe of the reference's own filters (apply-cmvn | splice-feats | subsample-feats |
         # add-deltas, train_ctc_parallel.sh:95-110): read the raw table here and run the filters on the device

@@ -75,6 +75,26 @@ def test_cli_error_contract(gpu, tmp_path):
     assert r.returncode == 0 and any("accu" in L for L in nnet_io.read_nnet(str(tmp_path / "o")))
 
 
+def test_config_file_runs_like_the_same_options_on_the_command_line(gpu, tmp_path):
+    """`--config=conf/train.conf` (parse-options.cc:338-400,470-506): one --x=y per line, comments, names with `_`; options on the
+    command line override it.  Both trainers; the models equal the run with the options spelled out, byte for byte."""
+    cfg = synth.config("tiny_bi")
+    feats, labs, scp, lab = _dataset(tmp_path, D=cfg["D"], K=cfg["K"])
+    m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(max_grad=50.0, **cfg), binary=True)
+    conf = tmp_path / "train.conf"
+    conf.write_text("# conf/train.conf\n--learn-rate=0.5      # overridden on the command line\n--momentum=0.9\n\n--num_sequence=4\n--frame-limit=90\n")
+    outs = {}
+    for name, cmd in (("python", [sys.executable, "-m", "eesen_amd.train_ctc_parallel"]), ("native", [os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")])):
+        for how, opts in (("config", [f"--config={conf}", "--learn-rate=0.01"]),
+                          ("spelled", ["--learn-rate=0.01", "--momentum=0.9", "--num-sequence=4", "--frame-limit=90"])):
+            out = str(tmp_path / f"{name}_{how}.nnet")
+            r = subprocess.run(cmd + opts + ["scp:" + scp, "ark:" + lab, m_in, out], capture_output=True, text=True, cwd=ROOT, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert r.stderr.splitlines()[0].rstrip().endswith(out)      # --print-args: the command line, first thing on stderr
+            outs[name, how] = open(out, "rb").read()
+    assert outs["python", "config"] == outs["python", "spelled"] == outs["native", "config"] == outs["native", "spelled"]
+
+
 def test_net_output_extract(gpu, tmp_path):
     """net-output-extract (forward for decoding): log-posteriors minus scaled log-priors, per utterance, against the oracle
     at S = 1; batching several utterances must not change a single bit on valid frames."""
@@ -288,24 +308,33 @@ def test_two_jobs_with_uneven_per_job_lists_through_the_rccl_standin(gpu, tmp_pa
 
 
 def test_shared_list_dealing_is_opt_in(gpu, tmp_path):
-    """Without --shard-shared-list a job trains EVERY minibatch of the list it was handed (reference semantics: the list is the
-    job's shard), with it job J trains minibatches J-1, J-1+N, ... -- checked through the utterance counts of a one-job-of-two
-    cross-validation run (which exchanges nothing)."""
+    """A job trains EVERY minibatch of the list it was handed (reference semantics: the list is the job's shard); with
+    --shard-shared-list=true job J trains minibatches J-1, J-1+N, ... of a list all jobs read -- checked through the utterance
+    counts of a one-job-of-two cross-validation run.  The SAME list on every job without that switch (a launcher that hands all
+    ranks one command line and no JOB to substitute) would train N copies of every minibatch: refused, loudly."""
+    import shutil
     import socket
     from tests.test_gpu_multirank import fake_rccl_path
-    exe = os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")
     cfg = synth.config("tiny_bi")
     feats, labs, scp, lab = _dataset(tmp_path, n=12, D=cfg["D"], K=cfg["K"])
+    for j in (1, 2):
+        shutil.copy(scp, str(tmp_path / f"feats.{j}.scp"))
+    per_job = "scp:" + str(tmp_path / "feats.JOB.scp")
     m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(**cfg), binary=True)
-    for extra, want in (([], (12, 12)), (["--shard-shared-list=true"], (6, 6))):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        env = dict(os.environ, EESEN_RCCL_LIBRARY=fake_rccl_path(), EESEN_PERSISTENT="0", FAKE_RCCL_QUIET="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        ps = [subprocess.Popen([exe, "--device=0", "--cross-validate=true", "--num-sequence=2", "--num-jobs=2", f"--job-id={j}"] + extra +
-                               ["scp:" + scp, "ark:" + lab, m_in], env=env, stderr=subprocess.PIPE, text=True) for j in (1, 2)]
-        errs = [p.communicate(timeout=600)[1] for p in ps]
-        assert [p.returncode for p in ps] == [0, 0], errs
-        got = tuple(int(re.search(r"Done (\d+) files", e).group(1)) for e in errs)
-        assert got == want, (extra, got)
+    for cmd in ([os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")], [sys.executable, "-m", "eesen_amd.train_ctc_parallel"]):
+        for extra, rspec, want in (([], per_job, (12, 12)), (["--shard-shared-list=true"], "scp:" + scp, (6, 6)), ([], "scp:" + scp, None)):
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            env = dict(os.environ, EESEN_RCCL_LIBRARY=fake_rccl_path(), EESEN_PERSISTENT="0", FAKE_RCCL_QUIET="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            ps = [subprocess.Popen(cmd + ["--device=0", "--cross-validate=true", "--num-sequence=2", "--num-jobs=2", f"--job-id={j}"] + extra +
+                                   [rspec, "ark:" + lab, m_in], env=env, stderr=subprocess.PIPE, text=True, cwd=ROOT) for j in (1, 2)]
+            errs = [p.communicate(timeout=600)[1] for p in ps]
+            if want is None:
+                assert [p.returncode for p in ps] == [255, 255], errs
+                assert all("were given the same feature rspecifier" in e and "--shard-shared-list=true" in e for e in errs), errs
+                continue
+            assert [p.returncode for p in ps] == [0, 0], errs
+            got = tuple(int(re.search(r"Done (\d+) files", e).group(1)) for e in errs)
+            assert got == want, (extra, got)
 
 
 def test_seam2_layer_adaptor_inside_the_reference_net(gpu, tmp_path):

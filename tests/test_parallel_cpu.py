@@ -145,9 +145,9 @@ def test_python_trainer_treats_its_list_as_its_own_shard(monkeypatch, tmp_path):
     from eesen_amd import train_ctc_parallel as t
     src = inspect.getsource(t.main)
     assert "if world > 1 and o.shard_shared_list:" in src and '"JOB" in feature_rspecifier' not in src
-    o = t.build_parser().parse_args(["--num-jobs=4", "--job-id=3", "scp:feats_tr.3.scp", "ark:l", "m", "o"])
-    assert o.shard_shared_list is False
-    assert t.build_parser().parse_args(["--shard-shared-list=true", "a", "b", "c", "d"]).shard_shared_list is True
+    o = t.build_parser().read(["--print-args=false", "--num-jobs=4", "--job-id=3", "scp:feats_tr.3.scp", "ark:l", "m", "o"])
+    assert o.shard_shared_list is False and o.num_jobs == 4 and o.job_id == 3 and o.args == ["scp:feats_tr.3.scp", "ark:l", "m", "o"]
+    assert t.build_parser().read(["--print-args=false", "--shard-shared-list=true", "a", "b", "c", "d"]).shard_shared_list is True
 
 
 def test_rendezvous_survives_stray_and_half_open_peers():
