@@ -37,6 +37,7 @@ from eesen_amd import synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: bf16 MFMA dense peak (the sparsity-inflated headline figure is twice that)
 PEAK_HBM_GBS = 8000.0
+PEAK_XGMI_GBS = 7 * 153.0          # same guide: 7 xGMI links x ~153 GB/s per GPU (point-to-point: a ring step is bound by ONE link)
 
 
 def flops_per_frame(cfg) -> float:
@@ -519,12 +520,15 @@ def main():
         dom = max(kern, key=lambda n: kern[n]["total_s"])
         # HBM traffic per launch and matrix-pipe occupancy of the dominant kernel, from the committed PMC passes (rocprofv3 --pmc cannot
         # run inside this process); only quoted when the workload is the one the counters were collected on
-        traffic = mfma_busy = None
+        traffic = mfma_busy = traffic_source = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt["config"] == {"config": args.config, "T": T, "S": S} and not (args.H or args.layers):
                 traffic = pt["bytes_per_launch"].get(dom)
                 mfma_busy = pt.get("mfma_busy", {}).get(dom)
+                # where the counters come from: the tables, the commit they were collected at, and the switches of that run
+                traffic_source = {"file": "profiles/pmc_traffic.json", "tables": pt.get("source"), "commit": pt.get("commit"),
+                                  "switches": pt.get("switches"), "kernel": pt.get("kernels", {}).get(dom)}
         except Exception:
             pass
         # The launch that runs ALONE on the chip: in the backward pass the top LSTM layer's recurrence starts when no side-stream
@@ -545,7 +549,7 @@ def main():
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["executed"], "peak": kern[dom]["peak"],
-                    "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": traffic, "mfma_busy": mfma_busy, "alone": alone,
+                    "unit": "TFLOP/s", "frac": kern[dom]["frac"], "traffic": traffic, "traffic_source": traffic_source, "mfma_busy": mfma_busy, "alone": alone,
                     "avg_launch_us": kern[dom]["avg_us"], "flops_per_launch": kern[dom]["flops"],
                     "note": ("one launch = the whole T-step recurrence of a layer; its duration is set by the per-step chain -- a 32 KB "
                              "operand fetch through one CU's L1 beside 0.9 us of MFMA (4 x 32 tile on v_mfma_f32_4x4x1_16B_f32 with the "
@@ -628,6 +632,31 @@ def main():
             "phase_ms_per_step": {k: 1e3 * v / K for k, v in {**phases, **{'ctc_' + a: b for a, b in ctc_ph.items()}}.items()},
             "roofline": roofline,
         }
+        if comm is not None and args.comm == "native":
+            # The exchange (replaces communicator.h:39-170), from the library's own events (eesen_net_get_phase_spans,
+            # phases 6 and 7), rank 0's view: per gradient bucket the all-reduce on the communication stream -- its duration, the bus
+            # bandwidth 2 (N-1)/N x bytes / time a ring moves per GPU, against the xGMI peak of one GPU (7 links x 153 GB/s) -- and what of
+            # it the backward pass did NOT hide (the time eesen_net_update's stream waited for buckets).
+            order = net.BucketOrder()
+            nb = max(1, len(order))
+            ar = [sec for nm, sec in spans if nm == "allreduce"]
+            ex = [sec for nm, sec in spans if nm == "allreduce_exposed"]
+            bytes_of = {li: 4.0 * sum(int(np.size(p)) for p in layers[li]["params"]) for li in order}
+            ring = 2.0 * (world - 1) / world
+            buckets = []
+            for bi, li in enumerate(order):
+                tt = ar[bi::nb]
+                sec = sum(tt) / max(1, len(tt))
+                gbs = ring * bytes_of[li] / sec / 1e9 if sec > 0 else 0.0
+                buckets.append({"layer": li, "MB": bytes_of[li] / 1e6, "ms": 1e3 * sec, "bus_GBps": gbs, "frac_of_xgmi_peak": gbs / PEAK_XGMI_GBS})
+            tot_b, tot_s = sum(bytes_of.values()), sum(ar) / K
+            line["phase_ms_per_step"]["allreduce"] = 1e3 * tot_s
+            line["phase_ms_per_step"]["allreduce_exposed"] = 1e3 * sum(ex) / K
+            roofline["exchange"] = {"bound": "xgmi", "achieved": ring * tot_b / tot_s / 1e9 if tot_s > 0 else 0.0, "peak": PEAK_XGMI_GBS, "unit": "GB/s",
+                                    "frac": (ring * tot_b / tot_s / 1e9 / PEAK_XGMI_GBS) if tot_s > 0 else 0.0, "bytes_per_step": tot_b,
+                                    "ms_per_step": 1e3 * tot_s, "exposed_ms_per_step": 1e3 * sum(ex) / K, "buckets": buckets,
+                                    "note": "bus bandwidth of a ring all-reduce, 2 (N-1)/N x bytes / time, on rank 0; peak = 7 xGMI links x 153 GB/s per GPU"
+                                            + ("; ONE rank: nothing crosses a link, the figure is the collective's launch + copy cost" if world == 1 else "")}
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg)
@@ -667,7 +696,9 @@ def self_launch(n: int) -> int:
         port = s0.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        # EESEN_BENCH_SHARE_GPU=<index> (tests): every rank on that ONE device -- the multi-rank path of this file through the test-only
+        # RCCL stand-in (tests/test_gpu_parallel.py); never a measurement
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=os.environ.get("EESEN_BENCH_SHARE_GPU", str(r)), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))

@@ -54,6 +54,7 @@ SIGNATURES = {
     "eesen_net_set_forward_precision": (_i, [_vp, _i]),
     "eesen_net_bf16_recurrence_layers": (_i, [_vp, _vp]),
     "eesen_net_recurrence_info": (_i, [_vp, _pi]),
+    "eesen_net_debug_set_error_word": (_i, [_vp, C.c_uint]),
     "eesen_net_synchronize": (_i, [_vp]),
     "eesen_net_set_profiling": (_i, [_vp, _i]),
     "eesen_net_get_phase_times": (_i, [_vp, _vp]),

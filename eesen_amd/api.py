@@ -389,6 +389,10 @@ class Net:
         self.recoveries = a[3]
         return dict(lstm_layers=a[0], fwd_persistent=a[1], bwd_persistent=a[2])
 
+    def _raise_error_word(self, value: int):
+        """Test hook: what a recurrence kernel (1) / the milestone waiter (2) stores when it gives up."""
+        check(self.lib.eesen_net_debug_set_error_word(self.h, int(value)))
+
     def Synchronize(self):
         check(self.lib.eesen_net_synchronize(self.h))
 
@@ -398,12 +402,12 @@ class Net:
 
     def PhaseSpans(self):
         """[(phase name, seconds)] of every timed span since the last PhaseTimes(), in record order (call before PhaseTimes)."""
-        names = ["input_gemm", "recurrence_fwd", "affine_softmax", "recurrence_bwd", "grad_gemm", "update"]
+        names = ["input_gemm", "recurrence_fwd", "affine_softmax", "recurrence_bwd", "grad_gemm", "update", "allreduce", "allreduce_exposed"]
         n = C.c_int()
         check(self.lib.eesen_net_get_phase_spans(self.h, None, None, 0, C.byref(n)))
         ph, se = (C.c_int * max(n.value, 1))(), (C.c_float * max(n.value, 1))()
         check(self.lib.eesen_net_get_phase_spans(self.h, ph, se, n.value, C.byref(n)))
-        return [(names[ph[i]] if 0 <= ph[i] < 6 else str(ph[i]), float(se[i])) for i in range(n.value)]
+        return [(names[ph[i]] if 0 <= ph[i] < len(names) else str(ph[i]), float(se[i])) for i in range(n.value)]
 
     def PhaseTimes(self) -> dict:
         out = np.zeros(6, np.float32)

@@ -201,6 +201,13 @@ int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {  // four ints
     out3[3] = net->recoveries;
   });
 }
+int eesen_net_debug_set_error_word(eesen_net_t* net, unsigned value) {
+  return guard([&] {
+    REQ_PTR(net);
+    EESEN_HIP_CHECK(hipSetDevice(net->device));
+    EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(net->ctl.p + kCtlWords - 1), (int)value, 1, net->st));
+  });
+}
 int eesen_net_synchronize(eesen_net_t* net) {
   return guard([&] { REQ_PTR(net); net->sync(); });
 }

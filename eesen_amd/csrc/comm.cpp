@@ -132,20 +132,16 @@ void comm_exchange(const char* addr, int port, int rank, int world, char* buf, i
     sockaddr_in sa{};
     sa.sin_family = AF_INET;
     sa.sin_port = htons((uint16_t)port);
-    // listen on the interface the peers were told to reach (--comm-addr / MASTER_ADDR), not on every one; a name that does not
-    // resolve to a local address (a load-balancer name, 0.0.0.0) falls back to all interfaces
+    // Listen on ONE interface only when the caller named it as a numeric address (--comm-addr=10.0.0.5 / MASTER_ADDR=127.0.0.1): that
+    // is an explicit choice.  A host NAME is what the peers were told to reach, not a statement about local interfaces -- on hosts
+    // whose /etc/hosts maps their own name to loopback (Debian / Ubuntu: 127.0.1.1) binding to its local resolution would succeed on
+    // loopback and remote peers, who resolve the real address, could never connect: names listen on every interface.
     sa.sin_addr.s_addr = htonl(INADDR_ANY);
     bool bound = false;
     if (addr && *addr) {
-      addrinfo hints{}, *res = nullptr;
-      hints.ai_family = AF_INET;
-      hints.ai_socktype = SOCK_STREAM;
-      if (getaddrinfo(addr, nullptr, &hints, &res) == 0 && res) {
-        sockaddr_in sb = sa;
-        sb.sin_addr = reinterpret_cast<sockaddr_in*>(res->ai_addr)->sin_addr;
+      sockaddr_in sb = sa;
+      if (inet_pton(AF_INET, addr, &sb.sin_addr) == 1 && sb.sin_addr.s_addr != htonl(INADDR_ANY))
         bound = ::bind(ls.fd, reinterpret_cast<sockaddr*>(&sb), sizeof(sb)) == 0;
-      }
-      if (res) freeaddrinfo(res);
     }
     if (!bound && ::bind(ls.fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0)
       throw Error(EESEN_ERR_IO, "rendezvous: cannot bind port " + std::to_string(port) + ": " + strerror(errno));
@@ -392,7 +388,17 @@ void Net::bucket_allreduce(int li, hipStream_t producer) {
   EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], producer));
   EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_ready[li], 0));
   const bool top = li == top_trainable();  // its block ends at P: the liveness word (4 floats of padding) rides along
+  // phase 6 of the profiling spans (eesen_net_get_phase_spans): this bucket's collective on the communicator's stream, from the
+  // moment the bucket is ready AND the stream is free to the end of the all-reduce
+  // A rank whose recurrence kernels raised the error word in this step (a bounded spin gave up, or the early-GEMM waiter did) holds
+  // garbage gradients.  It must neither put them into the sum nor skip the update the other ranks make (they would diverge): it
+  // contributes ZERO -- decided on the device, where the word is -- and then applies the same summed gradient as everybody else.
+  // Its liveness word goes with the top bucket, so a step in which EVERY rank failed is a no-op on every rank alike.
+  if (ctl.p) zero_if_set(comm->st, fresh.p + layers[li].p_off, (long)(layers[li].p_n + (top ? kLiveWords : 0)), ctl.p + kCtlWords - 1);
+  grads_sanitized = true;
+  const int ti_ = timer.begin(comm->st, 6);
   comm->allreduce_f32(fresh.p + layers[li].p_off, layers[li].p_n + (top ? kLiveWords : 0), comm->st);
+  timer.end(comm->st, ti_);
   EESEN_HIP_CHECK(hipEventRecord(ev_bucket[li], comm->st));
   bucket_pending[li] = 1;
 }
@@ -412,6 +418,7 @@ void Net::backpropagate_zero() {
   EESEN_HIP_CHECK(hipSetDevice(device));
   if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, (P + kLiveWords) * sizeof(float), st));
   bucket_log.clear();
+  live_valid = comm != nullptr;
   for (int li = (int)layers.size() - 1; li >= 0; --li) bucket_allreduce(li, st);
 }
 
@@ -435,6 +442,8 @@ void Net::allreduce_grads(Comm* c) {
   EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
   EESEN_REQUIRE(c && c->device == device, EESEN_ERR_INVALID, "communicator missing or on another device");
   EESEN_HIP_CHECK(hipSetDevice(device));
+  if (ctl.p) zero_if_set(st, fresh.p, (long)P, ctl.p + kCtlWords - 1);   // a failed step contributes zero (see bucket_allreduce)
+  grads_sanitized = true;
   c->allreduce_f32(fresh.p, P, st);  // ordered on the compute stream: after Backpropagate's kernels, before Update's
 }
 

@@ -92,7 +92,7 @@ struct LstmLayerDev {
 float handoff_flight_ns();
 // one wave that returns once *word >= target (or when the recurrence kernels' error word is raised; it raises that word itself
 // if it ever gives up): puts a stream behind a milestone of a kernel that is still running on another stream
-void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err);
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err, double limit_s = 2.0);   // gives up after limit_s seconds of wall clock
 // One recurrence step of every direction: fw direction handles t = step, bw direction t = T-1-step.
 void lstm_fwd_step(hipStream_t st, const LstmLayerDev& L, int step);
 // One step of the backward recurrence: fw direction handles t = T-1-step, bw direction t = step.
@@ -158,6 +158,8 @@ void row_argmax(hipStream_t st, const float* m, int ld, int rows, int K, int* id
 // live (may be null): device float; when ZERO at execution time the update is a no-op (data-parallel closing round, comm.cpp)
 void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, long n, float mmt, float lr_coef,
                 float max_grad, const unsigned* skip = nullptr, const float* live = nullptr);
+// p[0..n) = 0 when *word != 0 at execution time (the recurrence kernels' error word): see optim.hip / comm.cpp
+void zero_if_set(hipStream_t st, float* p, long n, const unsigned* word);
 // Adagrad (rmsprop = false) / RMSProp update of one flat parameter block, see optim.hip
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,
                      float max_grad, float eps, float rho, float one_minus_rho, bool rmsprop, const unsigned* skip = nullptr,

@@ -31,6 +31,8 @@
 // fetch consumes each 32-float chunk as two 16-float halves); tests assert exactly that.
 #include "kernels.h"
 
+#include <mutex>
+
 namespace eesen {
 namespace {
 
@@ -147,40 +149,51 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
   if (threadIdx.x != 0) return;
   unsigned* mine = flags + (blockIdx.x == 0 ? 0 : 32);
   unsigned* theirs = flags + (blockIdx.x == 0 ? 32 : 0);
+  unsigned* dead = flags + 16;   // either side gave up: the other leaves at once instead of spinning through every remaining round
   const unsigned long long t0 = wall_clock64();
-  for (int i = 1; i <= rounds; ++i) {
+  bool ok = true;
+  for (int i = 1; i <= rounds && ok; ++i) {
     if (blockIdx.x == 0) __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spins = 0; spins < (1 << 22); ++spins)
-      if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)i) break;
+    ok = false;
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+      if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)i) { ok = true; break; }
+      if ((spins & 255) == 255 && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+    }
+    if (!ok) { __hip_atomic_store(dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // (the two workgroups were not co-resident)
     if (blockIdx.x != 0) __hip_atomic_store(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (blockIdx.x == 0) out[0] = wall_clock64() - t0;
+  if (blockIdx.x == 0) out[0] = ok ? wall_clock64() - t0 : 0ull;   // 0: no measurement (the host falls back to the default delays)
 }
 
 // (unsigned* err: this kernel may RAISE the error word too)
-__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err) {
+__global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err, unsigned long long limit_ticks) {
   if (threadIdx.x != 0) return;
-  // ~1 us per poll, bounded at ~2 s: two orders of magnitude above any recurrence this waits on (the producer's stream raises the
-  // word itself behind that kernel).  A wait that does give up must not let the consumer behind it pass for a success: it raises
-  // the error word (value 2), the step is dropped like one whose recurrence kernel gave up, and the host goes on WITHOUT the early
-  // GEMM (the persistent kernels stay).  The one known
-  // way to get there: a tool that lets only ONE kernel run at a time (rocprofv3 --pmc) and picks this one before the
-  // recurrence -- collect counters with EESEN_FWD_MID=0 (scripts/collect_profiles.sh does).  Tried instead: a command-processor
-  // wait (hipStreamWaitValue64 on signal memory), which cannot dead-lock -- it works, and costs 2.2 ms per cfg2 step (38.5 ->
-  // 40.7-40.9 ms) where this kernel gains 0.85.
-  for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+  // ~1 us per poll, bounded on the WALL CLOCK (limit_ticks of 10 ns; the host scales it with the recurrence it waits on and with the
+  // spin limit, which a communicator raises tenfold: wait_for_word): orders of magnitude above any recurrence this waits on, and the
+  // producer's stream raises the word itself behind that kernel.  A wait that does give up must not let the consumer behind it pass
+  // for a success: it raises the error word (value 2), the step is dropped like one whose recurrence kernel gave up (in a
+  // data-parallel run: contributes a zero gradient), and the host goes on WITHOUT the early GEMM (the persistent kernels stay).
+  // The one known way to get there: a tool that lets only ONE kernel run at a time (rocprofv3 --pmc) and picks this one before the
+  // recurrence -- EESEN_FWD_MID=2 orders the side stream with a command-processor wait instead, which cannot dead-lock
+  // (net.cpp; it costs 2.2 ms per cfg2 step where this kernel gains 0.85, so it is the profiling arm, not the default).
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
-    if ((spins & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if ((spins & 15) == 15) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+      if (wall_clock64() - t0 > limit_ticks) break;
+    }
     __builtin_amdgcn_s_sleep(32);
   }
   __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2: "the milestone wait gave up" (net.cpp: check_device_error)
 }
 
 // LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published
-// step milestone_step; the last of them raises the flag word the host's side stream waits for
+// step milestone_step; the last of them raises the flag word the host's side stream waits for -- with a polling kernel, or
+// (EESEN_FWD_MID=2) with its command processor on signal memory, which is host-coherent: system scope (once per group and launch)
 __device__ __forceinline__ void report_milestone(unsigned* ms, unsigned ngroups) {
-  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups)
-    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u == ngroups)
+    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.
@@ -1569,6 +1582,8 @@ void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) 
 // process, ~3 ms: 2000 round trips, the median of five runs).  The first-poll delays of the recurrence kernels are multiples of it.
 float handoff_flight_ns() {
   static float cache[64] = {0};
+  static std::mutex mu;                       // Nets may be created from several host threads
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0.f;
   if (cache[dev] > 0.f) return cache[dev];
@@ -1583,12 +1598,13 @@ float handoff_flight_ns() {
     hipLaunchKernelGGL(handoff_pingpong_kernel, dim3(2), dim3(64), 0, nullptr, flags, out, rounds);
     unsigned long long ticks = 0;
     EESEN_HIP_CHECK(hipMemcpy(&ticks, out, sizeof(ticks), hipMemcpyDeviceToHost));
-    ns[rep] = 10.0 * (double)ticks / (2.0 * rounds);
+    // 0 ticks: the two workgroups never saw each other (not co-resident on a busy device): no measurement, the default flight
+    ns[rep] = ticks ? 10.0 * (double)ticks / (2.0 * rounds) : 500.0;
   }
   std::sort(ns, ns + 5);
   (void)hipFree(flags);
   (void)hipFree(out);
-  cache[dev] = (float)ns[2];
+  cache[dev] = (float)std::min(2000.0, std::max(100.0, ns[2]));
   return cache[dev];
 }
 
@@ -1785,8 +1801,9 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
 // group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
 // 0 = the kernel does not apply (narrow layers take the 4 x 32
 // tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
-void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err) {
-  hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err);
+void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err, double limit_s) {
+  const unsigned long long ticks = (unsigned long long)(std::max(0.05, limit_s) * 1e8);   // wall_clock64: 100 MHz
+  hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err, ticks);
   check_launch("wait_for_word");
 }
 

@@ -193,6 +193,7 @@ Net::~Net() {
                        pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
       }
   }
+  if (mile_sig) (void)hipFree(mile_sig);
   if (lens_pin) (void)hipHostFree(lens_pin);
   if (err_pin) (void)hipHostFree(err_pin);
   if (live_pin) (void)hipHostFree(live_pin);
@@ -220,8 +221,10 @@ void Net::sync() {
 // The error word of the persistent recurrence kernels.  While it is set every persistent kernel leaves at its first poll, the
 // update kernels skip (optim.hip) and a guarded Ctc drops the minibatch from its statistics (eesen_ctc_set_guard), so nothing
 // computed under it reaches the model or the accuracy: `lost` minibatches -- the one that raised it and those the host had
-// already enqueued behind it -- are not applied.  Without a data-parallel communicator the run continues on the
-// one-launch-per-step kernels; with one, the other ranks HAVE applied their steps, the ranks would diverge: that stays fatal.
+// already enqueued behind it -- are not applied.  The run continues on the one-launch-per-step kernels.  With a data-parallel
+// communicator the other ranks HAVE stepped, so "not applied" would let the ranks diverge: there the failed rank's gradients enter
+// the all-reduce as ZEROS (decided on the device, comm.cpp: bucket_allreduce) and it applies the same summed update as the others
+// -- the run loses this rank's share of those minibatches and nothing else (round 3 raised an error here, for either value).
 // consumer = the caller is about to READ something the last Propagate produced (get_output, Synchronize before a host copy,
 // the inference and cross-validation paths): that forward pass is then re-run on the per-step kernels before returning, so a
 // timed-out Propagate never hands out garbage with status OK.
@@ -239,18 +242,20 @@ void Net::check_device_error(bool consumer) {
   if (only_waiter) tn.fwd_mid = 0;
   else { persistent = 0; gate_fwd = false; overlap = false; }
   ++recoveries;
-  if (comm) throw Error(EESEN_ERR_HIP, "persistent recurrence kernel gave up waiting for a peer workgroup (not all workgroups "
-                                       "resident?) in a data-parallel run; rerun with EESEN_PERSISTENT=0");
   const int lost = std::max(1, steps_since_clean);
   steps_since_clean = 0;
   const bool rerun = consumer && propagated && input.p && rows > 0;
+  // In a data-parallel run the other ranks HAVE stepped: this rank's gradients of those minibatches went into the all-reduce as
+  // zeros (comm.cpp: bucket_allreduce) and it applied the same summed update as everybody, so the models stay identical -- the
+  // run loses this rank's share of those steps, nothing else.
+  const char* what = comm ? "contributed a ZERO gradient to the data-parallel sum (the ranks' models stay identical)" : "were NOT applied";
   if (only_waiter)
     fprintf(stderr, "WARNING (eesen_hip) the side stream's wait for a forward-recurrence milestone gave up (kernels serialised by a tool?): "
-                    "%d minibatch(es) in flight were NOT applied%s; continuing without the early input GEMM (EESEN_FWD_MID=0)\n", lost,
+                    "%d minibatch(es) in flight %s%s; continuing without the early input GEMM (EESEN_FWD_MID=0)\n", lost, what,
             rerun ? " and the last forward pass is re-run" : "");
   else
     fprintf(stderr, "WARNING (eesen_hip) a persistent recurrence kernel gave up waiting for a peer workgroup (GPU shared or preempted?): "
-                    "%d minibatch(es) in flight were NOT applied%s; continuing with the one-launch-per-step kernels\n", lost,
+                    "%d minibatch(es) in flight %s%s; continuing with the one-launch-per-step kernels\n", lost, what,
             rerun ? " and the last forward pass is re-run" : "");
   if (rerun) {
     forward_pass();
@@ -692,14 +697,41 @@ void Net::forward_pass() {
       const int mile_step = (3 * T) / 4;   // measured at cfg2, same box: 60 % 39.4, 67 % 38.7, 75 % 38.2, 82 % 38.85, 88 % 38.8, off 39.0 ms
       const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
                             T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
+      // EESEN_FWD_MID=2 (the profiling arm): the SAME kernels on the SAME overlap, but the side stream is put behind the milestone by
+      // its COMMAND PROCESSOR (hipStreamWaitValue64 on 8 bytes of signal memory: count in the low word, flag in the high one) instead of
+      // by a spinning one-wave kernel -- no shader waits for another kernel, so a tool that lets only one kernel run at a time
+      // (rocprofv3 --pmc) cannot dead-lock the schedule, and counters can be collected for the recurrence UNDER the early GEMM.
+      // It costs 2.2 ms per cfg2 step where the spinning waiter gains 0.85, hence not the default.
+      bool mid_cp = plan_mid && tn.fwd_mid == 2 && mile_sig_ok != 0;
+      if (mid_cp && mile_sig_ok < 0) {   // first use: is there a stream wait on this device, and signal memory for it?
+        int can = 0;
+        void* q = nullptr;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
+            hipExtMallocWithFlags(&q, 8, hipMallocSignalMemory) == hipSuccess && q) {
+          mile_sig = static_cast<unsigned*>(q);
+          mile_sig_ok = 1;
+        } else {
+          (void)hipGetLastError();
+          mile_sig_ok = 0;
+          mid_cp = false;
+        }
+      }
       { const int ti_ = timer.begin(st, 1);
       LstmLayerDev v = lstm_view(*this, L);
       v.poll_delay = delay_fwd;
       if (plan_mid) {
-        mile.reserve(32);
-        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
-        EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
-        v.milestone = mile.p;
+        if (mid_cp) {   // reset, then the side stream behind the flag BEFORE the recurrence is committed
+          EESEN_HIP_CHECK(hipStreamWriteValue64(st, mile_sig, 0, 0));
+          EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
+          EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+          EESEN_HIP_CHECK(hipStreamWaitValue64(st2, mile_sig, 1ull << 32, hipStreamWaitValueGte, 0xFFFFFFFF00000000ull));
+          v.milestone = mile_sig;
+        } else {
+          mile.reserve(32);
+          EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
+          EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
+          v.milestone = mile.p;
+        }
         v.milestone_step = mile_step;
       }
       const bool pers = persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p,
@@ -725,7 +757,8 @@ void Net::forward_pass() {
         g_gated = true;
       }
       if (plan_mid) {
-        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));   // released at the latest here
+        if (mid_cp) EESEN_HIP_CHECK(hipStreamWriteValue64(st, mile_sig, 1ull << 32, 0));               // released at the latest here
+        else EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));
         const int ldG2 = nxt->ndir * 4 * nxt->H;
         nxt->G.reserve((size_t)rows * ldG2);
         // whole 256-row tiles: the two ends (main stream, critical path) keep the GEMM's 256 x 256 flavour; the middle part takes the
@@ -737,8 +770,12 @@ void Net::forward_pass() {
       }
       if (plan_mid && mid_r1 > mid_r0) {
         const int ldG2 = nxt->ndir * 4 * nxt->H;
-        EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
-        wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1);
+        if (!mid_cp) {
+          EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+          // bounded on the wall clock: 2 s for a recurrence of up to 1000 steps, longer for longer ones, tenfold under a communicator
+          // (whose collectives may delay the recurrence's residency: set_comm raises spin_limit the same way)
+          wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1, 2.0 * std::max(1.0, T / 1000.0) * std::max(1.0, spin_limit / 400000.0));
+        }
         const int tj_ = timer.begin(st2, 0);
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,
@@ -813,6 +850,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   bool side_pending[2] = {false, false};
   bucket_log.clear();
   info_bwd_persistent = 0;
+  live_valid = comm != nullptr;
   if (comm) {  // this rank has a minibatch: liveness 1 rides with the top layer's gradient bucket (comm.cpp)
     comm_check_alive(comm);
     EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fresh.p + P), 0x3f800000, 1, st));
@@ -945,8 +983,12 @@ void Net::update() {
   // A persistent recurrence kernel that gave up waiting for a peer (error word raised) leaves garbage gradients: the update
   // kernels read the word ON THE DEVICE and do nothing then, so a failed step never reaches the parameters; the host notices
   // at its next poll and continues on the per-step kernels (check_device_error).
-  const unsigned* skip = persistent ? ctl.p + kCtlWords - 1 : nullptr;
-  const float* live = comm ? fresh.p + P : nullptr;   // 0 after the all-reduce: no rank had a minibatch -- the closing round, a no-op
+  // (After a data-parallel exchange the word is NOT looked at here: a failed rank has contributed zeros to the sum instead -- on the
+  // device, before the all-reduce -- and must apply the same summed gradient as the others, or the ranks would diverge.)
+  const unsigned* skip = persistent && !grads_sanitized ? ctl.p + kCtlWords - 1 : nullptr;
+  // 0 after the all-reduce: no rank had a minibatch -- the closing round, a no-op.  Only looked at when THIS step wrote it
+  // (Backpropagate / BackpropagateZero): an Update whose gradients came another way must not be gated on a stale word.
+  const float* live = comm && live_valid ? fresh.p + P : nullptr;
   comm_check_alive(comm);
   { const int ti_ = timer.begin(st, 5);
   // top-down, the order in which Backpropagate completed (and all-reduced) the layers' gradients
@@ -954,7 +996,11 @@ void Net::update() {
     Layer& L = layers[li];
     if (L.p_n) {
       if (comm && li < (int)bucket_pending.size() && bucket_pending[li]) {
+        // phase 7 of the profiling spans: what the compute stream WAITS for this bucket -- the part of the exchange that the
+        // backward pass of the lower layers did not hide (first event: the stream has reached the update; second: the bucket is in)
+        const int tw_ = timer.begin(st, 7);
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_bucket[li], 0));
+        timer.end(st, tw_);
         bucket_pending[li] = 0;
       }
       if (rule == 0) {
@@ -968,6 +1014,8 @@ void Net::update() {
   }
   refresh_derived();
   timer.end(st, ti_); }
+  grads_sanitized = false;
+  live_valid = false;
   if (persistent) arm_device_error_poll();
 }
 

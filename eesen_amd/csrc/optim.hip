@@ -71,6 +71,14 @@ __global__ __launch_bounds__(256) void adaptive_update_kernel(float* __restrict_
   }
 }
 
+// p[0..n) = 0 if *word != 0 (decided on the device, at execution time): a rank whose recurrence kernels raised the error word in
+// this step must not put its garbage gradient into the all-reduce -- it contributes zero, like a rank without a minibatch (comm.cpp)
+__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ p, long n, const unsigned* __restrict__ word) {
+  if (*word == 0u) return;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
 // 32x32 LDS-tiled transpose, coalesced on both sides
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, int rows, int cols,
                                                           float* __restrict__ dst) {
@@ -107,6 +115,12 @@ void sgd_update(hipStream_t st, float* param, float* corr, const float* fresh, l
   const int blocks = (int)std::min<long>(cdivl(n / 4 + 1, 256), 2048);
   hipLaunchKernelGGL(sgd_update_kernel, dim3(blocks), dim3(256), 0, st, param, corr, fresh, n, mmt, lr_coef, max_grad, skip, live);
   check_launch("sgd_update");
+}
+
+void zero_if_set(hipStream_t st, float* p, long n, const unsigned* word) {
+  if (n <= 0 || !word) return;
+  hipLaunchKernelGGL(zero_if_set_kernel, dim3(256), dim3(256), 0, st, p, n, word);
+  check_launch("zero_if_set");
 }
 
 void adaptive_update(hipStream_t st, float* param, float* corr, const float* fresh, float* accu, long n, float mmt, float lr,

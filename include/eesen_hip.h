@@ -167,8 +167,13 @@ int eesen_net_bf16_recurrence_layers(eesen_net_t* net, int* layers);
  * took the one-launch-per-step kernels), and the number of recoveries so far.  A recovery: a cooperative recurrence
  * kernel whose bounded spin gave up (its workgroups were not all resident -- GPU shared or preempted) raises a device
  * word; the update kernels of that step see it and leave the model untouched, and the handle continues on the per-step
- * kernels with a WARNING on stderr (fatal only when a communicator is attached: the other ranks did apply their step). */
+ * kernels with a WARNING on stderr.  With a communicator attached the other ranks do apply their step: the failed rank's
+ * gradients then enter the all-reduce as zeros (decided on the device) and it applies the same summed update, so the ranks' models
+ * stay identical and the run only loses that rank's share of the minibatches in flight. */
 int eesen_net_recurrence_info(eesen_net_t* net, int* out4);
+/* Test hook: stores `value` into that device word on the handle's stream, as a kernel that gave up would (1: a recurrence
+ * kernel's bounded spin, 2: the side stream's wait for a forward milestone), so that the recovery paths can be exercised. */
+int eesen_net_debug_set_error_word(eesen_net_t* net, unsigned value);
 /* Block until everything enqueued on the handle's stream has finished. */
 int eesen_net_synchronize(eesen_net_t* net);
 /* Seconds spent (HIP events on the handle's stream) in the phases of the last step, for bench.py:
@@ -180,7 +185,11 @@ int eesen_net_get_phase_times(eesen_net_t* net, float* out6);
 /* The individual timed spans behind those sums, in the order they were recorded: phases[i] (index as above) and seconds[i]
  * of span i, up to `cap`; *n = spans recorded since the last eesen_net_get_phase_times.  One span per kernel group of a
  * layer (e.g. one per layer and step for the recurrences, top layer first in the backward pass), so a caller can separate
- * the launch that runs alone on the chip from those that share it with side-stream work.  Call BEFORE get_phase_times. */
+ * the launch that runs alone on the chip from those that share it with side-stream work.  Call BEFORE get_phase_times.
+ * With a communicator attached two more span kinds appear here (they are not part of out6): phase 6 = one gradient bucket's
+ * all-reduce on the communicator's stream (from "bucket ready and stream free" to the end of the collective; in the order of
+ * eesen_net_bucket_order), phase 7 = the time the compute stream waited for one bucket inside eesen_net_update -- the part of
+ * the exchange the lower layers' backward pass did not hide. */
 int eesen_net_get_phase_spans(eesen_net_t* net, int* phases, float* seconds, int cap, int* n);
 
 /* ---- data-parallel exchange: one process per GPU, RCCL over xGMI ------------------------------------------------------

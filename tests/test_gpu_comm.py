@@ -97,18 +97,50 @@ def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name,
     nb.SetComm(None)
 
 
-def test_timed_out_recurrence_is_fatal_in_a_data_parallel_run(gpu, comm, monkeypatch):
-    """With a communicator attached the other ranks HAVE applied the step a failed rank skipped: continuing would let the ranks
-    diverge, so the failure is raised instead of recovered (cf. test_gpu_parity.py::test_recovery_from_a_timed_out_persistent_kernel)."""
-    from eesen_amd.api import Net, Ctc, EesenError
-    cfg = synth.config("small_bi")
+def test_timed_out_recurrence_contributes_zero_in_a_data_parallel_run(gpu, comm, monkeypatch, capfd):
+    """With a communicator attached the other ranks DO apply the step a failed rank could not compute, so the failed rank can
+    neither put its garbage gradient into the sum nor skip the update (the ranks would diverge).  Its gradients enter the
+    all-reduce as ZEROS -- decided on the device, where the error word is -- its liveness word with them, and it applies the summed
+    update like everybody else; the host notices later, warns, and carries on (round 3 raised an error here, also for the harmless
+    value 2 of a milestone waiter that gave up: VERDICT r3 item 4c).  One rank: the sum is zero, liveness 0 -> the model does not
+    move; the next step runs on the per-step kernels (value 1) / without the early input GEMM (value 2) and equals a clean step."""
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config("small_bi"); cfg.update(S=32, T=64)        # (the middle-first schedule needs T >= 32 and a second LSTM layer)
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
-    monkeypatch.setenv("EESEN_SPIN_LIMIT", "0")
-    net = Net.from_layers(layers)
-    net.SetComm(comm)                      # (an explicit EESEN_SPIN_LIMIT is respected; otherwise attaching raises the bound)
-    monkeypatch.delenv("EESEN_SPIN_LIMIT")
-    net.SetSeqLengths(batch.lens)
-    with pytest.raises(EesenError, match="gave up waiting for a peer workgroup"):
-        net.Propagate(batch.feats)
-        net.Synchronize()
-    net.SetComm(None)
+
+    def one_step(net, ctc):
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        d = ctc.EvalParallel(batch.lens, out, batch.labels, want_pzx=False)
+        net.Backpropagate(d)
+
+    clean = Net.from_layers(layers); clean.SetTrainOptions(1e-3, 0.9); clean.SetComm(comm)
+    one_step(clean, Ctc()); clean.Synchronize()
+    want = clean.GetParams()
+    clean.SetComm(None)
+    for value, spin in ((1, "0"), (2, None)):
+        if value == 1:
+            monkeypatch.setenv("EESEN_SPIN_LIMIT", spin)          # every bounded spin of the recurrence kernels gives up at once: value 1
+        net = Net.from_layers(layers)
+        net.SetTrainOptions(1e-3, 0.9)
+        net.SetComm(comm)                  # (an explicit EESEN_SPIN_LIMIT is respected; otherwise attaching raises the bound)
+        if value == 1:
+            monkeypatch.delenv("EESEN_SPIN_LIMIT")
+        ctc = Ctc(); ctc.SetGuard(net)
+        before = net.GetParams()
+        if value == 2:
+            net._raise_error_word(2)       # what wait_for_word_kernel stores when it gives up (lstm_persistent.hip)
+        one_step(net, ctc)
+        net.Synchronize()                  # the host notices here: a WARNING, not an exception
+        err = capfd.readouterr().err
+        assert "contributed a ZERO gradient to the data-parallel sum" in err, err
+        assert ("continuing with the one-launch-per-step kernels" in err) == (value == 1)
+        assert ("continuing without the early input GEMM" in err) == (value == 2)
+        assert np.array_equal(net.GetParams(), before)            # zero sum, liveness 0: the step did not move the model
+        assert net.RecurrenceInfo() is not None and net.recoveries == 1
+        one_step(net, ctc); net.Synchronize()                     # the next step is a clean one
+        ri = net.RecurrenceInfo()
+        assert (ri["fwd_persistent"] == 0) == (value == 1), ri
+        assert rel_err(net.GetParams(), want) < 1e-6
+        assert net.LiveRanks() == 1
+        net.SetComm(None)
