@@ -55,20 +55,42 @@ def flops_per_frame(cfg) -> float:
     return total
 
 
-def pipe_bound(cfg, split_gemm: bool = True) -> dict:
+def fwd_rec_products(cfg, S: int, forward_mode: int = 0) -> int:
+    """How the FORWARD recurrent product of this configuration is executed (lstm_persistent.hip: bf_plan): 0 = on the fp32-input
+    MFMA; n > 0 = on the bf16 pipe as n bf16 products per fp32 product -- 6 for the fp32-class 3-way split the narrow tile takes
+    (H <= 512, S > 16; EESEN_FWD_SPLIT), 2 (W_m as hi + lo planes; 1 with EESEN_BF16_REC_WPLANES=1) for BASELINE config 4's bf16
+    forward (--forward-precision bf16) on layers of 256 .. 1024 cells."""
+    if os.environ.get("EESEN_PERSISTENT", "1") == "0" or cfg["H"] % 32 != 0:
+        return 0
+    H = cfg["H"]
+    if forward_mode == 1 and H % 256 == 0 and H <= 1024:
+        return 1 if os.environ.get("EESEN_BF16_REC_WPLANES") == "1" else 2
+    narrow = H % 8 == 0 and S > 16 and (H // 32 + 7) // 8 <= 2
+    if narrow and os.environ.get("EESEN_FWD_SPLIT", "1") != "0" and os.environ.get("EESEN_FWD_Q4", "0") == "0":
+        return 6
+    return 0
+
+
+def pipe_bound(cfg, split_gemm: bool = True, fwd_products: int = 0) -> dict:
     """The step's flops by matrix pipe and the time the two pipes need for them at their peaks.  Per layer and direction the
-    recurrence kernels execute the forward and the backward recurrent product (16 H^2 per frame) on the fp32 pipe
-    (v_mfma_f32_16x16x4_f32 / 4x4x1); everything else is GEMM: on the bf16 pipe as six bf16 products per fp32 product (the exact
-    3-way split), or on the fp32 pipe in EESEN_GEMM_MODE=f32.  frac = bound / measured time is <= 1 by construction."""
+    recurrence kernels execute the forward and the backward recurrent product (8 H^2 per frame each).  The backward one runs on
+    the fp32 pipe (v_mfma_f32_16x16x4_f32 / 4x4x1); the forward one too, unless `fwd_products` says it runs on the bf16 pipe as that
+    many bf16 products per fp32 product (fwd_rec_products).  Everything else is GEMM: on the bf16 pipe as six bf16 products per
+    fp32 product (the exact 3-way split), or on the fp32 pipe in EESEN_GEMM_MODE=f32.  frac = bound / measured time is <= 1 by
+    construction."""
     nd = 2 if cfg["kind"].startswith("BiLstm") else 1
     rec = float(cfg["layers"]) * nd * 16.0 * cfg["H"] * cfg["H"]
     gemm = flops_per_frame(cfg) - rec
+    rec_f32 = rec if not fwd_products else rec / 2
+    rec_bf16 = 0.0 if not fwd_products else fwd_products * rec / 2
     if split_gemm:
-        sec = rec / (PEAK_F32_MFMA_TFLOPS * 1e12) + 6.0 * gemm / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+        bf16 = 6.0 * gemm + rec_bf16
+        sec = rec_f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
     else:
-        sec = (rec + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12)
-    return {"f32_pipe_flops_per_frame": rec, "gemm_flops_per_frame_fp32_equivalent": gemm,
-            "bf16_pipe_executed_flops_per_frame": 6.0 * gemm if split_gemm else 0.0, "bound_us_per_frame": 1e6 * sec}
+        bf16 = rec_bf16
+        sec = (rec_f32 + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
+    return {"f32_pipe_flops_per_frame": rec_f32 + (0.0 if split_gemm else gemm), "gemm_flops_per_frame_fp32_equivalent": gemm,
+            "bf16_pipe_executed_flops_per_frame": bf16, "forward_recurrence_bf16_products": fwd_products, "bound_us_per_frame": 1e6 * sec}
 
 
 def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
@@ -226,12 +248,12 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
             "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
             "bf16_recurrence_layers": net.Bf16RecurrenceLayers(),
             "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
-            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg)["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
+            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, True, fwd_rec_products(cfg, batch.S, int(forward_bf16)))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
 
 
-def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120) -> dict:
+def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int = 25000) -> dict:
     """Not the headline: the reference's OWN recipe shape -- 4 x 320 BiLSTM on 120-d features (40 fbanks + deltas), ~45 phone
     targets, --num-sequence 10 (20 as the second point) --frame-num-limit 25000, utterances of a length-sorted list with WSJ-like
     durations (asr_egs/wsj/run_ctc_phn.sh:65-85, steps/train_ctc_parallel.sh:13-21) -- through the trainer's own path: greedy
@@ -244,7 +266,7 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120) -> dict:
     lens = np.sort(np.clip(rng.gamma(6.0, 130.0, size=n_utts), 150, 1600).astype(int))        # ~7.8 s mean, sorted as the recipes do
     utts = [(f"utt{i:04d}", rng.standard_normal((int(n), cfg["D"])).astype(np.float32)) for i, n in enumerate(lens)]
     labs = {k: rng.integers(1, cfg["K"], size=max(1, m.shape[0] // 10)).astype(np.int32) for k, m in utts}
-    groups = list(assemble(iter(utts), labs, num_sequence, 25000, cfg["D"], interleaved=False))
+    groups = list(assemble(iter(utts), labs, num_sequence, frame_limit, cfg["D"], interleaved=False))
     net = Net.from_layers(synth.make_model(max_grad=50.0, **cfg), device=dev)
     net.SetTrainOptions(4e-5, 0.9)
     ctc = Ctc(device=dev)
@@ -277,7 +299,7 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120) -> dict:
     dt = time.perf_counter() - t0
     padded = float(sum(g.T * g.S for g in groups)); real = float(sum(int(g.lens.sum()) for g in groups))
     fpf = flops_per_frame(cfg)
-    return {"workload": f"4x320 BiLSTM, D=120, K=46, --num-sequence {num_sequence} --frame-num-limit 25000, {n_utts} length-sorted utterances "
+    return {"workload": f"4x320 BiLSTM, D=120, K=46, --num-sequence {num_sequence} --frame-num-limit {frame_limit}, {n_utts} length-sorted utterances "
                         f"of {int(lens.min())}-{int(lens.max())} frames in {len(groups)} minibatches (S = {min(g.S for g in groups)}-{max(g.S for g in groups)})",
             "minibatches": len(groups), "ms_per_minibatch": 1e3 * dt / len(groups), "padded_frames_per_s": padded / dt, "real_frames_per_s": real / dt,
             "whole_step_tflops_fp32_equivalent": fpf * padded / dt / 1e12, "flops_per_frame": fpf,
@@ -477,7 +499,9 @@ def main():
         K = args.steps
         value = padded * K / dt
         fpf = flops_per_frame(cfg)
-        pb = pipe_bound(cfg, os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"))
+        fwd_mode = {"f32": 0, "bf16": 1, "bf16-gemm": 2}[args.forward_precision]
+        fprod = fwd_rec_products(cfg, batch.S, fwd_mode)
+        pb = pipe_bound(cfg, os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"), fprod)
         nd = 2 if cfg["kind"].startswith("BiLstm") else 1
         H, S, T, nl = cfg["H"], batch.S, batch.T, cfg["layers"]
         # per-launch algorithmic work of the three kernels that carry the step (DESIGN.md "kernels")
@@ -505,8 +529,11 @@ def main():
                      ("gemm_f32_split_bf16_big_kernel" if big else "gemm_f32_split_bf16_kernel")) + \
                     ("(input->gates: 2 ends + gemm_f32_split_bf16_kernel middle under the recurrence)" if mid_first and split and not bf16_fwd else "(input->gates)")
         bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn
+        # the forward recurrence on the bf16 pipe (lstm_fwd_persistent_bf_kernel): the fp32-class 3-way split of the narrow tile (six
+        # products), or config 4's bf16 forward (m_t one plane, W_m hi + lo: two products)
+        fwd_name = "lstm_fwd_" + kn if not fprod else f"lstm_fwd_persistent_bf_kernel<AP={3 if fprod == 6 else 1}, WP={3 if fprod == 6 else fprod}>"
         kern = {
-            "lstm_fwd_" + kn: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
+            fwd_name: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32" if not fprod else "bf16", products=fprod or 1),
             bwd_name: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
             gemm_name: dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops, pipe="f32" if (not split and not bf16_fwd) else "bf16"),
         }
@@ -514,7 +541,7 @@ def main():
             k["avg_us"] = 1e6 * k["total_s"] / k["launches"]
             k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12      # fp32-equivalent (algorithmic) TFLOP/s
             # what the matrix pipe EXECUTES: the split GEMM runs six bf16 products per fp32 product (one with bf16-rounded forward operands)
-            k["executed"] = k["achieved"] * (1 if k["pipe"] == "f32" else (1 if bf16_fwd else 6))
+            k["executed"] = k["achieved"] * (1 if k["pipe"] == "f32" else k.get("products", 1 if bf16_fwd else 6))
             k["peak"] = PEAK_F32_MFMA_TFLOPS if k["pipe"] == "f32" else PEAK_BF16_MFMA_TFLOPS
             k["frac"] = k["executed"] / k["peak"]                                     # never above 1: executed flops over that pipe's peak
         dom = max(kern, key=lambda n: kern[n]["total_s"])
@@ -673,7 +700,10 @@ def main():
             sec = {}
             for name, fn in (("cfg4", lambda: secondary_leg("cfg4", dev)), ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, forward_bf16=True)),
                              ("cfg5", lambda: secondary_leg("cfg5", dev, steps=3, warmup=1)),
-                             ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20))):
+                             ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20)),
+                             # the same shape with the minibatch this part wants (INTEGRATION.md "Which --num-sequence"): the frame limit raised
+                             # so that --num-sequence is what bounds a minibatch
+                             ("wsj_recipe_shape_S32", lambda: recipe_leg(dev, 32, 256, 100000)), ("wsj_recipe_shape_S64", lambda: recipe_leg(dev, 64, 256, 100000))):
                 try:
                     sec[name] = fn()
                 except Exception as e:  # noqa: BLE001

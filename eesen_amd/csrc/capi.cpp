@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <algorithm>
+
 #include "guard.h"
 #include "net.h"
 
@@ -268,7 +270,17 @@ int eesen_ctc_set_guard(eesen_ctc_t* ctc, eesen_net_t* net) {
   return guard([&] {
     REQ_PTR(ctc);
     ctc->flush();
+    // the guard word is read with copies enqueued on the Ctc's stream: only in the Net's own stream are they ordered behind the
+    // kernels that raise it (a Net and a Ctc created without a stream share the device's default stream, like the reference's
+    // single-stream CuDevice)
+    if (net) EESEN_REQUIRE(net->device == ctc->device && net->st == ctc->st, EESEN_ERR_INVALID, "eesen_ctc_set_guard: the Ctc and the Net must live on the same device and stream");
+    if (ctc->guard_net) {   // unhook from the Net guarded so far
+      auto& g = ctc->guard_net->guards;
+      g.erase(std::remove(g.begin(), g.end(), static_cast<Ctc*>(ctc)), g.end());
+    }
     ctc->guard = net && net->ctl.p ? net->ctl.p + kCtlWords - 1 : nullptr;
+    ctc->guard_net = ctc->guard ? net : nullptr;
+    if (ctc->guard_net) net->guards.push_back(ctc);
   });
 }
 int eesen_ctc_dropped(eesen_ctc_t* ctc, long* minibatches) {

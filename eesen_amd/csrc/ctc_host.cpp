@@ -5,6 +5,9 @@
 #include <cmath>
 #include <fstream>
 
+#include <algorithm>
+#include <limits>
+
 #include "net.h"
 
 namespace eesen {
@@ -23,6 +26,10 @@ Ctc::Ctc(int dev, void* stream) : device(dev) {
 Ctc::~Ctc() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(st);
+  if (guard_net) {
+    auto& g = guard_net->guards;
+    g.erase(std::remove(g.begin(), g.end(), this), g.end());
+  }
   for (auto& x : ev)
     if (x) (void)hipEventDestroy(x);
   auto drop = [](Pin& pin) {
@@ -164,7 +171,9 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   sequences += S;
   if (pzx_host) {
     flush();  // keeps the accumulation order of the calls
-    for (int s = 0; s < S; ++s) pzx_host[s] = pz[s];
+    // a minibatch computed from a timed-out forward pass (guard word set) has no ln p: NaN, never garbage with status OK
+    const bool bad = reinterpret_cast<const unsigned*>(pz)[S] != 0;
+    for (int s = 0; s < S; ++s) pzx_host[s] = bad ? std::numeric_limits<float>::quiet_NaN() : pz[s];
   }
   last_lens.assign(frame_num_utt, frame_num_utt + S);
   last_T = T; last_S = S; last_Lpad = Lpad; last_Lprime = Lprime;

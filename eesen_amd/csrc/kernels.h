@@ -84,9 +84,13 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
-  // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on ONE bf16 plane with
-  // fp32 accumulation (lstm_fwd_persistent_bf16_kernel); X then holds the exchange copy of m as bf16
+  // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on bf16 operands with
+  // fp32 accumulation (lstm_fwd_persistent_bf_kernel<.., AP = 1, WP>): m_t as ONE bf16 plane in the exchange buffer X, W_m as hi + lo
+  // planes (1) or one plane (2: EESEN_BF16_REC_WPLANES=1, the A/B arm)
   int fwd_bf16 = 0;
+  // fp32-class forward recurrence on the bf16 matrix pipe (3-way split of both operands, six products; tuning.h: EESEN_FWD_SPLIT)
+  int fwd_split = 0;
+  int fwd_q4 = 0;     // the 4-sequence x 32-unit forward tile (tuning.h: EESEN_FWD_Q4)
   int fwd_mux2 = 0;   // experiment: narrow layers through the time-multiplexed forward kernel (tuning.h: EESEN_FWD_MUX2)
 };
 float handoff_flight_ns();
@@ -119,6 +123,8 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
 // true when lstm_fwd_persistent would run this layer's recurrence on the bf16 kernel (L.fwd_bf16 set and the shape allows)
 bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L);
+// the forward tile this layer takes leaves room on a CU for a 128 x 128 GEMM workgroup (net.cpp: "the middle first")
+bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L);
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);

@@ -363,29 +363,193 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward, bf16 recurrence (eesen_net_set_forward_precision(1): BASELINE config 4's "bf16 forward / fp32 CTC accumulate").
-// The time loop being replaced is bilstm-parallel-layer.h:112-149,165-204; what changes against lstm_fwd_persistent_kernel is the
-// ARITHMETIC OF THE RECURRENT PRODUCT m_{t-1} W_m^T only: W_m is rounded to nearest-even bf16 once per launch (ONE plane: 16 * CPW
-// registers per lane for the workgroup's 64 gate rows instead of 32 * CPW of fp32), m_t is rounded to bf16 once, where the cell
-// writes it into the exchange buffer (LstmLayerDev::X reinterpreted as bf16: HALF the bytes every consumer fetches per step --
-// the fetch is what bounds the fp32 step), and the products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 4 * CPW
-// instructions of ~17 cycles per wave and step instead of 32 * CPW of 32 cycles.  Gate pre-activations, the cell state c, the
-// peephole terms, the activations and everything the kernel writes for the backward pass (G, C, Y) stay fp32; the backward pass
-// is the fp32 one.  Tile: 16 sequences x 16 units (the wide fp32 tile's geometry, one workgroup per CU at H = 1024, S = 32).
-// Exchange layout (bf16): block of (t, dir, sequence tile) = [32-unit chunk][k quad][16 sequences][8 bf16]: lane (sequence li,
-// quad kq) of chunk ch reads 16 bytes at ((ch * 4 + kq) * 16 + li) * 16 -- the 16 lanes of a quad read 256 contiguous bytes.
-// A and B fragments use the same lane -> k assignment (lane (li, kq) holds k = 32 ch + 8 kq .. + 7), so the contraction is exact
-// whatever the instruction's internal k order.
+// forward, 4 sequences x 32 units per workgroup (round 4; EESEN_FWD_Q4): the forward twin of lstm_bwd_persistent_q4_kernel.
+// The 16 x 8 tile fetches m_{t-1} of 16 sequences -- 32 KB per workgroup and step at H = 512 -- and that fetch, at the ~34-40 GB/s
+// a CU fills its L1 with freshly written lines, is 0.8-1.0 us of the 3.1 us step.  On the 16-block v_mfma_f32_4x4x1_16B_f32 with
+// the A-operand broadcast (CBSZ = 3: all eight blocks of a k class share the A lanes of block ABID) a workgroup's 512 outputs can
+// be 4 sequences x 128 gate rows (32 units) instead: the same MFMA time (128 two-pass instructions per wave and step), W_m still
+// resident (128 gate rows x 64 k per wave = 128 registers per lane, the last row group in LDS as in the backward twin), still one
+// workgroup per CU (H/32 x ndir x S/4 = 256 at cfg2) -- and a QUARTER of the fetch: 4 sequences x 2 KB = ONE b128 load per lane
+// and step, whole 128-byte lines straight out of Y (no exchange copy needed).  Hand-off groups shrink from 64 to 16 workgroups
+// (one (direction, 4-sequence tile) each, two groups per XCD with the XCD-aware role map).
+//   lane l: k class ks = l >> 5, block ab = (l >> 2) & 7, x = l & 3; wave w owns k = 64 w .. 64 w + 63 (H <= 512)
+//   A: lane (ks, ab, x) loads 16 bytes of sequence x at k = 64 w + (ks * 8 + ab) * 4; instruction (r, ABID) takes component r:
+//      class ks covers k = 64 w + ks * 32 + ABID * 4 + r
+//   B: lane (ks, cb = ab, x), row group rg holds W_m[gate row rg * 32 + cb * 4 + x][that k]
+//   D: vgpr i, lane (ks, cb, x) -> out[sequence i][gate row rg * 32 + cb * 4 + x], partial over (wave, ks): summed through LDS
+// The sum over k is formed in a different order than in lstm_fwd_step_kernel: NOT bit-identical to the per-step kernels (the
+// 16 x 8 tile is; EESEN_FWD_Q4=0 restores it), parity ~1e-6 like every backward variant.  Shapes: H % 64 == 0, H <= 512,
+// S % 4 == 0, no dropout.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_q4_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err, int spin_limit,
+                                                                         unsigned long long* trace, Role R) {
+  constexpr int ST = 4, UW = 32, GR = 4 * UW, RGN = 4, RW = GR + 4;   // sequences, units, gate rows per workgroup; row groups of 32 gate rows
+  constexpr int LDSG = 1, REGG = RGN - LDSG;                           // row groups whose W_m values live in LDS / in registers
+  __shared__ __attribute__((aligned(16))) float4 bl[LDSG][8][NW * 64];   // [row group][ABID][thread]: components r
+  __shared__ __attribute__((aligned(16))) float red[NW][2 * ST][RW];     // [wave][k class x sequence][gate row]
+  __shared__ int s_go;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int u0 = bx * UW, s0 = bz * ST;
+  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
+  const unsigned nblk = R.nblk;
+  const int ks = lane >> 5, ab = (lane >> 2) & 7, x = lane & 3;
+  const int kw = wave * 64;                       // this wave's 64 k
+  const bool w_ok = kw < H;                       // H < 512: the upper waves hold zeros and only take part in barriers and the reduction
+  float bw[REGG][4][8];                           // [row group][component r][ABID]
+  {
+#pragma unroll
+    for (int g = 0; g < RGN; ++g) {
+      const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + g * 32 + ab * 4 + x) * H + kw + ks * 32;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w_ok) v = *reinterpret_cast<const float4*>(Wr + q * 4);
+        if (g < REGG) { bw[g < REGG ? g : 0][0][q] = v.x; bw[g < REGG ? g : 0][1][q] = v.y; bw[g < REGG ? g : 0][2][q] = v.z; bw[g < REGG ? g : 0][3][q] = v.w; }
+        else bl[g < REGG ? 0 : g - REGG][q][tid] = v;
+      }
+    }
+  }
+  const int es = tid >> 5, eu = tid & 31;
+  const int s_e = s0 + es;
+  const bool e_ok = tid < ST * UW && s_e < S;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
+  float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y);
+  __syncthreads();   // bl is complete
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? step : T - 1 - step;
+    const int tp = dir == 0 ? t - 1 : t + 1;
+    f32x4 ac[RGN];
+#pragma unroll
+    for (int g = 0; g < RGN; ++g) ac[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    EESEN_STAMP(0);
+    if (step > 0) {
+      if (wave == EESEN_POLL_WAVE) {
+        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      EESEN_STAMP(1);
+      if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)
+        report_milestone(L.milestone, (unsigned)(R.ndir * R.nz));
+      const unsigned arow = (unsigned)(((size_t)((tp + 1) * S + s0 + x) * ldY + (size_t)dir * H) * 4);   // < 2 GB, checked on the host
+      const f32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(rY, (w_ok && s0 + x < S) ? arow + (unsigned)(kw + (ks * 8 + ab) * 4) * 4u : 0x80000000u, 0, 0);
+#pragma unroll
+      for (int g = 0; g < RGN; ++g) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {   // ABID 2h and 2h + 1
+          float w0[4], w1[4];
+          if (g < REGG) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { w0[r] = bw[g < REGG ? g : 0][r][2 * h]; w1[r] = bw[g < REGG ? g : 0][r][2 * h + 1]; }
+          } else {
+            int lt = tid;
+            asm volatile("" : "+v"(lt));   // opaque per step: hoisted out of the loop the reads would be registers again
+            const float4 v0 = bl[g < REGG ? 0 : g - REGG][2 * h][lt], v1 = bl[g < REGG ? 0 : g - REGG][2 * h + 1][lt];
+            w0[0] = v0.x; w0[1] = v0.y; w0[2] = v0.z; w0[3] = v0.w;
+            w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (h == 0)      { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 0, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 1, 0); }
+            else if (h == 1) { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 2, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 3, 0); }
+            else if (h == 2) { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 4, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 5, 0); }
+            else             { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 6, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 7, 0); }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < RGN; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][g * 32 + ab * 4 + x] = ac[g][i];
+    __syncthreads();
+    EESEN_STAMP(2);
+    if (e_ok) {
+      float4 pre = gx;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float4 v0 = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
+        const float4 v1 = *reinterpret_cast<const float4*>(&red[w][4 + es][eu * 4]);
+        pre.x += v0.x + v1.x; pre.y += v0.y + v1.y; pre.z += v0.z + v1.z; pre.w += v0.w + v1.w;
+      }
+      float g = tanhf_(pre.x);
+      float i = sigmoidf_(pre.y + p_i * cprev);
+      float f = sigmoidf_(pre.z + p_f * cprev);
+      float c = g * i + cprev * f;
+      float h = tanhf_(c);
+      float o = sigmoidf_(pre.w + p_o * c);
+      float m = h * o;
+      if (t >= len) { g = i = f = o = c = m = 0.f; }
+      *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e) * ldG + gcol) = make_float4(g, i, f, o);
+      const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
+      L.C[o1] = c;
+      __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by the group's other workgroups next step
+      cprev = c;
+    }
+    EESEN_STAMP(3);
+    {
+      if (tid < ST * UW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      EESEN_STAMP(4);
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok && step + 1 < T)
+        gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward on the bf16 matrix pipe: lstm_fwd_persistent_bf_kernel<CPW, NT, AP, WP>.  The recurrent product m_{t-1} W_m^T on
+// v_mfma_f32_16x16x32_bf16 (fp32 accumulation; ~17 cycles per 16 x 16 x 32 block where the fp32-input form takes 8 x 32), with
+// both operands held as bf16 PLANES: a value x is rounded to nearest-even bf16, the remainder (exact in fp32) is rounded again,
+// and so on -- P planes carry 8 + 9 (P - 1) significant bits, three of them ALL 24 bits of an fp32 value.  W_m's WP planes are
+// resident in registers for the whole layer pass; m_t is split into AP planes ONCE, by the thread that computes it, and travels
+// as bf16 in the exchange buffer (LstmLayerDev::X: per (t, dir, 16-sequence tile) block AP planes of
+// [32-unit chunk][k quad][16 sequences][8 bf16]; lane (sequence li, quad kq) of chunk ch reads 16 bytes at
+// ((ch * 4 + kq) * 16 + li) * 16 of each plane -- 16 lanes read 256 contiguous bytes).  Of the AP x WP cross products those with
+// plane indices i + j <= max(AP, WP) - 1 are formed, smallest first.  A and B fragments use the same lane -> k assignment, so the
+// contraction is exact whatever the instruction's internal k order.  Two uses:
+//   <AP = 3, WP = 3>  fp32-class arithmetic (the 3-way split of gemm.hip inside the recurrence): six products per fp32 product,
+//        dropped terms <= 2^-23 |ab|, i.e. one fp32 rounding.  24 instructions of 17 cycles per wave and step at H = 512 instead
+//        of 32 of 32 cycles: the fp32 MFMA chain was 0.9 of the 3.1 us step.  Round 2 costed this with the A operand split by
+//        every CONSUMER (90-230 VALU instructions per step: not worth it) or stored pre-split at 1.5x the fetch (then thought
+//        to be the bound; the 4 x 32 forward tile of round 4 -- a QUARTER of the fetch, no faster -- showed it is not).  The
+//        narrow tile (16 sequences x 8 units) only: three planes of the wide tile's W_m do not fit the register file.
+//        Not bit-identical to lstm_fwd_step_kernel any more (EESEN_FWD_SPLIT=0 restores the fp32-input kernel, which is).
+//   <AP = 1, WP = 2>  BASELINE config 4's "bf16 forward" (eesen_net_set_forward_precision(1)): m_t rounded to ONE bf16 plane --
+//        half the bytes every consumer fetches per step --, W_m as hi + lo (17 bits).  With W_m as ONE plane as well
+//        (EESEN_BF16_REC_WPLANES=1) the gradients sit 2.7x further from the reference (0.18 against 0.069 max-norm at full
+//        cfg4 size): a weight rounded to 8 bits is a systematic perturbation of the model that every one of the T steps sees,
+//        the rounding of m_t is noise.  Gate pre-activations, cell state, activations and everything stored for the backward
+//        pass (G, C, Y) stay fp32; the backward pass is the fp32 one.
+// Tile: 16 sequences x 4 NT units; CPW 32-unit chunks of K = H per wave.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned rne_bf16(float x) {   // round-to-nearest-even bf16 (gemm.hip: rne_bf16_bits), in the low 16 bits
   const unsigned b = __float_as_uint(x);
   return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
 }
-template <int CPW>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
-                                                                           int spin_limit, unsigned long long* trace, Role R) {
-  constexpr int ST = 16, NT = 4, UB = 16, RW = 16 * NT + 4;
+// lane i of every quad receives lane i ^ 1 / i ^ 2 (DPP quad_perm: a VALU move, where __shfl_xor goes through the LDS crossbar)
+__device__ __forceinline__ unsigned quad_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned quad_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }
+template <int CPW, int NT, int AP, int WP>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err,
+                                                                         int spin_limit, unsigned long long* trace, Role R) {
+  constexpr int ST = 16, UB = 4 * NT, RW = 16 * NT + 4, SMAX = (AP > WP ? AP : WP) - 1;
   __shared__ __attribute__((aligned(16))) float red[NW][ST][RW];
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
@@ -399,8 +563,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmL
   const unsigned nblk = R.nblk;
   const int li = lane & 15, kq = lane >> 4;
   const int nch = H / 32;
-  // this wave's part of the workgroup's 64 gate rows of W_m, as ONE bf16 plane, resident for the whole layer pass
-  bf16x8_t b[NT][CPW];
+  // this wave's part of the workgroup's 16 NT gate rows of W_m as WP bf16 planes, resident for the whole layer pass
+  bf16x8_t b[WP][NT][CPW];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + n * 16 + li) * H;
@@ -408,15 +572,23 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmL
     for (int c = 0; c < CPW; ++c) {
       float w[8];
       ld8_plain(Wr, (wave + c * NW) * 32 + kq * 8, H, true, w);
-      f32x4 pk;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pk[j] = __uint_as_float(rne_bf16(w[2 * j]) | (rne_bf16(w[2 * j + 1]) << 16));
-      b[n][c] = __builtin_bit_cast(bf16x8_t, pk);
+      for (int pl = 0; pl < WP; ++pl) {
+        f32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned h0 = rne_bf16(w[2 * j]), h1 = rne_bf16(w[2 * j + 1]);
+          pk[j] = __uint_as_float(h0 | (h1 << 16));
+          w[2 * j] -= __uint_as_float(h0 << 16);          // exact: the next plane rounds the remainder
+          w[2 * j + 1] -= __uint_as_float(h1 << 16);
+        }
+        b[pl][n][c] = __builtin_bit_cast(bf16x8_t, pk);
+      }
     }
   }
   const int es = tid / UB, eu = tid % UB;
   const int s_e = s0 + es;
-  const bool e_act = tid < ST * UB;            // the four cell waves (all of their lanes take part in the packing shuffles)
+  const bool e_act = tid < ST * UB;            // the cell waves (all of their lanes take part in the packing shuffles)
   const bool e_ok = e_act && s_e < s_end;
   float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;
   int len = 0;
@@ -429,7 +601,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmL
   float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
   const __amdgpu_buffer_rsrc_t rX = make_rsrc(L.X);
-  const unsigned xblk = (unsigned)nch * 1024u;                                       // bytes per block
+  const unsigned xpl = (unsigned)nch * 1024u;                                        // bytes per plane of a block
+  const unsigned xblk = xpl * AP;                                                    // bytes per block
   const int zt = (L.s_begin / ST) + bz;
   const int nzall = (S + ST - 1) / ST;
   unsigned char* const xbytes = reinterpret_cast<unsigned char*>(L.X);
@@ -453,18 +626,27 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmL
       const unsigned xb = ((unsigned)(tp * L.ndir + dir) * (unsigned)nzall + (unsigned)zt) * xblk;
       constexpr unsigned kOob = 0x80000000u;
       const bool rok = s0 + li < s_end;
-      f32x4 a[CPW];
+      f32x4 a[AP][CPW];
 #pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        const int ch = wave + c * NW;
-        a[c] = __builtin_amdgcn_raw_buffer_load_b128(rX, rok ? xb + (unsigned)(((ch * 4 + kq) * 16 + li) * 16) : kOob, 0, 0);
-      }
+      for (int pl = 0; pl < AP; ++pl)
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const int ch = wave + c * NW;
+          a[pl][c] = __builtin_amdgcn_raw_buffer_load_b128(rX, (rok && ch < nch) ? xb + (unsigned)pl * xpl + (unsigned)(((ch * 4 + kq) * 16 + li) * 16) : kOob, 0, 0);
+        }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < CPW; ++c)
+      for (int sum = SMAX; sum >= 0; --sum)      // the smallest cross products first
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[c]), b[n][c], acc[n], 0, 0, 0);
+        for (int i = 0; i < AP; ++i) {
+          const int j = sum - i;
+          if (j < 0 || j >= WP) continue;
+#pragma unroll
+          for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i][c]), b[j < WP && j >= 0 ? j : 0][n][c], acc[n], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -487,23 +669,27 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf16_kernel(LstmL
       float o = sigmoidf_(pre.w + p_o * c);
       float m = h * o;
       if (t >= len || !e_ok) { g = i = f = o = c = m = 0.f; }
-      // four adjacent units -> one 8-byte word of the exchange block (a single 8-byte store is single-copy atomic; write-through)
-      unsigned pk = rne_bf16(m);
-      pk |= (unsigned)__shfl_xor((int)pk, 1) << 16;                         // valid in even lanes: (m[eu], m[eu + 1])
-      const unsigned pk2 = (unsigned)__shfl_xor((int)pk, 2);                 // lanes eu % 4 == 0: the pair of (eu + 2, eu + 3)
       if (e_ok) {
         *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e) * ldG + gcol) = make_float4(g, i, f, o);
         const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
         L.C[o1] = c;
         __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((eu & 3) == 0) {
-          const int k = u0 + eu;
-          const size_t xo = ((size_t)(t * L.ndir + dir) * nzall + zt) * (size_t)xblk +
-                            (size_t)((((k >> 5) * 4 + ((k & 31) >> 3)) * 16 + es) * 16 + (k & 7) * 2);
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(xbytes + xo), (unsigned long long)pk | ((unsigned long long)pk2 << 32),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         cprev = c;
+      }
+      // the AP planes of m: four adjacent units -> one 8-byte word per plane (a single 8-byte store is single-copy atomic; write-through)
+      const int k = u0 + eu;
+      const size_t xo = ((size_t)(t * L.ndir + dir) * nzall + zt) * (size_t)xblk +
+                        (size_t)((((k >> 5) * 4 + ((k & 31) >> 3)) * 16 + es) * 16 + (k & 7) * 2);
+      float rem = m;
+#pragma unroll
+      for (int pl = 0; pl < AP; ++pl) {
+        const unsigned hb = rne_bf16(rem);
+        rem -= __uint_as_float(hb << 16);                                      // exact
+        const unsigned pk = hb | (quad_xor1(hb) << 16);                        // valid in even lanes: (unit eu, eu + 1)
+        const unsigned pk2 = quad_xor2(pk);                                     // lanes eu % 4 == 0: the pair of (eu + 2, eu + 3)
+        if (e_ok && (eu & 3) == 0)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(xbytes + xo + (size_t)pl * xpl), (unsigned long long)pk | ((unsigned long long)pk2 << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     EESEN_STAMP(3);
@@ -1626,26 +1812,63 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   return {2, 1};
 }
 
-// the bf16 forward recurrence (lstm_fwd_persistent_bf16_kernel) applies: requested, exchange buffer present, whole 256-unit
-// multiples (each of the 8 waves owns CPW = H / 256 chunks of 32 units), no recurrent dropout
-static bool fwd_bf16_ok(const LstmLayerDev& L) {
-  return L.fwd_bf16 && L.X != nullptr && !L.drop_mode && L.H % 256 == 0 && L.H / 256 <= 4 && L.T >= 2 &&
-         (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 1024 < ((size_t)1 << 31);
-}
-static bool fwd_bf16_fits(const LstmLayerDev& L, int Sw) {
-  dim3 grid(L.H / 16, L.ndir, cdiv(Sw, 16));
-  switch (L.H / 256) {
-    case 1: return fits(lstm_fwd_persistent_bf16_kernel<1>, grid, NW * 64);
-    case 2: return fits(lstm_fwd_persistent_bf16_kernel<2>, grid, NW * 64);
-    case 3: return fits(lstm_fwd_persistent_bf16_kernel<3>, grid, NW * 64);
-    default: return fits(lstm_fwd_persistent_bf16_kernel<4>, grid, NW * 64);
+// Which instantiation of lstm_fwd_persistent_bf_kernel, if any, this layer's forward recurrence takes:
+//   * BASELINE config 4's bf16 forward (L.fwd_bf16: 1 = W_m as hi + lo planes, 2 = one plane; m_t one plane): the wide tile's
+//     geometry (16 sequences x 16 units), whole 256-unit multiples (each of the 8 waves owns CPW = H / 256 chunks of 32 units);
+//   * the fp32-class 3-way split (L.fwd_split; three planes each): wherever the narrow 16 x 8 fp32 tile would be taken.
+// Both: exchange buffer present, no recurrent dropout, block offsets within 32 bits.
+struct BfPlan { bool on; int cpw, nt, ap, wp; };
+static FwdTile fwd_tile(const LstmLayerDev& L);
+static BfPlan bf_plan(const LstmLayerDev& L) {
+  const BfPlan off{false, 0, 0, 0, 0};
+  if (L.X == nullptr || L.drop_mode || L.T < 2 || L.H % 32 != 0) return off;
+  auto small = [&](int ap) { return (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 1024 * ap < ((size_t)1 << 31); };
+  if (L.fwd_bf16) {
+    if (L.H % 256 != 0 || L.H / 256 > 4 || !small(1)) return off;
+    return {true, L.H / 256, 4, 1, L.fwd_bf16 == 2 ? 1 : 2};
   }
+  if (L.fwd_split) {
+    const FwdTile ft = fwd_tile(L);
+    const int need = (L.H / 32 + NW - 1) / NW;
+    if (ft.mt != 1 || ft.nt != 2 || need > 2 || L.H % 8 != 0 || !small(3)) return off;
+    return {true, need, 2, 3, 3};
+  }
+  return off;
+}
+// calls F<CPW, NT, AP, WP>() for the instantiation of the plan (the combinations bf_plan can return)
+#define EESEN_BF_DISPATCH(P, F)                                                                           \
+  do {                                                                                                    \
+    if ((P).nt == 2) { if ((P).cpw <= 1) F(1, 2, 3, 3); else F(2, 2, 3, 3); }                              \
+    else if ((P).wp == 1) { switch ((P).cpw) { case 1: F(1, 4, 1, 1); break; case 2: F(2, 4, 1, 1); break; case 3: F(3, 4, 1, 1); break; default: F(4, 4, 1, 1); } } \
+    else { switch ((P).cpw) { case 1: F(1, 4, 1, 2); break; case 2: F(2, 4, 1, 2); break; case 3: F(3, 4, 1, 2); break; default: F(4, 4, 1, 2); } } \
+  } while (0)
+static bool bf_fits(const LstmLayerDev& L, const BfPlan& P, int Sw) {
+  dim3 grid(L.H / (4 * P.nt), L.ndir, cdiv(Sw, 16));
+#define EESEN_BF_FITS(C, N, A, W) return fits(lstm_fwd_persistent_bf_kernel<C, N, A, W>, grid, NW * 64)
+  EESEN_BF_DISPATCH(P, EESEN_BF_FITS);
+#undef EESEN_BF_FITS
+  return false;
+}
+
+// the 4-sequence x 32-unit forward tile (lstm_fwd_persistent_q4_kernel) applies: wherever the 16 x 8 tile would be taken, whole
+// 64-unit multiples up to 512 cells, whole 4-sequence tiles, no recurrent dropout, all workgroups co-resident
+static bool fwd_q4_ok(const LstmLayerDev& L) {
+  if (!L.fwd_q4 || L.drop_mode || L.H % 64 != 0 || L.H > 512 || L.S % 4 != 0 || L.S < 8 || L.T < 2) return false;
+  const FwdTile ft = fwd_tile(L);
+  if (ft.mt != 1 || ft.nt != 2) return false;
+  dim3 grid(L.H / 32, L.ndir, L.S / 4);
+  return (size_t)grid.y * grid.z * kShards * kShardStride <= (size_t)kCtlHalf && fits(lstm_fwd_persistent_q4_kernel, grid, NW * 64);
 }
 
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg) {
-  if (fwd_bf16_ok(L)) {
-    *nblk = L.H / 16; *nz = cdiv(L.S, 16);
-    if (units_per_wg) *units_per_wg = 16;
+  if (const BfPlan P = bf_plan(L); P.on) {
+    *nblk = L.H / (4 * P.nt); *nz = cdiv(L.S, 16);
+    if (units_per_wg) *units_per_wg = 4 * P.nt;
+    return;
+  }
+  if (fwd_q4_ok(L)) {
+    *nblk = L.H / 32; *nz = L.S / 4;
+    if (units_per_wg) *units_per_wg = 32;
     return;
   }
   const FwdTile ft = fwd_tile(L);
@@ -1668,7 +1891,16 @@ static int pick_windows(int S, int seq_tile, F fits_with) {
 
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
 
-bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return fwd_bf16_ok(L) && lstm_fwd_persistent_windows(L) > 0; }
+bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return L.fwd_bf16 && bf_plan(L).on && lstm_fwd_persistent_windows(L) > 0; }
+// true when the forward tile this layer takes leaves register and LDS room for a 128 x 128 GEMM workgroup on the same CU (the
+// early middle part of the next layer's input GEMM, net.cpp): the narrow fp32 tiles (<= 8 units, <= 131 VGPRs) and the 4 x 32
+// tile (its last W_m row group in LDS for that reason); the wide fp32 tile (206 VGPRs) does not
+bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L) {
+  if (const BfPlan P = bf_plan(L); P.on) return P.nt <= 2;   // (the bf16 forward's successor in BASELINE config 4 is a projection, not an LSTM layer)
+  if (fwd_q4_ok(L)) return true;
+  const FwdTile ft = fwd_tile(L);
+  return 4 * ft.nt <= 8;
+}
 
 bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, unsigned* err, int spin_limit,
                          unsigned long long* trace, hipEvent_t after_reset) {
@@ -1685,22 +1917,20 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
   const int nwin = lstm_fwd_persistent_windows(L0);
   if (nwin == 0) return false;
   if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
-  if (fwd_bf16_ok(L0)) {   // BASELINE config 4's bf16 forward: the recurrent product on one bf16 plane (lstm_fwd_persistent_bf16_kernel)
+  if (const BfPlan P = bf_plan(L0); P.on) {   // on the bf16 matrix pipe: config 4's bf16 forward, or the fp32-class 3-way split (lstm_fwd_persistent_bf_kernel)
     for (int w = 0; w < nwin; ++w) {
       LstmLayerDev L = L0;
       L.s_count = L0.S / nwin;
       L.s_begin = w * L.s_count;
-      dim3 grid(L.H / 16, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
+      dim3 grid(L.H / (4 * P.nt), L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
       const dim3 grid1(grid.x * grid.y * grid.z);
       const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
-      switch (L.H / 256) {
-        case 1: coop_launch(st, lstm_fwd_persistent_bf16_kernel<1>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
-        case 2: coop_launch(st, lstm_fwd_persistent_bf16_kernel<2>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
-        case 3: coop_launch(st, lstm_fwd_persistent_bf16_kernel<3>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
-        default: coop_launch(st, lstm_fwd_persistent_bf16_kernel<4>, grid1, block, L, cnt, err, spin_limit, trace, role); break;
-      }
+      if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));
+#define EESEN_BF_LAUNCH(C, N, A, W) coop_launch(st, lstm_fwd_persistent_bf_kernel<C, N, A, W>, grid1, block, L, cnt, err, spin_limit, trace, role)
+      EESEN_BF_DISPATCH(P, EESEN_BF_LAUNCH);
+#undef EESEN_BF_LAUNCH
     }
     return true;
   }
@@ -1719,6 +1949,21 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * nz * kShards * kShardStride, st));
       if (xchg) coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, true>, grid1, block, L, cnt, err, spin_limit, role);
       else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
+      return true;
+    }
+  }
+  // The 4-sequence x 32-unit tile (lstm_fwd_persistent_q4_kernel): wherever the 16 x 8 tile would be taken and the shape allows
+  if (nwin == 1 && fwd_q4_ok(L0)) {
+    dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
+    const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
+    {
+      LstmLayerDev L = L0;
+      L.s_begin = 0; L.s_count = 0;
+      const dim3 grid1(grid.x * grid.y * grid.z);
+      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
+      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
+      if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));
+      coop_launch(st, lstm_fwd_persistent_q4_kernel, grid1, block, L, cnt, err, spin_limit, trace, role);
       return true;
     }
   }
@@ -1781,7 +2026,7 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
 
 // number of sequence windows the forward pass of this layer takes (0: no persistent tile fits; 1: the whole batch at once)
 int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
-  if (fwd_bf16_ok(L)) return pick_windows(L.S, 16, [&](int Sw) { return fwd_bf16_fits(L, Sw); });
+  if (const BfPlan P = bf_plan(L); P.on) return pick_windows(L.S, 16, [&](int Sw) { return bf_fits(L, P, Sw); });
   const int nch = (L.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
   const FwdTile ft = fwd_tile(L);

@@ -176,6 +176,11 @@ Net::Net(int dev, void* stream) : device(dev) {
 Net::~Net() {
   (void)hipSetDevice(device);
   (void)hipStreamSynchronize(st);
+  for (Ctc* c : guards) {   // a Ctc that outlives this Net must not keep reading its (about to be freed) error word
+    (void)hipStreamSynchronize(c->st);
+    c->guard = nullptr;
+    c->guard_net = nullptr;
+  }
   if (trace.p) {  // EESEN_TRACE=1: timeline of workgroup 0 of the last persistent launches (shader-clock ticks)
     std::vector<unsigned long long> h(1280);
     if (hipMemcpy(h.data(), trace.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -482,8 +487,9 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.lens = net.lens_d.p;
   d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
   d.drop_mode = L.cur_drop_mode;
-  d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
-  d.fwd_mux2 = net.tn.fwd_mux2;
+  d.fwd_bf16 = net.fwd_bf16_rec ? (net.tn.bf16_rec_wplanes == 1 ? 2 : 1) : 0;
+  d.fwd_split = net.tn.fwd_split;
+  d.fwd_mux2 = net.tn.fwd_mux2; d.fwd_q4 = net.tn.fwd_q4;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
@@ -640,7 +646,7 @@ void Net::forward_pass() {
       L.C.reserve(state);
       L.Y.reserve(state);
       // exchange copy of Y in the persistent forward kernel's fetch order (LstmLayerDev::X)
-      if (persistent && H % 32 == 0) L.X.reserve((size_t)T * nd * ((S + 15) / 16) * (size_t)(H / 32) * 512);
+      if (persistent && H % 32 == 0) L.X.reserve((size_t)T * nd * ((S + 15) / 16) * (size_t)(H / 32) * 768);   // (room for three bf16 planes)
       // boundary row blocks t = -1 and t = T (bilstm-parallel-layer.h:393-394)
       const size_t blk = (size_t)S * ldY * sizeof(float);
       EESEN_HIP_CHECK(hipMemsetAsync(L.C.p, 0, blk, st));
@@ -695,7 +701,7 @@ void Net::forward_pass() {
       // no GEMM workgroup fits on a CU (section 9), the early part would only queue.  Same GEMM, same rows: results are
       // bit-identical to the one-launch GEMM (every output row is its own dot products).
       const int mile_step = (3 * T) / 4;   // measured at cfg2, same box: 60 % 39.4, 67 % 38.7, 75 % 38.2, 82 % 38.85, 88 % 38.8, off 39.0 ms
-      const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && gate_units <= 8 && nd == 2 && nxt && nxt->is_lstm() &&
+      const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && lstm_fwd_persistent_leaves_room(lstm_view(*this, L)) && nd == 2 && nxt && nxt->is_lstm() &&
                             T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
       // EESEN_FWD_MID=2 (the profiling arm): the SAME kernels on the SAME overlap, but the side stream is put behind the milestone by
       // its COMMAND PROCESSOR (hipStreamWaitValue64 on 8 bytes of signal memory: count in the low word, flag in the high one) instead of

@@ -151,6 +151,7 @@ struct Net {
   Comm* comm = nullptr;                       // not owned
   std::vector<hipEvent_t> ev_ready, ev_bucket;
   std::vector<char> bucket_pending;
+  std::vector<struct Ctc*> guards;   // the Ctc objects guarding on this Net's error word (eesen_ctc_set_guard): unhooked in ~Net
   bool grads_sanitized = false;   // this step's gradients went through an all-reduce that zeroed them on a raised error word: update() must apply
   bool live_valid = false;        // the liveness word behind the gradient buffer was written for THIS step (backpropagate / backpropagate_zero)
   std::vector<int> bucket_log;                // layer order of the last Backpropagate's buckets (tests)
@@ -214,6 +215,7 @@ struct Ctc {
   // minibatch's ln p / decoded ids; a minibatch computed while it was set (a timed-out persistent forward pass: garbage
   // activations) is DROPPED from the statistics instead of being folded into the objective and TOKEN_ACCURACY.
   const unsigned* guard = nullptr;
+  struct Net* guard_net = nullptr;   // whose error word `guard` points at: that Net unhooks the guard when it is destroyed first (eesen_ctc_set_guard)
   long dropped = 0;
   std::string seq_out;         // --sequence-out-file of the trainer (ctc-loss.cc:247-250,282-291): decoded sequences are appended here
   unsigned ppzx_idx = 0, perr_idx = 0;

@@ -20,6 +20,10 @@
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
+//   EESEN_FWD_SPLIT         1        0: narrow forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of
+//                                    the 3-way bf16 split of both operands (fp32-class: six products, one fp32 rounding per product)
+//   EESEN_BF16_REC_WPLANES  2        1: config 4's bf16 forward recurrence with W_m as ONE bf16 plane instead of hi + lo
+//   EESEN_FWD_Q4            0        1: 4-sequence x 32-unit forward tile (H <= 512) instead of the 16 x 8 tile
 //   EESEN_FWD_MUX2          0        1 | 2: narrow layers (H = 512, S = 32) through the time-multiplexed forward kernel as well -- two
 //                                    16-sequence chains per workgroup, 4 (1) or 8 (2) units; measured slower than one chain per CU
 //                                    (DESIGN.md section 9), kept as the A/B arm
@@ -48,7 +52,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0, fwd_q4 = 0, fwd_split = 1, bf16_rec_wplanes = 2;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -71,6 +75,9 @@ struct Tuning {
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
     t.fwd_mux2 = num("EESEN_FWD_MUX2", 0);
+    t.fwd_q4 = num("EESEN_FWD_Q4", 0);
+    t.fwd_split = num("EESEN_FWD_SPLIT", 1);
+    t.bf16_rec_wplanes = num("EESEN_BF16_REC_WPLANES", 2);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;

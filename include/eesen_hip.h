@@ -272,7 +272,9 @@ int eesen_ctc_set_sequence_out_file(eesen_ctc_t* ctc, const char* path);
  * garbage activations and raises a device word (eesen_net_recurrence_info); the Net recovers on its own, but a minibatch the
  * host had already handed to the Ctc would fold a garbage ln p and garbage decodes into the objective and TOKEN_ACCURACY.  With
  * a guard the word's value travels back with every minibatch's results, and a minibatch computed while it was set is dropped
- * from ALL running totals (eesen_ctc_dropped counts them; one WARNING on stderr).  net == NULL removes the guard. */
+ * from ALL running totals (eesen_ctc_dropped counts them; one WARNING on stderr) and the ln p values eesen_ctc_eval_parallel hands
+ * back for it read NaN.  The Ctc and the Net must share device and stream (the word is read in stream order); either may be
+ * destroyed first.  net == NULL removes the guard. */
 int eesen_ctc_set_guard(eesen_ctc_t* ctc, eesen_net_t* net);
 int eesen_ctc_dropped(eesen_ctc_t* ctc, long* minibatches);
 /* Running totals: Ctc::NumErrorTokens/NumRefTokens (ctc-loss.h:58-59) and the sums behind

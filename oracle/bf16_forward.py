@@ -5,8 +5,9 @@ is the reference's OWN forward equations with the variant's roundings applied at
 (eesen_net_set_forward_precision) names:
   * (gemm)  every forward GEMM -- x W_x^T of an LSTM layer (bilstm-parallel-layer.h:109-110,163-164), an <AffineTransform>
             (affine-trans-layer.h:161-166) -- rounds BOTH operands to nearest-even bf16, products and sums in fp32 or wider;
-  * (rec)   the recurrent product m_{t-1} W_m^T (bilstm-parallel-layer.h:116-118,171-173) rounds W_m and m_{t-1} to bf16; the gate
-            pre-activations, the cell state and the activations stay fp32.
+  * (rec)   the recurrent product m_{t-1} W_m^T (bilstm-parallel-layer.h:116-118,171-173) rounds m_{t-1} to ONE bf16 value and holds
+            W_m as `w_planes` bf16 planes (round to nearest even, round the exact remainder again: 2 planes = 17 significant bits,
+            the library's default; 1 = the single-plane arm); the gate pre-activations, the cell state and the activations stay fp32.
 With both switched off this is the plain forward pass and must equal the C oracle / the golden fixtures (tests/test_bf16_forward_oracle.py
 pins it), which is what makes the roundings the only difference.  Cell equations: bilstm-parallel-layer.h:120-148 (g = tanh, i / f with
 the peepholes on c_{t-1}, c = g i + c_{t-1} f, o with the peephole on c_t, m = tanh(c) o).  Padding frames (t >= len_s) carry zero state in
@@ -25,6 +26,19 @@ def round_bf16(a):
     return r.view(np.float32).reshape(np.shape(a))
 
 
+def bf16_planes(a, planes):
+    """The value `planes` successive bf16 roundings keep of a (each plane rounds the exact remainder of the ones before): what
+    lstm_fwd_persistent_bf_kernel multiplies with when it holds an operand as that many planes."""
+    a = np.ascontiguousarray(a, np.float32)
+    kept = np.zeros_like(a)
+    rem = a.copy()
+    for _ in range(planes):
+        p = round_bf16(rem)
+        kept = kept + p          # exact: the planes do not overlap
+        rem = rem - p
+    return kept
+
+
 def _mm(a, b_t, bf16):
     """a [n x k] times b_t [m x k] transposed, fp64 accumulation; operands rounded to bf16 on request."""
     if bf16:
@@ -36,14 +50,14 @@ def _sig(x):
     return 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
 
 
-def _lstm_direction(gx, Wm, peep, lens, T, S, H, reverse, bf16_rec, teacher=None):
+def _lstm_direction(gx, Wm, peep, lens, T, S, H, reverse, bf16_rec, teacher=None, w_planes=2):
     """gx [T, S, 4H] = x W_x^T + bias in the FILE's gate order g | i | f | o; returns m [T, S, H] (zero on padding).
     teacher [T, S, H]: another implementation's m; when given, step t takes ITS m of the previous step as the recurrent input
     (the cell state is still carried here), so that a comparison of the two outputs is one step deep everywhere: an m that
     falls on the other side of a bf16 rounding boundary in one of the two cannot amplify through the chain."""
     p_i, p_f, p_o = [np.asarray(p, np.float64) for p in peep]
     m_out = np.zeros((T, S, H), np.float32)
-    Wm_r = round_bf16(Wm) if bf16_rec else np.asarray(Wm, np.float32)
+    Wm_r = bf16_planes(Wm, w_planes) if bf16_rec else np.asarray(Wm, np.float32)
     for s in range(S):
         c = np.zeros(H, np.float64)
         m = np.zeros(H, np.float32)
@@ -63,7 +77,7 @@ def _lstm_direction(gx, Wm, peep, lens, T, S, H, reverse, bf16_rec, teacher=None
     return m_out
 
 
-def forward(layers, feats, lens, T, S, bf16_gemm=False, bf16_rec=False, teacher=None):
+def forward(layers, feats, lens, T, S, bf16_gemm=False, bf16_rec=False, teacher=None, w_planes=2):
     """layers: eesen_amd.synth.make_model / nnet_io.read_nnet dicts (parameters in the file's order); feats [T*S x D] time-major
     interleaved.  Returns net_out [T*S x K].  teacher: for a net that is ONE (Bi)LSTM layer, another implementation's output
     [T*S x ndir*H] to take the recurrent inputs from (see _lstm_direction)."""
@@ -79,7 +93,7 @@ def forward(layers, feats, lens, T, S, bf16_gemm=False, bf16_rec=False, teacher=
                 Wx, Wm, bias, pi, pf, po = L["params"][6 * d: 6 * d + 6]
                 gx = (_mm(x, Wx, bf16_gemm) + np.asarray(bias, np.float32)).reshape(T, S, 4 * H)
                 tch = None if teacher is None else np.asarray(teacher, np.float32).reshape(T, S, nd * H)[:, :, d * H:(d + 1) * H]
-                outs.append(_lstm_direction(gx, Wm, (pi, pf, po), lens, T, S, H, d == 1, bf16_rec, tch))
+                outs.append(_lstm_direction(gx, Wm, (pi, pf, po), lens, T, S, H, d == 1, bf16_rec, tch, w_planes))
             x = np.concatenate(outs, axis=2).reshape(T * S, nd * H)
         elif t == "AffineTransform":
             W, b = L["params"]

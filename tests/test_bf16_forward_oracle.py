@@ -27,6 +27,16 @@ def test_round_bf16_is_round_to_nearest_even():
     assert np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
 
 
+def test_planes_carry_8_then_9_more_bits_each():
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(4096) * np.exp(rng.uniform(-8, 8, 4096))).astype(np.float32)
+    e1 = np.max(np.abs(bf.bf16_planes(x, 1) - x) / np.abs(x))
+    e2 = np.max(np.abs(bf.bf16_planes(x, 2) - x) / np.abs(x))
+    assert 2.0 ** -10 < e1 <= 2.0 ** -8 and 2.0 ** -19 < e2 <= 2.0 ** -16      # half an ulp of 8, then of 8 + 9 = 17 significant bits
+    assert np.array_equal(bf.bf16_planes(x, 3), x)                      # three planes: every fp32 value exactly
+    assert np.array_equal(bf.bf16_planes(x, 1), bf.round_bf16(x))
+
+
 def test_the_two_roundings_move_the_output_by_what_eight_bits_allow():
     cfg, layers, batch, g = load_golden("small_bi")
     vm = valid_mask(batch.lens, batch.T, batch.S)
