@@ -1806,7 +1806,9 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   int ncu = 256, dev = 0;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const bool t16_ok = L.H % 8 == 0 && L.S > 16;
+  // (wide layers take the 16-sequence tile at ANY batch size: their 32 x 4 tile would need H/4 x ndir workgroups -- 512 at H = 1024 --
+  // and a batch of <= 16 sequences fell back to the per-step kernels: seen at S = 16, T = 3000 with the six-layer cfg5 stack, round 4)
+  const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2);
   if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > ncu)) return {1, 4};
   if (t16_ok && need <= 2) return {1, 2};
   return {2, 1};
