@@ -2,21 +2,21 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r02b}
 rm -rf $O/prof_$TAG $O/pmc_${TAG}_*
-rocprofv3 --kernel-trace -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --main-only > $O/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --main-only > $O/prof_$TAG.log 2>&1
 # counter passes let one kernel run at a time: the spinning milestone waiter of the side stream could be picked before the recurrence
 # it waits for (it then runs into its bound: one warning, one lost minibatch, no early GEMM from there on).  EESEN_FWD_MID=2 keeps the
 # SAME kernels and the same split of the input GEMM, but orders the side stream with a command-processor wait (net.cpp), which
 # cannot dead-lock: the counters below belong to the schedule the bench runs (round 3 collected them with EESEN_FWD_MID=0)
-export EESEN_FWD_MID=2
+export EESEN_FWD_MID=${EESEN_PMC_FWD_MID:-2}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${TAG}_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --main-only > $O/pmc_${TAG}_$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${TAG}_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --main-only > $O/pmc_${TAG}_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $O/pmc_${TAG}_SQ -o pmc -- python $R/bench.py --steps 2 --warmup 1 --main-only > $O/pmc_${TAG}_SQ.log 2>&1
-GEMM_BENCH_ONLY="one tile" rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_${TAG}_calib -o pmc -- python $R/scripts/gemm_bench.py > $O/pmc_${TAG}_calib.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace -d $O/pmc_${TAG}_SQ -o pmc -- python $R/bench.py --steps 2 --warmup 1 --main-only > $O/pmc_${TAG}_SQ.log 2>&1
+GEMM_BENCH_ONLY="one tile" timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_${TAG}_calib -o pmc -- python $R/scripts/gemm_bench.py > $O/pmc_${TAG}_calib.log 2>&1
 unset EESEN_FWD_MID
 cd $R
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_calib -name "*.db") > $O/${TAG}_pmc_fetch_calibration.md
-python bench.py --steps 20 --warmup 3 > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 python scripts/rocpd_summary.py $(find $O/prof_$TAG -name "*_results.db" | head -1) > $O/${TAG}_kernel_stats.md
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_FETCH_SIZE $O/pmc_${TAG}_WRITE_SIZE -name "*.db") > $O/${TAG}_pmc_fetch_write.md
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_SQ -name "*.db") > $O/${TAG}_pmc_sq.md

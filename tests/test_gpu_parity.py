@@ -358,6 +358,40 @@ def test_persistent_recurrence_matches_step_kernels(gpu, cfg_name, over, split, 
     assert rel_err(res["1"][1], res["0"][1]) < (1e-6 if split == "0" else 1e-5)
 
 
+@pytest.mark.parametrize("arm", [{"EESEN_FWD_SPLIT": "0"}, {"EESEN_FWD_Q4": "1", "EESEN_FWD_SPLIT": "0"}, {"EESEN_FWD_MUX2": "1", "EESEN_FWD_SPLIT": "0"},
+                                 {"EESEN_FWD_MUX2": "2", "EESEN_FWD_SPLIT": "0"}])
+def test_forward_recurrence_arms_agree_with_the_default(gpu, arm, monkeypatch):
+    """The A/B arms of the narrow forward recurrence that DESIGN.md section 4 measures -- the fp32-input MFMA tile (EESEN_FWD_SPLIT=0),
+    the 4-sequence x 32-unit tile (EESEN_FWD_Q4), two sequence tiles per workgroup (EESEN_FWD_MUX2 = 1 | 2) -- against the default
+    (three bf16 planes of both operands, six products): the same arithmetic up to the order of an fp32 sum, so softmax outputs within
+    2e-6, gradients within 1e-4, each arm bit-identical run to run, every layer pass on a persistent kernel."""
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config("cfg2"); cfg.update(T=48, layers=2)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+
+    def run():
+        net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+        res = []
+        for _ in range(2):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            d = ctc.EvalParallel(batch.lens, out, batch.labels)
+            net.BackpropagateNoUpdate(d)
+            res.append((out.numpy(), net.GetGrads()))
+        ri = net.RecurrenceInfo()
+        assert ri["fwd_persistent"] == ri["bwd_persistent"] == ri["lstm_layers"] == 2, ri
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        return res[0]
+
+    base = run()
+    for k, v in arm.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    assert not np.array_equal(got[0], base[0])          # another kernel really ran
+    assert rel_err(got[0], base[0]) < 2e-6 and rel_err(got[1], base[1]) < 1e-4
+
+
 @pytest.mark.parametrize("over", [dict(T=200, S=16, H=64, layers=3), dict(T=130, S=20, H=96, layers=2, min_frac=0.3)])
 def test_middle_first_input_gemm_is_bit_identical(gpu, over, monkeypatch):
     """net.cpp "the middle first": the middle rows of the next layer's input GEMM start on the side stream when both chains of the

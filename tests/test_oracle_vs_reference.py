@@ -198,3 +198,30 @@ def test_dropout_restatement_matches_the_reference(tmp_path, name):
     # test mode: no dropout at all (masks are pre-scaled so inference needs none, :75-76)
     ref.set_mode(False); orc.set_mode(False)
     assert rel_err(orc.propagate(batch.feats)[vm], ref.propagate(batch.feats)[vm]) < 1e-5
+
+
+@pytest.mark.parametrize("cfg_name", ["small_bi", "proj"])
+def test_layer_by_layer_backward_of_the_driver_is_net_backpropagate(cfg_name):
+    """oracle/ref_build/ref_driver.cc: ref_net_backpropagate_lowmem runs the reference's own per-layer Backpropagate + Update in
+    Net::Backpropagate's order (net.cc:88-108) and releases each BiLstm layer's state buffers after use -- what lets the largest
+    full-size arbiters (cfg3, cfg5's 3000-frame bucket: oracle/fullsize.py) fit the host.  Same calls, same order: bit-identical
+    to Net::Backpropagate over three momentum steps with clipping, in_diff and parameters."""
+    cfg = synth.config("small_bi")
+    if cfg_name == "proj":
+        cfg.update(proj=24, layers=3)
+    layers = synth.make_model(seed=11, max_grad=0.05, **cfg)
+    batch = synth.make_batch(**{**cfg, "seed": 11})
+    res = []
+    for lowmem in (False, True):
+        ref = _ref_net(layers)
+        ref.set_train_options(1e-3, 0.9)
+        idfs = []
+        for _ in range(3):
+            ref.set_seq_lengths(batch.lens)
+            out = ref.propagate(batch.feats)
+            c = refbind.cuda_ctc_eval_parallel(out, batch.T, batch.S, batch.lens, batch.label_ids, batch.label_off)
+            idfs.append(ref.backpropagate(c["diff"], True, lowmem=lowmem))
+        res.append((idfs, ref.get_params()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][1], res[1][1])
