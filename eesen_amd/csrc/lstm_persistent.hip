@@ -174,8 +174,8 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
   // for a success: it raises the error word (value 2), the step is dropped like one whose recurrence kernel gave up (in a
   // data-parallel run: contributes a zero gradient), and the host goes on WITHOUT the early GEMM (the persistent kernels stay).
   // The one known way to get there: a tool that lets only ONE kernel run at a time (rocprofv3 --pmc) and picks this one before the
-  // recurrence -- EESEN_FWD_MID=2 orders the side stream with a command-processor wait instead, which cannot dead-lock
-  // (net.cpp; it costs 2.2 ms per cfg2 step where this kernel gains 0.85, so it is the profiling arm, not the default).
+  // recurrence -- collect counters with EESEN_FWD_MID=0 (scripts/collect_profiles.sh does).  A command-processor wait
+  // (hipStreamWaitValue64) instead costs 2.2 ms per cfg2 step and DEAD-LOCKS under that tool, without a bound (net.cpp).
   const unsigned long long t0 = wall_clock64();
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
@@ -189,11 +189,10 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
 }
 
 // LstmLayerDev::milestone: the first workgroup of every (direction, sequence tile) group reports once its group has published
-// step milestone_step; the last of them raises the flag word the host's side stream waits for -- with a polling kernel, or
-// (EESEN_FWD_MID=2) with its command processor on signal memory, which is host-coherent: system scope (once per group and launch)
+// step milestone_step; the last of them raises the flag word the host's side stream waits for
 __device__ __forceinline__ void report_milestone(unsigned* ms, unsigned ngroups) {
-  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u == ngroups)
-    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (__hip_atomic_fetch_add(ms, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == ngroups)
+    __hip_atomic_store(ms + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Debug timeline (EESEN_TRACE=1): workgroup (0,0,0), thread 0 stamps the shader clock at 5 points of the first 128 steps.

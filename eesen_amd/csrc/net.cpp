@@ -198,7 +198,6 @@ Net::~Net() {
                        pass ? "bwd" : "fwd", seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, n);
       }
   }
-  if (mile_sig) (void)hipFree(mile_sig);
   if (lens_pin) (void)hipHostFree(lens_pin);
   if (err_pin) (void)hipHostFree(err_pin);
   if (live_pin) (void)hipHostFree(live_pin);
@@ -703,41 +702,19 @@ void Net::forward_pass() {
       const int mile_step = (3 * T) / 4;   // measured at cfg2, same box: 60 % 39.4, 67 % 38.7, 75 % 38.2, 82 % 38.85, 88 % 38.8, off 39.0 ms
       const bool plan_mid = persistent && overlap && tn.fwd_mid && !plan_gate && !L.cur_fwd_drop && lstm_fwd_persistent_leaves_room(lstm_view(*this, L)) && nd == 2 && nxt && nxt->is_lstm() &&
                             T >= 32 && mile_step + 1 < T && lstm_fwd_persistent_windows(lstm_view(*this, L)) == 1;
-      // EESEN_FWD_MID=2 (the profiling arm): the SAME kernels on the SAME overlap, but the side stream is put behind the milestone by
-      // its COMMAND PROCESSOR (hipStreamWaitValue64 on 8 bytes of signal memory: count in the low word, flag in the high one) instead of
-      // by a spinning one-wave kernel -- no shader waits for another kernel, so a tool that lets only one kernel run at a time
-      // (rocprofv3 --pmc) cannot dead-lock the schedule, and counters can be collected for the recurrence UNDER the early GEMM.
-      // It costs 2.2 ms per cfg2 step where the spinning waiter gains 0.85, hence not the default.
-      bool mid_cp = plan_mid && tn.fwd_mid == 2 && mile_sig_ok != 0;
-      if (mid_cp && mile_sig_ok < 0) {   // first use: is there a stream wait on this device, and signal memory for it?
-        int can = 0;
-        void* q = nullptr;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
-            hipExtMallocWithFlags(&q, 8, hipMallocSignalMemory) == hipSuccess && q) {
-          mile_sig = static_cast<unsigned*>(q);
-          mile_sig_ok = 1;
-        } else {
-          (void)hipGetLastError();
-          mile_sig_ok = 0;
-          mid_cp = false;
-        }
-      }
+      // (Round 3 built, and round 4 re-tried as a profiling arm, a COMMAND-PROCESSOR wait instead of the spinning waiter --
+      // hipStreamWaitValue64 on signal memory.  It costs 2.2 ms per cfg2 step, and it is NOT immune to kernel-serialising tools, as
+      // had been assumed: under `rocprofv3 --pmc` the run dead-locked for the whole 40 minutes of a GPU call (the tool holds the
+      // recurrence's dispatch back behind the side queue's pending wait packet), with no bound to give up at.  The spinning waiter
+      // below gives up after a wall-clock bound and the run continues; counter passes set EESEN_FWD_MID=0.)
       { const int ti_ = timer.begin(st, 1);
       LstmLayerDev v = lstm_view(*this, L);
       v.poll_delay = delay_fwd;
       if (plan_mid) {
-        if (mid_cp) {   // reset, then the side stream behind the flag BEFORE the recurrence is committed
-          EESEN_HIP_CHECK(hipStreamWriteValue64(st, mile_sig, 0, 0));
-          EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
-          EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
-          EESEN_HIP_CHECK(hipStreamWaitValue64(st2, mile_sig, 1ull << 32, hipStreamWaitValueGte, 0xFFFFFFFF00000000ull));
-          v.milestone = mile_sig;
-        } else {
-          mile.reserve(32);
-          EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
-          EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
-          v.milestone = mile.p;
-        }
+        mile.reserve(32);
+        EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
+        EESEN_HIP_CHECK(hipEventRecord(ev_gate_reset, st));
+        v.milestone = mile.p;
         v.milestone_step = mile_step;
       }
       const bool pers = persistent && lstm_fwd_persistent(st, v, ctl.p, ctl.p + kCtlWords - 1, spin_limit, trace.p,
@@ -763,8 +740,7 @@ void Net::forward_pass() {
         g_gated = true;
       }
       if (plan_mid) {
-        if (mid_cp) EESEN_HIP_CHECK(hipStreamWriteValue64(st, mile_sig, 1ull << 32, 0));               // released at the latest here
-        else EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));
+        EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(mile.p + 1), 1, 1, st));   // released at the latest here
         const int ldG2 = nxt->ndir * 4 * nxt->H;
         nxt->G.reserve((size_t)rows * ldG2);
         // whole 256-row tiles: the two ends (main stream, critical path) keep the GEMM's 256 x 256 flavour; the middle part takes the
@@ -776,12 +752,10 @@ void Net::forward_pass() {
       }
       if (plan_mid && mid_r1 > mid_r0) {
         const int ldG2 = nxt->ndir * 4 * nxt->H;
-        if (!mid_cp) {
-          EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
-          // bounded on the wall clock: 2 s for a recurrence of up to 1000 steps, longer for longer ones, tenfold under a communicator
-          // (whose collectives may delay the recurrence's residency: set_comm raises spin_limit the same way)
-          wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1, 2.0 * std::max(1.0, T / 1000.0) * std::max(1.0, spin_limit / 400000.0));
-        }
+        EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_gate_reset, 0));
+        // bounded on the wall clock: 2 s for a recurrence of up to 1000 steps, longer for longer ones, tenfold under a communicator
+        // (whose collectives may delay the recurrence's residency: set_comm raises spin_limit the same way)
+        wait_for_word(st2, mile.p + 1, 1u, ctl.p + kCtlWords - 1, 2.0 * std::max(1.0, T / 1000.0) * std::max(1.0, spin_limit / 400000.0));
         const int tj_ = timer.begin(st2, 0);
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,

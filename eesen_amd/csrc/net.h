@@ -108,8 +108,6 @@ struct Net {
   bool overlap = true;
   hipEvent_t ev_gate_reset = nullptr, ev_gate_done = nullptr;  // gated / early input GEMM of the next layer (forward)
   DevBuf<unsigned> mile;      // progress milestone of the running forward recurrence (LstmLayerDev::milestone)
-  unsigned* mile_sig = nullptr;   // EESEN_FWD_MID=2: the same two words as 8 bytes of SIGNAL memory, waited for by the side stream's command processor
-  int mile_sig_ok = -1;           // -1 not probed yet, 0 no stream wait on this device, 1 in use
   bool gate_fwd = true;
   bool fwd_bf16 = false;      // eesen_net_set_forward_precision(1 | 2): forward GEMMs on bf16-rounded operands (BASELINE config 4)
   bool fwd_bf16_rec = false;  // ... (1 only): and the forward time recurrence on one bf16 plane of W_m / a bf16 exchange of m_t (lstm_fwd_persistent_bf16_kernel)

@@ -29,10 +29,8 @@
 //                                    (DESIGN.md section 9), kept as the A/B arm
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
-//   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part);
-//                                    2: early middle part, the side stream ordered by a command-processor wait (hipStreamWaitValue64)
-//                                    instead of the spinning waiter kernel -- slower, but immune to kernel-serialising tools: the
-//                                    arm the counter passes of scripts/collect_profiles.sh use
+//   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
+//                                    what counter-collecting runs (rocprofv3 --pmc lets ONE kernel run at a time) must set
 //   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 split / 32 f32)
 //   ---- diagnostics -------------------------------------------------------------------------------------------------------
 //   EESEN_TRACE             0        1: in-kernel s_memtime timeline of workgroup 0, printed when the Net is destroyed

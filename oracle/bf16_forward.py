@@ -54,26 +54,33 @@ def _lstm_direction(gx, Wm, peep, lens, T, S, H, reverse, bf16_rec, teacher=None
     """gx [T, S, 4H] = x W_x^T + bias in the FILE's gate order g | i | f | o; returns m [T, S, H] (zero on padding).
     teacher [T, S, H]: another implementation's m; when given, step t takes ITS m of the previous step as the recurrent input
     (the cell state is still carried here), so that a comparison of the two outputs is one step deep everywhere: an m that
-    falls on the other side of a bf16 rounding boundary in one of the two cannot amplify through the chain."""
+    falls on the other side of a bf16 rounding boundary in one of the two cannot amplify through the chain.
+    All sequences advance together (step n of sequence s is frame n, or len_s - 1 - n in the reverse direction)."""
     p_i, p_f, p_o = [np.asarray(p, np.float64) for p in peep]
+    lens = np.asarray(lens, np.int64)
     m_out = np.zeros((T, S, H), np.float32)
-    Wm_r = bf16_planes(Wm, w_planes) if bf16_rec else np.asarray(Wm, np.float32)
-    for s in range(S):
-        c = np.zeros(H, np.float64)
-        m = np.zeros(H, np.float32)
-        steps = range(int(lens[s]) - 1, -1, -1) if reverse else range(int(lens[s]))
-        for n, t in enumerate(steps):
-            if teacher is not None and n > 0:
-                m = np.asarray(teacher[t + 1 if reverse else t - 1, s], np.float32)
-            mp = round_bf16(m) if bf16_rec else m
-            pre = gx[t, s].astype(np.float64) + (mp.astype(np.float64) @ Wm_r.astype(np.float64).T).astype(np.float32)
-            g = np.tanh(pre[0:H])
-            i = _sig((pre[H:2 * H] + p_i * c).astype(np.float32))
-            f = _sig((pre[2 * H:3 * H] + p_f * c).astype(np.float32))
-            c = g * i + c * f
-            o = _sig((pre[3 * H:4 * H] + p_o * c).astype(np.float32))
-            m = (np.tanh(c) * o).astype(np.float32)
-            m_out[t, s] = m
+    Wt = (bf16_planes(Wm, w_planes) if bf16_rec else np.asarray(Wm, np.float32)).astype(np.float64).T      # [H x 4H]
+    c = np.zeros((S, H), np.float64)
+    m = np.zeros((S, H), np.float32)
+    sidx = np.arange(S)
+    for n in range(int(lens.max())):
+        act = n < lens
+        t = np.where(reverse, lens - 1 - n, n)
+        t = np.where(act, t, 0)
+        if teacher is not None and n > 0:
+            tp = np.where(act, t + 1 if reverse else t - 1, 0)
+            m = np.asarray(teacher[tp, sidx], np.float32)
+        mp = round_bf16(m) if bf16_rec else m
+        pre = gx[t, sidx].astype(np.float64) + (mp.astype(np.float64) @ Wt).astype(np.float32)
+        g = np.tanh(pre[:, 0:H])
+        i = _sig((pre[:, H:2 * H] + p_i * c).astype(np.float32))
+        f = _sig((pre[:, 2 * H:3 * H] + p_f * c).astype(np.float32))
+        cn = g * i + c * f
+        o = _sig((pre[:, 3 * H:4 * H] + p_o * cn).astype(np.float32))
+        mn = (np.tanh(cn) * o).astype(np.float32)
+        c = np.where(act[:, None], cn, c)
+        m = np.where(act[:, None], mn, m)
+        m_out[t[act], sidx[act]] = mn[act]
     return m_out
 
 

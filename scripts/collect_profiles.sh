@@ -3,11 +3,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r02b}
 rm -rf $O/prof_$TAG $O/pmc_${TAG}_*
 timeout 600 rocprofv3 --kernel-trace -d $O/prof_$TAG -o $TAG -- python $R/bench.py --steps 3 --warmup 1 --main-only > $O/prof_$TAG.log 2>&1
-# counter passes let one kernel run at a time: the spinning milestone waiter of the side stream could be picked before the recurrence
-# it waits for (it then runs into its bound: one warning, one lost minibatch, no early GEMM from there on).  EESEN_FWD_MID=2 keeps the
-# SAME kernels and the same split of the input GEMM, but orders the side stream with a command-processor wait (net.cpp), which
-# cannot dead-lock: the counters below belong to the schedule the bench runs (round 3 collected them with EESEN_FWD_MID=0)
-export EESEN_FWD_MID=${EESEN_PMC_FWD_MID:-2}
+# counter passes let one kernel run at a time: the side stream's milestone waiter could be picked before the recurrence it waits for
+# (it then runs into its wall-clock bound: one warning, one lost minibatch, no early GEMM from there on).  The recurrence kernels are
+# the same with EESEN_FWD_MID=0; the input GEMM is one launch instead of three.  (A command-processor wait -- hipStreamWaitValue64 --
+# was tried as the arm for these passes in round 4: it dead-locked under --pmc for the whole 40 minutes of the call.)
+export EESEN_FWD_MID=0
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${TAG}_$c -o pmc -- python $R/bench.py --steps 2 --warmup 1 --main-only > $O/pmc_${TAG}_$c.log 2>&1
 done

@@ -1,6 +1,5 @@
 #!/bin/bash
-# round-4 profile collection: cfg2 (kernel trace; PMC passes in separate runs with EESEN_FWD_MID=2, the command-processor arm of the
-# early-GEMM schedule; timeline; the default bench line) + cfg4 fp32 and cfg4 bf16-forward kernel traces / timelines
+# round-4 profile collection: cfg2 (kernel trace; PMC passes in separate runs with EESEN_FWD_MID=0; timeline; the default bench line) + cfg4 fp32 and cfg4 bf16-forward kernel traces / timelines
 TAG=${1:-r04}; bash scripts/collect_profiles.sh $TAG
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
