@@ -45,6 +45,7 @@ def main(tag, commit, switches):
            "config": {"config": "cfg2", "T": 1000, "S": 32}, "bytes_per_launch": {}, "mfma_busy": {}, "kernels": {},
            "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per dispatch (profiled launches: rocprofv3 --pmc lets ONE kernel run at a time)"}
     for key, prefix, fmul in (("lstm_bwd_persistent_q4_kernel", "lstm_bwd_persistent_q4_kernel", 2.0), ("lstm_fwd_persistent_kernel", "lstm_fwd_persistent_kernel", 2.0),
+                              ("lstm_fwd_persistent_bf_kernel<AP=3, WP=3>", "lstm_fwd_persistent_bf_kernel<2, 2, 3, 3>", 2.0),
                               ("gemm_f32_split_bf16_big_kernel(input->gates)", "gemm_f32_split_bf16_big_kernel<true, false>", 1.59)):
         name, r = find(fw, prefix)
         if r:
