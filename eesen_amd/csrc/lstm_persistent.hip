@@ -51,6 +51,10 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * EESEN_RCP(
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
+// one float through a buffer resource; an offset at or above num_records (0x80000000) reads as zero without touching memory
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
 // 8 consecutive floats at row[k..k+7] (k, kmax multiples of 4) through the sc1 path; zeros outside
 // Tried: consumers reading the handed-off rows with sc1 (L1-bypassing) loads.  Measured on MI355X
 // this makes every workgroup pull its own copy through the Infinity Fabric (16 MB per backward step, ~27 GB/s per CU).
@@ -1169,10 +1173,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 //   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
 // Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
 // ------------------------------------------------------------------------------------------------
-template <int CPW>
+// EARLY (round 4, EESEN_BWD_EARLY, see "The cell operands at the top of the step" in DESIGN.md section 4): where the cell waves ask
+// for g, i, f, o | dY | c_t | c_{t-1} of a step.  false: at the END of the step before, behind the publish -- the loaded c_{t-1}
+// rotates into a loop-carried register, so hipcc waits for those HBM loads (and, in wave 0, for the acknowledgement of the counter
+// increment in front of them) at the bottom of the loop: the cell waves reach the next step's barrier ~1.2 us after the publish,
+// later than the poll they are supposed to be waiting for.  true: at the TOP of the step they belong to, behind the operand loads
+// (branch-free buffer loads, lanes without a cell read out of range), consumed 1.3 us later in the cell phase; the counter
+// increment comes from wave 6, which has nothing to wait for.  Same loads, same values: bit-identical gate gradients.
+template <int CPW, bool EARLY>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                          float* __restrict__ DG, unsigned* cnt, unsigned* err,
-                                                                         int spin_limit, Role R) {
+                                                                         int spin_limit, unsigned long long* trace, Role R) {
   constexpr int ST = 4, UW = 32, P = CPW / 2;         // sequences, units per workgroup; (load, 64-float) pairs per wave
   constexpr int LDSP = CPW == 8 ? 1 : 0, REGP = P - LDSP;   // pairs whose B values live in LDS / registers
   __shared__ __attribute__((aligned(16))) float4 bl[LDSP ? LDSP : 1][8][LDSP ? NW * 64 : 1];   // [pair][ABID][thread]
@@ -1228,11 +1239,19 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     }
   }
   const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(L.G), rC = make_rsrc(L.C), rdY = make_rsrc(dY);   // (EARLY)
+  constexpr unsigned kOob = 0x80000000u;   // >= num_records: reads as zero, no memory access
   __syncthreads();   // bl is complete
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
     f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 a4[P];
+    // the cell operands of THIS step: loop-carried from the end of the step before, or (EARLY) locals of the iteration, requested
+    // below -- never rotated through loop-carried registers, which is what made hipcc wait for them where they were issued
+    float4 gtc = gt;
+    float dyc = dy, ctc = c_t, cpc = c_p;
+    EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
@@ -1240,14 +1259,26 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
       }
       __syncthreads();
       if (!s_go) return;
+      EESEN_STAMP(1);
       const unsigned arow = (unsigned)(((size_t)(tn * S + s0 + x) * ldG + (size_t)dir * K4) * 4);
       const bool rok = s0 + x < S;
-      f32x4 a4[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int k = (wave + p * NW) * 64 + (ks * 8 + ab) * 4;
         a4[p] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow + (unsigned)k * 4u : 0x80000000u, 0, 0);
       }
+    }
+    if (EARLY) {   // BEHIND the operand loads (vmcnt returns in order: the MFMA chain waits for its own chunks only) and a whole MFMA
+                   // chain ahead of the cell phase that consumes them; step 0 has no chain and simply waits for them there
+      __builtin_amdgcn_sched_barrier(0);
+      const int tp = dir == 0 ? t - 1 : t + 1;
+      const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
+      gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S + s_e) * lddy + ycol) * 4) : kOob);
+      ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S + s_e) * ldY + ycol) * 4) : kOob);
+      cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S + s_e) * ldY + ycol) * 4) : kOob);
+    }
+    if (step > 0) {
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -1276,17 +1307,21 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][ab * 4 + x] = ac[0][i] + ac[1][i];
+    EESEN_STAMP(2);
     __syncthreads();
+    // every wave "uses" the requested values here (the lanes without a cell read zeros out of range, at once): nothing is pending over
+    // the loop's back edge, so hipcc has no reason to hold the next step's requests back behind a wait for these registers
+    if (EARLY) asm volatile("" :: "v"(gtc.x), "v"(gtc.y), "v"(gtc.z), "v"(gtc.w), "v"(dyc), "v"(ctc), "v"(cpc));
     if (e_ok) {
-      float dm = dy;
+      float dm = dyc;
 #pragma unroll
       for (int w = 0; w < NW; ++w) dm += red[w][es][eu] + red[w][4 + es][eu];
-      const float g = gt.x, i = gt.y, f = gt.z, o = gt.w;
-      const float h = tanhf_(c_t);
+      const float g = gtc.x, i = gtc.y, f = gtc.z, o = gtc.w;
+      const float h = tanhf_(ctc);
       const float dh = (1.f - h * h) * (dm * o);
       float dob = o * (1.f - o) * (dm * h);
       const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
-      float df = f * (1.f - f) * (dc * c_p);
+      float df = f * (1.f - f) * (dc * cpc);
       float di = i * (1.f - i) * (dc * g);
       float dg = (1.f - g * g) * (dc * i);
       float carry = dc * f;
@@ -1295,16 +1330,22 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
       __builtin_amdgcn_raw_buffer_store_b128(out, rDG, (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4), 0, kSc1);
       dcf = carry; dn_i = di; dn_f = df;
     }
+    EESEN_STAMP(3);
     if (step + 1 < T) {
       if (tid < ST * UW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok) {
-        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-        c_t = c_p;
-        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      EESEN_STAMP(4);
+      if (EARLY) {   // from a wave that is neither a cell wave nor the poller: nobody waits for the acknowledgement
+        if (tid == 6 * 64) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {
+          const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+          gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+          dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+          c_t = c_p;
+          c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+        }
       }
     }
   }
@@ -1366,7 +1407,7 @@ __device__ __forceinline__ bool px_take(const unsigned long long* px, int ku, in
 // Shapes: H % 256 == 0, 16-sequence tiles, no dropout.  Same cell arithmetic; the d_m sum is formed in a different order
 // (as every backward variant here: parity tests, not bit equality, hold it).
 // ------------------------------------------------------------------------------------------------
-template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * NW)
+template <int CPW, bool EARLY>   // CPW: 32-float chunks of this workgroup's K quarter per wave, (4H / 4) / (32 * NW); EARLY: see the 4 x 32 kernel
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                              float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
                                                                              unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
@@ -1427,6 +1468,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
   }
   if (tid == 0) s_fail = 0;   // (the first barrier of step 1 orders it)
   __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
+  __amdgpu_buffer_rsrc_t rG = make_rsrc(L.G), rC = make_rsrc(L.C), rdY = make_rsrc(dY);   // (EARLY) re-based with it
+  constexpr unsigned kOob = 0x80000000u;
   int tbS = 0;
 
   for (int step = 0; step < T; ++step) {
@@ -1436,9 +1479,20 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
       tbS = tb * S;
       rDG = make_rsrc(DG + (size_t)tbS * ldG);
+      if (EARLY) { rG = make_rsrc(L.G + (size_t)tbS * ldG); rC = make_rsrc(L.C + (size_t)tbS * ldY); rdY = make_rsrc(dY + (size_t)tbS * lddy); }
     }
     float dm_in = 0.f;
+    float4 gtc = gt;   // this step's cell operands: loop-carried (requested at the end of the step before) or, EARLY, locals requested below
+    float dyc = dy, ctc = c_t, cpc = c_p;
     EESEN_STAMP(0);
+    if (EARLY && step == 0) {   // (later steps: behind the operand loads)
+      const int tp = dir == 0 ? t - 1 : t + 1;
+      const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
+      gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
+      dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * lddy + ycol) * 4) : kOob);
+      ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
+      cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
+    }
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
@@ -1456,6 +1510,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave + c * NW) * 32 + kq * 8;
         ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
+      }
+      if (EARLY) {   // this step's cell operands BEHIND the operand loads, two MFMA passes ahead of the cell phase
+        __builtin_amdgcn_sched_barrier(0);
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
+        gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * lddy + ycol) * 4) : kOob);
+        ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
+        cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
       // pass 1: the siblings' three blocks (three accumulators interleaved)
@@ -1513,14 +1576,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       }
       EESEN_STAMP(3);
     }
+    if (EARLY) asm volatile("" :: "v"(gtc.x), "v"(gtc.y), "v"(gtc.z), "v"(gtc.w), "v"(dyc), "v"(ctc), "v"(cpc));   // (see the 4 x 32 kernel)
     if (e_ok) {
-      const float dm = dy + dm_in;
-      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
-      const float h = tanhf_(c_t);
+      const float dm = dyc + dm_in;
+      const float g_ = gtc.x, i = gtc.y, f = gtc.z, o = gtc.w;
+      const float h = tanhf_(ctc);
       const float dh = (1.f - h * h) * (dm * o);
       float dob = o * (1.f - o) * (dm * h);
       const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
-      float df = f * (1.f - f) * (dc * c_p);
+      float df = f * (1.f - f) * (dc * cpc);
       float di = i * (1.f - i) * (dc * g_);
       float dg = (1.f - g_ * g_) * (dc * i);
       float carry = dc * f;
@@ -1534,13 +1598,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       __syncthreads();
       if (s_fail) return;
       EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok) {  // next step's operands, issued after the publish
-        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-        c_t = c_p;
-        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      if (EARLY) {   // from a wave that is neither a cell wave (0-3) nor the poller (7): nobody waits for the acknowledgement
+        if (tid == 6 * 64) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e_ok) {  // next step's operands, issued after the publish
+          const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+          gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+          dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+          c_t = c_p;
+          c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+        }
       }
     }
   }
@@ -2091,18 +2159,27 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
     bool fit = false;
-    if (cpw == 8) fit = fits(lstm_bwd_persistent_q4_kernel<8>, grid, NW * 64);
-    else if (cpw == 4) fit = fits(lstm_bwd_persistent_q4_kernel<4>, grid, NW * 64);
-    else if (cpw == 2) fit = fits(lstm_bwd_persistent_q4_kernel<2>, grid, NW * 64);
+    const bool early = L0.bwd_early != 0;
+#define EESEN_Q4(CPW) (early ? fits(lstm_bwd_persistent_q4_kernel<CPW, true>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, false>, grid, NW * 64))
+    if (cpw == 8) fit = EESEN_Q4(8);
+    else if (cpw == 4) fit = EESEN_Q4(4);
+    else if (cpw == 2) fit = EESEN_Q4(2);
+#undef EESEN_Q4
     if (fit && cwords <= (size_t)kCtlHalf) {
       LstmLayerDev L = L0;
       L.s_begin = 0; L.s_count = 0;
       const dim3 grid1(grid.x * grid.y * grid.z);
       const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
-      if (cpw == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
-      else if (cpw == 4) coop_launch(st, lstm_bwd_persistent_q4_kernel<4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
-      else coop_launch(st, lstm_bwd_persistent_q4_kernel<2>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, role);
+#define EESEN_Q4(CPW)                                                                                                              \
+  do {                                                                                                                             \
+    if (early) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+    else coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+  } while (0)
+      if (cpw == 8) EESEN_Q4(8);
+      else if (cpw == 4) EESEN_Q4(4);
+      else EESEN_Q4(2);
+#undef EESEN_Q4
       return true;
     }
   }
@@ -2115,9 +2192,9 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
       if (c1 > (size_t)kCtlHalf) return false;
       switch (cpw) {
-        case 4: return fits(lstm_bwd_persistent_ksplit_kernel<4>, grid, NW * 64);
-        case 3: return fits(lstm_bwd_persistent_ksplit_kernel<3>, grid, NW * 64);
-        case 2: return fits(lstm_bwd_persistent_ksplit_kernel<2>, grid, NW * 64);
+        case 4: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<4, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<4, false>, grid, NW * 64);
+        case 3: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<3, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<3, false>, grid, NW * 64);
+        case 2: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<2, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<2, false>, grid, NW * 64);
         default: return false;
       }
     };
@@ -2158,9 +2235,15 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
         unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
         switch (cpw) {
-          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
-          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
-          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
+#define EESEN_KS(CPW)                                                                                                                  \
+  do {                                                                                                                                 \
+    if (L.bwd_early) coop_launch(st, lstm_bwd_persistent_ksplit_kernel<CPW, true>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); \
+    else coop_launch(st, lstm_bwd_persistent_ksplit_kernel<CPW, false>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace);            \
+  } while (0)
+          case 4: EESEN_KS(4); break;
+          case 3: EESEN_KS(3); break;
+          default: EESEN_KS(2); break;
+#undef EESEN_KS
         }
       }
       return true;

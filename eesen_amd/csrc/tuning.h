@@ -18,6 +18,9 @@
 //   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
 //   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
+//   EESEN_BWD_EARLY         0        1: the backward recurrence's cell waves request a step's g,i,f,o | dY | c operands at the TOP of that step
+//                                    (behind the operand loads) instead of at the end of the step before, and the counter increment comes from
+//                                    a wave nobody waits on (4 x 32 tile and K-split kernels; bit-identical gate gradients)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
 //   EESEN_FWD_SPLIT         1        0: narrow forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of
@@ -50,7 +53,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0, fwd_q4 = 0, fwd_split = 1, bf16_rec_wplanes = 2;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0, fwd_q4 = 0, fwd_split = 1, bf16_rec_wplanes = 2, bwd_early = 0;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -70,6 +73,7 @@ struct Tuning {
     t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
     t.bwd_q4 = num("EESEN_BWD_Q4", 1);
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
+    t.bwd_early = num("EESEN_BWD_EARLY", 0);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
     t.fwd_mux2 = num("EESEN_FWD_MUX2", 0);

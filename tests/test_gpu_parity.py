@@ -475,6 +475,38 @@ def test_backward_tiles_agree_and_are_deterministic(gpu, monkeypatch):
             assert np.array_equal(r[0], res[mode][0][0]) and np.array_equal(r[1], res[mode][0][1])
     assert rel_err(res["1"][0][0], res["0"][0][0]) < 1e-5 and rel_err(res["1"][0][1], res["0"][0][1]) < 1e-5
 
+@pytest.mark.parametrize("name,over", [("cfg2", dict(T=40, layers=2)), ("cfg2", dict(T=33, layers=1, H=256, S=12)), ("cfg2", dict()),
+                                       ("cfg4", dict(T=24, layers=2)), ("cfg4", dict(T=17, layers=1)), ("cfg4", dict(layers=2))])
+def test_early_cell_operands_are_bit_identical(gpu, name, over, monkeypatch):
+    """EESEN_BWD_EARLY: the backward recurrence's cell waves request a step's g,i,f,o | dY | c_t | c_{t-1} at the top of THAT step
+    (behind the operand loads of the MFMA chain) instead of at the end of the step before, and the counter increment comes from a
+    wave nobody waits on (4 x 32 tile: cfg2; K-split tile: cfg4).  Same loads, same values, same arithmetic: the gate gradients
+    -- and everything computed from them -- must be BIT-identical between the two arms, run after run."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config(name); cfg.update(over)
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EESEN_BWD_EARLY", mode)
+        net = Net.from_layers(layers); ctc = Ctc()
+        runs = []
+        for _ in range(3):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            idf = CuMatrix(batch.T * batch.S, cfg["D"])
+            net.BackpropagateNoUpdate(diff, idf)
+            runs.append((idf.numpy(), net.GetGrads()))
+        info = net.RecurrenceInfo()
+        assert info["bwd_persistent"] == info["lstm_layers"] and net.recoveries == 0, info
+        res[mode] = runs
+    ref = res["0"][0]
+    assert np.isfinite(ref[1]).all() and np.abs(ref[1]).max() > 0
+    for mode in ("0", "1"):
+        for r in res[mode]:
+            assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]), mode
+
+
 def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, capfd):
     """A hand-off that cannot complete (here: a spin bound of zero polls) must surface at the next synchronisation point --
     never as a hang or as silently wrong numbers: a WARNING on stderr and a fall-back to the per-step kernels (an exception
