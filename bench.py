@@ -698,8 +698,10 @@ def main():
             # the other single-GPU BASELINE configurations and the reference's own recipe shape, driver-timed in the same run
             del net, feats_dev, diff
             sec = {}
-            for name, fn in (("cfg4", lambda: secondary_leg("cfg4", dev)), ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, forward_bf16=True)),
-                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=3, warmup=1)),
+            # (10 / 5 timed steps: three were inside the box-to-box noise for comparing the cfg4 legs with each other)
+            for name, fn in (("cfg4", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2)),
+                             ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2, forward_bf16=True)),
+                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=5, warmup=1)),
                              ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20)),
                              # the same shape with the minibatch this part wants (INTEGRATION.md "Which --num-sequence"): the frame limit raised
                              # so that --num-sequence is what bounds a minibatch

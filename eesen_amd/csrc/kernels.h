@@ -84,7 +84,7 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
-  int bwd_early = 0;   // backward recurrence kernels: the cell operands of a step are requested at the top of that step (EESEN_BWD_EARLY)
+  int bwd_early = 0;   // 4 x 32 backward kernel: the cell operands of a step are requested at the top of that step (EESEN_BWD_EARLY; A/B arm)
   // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on bf16 operands with
   // fp32 accumulation (lstm_fwd_persistent_bf_kernel<.., AP = 1, WP>): m_t as ONE bf16 plane in the exchange buffer X, W_m as hi + lo
   // planes (1) or one plane (2: EESEN_BF16_REC_WPLANES=1, the A/B arm)

@@ -1173,13 +1173,16 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 //   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
 // Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
 // ------------------------------------------------------------------------------------------------
-// EARLY (round 4, EESEN_BWD_EARLY, see "The cell operands at the top of the step" in DESIGN.md section 4): where the cell waves ask
-// for g, i, f, o | dY | c_t | c_{t-1} of a step.  false: at the END of the step before, behind the publish -- the loaded c_{t-1}
-// rotates into a loop-carried register, so hipcc waits for those HBM loads (and, in wave 0, for the acknowledgement of the counter
-// increment in front of them) at the bottom of the loop: the cell waves reach the next step's barrier ~1.2 us after the publish,
-// later than the poll they are supposed to be waiting for.  true: at the TOP of the step they belong to, behind the operand loads
-// (branch-free buffer loads, lanes without a cell read out of range), consumed 1.3 us later in the cell phase; the counter
-// increment comes from wave 6, which has nothing to wait for.  Same loads, same values: bit-identical gate gradients.
+// EARLY (round 4, EESEN_BWD_EARLY; measured NEUTRAL, kept as the A/B arm -- DESIGN.md section 4 "The cell operands at the top of the
+// step"): where the cell waves ask for g, i, f, o | dY | c_t | c_{t-1} of a step.  false (default): at the END of the step before,
+// behind the publish -- the loaded c_{t-1} rotates into a loop-carried register, so hipcc waits for those HBM loads (and, in wave 0,
+// for the acknowledgement of the counter increment in front of them) at the bottom of the loop: the cell waves reach the next step's
+// barrier 0.9 us after the publish (timeline: publish -> next 2100 ticks, wait 330).  true: at the TOP of the step they belong to,
+// behind the operand loads (branch-free buffer loads, lanes without a cell read out of range), consumed a whole MFMA chain later;
+// the counter increment comes from wave 6, which waits for nothing: publish -> next 160 ticks -- and wait 1840, fetch + MFMA 3650
+// instead of 3010: the step is 7140 ticks either way.  The stall sat exactly under the one thing a step cannot go without: the
+// flight of the slowest peer's increment, the poll's way back and the operand rows' own round trip (first-poll delay + poll = the
+// same 0.87 us).  Same loads, same values: bit-identical gate gradients (tests/test_gpu_parity.py).
 template <int CPW, bool EARLY>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                          float* __restrict__ DG, unsigned* cnt, unsigned* err,
@@ -1407,7 +1410,7 @@ __device__ __forceinline__ bool px_take(const unsigned long long* px, int ku, in
 // Shapes: H % 256 == 0, 16-sequence tiles, no dropout.  Same cell arithmetic; the d_m sum is formed in a different order
 // (as every backward variant here: parity tests, not bit equality, hold it).
 // ------------------------------------------------------------------------------------------------
-template <int CPW, bool EARLY>   // CPW: 32-float chunks of this workgroup's K quarter per wave, (4H / 4) / (32 * NW); EARLY: see the 4 x 32 kernel
+template <int CPW>   // 32-float chunks of this workgroup's K quarter per wave: (4H / 4) / (32 * NW)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                              float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
                                                                              unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
@@ -1468,8 +1471,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
   }
   if (tid == 0) s_fail = 0;   // (the first barrier of step 1 orders it)
   __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
-  __amdgpu_buffer_rsrc_t rG = make_rsrc(L.G), rC = make_rsrc(L.C), rdY = make_rsrc(dY);   // (EARLY) re-based with it
-  constexpr unsigned kOob = 0x80000000u;
   int tbS = 0;
 
   for (int step = 0; step < T; ++step) {
@@ -1479,20 +1480,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
       tbS = tb * S;
       rDG = make_rsrc(DG + (size_t)tbS * ldG);
-      if (EARLY) { rG = make_rsrc(L.G + (size_t)tbS * ldG); rC = make_rsrc(L.C + (size_t)tbS * ldY); rdY = make_rsrc(dY + (size_t)tbS * lddy); }
     }
     float dm_in = 0.f;
-    float4 gtc = gt;   // this step's cell operands: loop-carried (requested at the end of the step before) or, EARLY, locals requested below
-    float dyc = dy, ctc = c_t, cpc = c_p;
     EESEN_STAMP(0);
-    if (EARLY && step == 0) {   // (later steps: behind the operand loads)
-      const int tp = dir == 0 ? t - 1 : t + 1;
-      const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
-      gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
-      dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * lddy + ycol) * 4) : kOob);
-      ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
-      cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
-    }
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
         const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
@@ -1510,15 +1500,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave + c * NW) * 32 + kq * 8;
         ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
-      }
-      if (EARLY) {   // this step's cell operands BEHIND the operand loads, two MFMA passes ahead of the cell phase
-        __builtin_amdgcn_sched_barrier(0);
-        const int tp = dir == 0 ? t - 1 : t + 1;
-        const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
-        gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
-        dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S - tbS + s_e) * lddy + ycol) * 4) : kOob);
-        ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
-        cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S - tbS + s_e) * ldY + ycol) * 4) : kOob);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
       // pass 1: the siblings' three blocks (three accumulators interleaved)
@@ -1576,15 +1557,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       }
       EESEN_STAMP(3);
     }
-    if (EARLY) asm volatile("" :: "v"(gtc.x), "v"(gtc.y), "v"(gtc.z), "v"(gtc.w), "v"(dyc), "v"(ctc), "v"(cpc));   // (see the 4 x 32 kernel)
     if (e_ok) {
-      const float dm = dyc + dm_in;
-      const float g_ = gtc.x, i = gtc.y, f = gtc.z, o = gtc.w;
-      const float h = tanhf_(ctc);
+      const float dm = dy + dm_in;
+      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
+      const float h = tanhf_(c_t);
       const float dh = (1.f - h * h) * (dm * o);
       float dob = o * (1.f - o) * (dm * h);
       const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
-      float df = f * (1.f - f) * (dc * cpc);
+      float df = f * (1.f - f) * (dc * c_p);
       float di = i * (1.f - i) * (dc * g_);
       float dg = (1.f - g_ * g_) * (dc * i);
       float carry = dc * f;
@@ -1598,17 +1578,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
       __syncthreads();
       if (s_fail) return;
       EESEN_STAMP(4);
-      if (EARLY) {   // from a wave that is neither a cell wave (0-3) nor the poller (7): nobody waits for the acknowledgement
-        if (tid == 6 * 64) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e_ok) {  // next step's operands, issued after the publish
-          const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-          gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-          dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-          c_t = c_p;
-          c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
-        }
+      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {  // next step's operands, issued after the publish
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
       }
     }
   }
@@ -2192,9 +2168,9 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
       if (c1 > (size_t)kCtlHalf) return false;
       switch (cpw) {
-        case 4: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<4, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<4, false>, grid, NW * 64);
-        case 3: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<3, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<3, false>, grid, NW * 64);
-        case 2: return L0.bwd_early ? fits(lstm_bwd_persistent_ksplit_kernel<2, true>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_kernel<2, false>, grid, NW * 64);
+        case 4: return fits(lstm_bwd_persistent_ksplit_kernel<4>, grid, NW * 64);
+        case 3: return fits(lstm_bwd_persistent_ksplit_kernel<3>, grid, NW * 64);
+        case 2: return fits(lstm_bwd_persistent_ksplit_kernel<2>, grid, NW * 64);
         default: return false;
       }
     };
@@ -2235,15 +2211,9 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
         EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
         unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
         switch (cpw) {
-#define EESEN_KS(CPW)                                                                                                                  \
-  do {                                                                                                                                 \
-    if (L.bwd_early) coop_launch(st, lstm_bwd_persistent_ksplit_kernel<CPW, true>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); \
-    else coop_launch(st, lstm_bwd_persistent_ksplit_kernel<CPW, false>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace);            \
-  } while (0)
-          case 4: EESEN_KS(4); break;
-          case 3: EESEN_KS(3); break;
-          default: EESEN_KS(2); break;
-#undef EESEN_KS
+          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
+          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
+          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
         }
       }
       return true;

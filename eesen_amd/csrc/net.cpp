@@ -282,7 +282,7 @@ void Net::arm_device_error_poll() {
 void Net::poll_device_error() {
   if (!err_armed || hipEventQuery(err_ev) != hipSuccess) return;  // not there yet: the next poll or sync() will see it
   err_armed = false;
-  if (*err_pin) check_device_error(/*consumer=*/false);  // re-reads the word, resets it and falls back (fatal under a communicator)
+  if (*err_pin) check_device_error(/*consumer=*/false);  // re-reads the word, resets it and falls back
   else steps_since_clean = 0;
 }
 
@@ -291,8 +291,7 @@ void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
   EESEN_REQUIRE(din > 0 && dout > 0, EESEN_ERR_INVALID, "layer dimensions must be positive");
   if (!layers.empty())  // net.cc:282-286
     EESEN_REQUIRE(layers.back().dout == din, EESEN_ERR_INVALID, "Dimensionality mismatch between consecutive layers");
-  layers.emplace_back();
-  Layer& L = layers.back();
+  Layer L;   // checked as a local: a refused layer leaves the net as it was
   L.kind = kind; L.din = din; L.dout = dout; L.coef = coef; L.max_grad = max_grad;
   switch (kind) {
     case EESEN_LAYER_BILSTM_PARALLEL:
@@ -312,10 +311,14 @@ void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
       EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "an activation layer needs InputDim == OutputDim");
       break;
     default:
-      layers.pop_back();
       throw Error(EESEN_ERR_INVALID, "unsupported layer kind " + std::to_string(kind));
   }
-  if (L.is_lstm()) EESEN_REQUIRE(L.H % 4 == 0, EESEN_ERR_INVALID, "LSTM cell count per direction must be a multiple of 4");
+  // the one shape restriction the reference does not have: the kernels fetch the state four cells at a time (INTEGRATION.md
+  // "Restrictions" names the model-file tool that pads such a model without changing what it computes)
+  if (L.is_lstm())
+    EESEN_REQUIRE(L.H % 4 == 0, EESEN_ERR_INVALID,
+                  "LSTM cell count per direction must be a multiple of 4 (python -m eesen_amd.model_tools pad-cells pads a model file to one)");
+  layers.push_back(std::move(L));
 }
 
 void Net::finalize() {

@@ -18,9 +18,9 @@
 //   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
 //   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
-//   EESEN_BWD_EARLY         0        1: the backward recurrence's cell waves request a step's g,i,f,o | dY | c operands at the TOP of that step
-//                                    (behind the operand loads) instead of at the end of the step before, and the counter increment comes from
-//                                    a wave nobody waits on (4 x 32 tile and K-split kernels; bit-identical gate gradients)
+//   EESEN_BWD_EARLY         0        1: the 4 x 32 backward kernel's cell waves request a step's g,i,f,o | dY | c operands at the TOP of
+//                                    that step (behind the operand loads) instead of at the end of the step before, and the counter
+//                                    increment comes from a wave nobody waits on; bit-identical, measured neutral
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
 //   EESEN_FWD_SPLIT         1        0: narrow forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of

@@ -5,6 +5,11 @@ iterations and before decoding.
     python -m eesen_amd.model_tools net-copy [--binary=B] [--remove-first-layers=N] [--remove-last-layers=N] <model-in> <model-out>
     python -m eesen_amd.model_tools format-to-nonparallel [--binary=B] <model-in> <model-out>
 
+and one tool the reference does not need (the library's single shape restriction, INTEGRATION.md "Restrictions"):
+
+    python -m eesen_amd.model_tools pad-cells [--binary=B] [--multiple=4] <model-in> <model-out>
+    python -m eesen_amd.model_tools unpad-cells [--binary=B] --cells=H1,H2,... <model-in> <model-out>
+
 Same options, argument order, checks and exit codes as /root/reference/src/netbin/{net-change-model,net-copy,format-to-nonparallel}.cc;
 binary output is byte-identical to the reference tools' (tests/test_model_tools.py pins it where oracle/_ref/netbin exists).
 """
@@ -117,7 +122,138 @@ def format_to_nonparallel(argv: List[str]) -> int:
     return 0
 
 
-TOOLS = {"net-change-model": net_change_model, "net-copy": net_copy, "format-to-nonparallel": format_to_nonparallel}
+# ---- cells per direction padded to a multiple of 4 ---------------------------------------------------------------------------------
+# libeesen_hip.so fetches the recurrent state four cells at a time and refuses an LSTM layer whose cell count per direction is not
+# a multiple of 4 (net.cpp: add_layer); the reference takes any.  A model with, say, <CellDim> 300 for a BiLstm (150 per direction)
+# is padded to 152 per direction with cells that are identically zero and stay so:
+#   a padded cell has zero W_x / W_m rows, zero bias, zero peepholes: g = tanh(0) = 0, i = f = o = 1/2, c_t = f c_{t-1} + i g = 0,
+#   m_t = o tanh(c_t) = 0 for every t;  the columns that read its output -- W_m's own columns and the next layer's input columns --
+#   are zero, so nothing downstream sees it: the padded net computes the original function.
+#   Training keeps it so: the cell receives d_m = 0 (zero columns above it), hence zero gate gradients, hence zero gradients of its own
+#   rows; and the gradient of a zero COLUMN is sum_t dG_t^T x_t over an input x that is identically 0.  SGD with momentum, the
+#   clipping and Adagrad / RMSProp all map (parameter 0, gradient 0, accumulator 0) to 0.  (Not so behind a <Sigmoid> layer, whose
+#   output for the padded cell is 1/2: refused, like a <Softmax> directly on a padded layer.)
+# Every tool of either code base reads the padded file; unpad-cells cuts it back (and checks that what it cuts is zero).
+def _lstm_dirs(t: str) -> int:
+    return 2 if t.startswith("BiLstm") else 1
+
+
+def _expand(a, axis: int, H: int, Hp: int, blocks: int):
+    """Splits `axis` into `blocks` runs of H entries and pads each run with Hp - H zeros."""
+    import numpy as np
+    a = np.asarray(a, np.float32)
+    sh = list(a.shape)
+    assert sh[axis] == blocks * H, (sh, axis, blocks, H)
+    sh[axis:axis + 1] = [blocks, H]
+    a = a.reshape(sh)
+    pad = [(0, 0)] * a.ndim
+    pad[axis + 1] = (0, Hp - H)
+    a = np.pad(a, pad)
+    sh[axis:axis + 2] = [blocks * Hp]
+    return np.ascontiguousarray(a.reshape(sh))
+
+
+def _shrink(a, axis: int, H: int, Hp: int, blocks: int, what: str):
+    import numpy as np
+    a = np.asarray(a, np.float32)
+    sh = list(a.shape)
+    assert sh[axis] == blocks * Hp, (sh, axis, blocks, Hp)
+    sh[axis:axis + 1] = [blocks, Hp]
+    a = a.reshape(sh)
+    keep = [slice(None)] * a.ndim; cut = list(keep)
+    keep[axis + 1] = slice(0, H); cut[axis + 1] = slice(H, Hp)
+    if np.any(a[tuple(cut)] != 0):
+        raise ValueError(f"unpad-cells: {what} is not zero where it would be cut -- not a model padded by pad-cells (or --cells is wrong)")
+    a = a[tuple(keep)]
+    sh[axis:axis + 2] = [blocks * H]
+    return np.ascontiguousarray(a.reshape(sh))
+
+
+def _repad(layers, new_H, fn):
+    """Shared walk of pad-cells / unpad-cells.  new_H(layer index, H) -> the layer's new cell count per direction;
+    fn(array, axis, H_old, H_new, blocks, what) resizes one axis made of `blocks` runs of H_old entries."""
+    out, col = [], None    # col = (H_old, H_new, blocks) of the columns the next layer reads, when they changed
+    for i, L in enumerate(layers):
+        L = dict(L); t = L["type"]
+        tens = {k: [p for p in L[k]] for k in ("params", "accu") if L.get(k)}
+        if L["type"] in ("Softmax", "Sigmoid") and col:
+            raise ValueError(f"layer {i}: a <{t}> directly on a padded LSTM layer would see the padded cells (sigmoid(0) = 1/2); not supported")
+        if col and t == "Tanh":                       # tanh(0) = 0: the padded columns pass through
+            L["input_dim"] = L["output_dim"] = col[1] * col[2]
+        elif nnet_io.is_lstm(t):
+            nd = _lstm_dirs(t); H = L["output_dim"] // nd; Hn = new_H(i, H)
+            for k, ts in tens.items():
+                for d in range(nd):
+                    wx, wm, b, pi, pf, po = ts[6 * d: 6 * d + 6]
+                    if col: wx = fn(wx, 1, col[0], col[1], col[2], f"layer {i} W_x columns")
+                    if Hn != H:
+                        wx = fn(wx, 0, H, Hn, 4, f"layer {i} W_x rows")
+                        wm = fn(fn(wm, 0, H, Hn, 4, f"layer {i} W_m rows"), 1, H, Hn, 1, f"layer {i} W_m columns")
+                        b = fn(b, 0, H, Hn, 4, f"layer {i} bias")
+                        pi, pf, po = (fn(v, 0, H, Hn, 1, f"layer {i} peephole") for v in (pi, pf, po))
+                    ts[6 * d: 6 * d + 6] = [wx, wm, b, pi, pf, po]
+            if col: L["input_dim"] = col[1] * col[2]
+            L["output_dim"] = nd * Hn
+            col = (H, Hn, nd) if Hn != H else None
+        elif t == "AffineTransform":
+            if col:
+                for k, ts in tens.items():
+                    ts[0] = fn(ts[0], 1, col[0], col[1], col[2], f"layer {i} weight columns")
+                L["input_dim"] = col[1] * col[2]
+            col = None
+        for k, ts in tens.items():
+            L[k] = ts
+        out.append(L)
+    if col:
+        raise ValueError("the last layer is a padded LSTM layer: its output dimension would change; not supported")
+    return out
+
+
+def pad_cells_layers(layers, multiple: int = 4):
+    return _repad(layers, lambda i, H: -(-H // multiple) * multiple, lambda a, ax, H, Hn, nb, what: _expand(a, ax, H, Hn, nb))
+
+
+def unpad_cells_layers(layers, cells):
+    idx = [i for i, L in enumerate(layers) if nnet_io.is_lstm(L["type"])]
+    if len(cells) != len(idx):
+        raise ValueError(f"unpad-cells: the model has {len(idx)} LSTM layers, --cells names {len(cells)}")
+    want = dict(zip(idx, cells))
+
+    def new_H(i, H):
+        if want[i] > H or want[i] <= 0:
+            raise ValueError(f"unpad-cells: layer {i} has {H} cells per direction, cannot cut to {want[i]}")
+        return want[i]
+    return _repad(layers, new_H, lambda a, ax, Hp, H, nb, what: _shrink(a, ax, H, Hp, nb, what))
+
+
+def pad_cells(argv: List[str]) -> int:
+    o, pos = _parse(argv, {"binary": (bool, True), "multiple": (int, 4)})
+    if len(pos) != 2 or o["multiple"] <= 0:
+        print("Usage:  pad-cells [--binary=true] [--multiple=4] <model-in> <model-out>", file=sys.stderr)
+        return 1
+    layers = nnet_io.read_nnet(pos[0])
+    padded = pad_cells_layers(layers, o["multiple"])
+    for i, (a, b) in enumerate(zip(layers, padded)):
+        if a["output_dim"] != b["output_dim"]:
+            print(f"LOG (pad-cells) layer {i} <{a['type']}>: <CellDim> {a['output_dim']} -> {b['output_dim']}", file=sys.stderr)
+    nnet_io.write_nnet(pos[1], padded, binary=o["binary"])
+    print(f"LOG (pad-cells) Written model to {pos[1]}", file=sys.stderr)
+    return 0
+
+
+def unpad_cells(argv: List[str]) -> int:
+    o, pos = _parse(argv, {"binary": (bool, True), "cells": (str, "")})
+    if len(pos) != 2 or not o["cells"]:
+        print("Usage:  unpad-cells [--binary=true] --cells=H1,H2,... (cells per direction of every LSTM layer) <model-in> <model-out>", file=sys.stderr)
+        return 1
+    layers = unpad_cells_layers(nnet_io.read_nnet(pos[0]), [int(x) for x in o["cells"].split(",")])
+    nnet_io.write_nnet(pos[1], layers, binary=o["binary"])
+    print(f"LOG (unpad-cells) Written model to {pos[1]}", file=sys.stderr)
+    return 0
+
+
+TOOLS = {"net-change-model": net_change_model, "net-copy": net_copy, "format-to-nonparallel": format_to_nonparallel,
+         "pad-cells": pad_cells, "unpad-cells": unpad_cells}
 
 
 def main(argv=None) -> int:

@@ -94,3 +94,54 @@ def test_usage_and_text_output(tmp_path, capsys):
     assert model_tools.main(["net-copy", "--binary=false", p, t]) == 0
     assert open(t).read().startswith("<Nnet>")
     assert np.array_equal(nnet_io.flatten_params(nnet_io.read_nnet(t)), nnet_io.flatten_params(nnet_io.read_nnet(p)))
+
+
+@pytest.mark.parametrize("kind,H,extra", [("BiLstmParallel", 10, {}), ("LstmParallel", 7, {}), ("BiLstmParallel", 6, dict(proj=9)),
+                                          ("BiLstmParallel", 5, dict(proj=6, proj_act="Tanh"))])
+def test_pad_cells_is_function_and_training_preserving(tmp_path, kind, H, extra):
+    """pad-cells (the tool behind the library's one shape restriction: cells per direction % 4 == 0): the padded model -- a file every
+    tool of either code base reads -- computes the ORIGINAL function bit for bit and stays padded with exact zeros through training
+    (momentum, clipping, Adagrad), here on the CPU restatement of the reference (oracle/); unpad-cells cuts it back and refuses a
+    model whose padding is not zero."""
+    from oracle.net import OracleNet, train_step
+    cfg = dict(kind=kind, layers=2, H=H, D=7, K=9, S=3, T=14); cfg.update(extra)
+    layers = synth.make_model(max_grad=5.0, **cfg); batch = synth.make_batch(**cfg)
+    src, dst, back = (str(tmp_path / n) for n in ("in.nnet", "pad.nnet", "back.nnet"))
+    nnet_io.write_nnet(src, layers, binary=True)
+    assert model_tools.main(["pad-cells", src, dst]) == 0
+    padded = nnet_io.read_nnet(dst)
+    nd = 2 if kind.startswith("Bi") else 1
+    assert all(L["output_dim"] % (4 * nd) == 0 for L in padded if nnet_io.is_lstm(L["type"]))
+    assert padded[-1]["output_dim"] == layers[-1]["output_dim"] and padded[0]["input_dim"] == layers[0]["input_dim"]
+    assert model_tools.main(["unpad-cells", f"--cells={H},{H}", dst, back]) == 0
+    assert open(back, "rb").read() == open(src, "rb").read()
+    for rule in ("SGD", "Adagrad"):
+        res = {}
+        for name, ls in (("orig", layers), ("pad", padded)):
+            net = OracleNet(ls); net.set_train_options(0.5, 0.9); net.set_update_algorithm(rule)
+            steps = []
+            for _ in range(3):
+                r = train_step(net, batch)
+                steps.append((r["net_out"].copy(), r["pzx"].copy(), r["in_diff"].copy()))
+            res[name] = (steps, net.to_layers())
+        for a, b in zip(res["orig"][0], res["pad"][0]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), rule
+        cut = model_tools.unpad_cells_layers(res["pad"][1], [H, H])       # raises unless the padding is still exactly zero
+        for La, Lb in zip(res["orig"][1], cut):
+            assert all(np.array_equal(x, y) for x, y in zip(La["params"], Lb["params"])), rule
+    bad = [dict(L) for L in padded]
+    bad[0] = dict(bad[0], params=[p.copy() for p in bad[0]["params"]]); bad[0]["params"][2][-1] = 0.25     # a padded cell's bias
+    with pytest.raises(ValueError, match="not zero"):
+        model_tools.unpad_cells_layers(bad, [H, H])
+
+
+def test_pad_cells_refuses_what_it_cannot_keep_equivalent(tmp_path):
+    cfg = dict(kind="BiLstmParallel", layers=2, H=5, D=7, K=9, proj=6, proj_act="Tanh")
+    layers = synth.make_model(**cfg)
+    direct_sigmoid = [layers[0], dict(type="Sigmoid", input_dim=10, output_dim=10, params=[])] + [dict(type="AffineTransform", input_dim=10, output_dim=9,
+                      params=[np.zeros((9, 10), np.float32), np.zeros(9, np.float32)])]
+    with pytest.raises(ValueError, match="Sigmoid"):
+        model_tools.pad_cells_layers(direct_sigmoid)
+    with pytest.raises(ValueError, match="last layer"):
+        model_tools.pad_cells_layers(layers[:1])
+    assert model_tools.pad_cells_layers(synth.make_model(**dict(cfg, H=8))) [0]["output_dim"] == 16     # nothing to do: unchanged
