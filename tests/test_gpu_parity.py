@@ -531,6 +531,43 @@ def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, 
     assert np.array_equal(out, ok.Propagate(batch.feats).numpy())
 
 
+@pytest.mark.parametrize("kind,H,S,T", [("BiLstmParallel", 10, 8, 30), ("LstmParallel", 7, 4, 21), ("BiLstmParallel", 150, 16, 40)])
+def test_a_model_padded_by_pad_cells_trains_like_the_original(gpu, kind, H, S, T, tmp_path):
+    """The library refuses LSTM layers whose cell count per direction is not a multiple of 4 and names `model_tools pad-cells`
+    (INTEGRATION.md "Restrictions").  The padded model ON THE DEVICE against the ORIGINAL model on the oracle: same outputs, same
+    ln p, same input gradient through three SGD steps with momentum and clipping; the model written back is still padded with exact
+    zeros (unpad-cells checks what it cuts) and, cut back, is the model the reference would have trained."""
+    from eesen_amd import model_tools, nnet_io
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    from oracle import net as onet
+    cfg = dict(kind=kind, layers=2, H=H, D=13, K=11, S=S, T=T)
+    layers = synth.make_model(max_grad=5.0, **cfg); batch = synth.make_batch(**cfg)
+    with pytest.raises(Exception, match="pad-cells"):
+        Net.from_layers(layers)
+    padded = model_tools.pad_cells_layers(layers)
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(0.02, 0.9)
+    net = Net.from_layers(padded); net.SetTrainOptions(0.02, 0.9)
+    ctc = Ctc()
+    for step in range(3):
+        o = onet.train_step(ora, batch, "f32")
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(batch.feats)
+        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+        in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
+        net.Backpropagate(diff, in_diff)
+        vm = valid_mask(batch.lens, batch.T, batch.S)
+        bar = TOL if step == 0 else 5 * TOL      # (two trajectories in fp32: the later steps carry the earlier steps' rounding)
+        assert rel_err(out.numpy()[vm], o["net_out"][vm]) < bar, step
+        assert rel_err(ctc.pzx, o["pzx"]) < bar, step
+        assert rel_err(in_diff.numpy(), o["in_diff"]) < 3 * bar, step
+    path = str(tmp_path / "trained.nnet")
+    net.Write(path, binary=True)
+    cut = model_tools.unpad_cells_layers(nnet_io.read_nnet(path), [H, H])      # raises unless every padded entry is still exactly 0
+    for La, Lb in zip(ora.to_layers(), cut):
+        for a, b in zip(La["params"], Lb["params"]):
+            assert rel_err(b, a) < 5 * TOL, La["type"]
+
+
 @pytest.mark.parametrize("over", [dict(S=1, T=37), dict(S=2, T=2), dict(S=17, T=9, H=20), dict(S=33, T=5, H=36, layers=1),
                                   dict(S=6, T=40, min_frac=0.2)])
 def test_odd_shapes_and_single_sequence(gpu, over):
