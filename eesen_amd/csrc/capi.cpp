@@ -327,6 +327,17 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
   });
 }
 
+int eesen_op_gemm_async(int device, void* stream, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, float* ws, long ws_floats, int extra_lds_bytes) {
+  return guard([&] {
+    REQ_PTR(A); REQ_PTR(B); REQ_PTR(C);
+    EESEN_REQUIRE(ws_floats >= 0 && (ws || ws_floats == 0) && extra_lds_bytes >= 0, EESEN_ERR_INVALID, "bad workspace / LDS cap");
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    gemm_f32(reinterpret_cast<hipStream_t>(stream), a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws, (size_t)ws_floats,
+             extra_lds_bytes);
+  });
+}
+
 int eesen_op_log_sub_prior(int device, void* stream, float* m_dev, int rows, int cols, int ld, int apply_log,
                            const float* log_priors_host, float prior_scale) {
   return guard([&] {

@@ -373,6 +373,12 @@ int eesen_op_gemm(int device, void* stream, int a_kc, int b_kc, int M, int N, in
                   const float* A, int lda, const float* B, int ldb, float beta, float* C, int ldc,
                   const float* bias);
 
+/* The same GEMM ENQUEUED on `stream` and nothing else (no allocation, no synchronisation): `ws` / `ws_floats` is the caller's split-K
+ * workspace (device memory, 0 floats = no split-K), `extra_lds_bytes` the unused dynamic LDS that caps the kernel's workgroups per CU --
+ * how Net::Backpropagate runs its weight-gradient GEMMs beside a recurrence (scripts/corun_probe.py measures what that costs either side). */
+int eesen_op_gemm_async(int device, void* stream, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, float* ws, long ws_floats, int extra_lds_bytes);
+
 /* Post-processing of net-output-extract (src/netbin/net-output-extract.cc:103-112) on a device matrix, in place:
  * CuMatrixBase::ApplyLog when apply_log != 0, then ClassPrior::SubtractOnLogpost (src/net/class-prior.cc:80-91)
  * m[r][k] -= prior_scale * log_priors[k] when log_priors_host (cols floats) is not NULL.  Synchronises. */
