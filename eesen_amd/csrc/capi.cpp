@@ -99,8 +99,8 @@ int eesen_net_layer_info(eesen_net_t* net, int idx, int* kind, int* in_dim, int*
     EESEN_REQUIRE(idx >= 0 && idx < (int)net->layers.size(), EESEN_ERR_INVALID, "layer index out of range");
     const Layer& L = net->layers[idx];
     if (kind) *kind = L.kind;
-    if (in_dim) *in_dim = L.din;
-    if (out_dim) *out_dim = L.dout;
+    if (in_dim) *in_dim = L.din_f;     // the model's own dimensions (an LSTM layer the library pads to a multiple of 4 cells reports what the file says)
+    if (out_dim) *out_dim = L.dout_f;
     if (coef) *coef = L.coef;
     if (max_grad) *max_grad = L.max_grad;
   });
@@ -119,10 +119,10 @@ int eesen_net_tensor_moments(eesen_net_t* net, int which, int layer, double* out
   });
 }
 int eesen_net_input_dim(eesen_net_t* net, int* dim) {
-  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.front().din; });
+  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.front().din_f; });
 }
 int eesen_net_output_dim(eesen_net_t* net, int* dim) {
-  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.back().dout; });
+  return guard([&] { REQ_PTR(net); REQ_PTR(dim); EESEN_REQUIRE(!net->layers.empty(), EESEN_ERR_STATE, "empty net"); *dim = net->layers.back().dout_f; });
 }
 int eesen_net_num_params(eesen_net_t* net, long* n) {
   return guard([&] { REQ_PTR(net); REQ_PTR(n); *n = net->num_params(); });

@@ -174,7 +174,8 @@ void adaptive_update(hipStream_t st, float* param, float* corr, const float* fre
 // Moments of a [rows x cols] region (leading dimension ld) of a flat buffer, as MomentStatistics prints them
 // (/root/reference/src/net/utils-functions.h:50-82): out6 = {min, max, mean, variance, skewness, kurtosis}, doubles on the
 // device; two passes (min / max / sum, then the central power sums), fp64 accumulation.  ws: >= 8 doubles of scratch.
-void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws);
+void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws,
+                    int nb = 0, int hf = 0, int hi = 0);   // (nb, hf, hi): column c of the tensor lives at (c / hf) * hi + c % hf of its row (0: at c)
 // dst[c][r] = src[r][c]  (rows x cols -> cols x rows), dense
 void transpose2d(hipStream_t st, const float* src, int rows, int cols, float* dst);
 // dst[r][0..cols) = src[r][0..cols) with different leading dimensions

@@ -66,8 +66,8 @@ int PhaseTimer::spans(int* phases, float* secs, int cap) {
 
 // ------------------------------------------------------------------------------------------ Layer
 long Layer::file_params() const {
-  if (is_lstm()) return (long)ndir * ((long)4 * H * din + (long)4 * H * H + 4 * H + 3 * H);  // bilstm-layer.h:991-998
-  if (kind == EESEN_LAYER_AFFINE) return (long)dout * din + dout;
+  if (is_lstm()) return (long)ndir * ((long)4 * Hf * din_f + (long)4 * Hf * Hf + 4 * Hf + 3 * Hf);  // bilstm-layer.h:991-998
+  if (kind == EESEN_LAYER_AFFINE) return (long)dout_f * din_f + dout_f;
   return 0;
 }
 
@@ -90,25 +90,25 @@ const char* Layer::marker() const {
 template <class F>
 static void for_each_param(const Layer& L, F f) {
   long fi = 0;
-  if (L.is_lstm()) {
-    const int H = L.H, D = L.din, D4 = pad4(L.din);
+  if (L.is_lstm()) {   // (file side: Hf cells, din_f input columns; internal: H cells -- the padded ones are the LAST rows u*4+q, u >= Hf, of a direction)
+    const int H = L.H, Hf = L.Hf, D = L.din_f, D4 = pad4(L.din);
     for (int dir = 0; dir < L.ndir; ++dir) {
-      for (int r = 0; r < 4 * H; ++r) {
-        const int q = r / H, u = r % H;
-        for (int d = 0; d < D; ++d) f(fi++, L.off_wx + ((size_t)dir * 4 * H + u * 4 + q) * D4 + d);
+      for (int r = 0; r < 4 * Hf; ++r) {
+        const int q = r / Hf, u = r % Hf;
+        for (int d = 0; d < D; ++d) f(fi++, L.off_wx + ((size_t)dir * 4 * H + u * 4 + q) * D4 + L.in_col(d));
       }
-      for (int r = 0; r < 4 * H; ++r) {
-        const int q = r / H, u = r % H;
-        for (int k = 0; k < H; ++k) f(fi++, L.off_wm + ((size_t)dir * 4 * H + u * 4 + q) * H + k);
+      for (int r = 0; r < 4 * Hf; ++r) {
+        const int q = r / Hf, u = r % Hf;
+        for (int k = 0; k < Hf; ++k) f(fi++, L.off_wm + ((size_t)dir * 4 * H + u * 4 + q) * H + k);
       }
-      for (int r = 0; r < 4 * H; ++r) f(fi++, L.off_bias + (size_t)dir * 4 * H + (r % H) * 4 + r / H);
+      for (int r = 0; r < 4 * Hf; ++r) f(fi++, L.off_bias + (size_t)dir * 4 * H + (r % Hf) * 4 + r / Hf);
       for (int g = 0; g < 3; ++g)
-        for (int u = 0; u < H; ++u) f(fi++, L.off_peep + ((size_t)dir * 3 + g) * H + u);
+        for (int u = 0; u < Hf; ++u) f(fi++, L.off_peep + ((size_t)dir * 3 + g) * H + u);
     }
   } else if (L.kind == EESEN_LAYER_AFFINE) {
     const int D4 = pad4(L.din);
     for (int r = 0; r < L.dout; ++r)
-      for (int d = 0; d < L.din; ++d) f(fi++, L.off_w + (size_t)r * D4 + d);
+      for (int d = 0; d < L.din_f; ++d) f(fi++, L.off_w + (size_t)r * D4 + L.in_col(d));
     for (int r = 0; r < L.dout; ++r) f(fi++, L.off_b + r);
   }
 }
@@ -286,44 +286,58 @@ void Net::poll_device_error() {
   else steps_since_clean = 0;
 }
 
-void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {
+void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {   // din, dout: the FILE's dimensions
   EESEN_REQUIRE(!finalized, EESEN_ERR_STATE, "net already finalized");
   EESEN_REQUIRE(din > 0 && dout > 0, EESEN_ERR_INVALID, "layer dimensions must be positive");
-  if (!layers.empty())  // net.cc:282-286
-    EESEN_REQUIRE(layers.back().dout == din, EESEN_ERR_INVALID, "Dimensionality mismatch between consecutive layers");
+  const Layer* prev = layers.empty() ? nullptr : &layers.back();
+  if (prev)  // net.cc:282-286
+    EESEN_REQUIRE(prev->dout_f == din, EESEN_ERR_INVALID, "Dimensionality mismatch between consecutive layers");
   Layer L;   // checked as a local: a refused layer leaves the net as it was
-  L.kind = kind; L.din = din; L.dout = dout; L.coef = coef; L.max_grad = max_grad;
+  L.kind = kind; L.coef = coef; L.max_grad = max_grad;
+  L.din_f = din; L.dout_f = dout;
+  L.din = prev ? prev->dout : din;                     // the internal width of what this layer reads ...
+  if (prev) { L.in_nb = prev->out_nb; L.in_hf = prev->out_hf; L.in_hi = prev->out_hi; }   // ... and where the file's columns are in it
+  L.dout = dout;
+  const char* sees_pad = "directly on an LSTM layer whose cell count per direction is not a multiple of 4 is not supported: it would see the "
+                         "zero cells the library pads such a layer with";
   switch (kind) {
     case EESEN_LAYER_BILSTM_PARALLEL:
       EESEN_REQUIRE(dout % 2 == 0, EESEN_ERR_INVALID, "<CellDim> of a BiLstm layer must be even");
-      L.ndir = 2; L.H = dout / 2;
+      L.ndir = 2; L.Hf = dout / 2;
       break;
     case EESEN_LAYER_LSTM_PARALLEL:
-      L.ndir = 1; L.H = dout;
+      L.ndir = 1; L.Hf = dout;
       break;
     case EESEN_LAYER_AFFINE:
       break;
     case EESEN_LAYER_SOFTMAX:
       EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "Softmax needs InputDim == OutputDim");
+      if (L.in_nb) throw Error(EESEN_ERR_INVALID, std::string("a <Softmax> ") + sees_pad);
       break;
     case EESEN_LAYER_SIGMOID:
     case EESEN_LAYER_TANH:
       EESEN_REQUIRE(din == dout, EESEN_ERR_INVALID, "an activation layer needs InputDim == OutputDim");
+      if (L.in_nb && kind == EESEN_LAYER_SIGMOID) throw Error(EESEN_ERR_INVALID, std::string("a <Sigmoid> ") + sees_pad + " (sigmoid(0) = 1/2)");
+      L.dout = L.din;                                  // tanh(0) = 0: the padded columns pass through
+      L.out_nb = L.in_nb; L.out_hf = L.in_hf; L.out_hi = L.in_hi;
       break;
     default:
       throw Error(EESEN_ERR_INVALID, "unsupported layer kind " + std::to_string(kind));
   }
-  // the one shape restriction the reference does not have: the kernels fetch the state four cells at a time (INTEGRATION.md
-  // "Restrictions" names the model-file tool that pads such a model without changing what it computes)
-  if (L.is_lstm())
-    EESEN_REQUIRE(L.H % 4 == 0, EESEN_ERR_INVALID,
-                  "LSTM cell count per direction must be a multiple of 4 (python -m eesen_amd.model_tools pad-cells pads a model file to one)");
+  if (L.is_lstm()) {   // the kernels fetch the recurrent state four cells at a time: H = Hf rounded up, the extra cells identically zero
+    L.H = pad4(L.Hf);
+    L.dout = L.ndir * L.H;
+    if (L.H != L.Hf) { L.out_nb = L.ndir; L.out_hf = L.Hf; L.out_hi = L.H; }
+  }
   layers.push_back(std::move(L));
 }
 
 void Net::finalize() {
   EESEN_REQUIRE(!finalized, EESEN_ERR_STATE, "net already finalized");
   EESEN_REQUIRE(!layers.empty(), EESEN_ERR_INVALID, "empty net");
+  EESEN_REQUIRE(layers.back().out_nb == 0, EESEN_ERR_INVALID,
+                "an LSTM layer whose cell count per direction is not a multiple of 4 cannot be the net's last layer: its output would carry the "
+                "zero cells the library pads it with (python -m eesen_amd.model_tools pad-cells writes the padded model out)");
   EESEN_HIP_CHECK(hipSetDevice(device));
   size_t off = 0;
   for (Layer& L : layers) {
@@ -387,19 +401,19 @@ int Net::tensor_moments(int which, int layer, double* out6_host, int cap_tensors
   EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size(), EESEN_ERR_INVALID, "layer index out of range");
   EESEN_REQUIRE(which >= 0 && which <= 2, EESEN_ERR_INVALID, "which: 0 parameters, 1 momentum buffers, 2 accumulators");
   const Layer& L = layers[layer];
-  struct Region { size_t off; long rows; int cols; long ld; };
-  std::vector<Region> reg;
+  struct Region { size_t off; long rows; int cols; long ld; int nb, hf, hi; };   // (nb, hf, hi): the column map of Layer::in_col
+  std::vector<Region> reg;   // the FILE's entries of every tensor: the zero cells of a padded LSTM layer are no statistics
   if (L.is_lstm()) {
-    const int H = L.H, D = L.din, D4 = pad4(D);
+    const int H = L.H, Hf = L.Hf, D4 = pad4(L.din);
     for (int dir = 0; dir < L.ndir; ++dir) {
-      reg.push_back({L.off_wx + (size_t)dir * 4 * H * D4, 4L * H, D, D4});
-      reg.push_back({L.off_wm + (size_t)dir * 4 * H * H, 4L * H, H, H});
-      reg.push_back({L.off_bias + (size_t)dir * 4 * H, 1, 4 * H, 4L * H});
-      for (int g = 0; g < 3; ++g) reg.push_back({L.off_peep + ((size_t)dir * 3 + g) * H, 1, H, H});
+      reg.push_back({L.off_wx + (size_t)dir * 4 * H * D4, 4L * Hf, L.din_f, D4, L.in_nb, L.in_hf, L.in_hi});
+      reg.push_back({L.off_wm + (size_t)dir * 4 * H * H, 4L * Hf, Hf, H, 0, 0, 0});
+      reg.push_back({L.off_bias + (size_t)dir * 4 * H, 1, 4 * Hf, 4L * H, 0, 0, 0});
+      for (int g = 0; g < 3; ++g) reg.push_back({L.off_peep + ((size_t)dir * 3 + g) * H, 1, Hf, H, 0, 0, 0});
     }
   } else if (L.kind == EESEN_LAYER_AFFINE) {
-    reg.push_back({L.off_w, L.dout, L.din, pad4(L.din)});
-    reg.push_back({L.off_b, 1, L.dout, L.dout});
+    reg.push_back({L.off_w, L.dout, L.din_f, pad4(L.din), L.in_nb, L.in_hf, L.in_hi});
+    reg.push_back({L.off_b, 1, L.dout, L.dout, 0, 0, 0});
   }
   const int n = (int)reg.size();
   if (!out6_host || n == 0) return n;
@@ -410,7 +424,8 @@ int Net::tensor_moments(int which, int layer, double* out6_host, int cap_tensors
   const float* base = (which == 0 ? params.p : which == 1 ? corr.p : accu.p) + L.p_off;
   DevBuf<double> d;
   d.reserve((size_t)n * 6 + 8);
-  for (int i = 0; i < n; ++i) eesen::tensor_moments(st, base + reg[i].off, reg[i].rows, reg[i].cols, reg[i].ld, d.p + (size_t)i * 6, d.p + (size_t)n * 6);
+  for (int i = 0; i < n; ++i)
+    eesen::tensor_moments(st, base + reg[i].off, reg[i].rows, reg[i].cols, reg[i].ld, d.p + (size_t)i * 6, d.p + (size_t)n * 6, reg[i].nb, reg[i].hf, reg[i].hi);
   EESEN_HIP_CHECK(hipStreamSynchronize(st));
   EESEN_HIP_CHECK(hipMemcpy(out6_host, d.p, (size_t)n * 6 * sizeof(double), hipMemcpyDeviceToHost));
   return n;

@@ -18,6 +18,17 @@ struct Layer {
   size_t p_off = 0, p_n = 0;
   // LSTM kinds
   int H = 0, ndir = 0;
+  // FILE-side dimensions: what the model file, the Net::GetParams order and eesen_net_layer_info carry.  They differ from the internal
+  // ones (din, dout, H -- what every kernel sees) only around an LSTM layer whose cell count per direction is not a multiple of 4:
+  // the library pads such a layer with cells that are identically zero and stay so (zero rows, bias and peepholes; zero columns
+  // wherever their output is read -- the argument and its test: eesen_amd/model_tools.py pad-cells, tests/test_gpu_parity.py), because
+  // the kernels fetch the state four cells at a time.  Parameter I/O (for_each_param), the statistics and the model writer map
+  // between the two; nothing else knows.
+  int din_f = 0, dout_f = 0, Hf = 0;
+  // where this layer's FILE input column d lives in its internal input: in_nb runs of in_hf columns, each at a stride of in_hi
+  // (in_nb = 0: identity); out_*: the same for the columns this layer hands on
+  int in_nb = 0, in_hf = 0, in_hi = 0, out_nb = 0, out_hf = 0, out_hi = 0;
+  int in_col(int d) const { return in_nb ? (d / in_hf) * in_hi + d % in_hf : d; }
   size_t off_wx = 0, off_bias = 0, off_wm = 0, off_peep = 0;  // relative to p_off
   DevBuf<float> WmT;      // [ndir][H x 4H], rebuilt after every parameter change
   DevBuf<float> G, C, Y;  // activations

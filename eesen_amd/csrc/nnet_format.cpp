@@ -293,9 +293,9 @@ void Net::write(const std::string& path, bool binary) {
                                                                : "<Softmax>";
     put_token(os, marker);
     put_token(os, "<InputDim>");
-    put_int(os, binary, L.din);
+    put_int(os, binary, L.din_f);    // the file's dimensions (Layer::din_f: an LSTM layer padded to a multiple of 4 cells is written unpadded)
     put_token(os, L.is_lstm() ? "<CellDim>" : "<OutputDim>");
-    put_int(os, binary, L.dout);
+    put_int(os, binary, L.dout_f);
     if (!binary) os << "\n";
     if (!L.trainable()) continue;
     put_token(os, "<LearnRateCoef>");
@@ -310,16 +310,16 @@ void Net::write(const std::string& path, bool binary) {
       }
     auto write_tensors = [&](const float*& q) {
       if (L.is_lstm()) {
-        const int H = L.H;
+        const int H = L.Hf;
         for (int d = 0; d < L.ndir; ++d) {
-          put_tensor(os, binary, q, 4 * H, L.din); q += (size_t)4 * H * L.din;
+          put_tensor(os, binary, q, 4 * H, L.din_f); q += (size_t)4 * H * L.din_f;
           put_tensor(os, binary, q, 4 * H, H);     q += (size_t)4 * H * H;
           put_tensor(os, binary, q, 4 * H, 0);     q += 4 * H;
           for (int g = 0; g < 3; ++g) { put_tensor(os, binary, q, H, 0); q += H; }
         }
       } else {
-        put_tensor(os, binary, q, L.dout, L.din); q += (size_t)L.dout * L.din;
-        put_tensor(os, binary, q, L.dout, 0);     q += L.dout;
+        put_tensor(os, binary, q, L.dout_f, L.din_f); q += (size_t)L.dout_f * L.din_f;
+        put_tensor(os, binary, q, L.dout_f, 0);       q += L.dout_f;
       }
     };
     if (pa) {

@@ -239,14 +239,15 @@ namespace {
 // {min, max, sum} in ws[0..2], pass 1 the central power sums and the six printed figures in out6.
 template <int PASS>
 __global__ __launch_bounds__(1024) void tensor_moments_kernel(const float* __restrict__ base, long rows, int cols, long ld,
-                                                              double* __restrict__ out6, double* __restrict__ ws) {
+                                                              double* __restrict__ out6, double* __restrict__ ws, int nb, int hf, int hi) {
   __shared__ double red[4][16];
   const long n = rows * cols;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a = PASS == 0 ? 1e300 : 0.0, b = PASS == 0 ? -1e300 : 0.0, c = 0.0, d = 0.0;
   const double mean = PASS == 1 ? ws[2] / (double)n : 0.0;
   for (long i = tid; i < n; i += 1024) {
-    const double v = (double)base[(i / cols) * ld + (i % cols)];
+    const int cf = (int)(i % cols);   // the FILE's column; (nb, hf, hi): where it lives in the row (Layer::in_col, net.h)
+    const double v = (double)base[(i / cols) * ld + (nb ? (cf / hf) * hi + cf % hf : cf)];
     if (PASS == 0) { a = fmin(a, v); b = fmax(b, v); c += v; }
     else { const double e = v - mean, e2 = e * e; a += e2; b += e2 * e; c += e2 * e2; }
   }
@@ -273,9 +274,9 @@ __global__ __launch_bounds__(1024) void tensor_moments_kernel(const float* __res
 }
 }  // namespace
 
-void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws) {
-  hipLaunchKernelGGL(tensor_moments_kernel<0>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws);
-  hipLaunchKernelGGL(tensor_moments_kernel<1>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws);
+void tensor_moments(hipStream_t st, const float* base, long rows, int cols, long ld, double* out6, double* ws, int nb, int hf, int hi) {
+  hipLaunchKernelGGL(tensor_moments_kernel<0>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws, nb, hf, hi);
+  hipLaunchKernelGGL(tensor_moments_kernel<1>, dim3(1), dim3(1024), 0, st, base, rows, cols, ld, out6, ws, nb, hf, hi);
   check_launch("tensor_moments");
 }
 

@@ -5,7 +5,8 @@ iterations and before decoding.
     python -m eesen_amd.model_tools net-copy [--binary=B] [--remove-first-layers=N] [--remove-last-layers=N] <model-in> <model-out>
     python -m eesen_amd.model_tools format-to-nonparallel [--binary=B] <model-in> <model-out>
 
-and one tool the reference does not need (the library's single shape restriction, INTEGRATION.md "Restrictions"):
+and one tool the reference does not need (libeesen_hip.so pads LSTM cell counts to multiples of 4 internally; this writes the padded model
+OUT, for the few places where the padding would show -- INTEGRATION.md "Restrictions"):
 
     python -m eesen_amd.model_tools pad-cells [--binary=B] [--multiple=4] <model-in> <model-out>
     python -m eesen_amd.model_tools unpad-cells [--binary=B] --cells=H1,H2,... <model-in> <model-out>
@@ -123,9 +124,10 @@ def format_to_nonparallel(argv: List[str]) -> int:
 
 
 # ---- cells per direction padded to a multiple of 4 ---------------------------------------------------------------------------------
-# libeesen_hip.so fetches the recurrent state four cells at a time and refuses an LSTM layer whose cell count per direction is not
-# a multiple of 4 (net.cpp: add_layer); the reference takes any.  A model with, say, <CellDim> 300 for a BiLstm (150 per direction)
-# is padded to 152 per direction with cells that are identically zero and stay so:
+# libeesen_hip.so fetches the recurrent state four cells at a time; the reference takes any cell count.  The library pads a layer whose
+# count per direction is not a multiple of 4 internally (net.cpp: add_layer, for_each_param) by exactly the construction below, which
+# this tool applies to the model FILE: <CellDim> 300 for a BiLstm (150 per direction) becomes 152 per direction, with cells that are
+# identically zero and stay so:
 #   a padded cell has zero W_x / W_m rows, zero bias, zero peepholes: g = tanh(0) = 0, i = f = o = 1/2, c_t = f c_{t-1} + i g = 0,
 #   m_t = o tanh(c_t) = 0 for every t;  the columns that read its output -- W_m's own columns and the next layer's input columns --
 #   are zero, so nothing downstream sees it: the padded net computes the original function.

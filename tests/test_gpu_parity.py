@@ -532,40 +532,67 @@ def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, 
 
 
 @pytest.mark.parametrize("kind,H,S,T", [("BiLstmParallel", 10, 8, 30), ("LstmParallel", 7, 4, 21), ("BiLstmParallel", 150, 16, 40)])
-def test_a_model_padded_by_pad_cells_trains_like_the_original(gpu, kind, H, S, T, tmp_path):
-    """The library refuses LSTM layers whose cell count per direction is not a multiple of 4 and names `model_tools pad-cells`
-    (INTEGRATION.md "Restrictions").  The padded model ON THE DEVICE against the ORIGINAL model on the oracle: same outputs, same
-    ln p, same input gradient through three SGD steps with momentum and clipping; the model written back is still padded with exact
-    zeros (unpad-cells checks what it cuts) and, cut back, is the model the reference would have trained."""
+def test_cell_counts_that_are_not_multiples_of_4(gpu, kind, H, S, T, tmp_path):
+    """The kernels fetch the recurrent state four cells at a time; the reference takes any <CellDim>.  The library pads such a layer
+    INSIDE (zero cells that stay zero: Layer::din_f / dout_f / Hf in csrc/net.h) and maps at the parameter / model-file boundary, so
+    the ORIGINAL model goes in and comes out: against the oracle on the original model through three SGD steps with momentum and
+    clipping; GetParams / Write in the file's own dimensions; and bit for bit what `model_tools pad-cells` + the library gives
+    (the same internal net), whose trained file unpad-cells cuts back only if every padded entry is still exactly zero."""
     from eesen_amd import model_tools, nnet_io
     from eesen_amd.api import Net, Ctc, CuMatrix
     from oracle import net as onet
     cfg = dict(kind=kind, layers=2, H=H, D=13, K=11, S=S, T=T)
     layers = synth.make_model(max_grad=5.0, **cfg); batch = synth.make_batch(**cfg)
-    with pytest.raises(Exception, match="pad-cells"):
-        Net.from_layers(layers)
     padded = model_tools.pad_cells_layers(layers)
     ora = onet.OracleNet(layers, "f32"); ora.set_train_options(0.02, 0.9)
-    net = Net.from_layers(padded); net.SetTrainOptions(0.02, 0.9)
+    nets = [Net.from_layers(layers), Net.from_layers(padded)]
+    assert nets[0].GetParams().size == nnet_io.flatten_params(layers).size
+    assert np.array_equal(nets[0].GetParams(), nnet_io.flatten_params(layers))
+    for n in nets:
+        n.SetTrainOptions(0.02, 0.9)
     ctc = Ctc()
+    vm = valid_mask(batch.lens, batch.T, batch.S)
     for step in range(3):
         o = onet.train_step(ora, batch, "f32")
-        net.SetSeqLengths(batch.lens)
-        out = net.Propagate(batch.feats)
-        diff = ctc.EvalParallel(batch.lens, out, batch.labels)
-        in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
-        net.Backpropagate(diff, in_diff)
-        vm = valid_mask(batch.lens, batch.T, batch.S)
+        got = []
+        for n in nets:
+            n.SetSeqLengths(batch.lens)
+            out = n.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
+            n.Backpropagate(diff, in_diff)
+            got.append((out.numpy(), ctc.pzx.copy(), in_diff.numpy()))
+        assert all(np.array_equal(a, b) for a, b in zip(*got)), step          # padded inside == padded by the tool
         bar = TOL if step == 0 else 5 * TOL      # (two trajectories in fp32: the later steps carry the earlier steps' rounding)
-        assert rel_err(out.numpy()[vm], o["net_out"][vm]) < bar, step
-        assert rel_err(ctc.pzx, o["pzx"]) < bar, step
-        assert rel_err(in_diff.numpy(), o["in_diff"]) < 3 * bar, step
-    path = str(tmp_path / "trained.nnet")
-    net.Write(path, binary=True)
-    cut = model_tools.unpad_cells_layers(nnet_io.read_nnet(path), [H, H])      # raises unless every padded entry is still exactly 0
-    for La, Lb in zip(ora.to_layers(), cut):
-        for a, b in zip(La["params"], Lb["params"]):
+        assert rel_err(got[0][0][vm], o["net_out"][vm]) < bar, step
+        assert rel_err(got[0][1], o["pzx"]) < bar, step
+        assert rel_err(got[0][2], o["in_diff"]) < 3 * bar, step
+    paths = [str(tmp_path / "direct.nnet"), str(tmp_path / "tool.nnet")]
+    for n, pth in zip(nets, paths):
+        n.Write(pth, binary=True)
+    direct = nnet_io.read_nnet(paths[0])
+    assert [(L["type"], L["input_dim"], L["output_dim"]) for L in direct] == [(L["type"], L["input_dim"], L["output_dim"]) for L in layers]
+    cut = model_tools.unpad_cells_layers(nnet_io.read_nnet(paths[1]), [H, H])      # raises unless every padded entry is still exactly 0
+    for La, Lb, Lc in zip(ora.to_layers(), cut, direct):
+        for a, b, c in zip(La["params"], Lb["params"], Lc["params"]):
+            assert np.array_equal(b, c), La["type"]
             assert rel_err(b, a) < 5 * TOL, La["type"]
+    info = nets[0].Info() if hasattr(nets[0], "Info") else None
+    assert info is None or "nan" not in str(info).lower()
+
+
+def test_cell_padding_is_refused_where_it_would_show(gpu):
+    from eesen_amd.api import Net
+    z = lambda *sh: np.zeros(sh, np.float32)
+    lstm = dict(type="BiLstmParallel", input_dim=5, output_dim=12, params=[z(24, 5), z(24, 6), z(24), z(6), z(6), z(6)] * 2)
+    with pytest.raises(Exception, match="last layer"):
+        Net.from_layers([lstm])
+    with pytest.raises(Exception, match="Sigmoid"):
+        Net.from_layers([lstm, dict(type="Sigmoid", input_dim=12, output_dim=12, params=[])])
+    ok = Net.from_layers([lstm, dict(type="Tanh", input_dim=12, output_dim=12, params=[]),
+                          dict(type="AffineTransform", input_dim=12, output_dim=4, params=[z(4, 12), z(4)]),
+                          dict(type="Softmax", input_dim=4, output_dim=4, params=[])])
+    assert ok.GetParams().size == 2 * (24 * 5 + 24 * 6 + 24 + 18) + 4 * 12 + 4
 
 
 @pytest.mark.parametrize("over", [dict(S=1, T=37), dict(S=2, T=2), dict(S=17, T=9, H=20), dict(S=33, T=5, H=36, layers=1),
