@@ -335,9 +335,6 @@ void Net::add_layer(int kind, int din, int dout, float coef, float max_grad) {  
 void Net::finalize() {
   EESEN_REQUIRE(!finalized, EESEN_ERR_STATE, "net already finalized");
   EESEN_REQUIRE(!layers.empty(), EESEN_ERR_INVALID, "empty net");
-  EESEN_REQUIRE(layers.back().out_nb == 0, EESEN_ERR_INVALID,
-                "an LSTM layer whose cell count per direction is not a multiple of 4 cannot be the net's last layer: its output would carry the "
-                "zero cells the library pads it with (python -m eesen_amd.model_tools pad-cells writes the padded model out)");
   EESEN_HIP_CHECK(hipSetDevice(device));
   size_t off = 0;
   for (Layer& L : layers) {
@@ -815,6 +812,12 @@ void Net::forward_pass() {
   out_ptr = x;
   out_cols = layers.back().dout;
   out_ld = ldx;
+  if (const Layer& Lb = layers.back(); Lb.out_nb) {   // a padded LSTM layer (or a Tanh over one) is the net's last layer (Seam 2: the only
+    const int ldo = pad4(Lb.dout_f);                  // one): the caller gets the file's columns, run by run
+    if (out_f.reserve((size_t)rows * ldo) && ldo != Lb.dout_f) EESEN_HIP_CHECK(hipMemsetAsync(out_f.p, 0, (size_t)rows * ldo * sizeof(float), st));
+    for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, x + (size_t)b * Lb.out_hi, ldx, out_f.p + (size_t)b * Lb.out_hf, ldo, rows, Lb.out_hf);
+    out_ptr = out_f.p; out_cols = Lb.dout_f; out_ld = ldo;
+  }
   propagated = true;
   if (persistent) arm_device_error_poll();
 }
@@ -859,8 +862,13 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   float* d = dA.p;
   int ld_d = pad4(Kout);
   float* dn = dB.p;
-  if (ld_d != Kout) EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
-  copy2d(st, out_diff, ldd, d, ld_d, rows, Kout);
+  if (const Layer& Lb = layers.back(); Lb.out_nb) {   // the caller's out_diff has the file's columns: the padded cells get zeros
+    EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
+    for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, out_diff + (size_t)b * Lb.out_hf, ldd, d + (size_t)b * Lb.out_hi, ld_d, rows, Lb.out_hf);
+  } else {
+    if (ld_d != Kout) EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
+    copy2d(st, out_diff, ldd, d, ld_d, rows, Kout);
+  }
 
   for (int li = (int)layers.size() - 1; li >= 0; --li) {
     Layer& L = layers[li];

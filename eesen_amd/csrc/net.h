@@ -111,6 +111,7 @@ struct Net {
   unsigned in_stage_idx = 0;
   const float* out_ptr = nullptr;
   int out_cols = 0, out_ld = 0;
+  DevBuf<float> out_f;   // the net's output in the FILE's columns when the last layer is an LSTM layer padded to a multiple of 4 cells (forward_pass)
   // backward scratch
   DevBuf<float> DGb[2], DCF, dA, dB, ws, ws2;
   DevBuf<float> bwd_px;       // partial-sum exchange space of the K-split backward kernel (wide layers)

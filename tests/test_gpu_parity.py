@@ -581,18 +581,44 @@ def test_cell_counts_that_are_not_multiples_of_4(gpu, kind, H, S, T, tmp_path):
     assert info is None or "nan" not in str(info).lower()
 
 
+@pytest.mark.parametrize("kind,H", [("BiLstmParallel", 6), ("LstmParallel", 10)])
+def test_a_padded_lstm_layer_as_the_whole_net(gpu, kind, H):
+    """Seam 2 runs ONE LSTM layer per handle (include/eesen_hip_layer.h): with a cell count that is not a multiple of 4 the handle's
+    output and out_diff still have the file's columns -- the padded cells are gathered out / scattered in at the net's ends."""
+    from eesen_amd.api import Net, CuMatrix
+    from oracle import net as onet
+    cfg = dict(kind=kind, layers=1, H=H, D=5, K=4, S=3, T=9)
+    layers = synth.make_model(**cfg)[:1]; batch = synth.make_batch(**cfg)
+    width = layers[0]["output_dim"]
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(1.0, 0.0); ora.set_seq_lengths(batch.lens)
+    want = ora.propagate(batch.feats)
+    od = np.random.default_rng(3).standard_normal(want.shape).astype(np.float32)
+    od[~valid_mask(batch.lens, batch.T, batch.S)] = 0.0
+    want_in = ora.backpropagate(od, update=False)
+    net = Net.from_layers(layers); net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats)
+    assert out.numpy().shape == (batch.T * batch.S, width)
+    vm = valid_mask(batch.lens, batch.T, batch.S)
+    assert rel_err(out.numpy()[vm], want[vm]) < TOL
+    in_diff = CuMatrix(batch.T * batch.S, cfg["D"])
+    net.BackpropagateNoUpdate(CuMatrix.from_numpy(od), in_diff)
+    assert rel_err(in_diff.numpy(), want_in) < TOL
+    assert rel_err(net.GetGrads(), ora.fresh_grads_flat().astype(np.float32)) < TOL
+
+
 def test_cell_padding_is_refused_where_it_would_show(gpu):
     from eesen_amd.api import Net
     z = lambda *sh: np.zeros(sh, np.float32)
     lstm = dict(type="BiLstmParallel", input_dim=5, output_dim=12, params=[z(24, 5), z(24, 6), z(24), z(6), z(6), z(6)] * 2)
-    with pytest.raises(Exception, match="last layer"):
-        Net.from_layers([lstm])
     with pytest.raises(Exception, match="Sigmoid"):
         Net.from_layers([lstm, dict(type="Sigmoid", input_dim=12, output_dim=12, params=[])])
+    with pytest.raises(Exception, match="Softmax"):
+        Net.from_layers([lstm, dict(type="Softmax", input_dim=12, output_dim=12, params=[])])
     ok = Net.from_layers([lstm, dict(type="Tanh", input_dim=12, output_dim=12, params=[]),
                           dict(type="AffineTransform", input_dim=12, output_dim=4, params=[z(4, 12), z(4)]),
                           dict(type="Softmax", input_dim=4, output_dim=4, params=[])])
     assert ok.GetParams().size == 2 * (24 * 5 + 24 * 6 + 24 + 18) + 4 * 12 + 4
+    assert Net.from_layers([lstm]).GetParams().size == 2 * (24 * 5 + 24 * 6 + 24 + 18)
 
 
 @pytest.mark.parametrize("over", [dict(S=1, T=37), dict(S=2, T=2), dict(S=17, T=9, H=20), dict(S=33, T=5, H=36, layers=1),
