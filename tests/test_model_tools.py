@@ -99,10 +99,11 @@ def test_usage_and_text_output(tmp_path, capsys):
 @pytest.mark.parametrize("kind,H,extra", [("BiLstmParallel", 10, {}), ("LstmParallel", 7, {}), ("BiLstmParallel", 6, dict(proj=9)),
                                           ("BiLstmParallel", 5, dict(proj=6, proj_act="Tanh"))])
 def test_pad_cells_is_function_and_training_preserving(tmp_path, kind, H, extra):
-    """pad-cells (the tool behind the library's one shape restriction: cells per direction % 4 == 0): the padded model -- a file every
-    tool of either code base reads -- computes the ORIGINAL function bit for bit and stays padded with exact zeros through training
-    (momentum, clipping, Adagrad), here on the CPU restatement of the reference (oracle/); unpad-cells cuts it back and refuses a
-    model whose padding is not zero."""
+    """pad-cells (the construction libeesen_hip.so applies INSIDE to LSTM layers whose cells per direction are not a multiple of 4, here
+    applied to the model file): the padded model -- a file every tool of either code base reads -- computes the ORIGINAL function bit
+    for bit and stays padded with exact zeros through training (momentum, clipping, Adagrad), on the CPU restatement of the reference
+    (oracle/); unpad-cells cuts it back and refuses a model whose padding is not zero.  (The device side of the same statement:
+    tests/test_gpu_parity.py::test_cell_counts_that_are_not_multiples_of_4.)"""
     from oracle.net import OracleNet, train_step
     cfg = dict(kind=kind, layers=2, H=H, D=7, K=9, S=3, T=14); cfg.update(extra)
     layers = synth.make_model(max_grad=5.0, **cfg); batch = synth.make_batch(**cfg)
