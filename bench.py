@@ -58,15 +58,15 @@ def flops_per_frame(cfg) -> float:
 def fwd_rec_products(cfg, S: int, forward_mode: int = 0) -> int:
     """How the FORWARD recurrent product of this configuration is executed (lstm_persistent.hip: bf_plan): 0 = on the fp32-input
     MFMA; n > 0 = on the bf16 pipe as n bf16 products per fp32 product -- 6 for the fp32-class 3-way split the narrow tile takes
-    (H <= 512, S > 16; EESEN_FWD_SPLIT), 2 (W_m as hi + lo planes; 1 with EESEN_BF16_REC_WPLANES=1) for BASELINE config 4's bf16
+    (H <= 512, S > 16; EESEN_FWD_SPLIT), 2 (m_t one plane, W_m as hi + lo planes) for BASELINE config 4's bf16
     forward (--forward-precision bf16) on layers of 256 .. 1024 cells."""
     if os.environ.get("EESEN_PERSISTENT", "1") == "0" or cfg["H"] % 32 != 0:
         return 0
     H = cfg["H"]
     if forward_mode == 1 and H % 256 == 0 and H <= 1024:
-        return 1 if os.environ.get("EESEN_BF16_REC_WPLANES") == "1" else 2
+        return 2
     narrow = H % 8 == 0 and S > 16 and (H // 32 + 7) // 8 <= 2
-    if narrow and os.environ.get("EESEN_FWD_SPLIT", "1") != "0" and os.environ.get("EESEN_FWD_Q4", "0") == "0":
+    if narrow and os.environ.get("EESEN_FWD_SPLIT", "1") != "0":
         return 6
     return 0
 

@@ -84,15 +84,12 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
-  int bwd_early = 0;   // 4 x 32 backward kernel: the cell operands of a step are requested at the top of that step (EESEN_BWD_EARLY; A/B arm)
   // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on bf16 operands with
-  // fp32 accumulation (lstm_fwd_persistent_bf_kernel<.., AP = 1, WP>): m_t as ONE bf16 plane in the exchange buffer X, W_m as hi + lo
-  // planes (1) or one plane (2: EESEN_BF16_REC_WPLANES=1, the A/B arm)
+  // fp32 accumulation (lstm_fwd_persistent_bf_kernel<.., AP = 1, WP = 2>): m_t as ONE bf16 plane in the exchange buffer X, W_m as
+  // hi + lo planes
   int fwd_bf16 = 0;
   // fp32-class forward recurrence on the bf16 matrix pipe (3-way split of both operands, six products; tuning.h: EESEN_FWD_SPLIT)
   int fwd_split = 0;
-  int fwd_q4 = 0;     // the 4-sequence x 32-unit forward tile (tuning.h: EESEN_FWD_Q4)
-  int fwd_mux2 = 0;   // experiment: narrow layers through the time-multiplexed forward kernel (tuning.h: EESEN_FWD_MUX2)
 };
 float handoff_flight_ns();
 // one wave that returns once *word >= target (or when the recurrence kernels' error word is raised; it raises that word itself

@@ -26,11 +26,14 @@
 // launch itself is an ordinary one) and otherwise falls back to the per-step kernels; a spin that exceeds its bound raises an
 // error word instead of hanging.
 //
-// Arithmetic is that of lstm.hip (same cell equations, K split over the 8 waves the same way): the forward pass is
-// bit-identical to the per-step path; the backward pass differs in the last bits (FMA contraction, and the full-line operand
-// fetch consumes each 32-float chunk as two 16-float halves); tests assert exactly that.
+// Arithmetic is that of lstm.hip (same cell equations, K split over the 8 waves the same way): the fp32-input forward kernel
+// (lstm_fwd_persistent_kernel) is bit-identical to the per-step path; the DEFAULT forward kernel of narrow layers since round 4,
+// lstm_fwd_persistent_bf_kernel<.,2,3,3> (the exact 3-way bf16 split, EESEN_FWD_SPLIT=1), is fp32-class but not bit-identical; the
+// backward pass differs in the last bits (FMA contraction, and the full-line operand fetch consumes each 32-float chunk as two
+// 16-float halves); tests assert exactly that.
 #include "kernels.h"
 
+#include <map>
 #include <mutex>
 
 namespace eesen {
@@ -366,156 +369,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward, 4 sequences x 32 units per workgroup (round 4; EESEN_FWD_Q4): the forward twin of lstm_bwd_persistent_q4_kernel.
-// The 16 x 8 tile fetches m_{t-1} of 16 sequences -- 32 KB per workgroup and step at H = 512 -- and that fetch, at the ~34-40 GB/s
-// a CU fills its L1 with freshly written lines, is 0.8-1.0 us of the 3.1 us step.  On the 16-block v_mfma_f32_4x4x1_16B_f32 with
-// the A-operand broadcast (CBSZ = 3: all eight blocks of a k class share the A lanes of block ABID) a workgroup's 512 outputs can
-// be 4 sequences x 128 gate rows (32 units) instead: the same MFMA time (128 two-pass instructions per wave and step), W_m still
-// resident (128 gate rows x 64 k per wave = 128 registers per lane, the last row group in LDS as in the backward twin), still one
-// workgroup per CU (H/32 x ndir x S/4 = 256 at cfg2) -- and a QUARTER of the fetch: 4 sequences x 2 KB = ONE b128 load per lane
-// and step, whole 128-byte lines straight out of Y (no exchange copy needed).  Hand-off groups shrink from 64 to 16 workgroups
-// (one (direction, 4-sequence tile) each, two groups per XCD with the XCD-aware role map).
-//   lane l: k class ks = l >> 5, block ab = (l >> 2) & 7, x = l & 3; wave w owns k = 64 w .. 64 w + 63 (H <= 512)
-//   A: lane (ks, ab, x) loads 16 bytes of sequence x at k = 64 w + (ks * 8 + ab) * 4; instruction (r, ABID) takes component r:
-//      class ks covers k = 64 w + ks * 32 + ABID * 4 + r
-//   B: lane (ks, cb = ab, x), row group rg holds W_m[gate row rg * 32 + cb * 4 + x][that k]
-//   D: vgpr i, lane (ks, cb, x) -> out[sequence i][gate row rg * 32 + cb * 4 + x], partial over (wave, ks): summed through LDS
-// The sum over k is formed in a different order than in lstm_fwd_step_kernel: NOT bit-identical to the per-step kernels (the
-// 16 x 8 tile is; EESEN_FWD_Q4=0 restores it), parity ~1e-6 like every backward variant.  Shapes: H % 64 == 0, H <= 512,
-// S % 4 == 0, no dropout.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_q4_kernel(LstmLayerDev L, unsigned* cnt, unsigned* err, int spin_limit,
-                                                                         unsigned long long* trace, Role R) {
-  constexpr int ST = 4, UW = 32, GR = 4 * UW, RGN = 4, RW = GR + 4;   // sequences, units, gate rows per workgroup; row groups of 32 gate rows
-  constexpr int LDSG = 1, REGG = RGN - LDSG;                           // row groups whose W_m values live in LDS / in registers
-  __shared__ __attribute__((aligned(16))) float4 bl[LDSG][8][NW * 64];   // [row group][ABID][thread]: components r
-  __shared__ __attribute__((aligned(16))) float red[NW][2 * ST][RW];     // [wave][k class x sequence][gate row]
-  __shared__ int s_go;
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = L.H, S = L.S, T = L.T;
-  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
-  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
-  const int u0 = bx * UW, s0 = bz * ST;
-  unsigned* my_cnt = cnt + (size_t)(dir * R.nz + bz) * kShards * kShardStride;
-  const unsigned nblk = R.nblk;
-  const int ks = lane >> 5, ab = (lane >> 2) & 7, x = lane & 3;
-  const int kw = wave * 64;                       // this wave's 64 k
-  const bool w_ok = kw < H;                       // H < 512: the upper waves hold zeros and only take part in barriers and the reduction
-  float bw[REGG][4][8];                           // [row group][component r][ABID]
-  {
-#pragma unroll
-    for (int g = 0; g < RGN; ++g) {
-      const float* Wr = L.Wm + ((size_t)dir * 4 * H + (size_t)u0 * 4 + g * 32 + ab * 4 + x) * H + kw + ks * 32;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (w_ok) v = *reinterpret_cast<const float4*>(Wr + q * 4);
-        if (g < REGG) { bw[g < REGG ? g : 0][0][q] = v.x; bw[g < REGG ? g : 0][1][q] = v.y; bw[g < REGG ? g : 0][2][q] = v.z; bw[g < REGG ? g : 0][3][q] = v.w; }
-        else bl[g < REGG ? 0 : g - REGG][q][tid] = v;
-      }
-    }
-  }
-  const int es = tid >> 5, eu = tid & 31;
-  const int s_e = s0 + es;
-  const bool e_ok = tid < ST * UW && s_e < S;
-  float p_i = 0.f, p_f = 0.f, p_o = 0.f, cprev = 0.f;
-  int len = 0;
-  if (e_ok) {
-    const float* pp = L.peep + (size_t)dir * 3 * H + u0 + eu;
-    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
-    len = L.lens[s_e];
-  }
-  const size_t gcol = (size_t)dir * 4 * H + (u0 + eu) * 4;
-  float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e_ok) gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? 0 : T - 1) * S + s_e) * ldG + gcol);
-  const __amdgpu_buffer_rsrc_t rY = make_rsrc(L.Y);
-  __syncthreads();   // bl is complete
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? step : T - 1 - step;
-    const int tp = dir == 0 ? t - 1 : t + 1;
-    f32x4 ac[RGN];
-#pragma unroll
-    for (int g = 0; g < RGN; ++g) ac[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    EESEN_STAMP(0);
-    if (step > 0) {
-      if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters(my_cnt, nblk, (unsigned)step, err, spin_limit, lane, L.poll_delay);
-        if (lane == 0) s_go = go ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_go) return;
-      EESEN_STAMP(1);
-      if (L.milestone && step == L.milestone_step + 1 && bx == 0 && tid == 0)
-        report_milestone(L.milestone, (unsigned)(R.ndir * R.nz));
-      const unsigned arow = (unsigned)(((size_t)((tp + 1) * S + s0 + x) * ldY + (size_t)dir * H) * 4);   // < 2 GB, checked on the host
-      const f32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(rY, (w_ok && s0 + x < S) ? arow + (unsigned)(kw + (ks * 8 + ab) * 4) * 4u : 0x80000000u, 0, 0);
-#pragma unroll
-      for (int g = 0; g < RGN; ++g) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {   // ABID 2h and 2h + 1
-          float w0[4], w1[4];
-          if (g < REGG) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { w0[r] = bw[g < REGG ? g : 0][r][2 * h]; w1[r] = bw[g < REGG ? g : 0][r][2 * h + 1]; }
-          } else {
-            int lt = tid;
-            asm volatile("" : "+v"(lt));   // opaque per step: hoisted out of the loop the reads would be registers again
-            const float4 v0 = bl[g < REGG ? 0 : g - REGG][2 * h][lt], v1 = bl[g < REGG ? 0 : g - REGG][2 * h + 1][lt];
-            w0[0] = v0.x; w0[1] = v0.y; w0[2] = v0.z; w0[3] = v0.w;
-            w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (h == 0)      { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 0, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 1, 0); }
-            else if (h == 1) { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 2, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 3, 0); }
-            else if (h == 2) { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 4, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 5, 0); }
-            else             { ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w0[r], ac[g], 3, 6, 0); ac[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[r], w1[r], ac[g], 3, 7, 0); }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < RGN; ++g)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][g * 32 + ab * 4 + x] = ac[g][i];
-    __syncthreads();
-    EESEN_STAMP(2);
-    if (e_ok) {
-      float4 pre = gx;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const float4 v0 = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
-        const float4 v1 = *reinterpret_cast<const float4*>(&red[w][4 + es][eu * 4]);
-        pre.x += v0.x + v1.x; pre.y += v0.y + v1.y; pre.z += v0.z + v1.z; pre.w += v0.w + v1.w;
-      }
-      float g = tanhf_(pre.x);
-      float i = sigmoidf_(pre.y + p_i * cprev);
-      float f = sigmoidf_(pre.z + p_f * cprev);
-      float c = g * i + cprev * f;
-      float h = tanhf_(c);
-      float o = sigmoidf_(pre.w + p_o * c);
-      float m = h * o;
-      if (t >= len) { g = i = f = o = c = m = 0.f; }
-      *reinterpret_cast<float4*>(L.G + (size_t)(t * S + s_e) * ldG + gcol) = make_float4(g, i, f, o);
-      const size_t o1 = (size_t)((t + 1) * S + s_e) * ldY + dir * H + u0 + eu;
-      L.C[o1] = c;
-      __hip_atomic_store(L.Y + o1, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by the group's other workgroups next step
-      cprev = c;
-    }
-    EESEN_STAMP(3);
-    {
-      if (tid < ST * UW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok && step + 1 < T)
-        gx = *reinterpret_cast<const float4*>(L.G + (size_t)((dir == 0 ? t + 1 : t - 1) * S + s_e) * ldG + gcol);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // forward on the bf16 matrix pipe: lstm_fwd_persistent_bf_kernel<CPW, NT, AP, WP>.  The recurrent product m_{t-1} W_m^T on
 // v_mfma_f32_16x16x32_bf16 (fp32 accumulation; ~17 cycles per 16 x 16 x 32 block where the fp32-input form takes 8 x 32), with
 // both operands held as bf16 PLANES: a value x is rounded to nearest-even bf16, the remainder (exact in fp32) is rounded again,
@@ -530,14 +383,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_q4_kernel(LstmLay
 //        dropped terms <= 2^-23 |ab|, i.e. one fp32 rounding.  24 instructions of 17 cycles per wave and step at H = 512 instead
 //        of 32 of 32 cycles: the fp32 MFMA chain was 0.9 of the 3.1 us step.  Round 2 costed this with the A operand split by
 //        every CONSUMER (90-230 VALU instructions per step: not worth it) or stored pre-split at 1.5x the fetch (then thought
-//        to be the bound; the 4 x 32 forward tile of round 4 -- a QUARTER of the fetch, no faster -- showed it is not).  The
+//        to be the bound; a 4 x 32 forward tile in round 4 -- a QUARTER of the fetch, no faster, since removed -- showed it is not).  The
 //        narrow tile (16 sequences x 8 units) only: three planes of the wide tile's W_m do not fit the register file.
 //        Not bit-identical to lstm_fwd_step_kernel any more (EESEN_FWD_SPLIT=0 restores the fp32-input kernel, which is).
 //   <AP = 1, WP = 2>  BASELINE config 4's "bf16 forward" (eesen_net_set_forward_precision(1)): m_t rounded to ONE bf16 plane --
-//        half the bytes every consumer fetches per step --, W_m as hi + lo (17 bits).  With W_m as ONE plane as well
-//        (EESEN_BF16_REC_WPLANES=1) the gradients sit 2.7x further from the reference (0.18 against 0.069 max-norm at full
-//        cfg4 size): a weight rounded to 8 bits is a systematic perturbation of the model that every one of the T steps sees,
-//        the rounding of m_t is noise.  Gate pre-activations, cell state, activations and everything stored for the backward
+//        half the bytes every consumer fetches per step --, W_m as hi + lo (17 bits).  (With W_m as ONE plane as well -- an arm
+//        of round 4, removed -- the gradients sat 2.7x further from the reference, 0.18 against 0.069 max-norm at full cfg4
+//        size: a weight rounded to 8 bits is a systematic perturbation of the model that every one of the T steps sees, the
+//        rounding of m_t is noise.)  Gate pre-activations, cell state, activations and everything stored for the backward
 //        pass (G, C, Y) stay fp32; the backward pass is the fp32 one.
 // Tile: 16 sequences x 4 NT units; CPW 32-unit chunks of K = H per wave.
 // ------------------------------------------------------------------------------------------------
@@ -1173,17 +1026,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 //   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
 // Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
 // ------------------------------------------------------------------------------------------------
-// EARLY (round 4, EESEN_BWD_EARLY; measured NEUTRAL, kept as the A/B arm -- DESIGN.md section 4 "The cell operands at the top of the
-// step"): where the cell waves ask for g, i, f, o | dY | c_t | c_{t-1} of a step.  false (default): at the END of the step before,
-// behind the publish -- the loaded c_{t-1} rotates into a loop-carried register, so hipcc waits for those HBM loads (and, in wave 0,
-// for the acknowledgement of the counter increment in front of them) at the bottom of the loop: the cell waves reach the next step's
-// barrier 0.9 us after the publish (timeline: publish -> next 2100 ticks, wait 330).  true: at the TOP of the step they belong to,
-// behind the operand loads (branch-free buffer loads, lanes without a cell read out of range), consumed a whole MFMA chain later;
-// the counter increment comes from wave 6, which waits for nothing: publish -> next 160 ticks -- and wait 1840, fetch + MFMA 3650
-// instead of 3010: the step is 7140 ticks either way.  The stall sat exactly under the one thing a step cannot go without: the
-// flight of the slowest peer's increment, the poll's way back and the operand rows' own round trip (first-poll delay + poll = the
-// same 0.87 us).  Same loads, same values: bit-identical gate gradients (tests/test_gpu_parity.py).
-template <int CPW, bool EARLY>
+// (Round 4 measured an arm that requests the cell operands of a step at the TOP of that step instead of at the end of the step
+// before, and bumps the counter from a wave nobody waits on: bit-identical, 7140 ticks per step either way -- the stall it removed
+// sat under the peers' own increment flight.  DESIGN.md section 4 "The cell operands at the top of the step" keeps the timeline;
+// the arm is gone.)
+template <int CPW>
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                          float* __restrict__ DG, unsigned* cnt, unsigned* err,
                                                                          int spin_limit, unsigned long long* trace, Role R) {
@@ -1242,18 +1089,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     }
   }
   const __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);
-  const __amdgpu_buffer_rsrc_t rG = make_rsrc(L.G), rC = make_rsrc(L.C), rdY = make_rsrc(dY);   // (EARLY)
-  constexpr unsigned kOob = 0x80000000u;   // >= num_records: reads as zero, no memory access
   __syncthreads();   // bl is complete
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
     f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 a4[P];
-    // the cell operands of THIS step: loop-carried from the end of the step before, or (EARLY) locals of the iteration, requested
-    // below -- never rotated through loop-carried registers, which is what made hipcc wait for them where they were issued
-    float4 gtc = gt;
-    float dyc = dy, ctc = c_t, cpc = c_p;
+    // the cell operands of THIS step: requested at the end of the step before, behind the publish
+    const float4 gtc = gt;
+    const float dyc = dy, ctc = c_t, cpc = c_p;
     EESEN_STAMP(0);
     if (step > 0) {
       if (wave == EESEN_POLL_WAVE) {
@@ -1270,16 +1114,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
         const int k = (wave + p * NW) * 64 + (ks * 8 + ab) * 4;
         a4[p] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow + (unsigned)k * 4u : 0x80000000u, 0, 0);
       }
-    }
-    if (EARLY) {   // BEHIND the operand loads (vmcnt returns in order: the MFMA chain waits for its own chunks only) and a whole MFMA
-                   // chain ahead of the cell phase that consumes them; step 0 has no chain and simply waits for them there
-      __builtin_amdgcn_sched_barrier(0);
-      const int tp = dir == 0 ? t - 1 : t + 1;
-      const f32x4 g4 = __builtin_amdgcn_raw_buffer_load_b128(rG, e_ok ? (unsigned)(((size_t)(t * S + s_e) * ldG + gcol) * 4) : kOob, 0, 0);
-      gtc = make_float4(g4[0], g4[1], g4[2], g4[3]);
-      dyc = ld1(rdY, e_ok ? (unsigned)(((size_t)(t * S + s_e) * lddy + ycol) * 4) : kOob);
-      ctc = ld1(rC, e_ok ? (unsigned)(((size_t)((t + 1) * S + s_e) * ldY + ycol) * 4) : kOob);
-      cpc = ld1(rC, e_ok ? (unsigned)(((size_t)((tp + 1) * S + s_e) * ldY + ycol) * 4) : kOob);
     }
     if (step > 0) {
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
@@ -1312,9 +1146,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][ab * 4 + x] = ac[0][i] + ac[1][i];
     EESEN_STAMP(2);
     __syncthreads();
-    // every wave "uses" the requested values here (the lanes without a cell read zeros out of range, at once): nothing is pending over
-    // the loop's back edge, so hipcc has no reason to hold the next step's requests back behind a wait for these registers
-    if (EARLY) asm volatile("" :: "v"(gtc.x), "v"(gtc.y), "v"(gtc.z), "v"(gtc.w), "v"(dyc), "v"(ctc), "v"(cpc));
     if (e_ok) {
       float dm = dyc;
 #pragma unroll
@@ -1338,17 +1169,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
       if (tid < ST * UW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       EESEN_STAMP(4);
-      if (EARLY) {   // from a wave that is neither a cell wave nor the poller: nobody waits for the acknowledgement
-        if (tid == 6 * 64) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e_ok) {
-          const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-          gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-          dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-          c_t = c_p;
-          c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
-        }
+      if (tid == 0) __hip_atomic_fetch_add(my_cnt + (bx & (kShards - 1)) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
       }
     }
   }
@@ -1784,14 +1611,32 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
   }
 }
 
+// EESEN_GPU_SHARE=n (tuning.h): this process may count on 1/n of the device's CUs -- n trainer processes on one GPU (the reference's
+// own two-jobs-one-GPU test mode; tests/test_gpu_multirank.py) each size their persistent grids against their share, so that all
+// of them are co-resident TOGETHER instead of relying on the spin time-outs to find out that they are not.
+static int gpu_share() {
+  static const int n = [] { const char* e = getenv("EESEN_GPU_SHARE"); const int v = e && *e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+  return n;
+}
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) return false;
+  {  // the occupancy of an instantiation does not change: asked once per (device, kernel) -- this runs several times per layer pass
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> cache;   // (instantiations of one template share a function TYPE: keyed by address)
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, reinterpret_cast<const void*>(kernel));
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) return false;
+      it = cache.emplace(key, nb).first;
+    }
+    nb = it->second;
+  }
   // the occupancy query can over-report by one workgroup per CU (CDNA4 guide): keep a margin of one
-  const long cap = (long)ncu * std::max(1, nb - 1);
+  const long cap = (long)ncu * std::max(1, nb - 1) / gpu_share();
   return (long)grid.x * grid.y * grid.z <= cap;
 }
 
@@ -1857,20 +1702,33 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   return {2, 1};
 }
 
+// Sequence windows: the smallest number of equal windows (each a multiple of the sequence tile) whose workgroups can all be
+// co-resident.  1 for every configuration but the largest (S = 64 at H = 1024 needs 512 workgroups of the wide tiles: two
+// windows of 32 sequences, run one after the other -- the sequences are independent chains).
+template <class F>
+static int pick_windows(int S, int seq_tile, F fits_with) {
+  for (int nwin = 1; nwin <= 8; nwin *= 2) {
+    if (S % nwin != 0 || (S / nwin) % seq_tile != 0) { if (nwin == 1 && fits_with(S)) return 1; continue; }
+    if (fits_with(S / nwin)) return nwin;
+  }
+  return 0;
+}
+
 // Which instantiation of lstm_fwd_persistent_bf_kernel, if any, this layer's forward recurrence takes:
-//   * BASELINE config 4's bf16 forward (L.fwd_bf16: 1 = W_m as hi + lo planes, 2 = one plane; m_t one plane): the wide tile's
+//   * BASELINE config 4's bf16 forward (L.fwd_bf16: W_m as hi + lo planes, m_t one plane): the wide tile's
 //     geometry (16 sequences x 16 units), whole 256-unit multiples (each of the 8 waves owns CPW = H / 256 chunks of 32 units);
 //   * the fp32-class 3-way split (L.fwd_split; three planes each): wherever the narrow 16 x 8 fp32 tile would be taken.
-// Both: exchange buffer present, no recurrent dropout, block offsets within 32 bits.
+// Both: exchange buffer present, no recurrent dropout, block offsets within 32 bits -- and the instantiation's workgroups co-resident in
+// SOME number of sequence windows: a shape or device on which only the bf16-pipe tile does not fit falls through to the fp32 tiles
+// (which ran in this slot before round 4) instead of dropping to the one-launch-per-step kernels.
 struct BfPlan { bool on; int cpw, nt, ap, wp; };
-static FwdTile fwd_tile(const LstmLayerDev& L);
-static BfPlan bf_plan(const LstmLayerDev& L) {
+static BfPlan bf_plan_shape(const LstmLayerDev& L) {
   const BfPlan off{false, 0, 0, 0, 0};
   if (L.X == nullptr || L.drop_mode || L.T < 2 || L.H % 32 != 0) return off;
   auto small = [&](int ap) { return (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 1024 * ap < ((size_t)1 << 31); };
   if (L.fwd_bf16) {
     if (L.H % 256 != 0 || L.H / 256 > 4 || !small(1)) return off;
-    return {true, L.H / 256, 4, 1, L.fwd_bf16 == 2 ? 1 : 2};
+    return {true, L.H / 256, 4, 1, 2};
   }
   if (L.fwd_split) {
     const FwdTile ft = fwd_tile(L);
@@ -1884,7 +1742,6 @@ static BfPlan bf_plan(const LstmLayerDev& L) {
 #define EESEN_BF_DISPATCH(P, F)                                                                           \
   do {                                                                                                    \
     if ((P).nt == 2) { if ((P).cpw <= 1) F(1, 2, 3, 3); else F(2, 2, 3, 3); }                              \
-    else if ((P).wp == 1) { switch ((P).cpw) { case 1: F(1, 4, 1, 1); break; case 2: F(2, 4, 1, 1); break; case 3: F(3, 4, 1, 1); break; default: F(4, 4, 1, 1); } } \
     else { switch ((P).cpw) { case 1: F(1, 4, 1, 2); break; case 2: F(2, 4, 1, 2); break; case 3: F(3, 4, 1, 2); break; default: F(4, 4, 1, 2); } } \
   } while (0)
 static bool bf_fits(const LstmLayerDev& L, const BfPlan& P, int Sw) {
@@ -1894,15 +1751,10 @@ static bool bf_fits(const LstmLayerDev& L, const BfPlan& P, int Sw) {
 #undef EESEN_BF_FITS
   return false;
 }
-
-// the 4-sequence x 32-unit forward tile (lstm_fwd_persistent_q4_kernel) applies: wherever the 16 x 8 tile would be taken, whole
-// 64-unit multiples up to 512 cells, whole 4-sequence tiles, no recurrent dropout, all workgroups co-resident
-static bool fwd_q4_ok(const LstmLayerDev& L) {
-  if (!L.fwd_q4 || L.drop_mode || L.H % 64 != 0 || L.H > 512 || L.S % 4 != 0 || L.S < 8 || L.T < 2) return false;
-  const FwdTile ft = fwd_tile(L);
-  if (ft.mt != 1 || ft.nt != 2) return false;
-  dim3 grid(L.H / 32, L.ndir, L.S / 4);
-  return (size_t)grid.y * grid.z * kShards * kShardStride <= (size_t)kCtlHalf && fits(lstm_fwd_persistent_q4_kernel, grid, NW * 64);
+static BfPlan bf_plan(const LstmLayerDev& L) {
+  BfPlan P = bf_plan_shape(L);
+  if (P.on && pick_windows(L.S, 16, [&](int Sw) { return bf_fits(L, P, Sw); }) == 0) P.on = false;
+  return P;
 }
 
 void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int* units_per_wg) {
@@ -1911,38 +1763,20 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
     if (units_per_wg) *units_per_wg = 4 * P.nt;
     return;
   }
-  if (fwd_q4_ok(L)) {
-    *nblk = L.H / 32; *nz = L.S / 4;
-    if (units_per_wg) *units_per_wg = 32;
-    return;
-  }
   const FwdTile ft = fwd_tile(L);
   *nblk = L.H / (4 * ft.nt);
   *nz = cdiv(L.S, 16 * ft.mt);
   if (units_per_wg) *units_per_wg = 4 * ft.nt;
 }
 
-// Sequence windows: the smallest number of equal windows (each a multiple of the sequence tile) whose workgroups can all be
-// co-resident.  1 for every configuration but the largest (S = 64 at H = 1024 needs 512 workgroups of the wide tiles: two
-// windows of 32 sequences, run one after the other -- the sequences are independent chains).
-template <class F>
-static int pick_windows(int S, int seq_tile, F fits_with) {
-  for (int nwin = 1; nwin <= 8; nwin *= 2) {
-    if (S % nwin != 0 || (S / nwin) % seq_tile != 0) { if (nwin == 1 && fits_with(S)) return 1; continue; }
-    if (fits_with(S / nwin)) return nwin;
-  }
-  return 0;
-}
-
 int lstm_fwd_persistent_windows(const LstmLayerDev& L);
 
 bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return L.fwd_bf16 && bf_plan(L).on && lstm_fwd_persistent_windows(L) > 0; }
 // true when the forward tile this layer takes leaves register and LDS room for a 128 x 128 GEMM workgroup on the same CU (the
-// early middle part of the next layer's input GEMM, net.cpp): the narrow fp32 tiles (<= 8 units, <= 131 VGPRs) and the 4 x 32
-// tile (its last W_m row group in LDS for that reason); the wide fp32 tile (206 VGPRs) does not
+// early middle part of the next layer's input GEMM, net.cpp): the narrow tiles (<= 8 units, <= 131 VGPRs); the wide fp32 tile
+// (206 VGPRs) does not
 bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L) {
   if (const BfPlan P = bf_plan(L); P.on) return P.nt <= 2;   // (the bf16 forward's successor in BASELINE config 4 is a projection, not an LSTM layer)
-  if (fwd_q4_ok(L)) return true;
   const FwdTile ft = fwd_tile(L);
   return 4 * ft.nt <= 8;
 }
@@ -1996,37 +1830,6 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
       else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
       return true;
     }
-  }
-  // The 4-sequence x 32-unit tile (lstm_fwd_persistent_q4_kernel): wherever the 16 x 8 tile would be taken and the shape allows
-  if (nwin == 1 && fwd_q4_ok(L0)) {
-    dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
-    const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
-    {
-      LstmLayerDev L = L0;
-      L.s_begin = 0; L.s_count = 0;
-      const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
-      if (after_reset) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));
-      coop_launch(st, lstm_fwd_persistent_q4_kernel, grid1, block, L, cnt, err, spin_limit, trace, role);
-      return true;
-    }
-  }
-  // EXPERIMENT (EESEN_FWD_MUX2, default 0; DESIGN.md section 9 "two chains per workgroup at cfg2"): the narrow layers through the
-  // time-multiplexed kernel -- 1: 4 units x two 16-sequence tiles per workgroup (same workgroup count as the default tile),
-  // 2: 8 units x two tiles on HALF the workgroups
-  if (L0.fwd_mux2 && nwin == 1 && ft.mt == 1 && ft.nt == 2 && need == 2 && !L0.drop_mode && L0.H % 32 == 0 && L0.X != nullptr &&
-      cdiv(L0.S, 16) == 2 && (size_t)L0.T * L0.ndir * 2 * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31)) {
-    const int nt = L0.fwd_mux2 == 2 ? 2 : 1;
-    dim3 grid(L0.H / (4 * nt), L0.ndir, 1), block(NW * 64);
-    LstmLayerDev L = L0;
-    L.s_begin = 0; L.s_count = 0;
-    const dim3 grid1(grid.x * grid.y * grid.z);
-    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * 2 * kShards * kShardStride, st));
-    if (nt == 2) coop_launch(st, lstm_fwd_persistent_mux_kernel<2, 2, true>, grid1, block, L, cnt, err, spin_limit, role);
-    else coop_launch(st, lstm_fwd_persistent_mux_kernel<2, 1, true>, grid1, block, L, cnt, err, spin_limit, role);
-    return true;
   }
   for (int w = 0; w < nwin; ++w) {
     LstmLayerDev L = L0;
@@ -2135,8 +1938,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
     bool fit = false;
-    const bool early = L0.bwd_early != 0;
-#define EESEN_Q4(CPW) (early ? fits(lstm_bwd_persistent_q4_kernel<CPW, true>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, false>, grid, NW * 64))
+#define EESEN_Q4(CPW) fits(lstm_bwd_persistent_q4_kernel<CPW>, grid, NW * 64)
     if (cpw == 8) fit = EESEN_Q4(8);
     else if (cpw == 4) fit = EESEN_Q4(4);
     else if (cpw == 2) fit = EESEN_Q4(2);
@@ -2147,11 +1949,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       const dim3 grid1(grid.x * grid.y * grid.z);
       const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
-#define EESEN_Q4(CPW)                                                                                                              \
-  do {                                                                                                                             \
-    if (early) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
-    else coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
-  } while (0)
+#define EESEN_Q4(CPW) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role)
       if (cpw == 8) EESEN_Q4(8);
       else if (cpw == 4) EESEN_Q4(4);
       else EESEN_Q4(2);

@@ -501,10 +501,9 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.lens = net.lens_d.p;
   d.rmask = L.cur_drop_mode ? L.rmask.p : nullptr;
   d.drop_mode = L.cur_drop_mode;
-  d.fwd_bf16 = net.fwd_bf16_rec ? (net.tn.bf16_rec_wplanes == 1 ? 2 : 1) : 0;
+  d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
   d.fwd_split = net.tn.fwd_split;
-  d.fwd_mux2 = net.tn.fwd_mux2; d.fwd_q4 = net.tn.fwd_q4;
-  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux; d.bwd_early = net.tn.bwd_early;
+  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
 

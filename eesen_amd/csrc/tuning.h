@@ -4,8 +4,9 @@
 // (i) fallbacks a deployment may need, (ii) A/B arms of the parity tests (a kernel against its slower twin), (iii) diagnostics --
 // and are read from the environment ONCE PER NET, when it is created (tests create a fresh Net per arm).  Everything else that
 // rounds 1 and 2 carried as experiment knobs (CU-masked side streams, cooperative launches, poll-wave / sleep / shard-count
-// variants, the L2-local hand-off, synthetic interference GEMMs, timing probes, ...) has been measured, written up in DESIGN.md
-// section 9 and REMOVED from the code.
+// variants, the L2-local hand-off, synthetic interference GEMMs, timing probes; round 4's arms that lost their A/B: the 4 x 32
+// forward tile, two chains per workgroup on narrow layers, W_m as one bf16 plane, the backward kernel's early operand request)
+// has been measured, written up in DESIGN.md section 9 and REMOVED from the code.
 //
 //   variable                default  meaning
 //   ---- fallbacks ---------------------------------------------------------------------------------------------------------
@@ -18,18 +19,10 @@
 //   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
 //   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
-//   EESEN_BWD_EARLY         0        1: the 4 x 32 backward kernel's cell waves request a step's g,i,f,o | dY | c operands at the TOP of
-//                                    that step (behind the operand loads) instead of at the end of the step before, and the counter
-//                                    increment comes from a wave nobody waits on; bit-identical, measured neutral
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
 //   EESEN_FWD_SPLIT         1        0: narrow forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of
 //                                    the 3-way bf16 split of both operands (fp32-class: six products, one fp32 rounding per product)
-//   EESEN_BF16_REC_WPLANES  2        1: config 4's bf16 forward recurrence with W_m as ONE bf16 plane instead of hi + lo
-//   EESEN_FWD_Q4            0        1: 4-sequence x 32-unit forward tile (H <= 512) instead of the 16 x 8 tile
-//   EESEN_FWD_MUX2          0        1 | 2: narrow layers (H = 512, S = 32) through the time-multiplexed forward kernel as well -- two
-//                                    16-sequence chains per workgroup, 4 (1) or 8 (2) units; measured slower than one chain per CU
-//                                    (DESIGN.md section 9), kept as the A/B arm
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
@@ -53,7 +46,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_mux2 = 0, fwd_q4 = 0, fwd_split = 1, bf16_rec_wplanes = 2, bwd_early = 0;
+  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -73,13 +66,9 @@ struct Tuning {
     t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
     t.bwd_q4 = num("EESEN_BWD_Q4", 1);
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
-    t.bwd_early = num("EESEN_BWD_EARLY", 0);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
-    t.fwd_mux2 = num("EESEN_FWD_MUX2", 0);
-    t.fwd_q4 = num("EESEN_FWD_Q4", 0);
     t.fwd_split = num("EESEN_FWD_SPLIT", 1);
-    t.bf16_rec_wplanes = num("EESEN_BF16_REC_WPLANES", 2);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;

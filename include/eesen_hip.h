@@ -151,12 +151,14 @@ int eesen_net_update(eesen_net_t* net);
  * src/base/kaldi-types.h:26-30).  mode 1: the whole forward pass multiplies in bf16 with fp32 accumulation --
  *   (a) the GEMMs of Propagate (input->gates, affine / projection) round both operands to nearest-even bf16 and run ONE
  *       v_mfma_f32_32x32x16_bf16 product;
- *   (b) the forward TIME RECURRENCE (the loop of src/net/bilstm-parallel-layer.h:112-149,165-204) keeps W_m as one bf16 plane,
- *       rounds m_t to bf16 once, at the cell write into the kernel's exchange buffer, and forms m_{t-1} W_m^T on
+ *   (b) the forward TIME RECURRENCE (the loop of src/net/bilstm-parallel-layer.h:112-149,165-204) keeps W_m as TWO bf16 planes
+ *       (hi + lo: 17 significant bits), rounds m_t to ONE bf16 plane, at the cell write into the kernel's exchange buffer, and
+ *       forms m_{t-1} W_m^T on
  *       v_mfma_f32_16x16x32_bf16 (layers with H a multiple of 256 up to 1024 cells per direction, no recurrent dropout; other
  *       layers keep the fp32 recurrence).  Gate pre-activations, cell state, activations, and everything stored for the
  *       backward pass stay fp32;
- * softmax, CTC, the whole backward pass and the update stay fp32.  mode 2: (a) only (the round-3 behaviour; A/B arm).
+ * softmax, CTC, the whole backward pass and the update stay fp32.  mode 2: (a) only.
+ * (Up to round 3 of this library value 1 meant (a) only; since round 4 it also selects (b), and (a) alone is value 2.)
  * mode 0 (default): fp32 everywhere.  Distances: tests/test_gpu_gemm.py::test_bf16_forward_variant against this library's fp32
  * path; against THE REFERENCE at BASELINE config 4's full size: tests/test_gpu_reference_fullsize.py, profiles/parity_cfg4.json. */
 int eesen_net_set_forward_precision(eesen_net_t* net, int mode);

@@ -17,13 +17,9 @@ from tests.util import rel_err, valid_mask
 pytestmark = pytest.mark.gpu
 
 
-def _forward(layers, batch, mode, w_planes=None, monkeypatch=None):
+def _forward(layers, batch, mode):
     from eesen_amd.api import Net
-    if w_planes is not None:
-        monkeypatch.setenv("EESEN_BF16_REC_WPLANES", str(w_planes))     # read when the Net is created
     net = Net.from_layers(layers)
-    if w_planes is not None:
-        monkeypatch.delenv("EESEN_BF16_REC_WPLANES")
     net.SetTrainOptions(1.0, 0.0)
     net.SetForwardPrecision(mode)
     net.SetSeqLengths(batch.lens)
@@ -38,19 +34,19 @@ SHAPES = [(256, 32, 40), (512, 20, 25), (768, 16, 12), (1024, 32, 10)]
 
 
 @pytest.mark.parametrize("H,S,T", SHAPES)
-def test_bf16_recurrence_step_by_step_against_the_reference_equations_with_its_roundings(gpu, H, S, T, monkeypatch):
+def test_bf16_recurrence_step_by_step_against_the_reference_equations_with_its_roundings(gpu, H, S, T):
     """One BiLSTM layer, its output m compared ONE STEP DEEP: the restatement takes the library's own m_{t-1} as the recurrent
     input of step t (teacher forcing), so an m that lands on the other side of a bf16 rounding boundary in one implementation
     cannot grow through the chain, and the bar is the fp32 one (2e-5 of the largest |m|: v_exp_f32 / v_rcp_f32 in the cell).
     The same comparison WITHOUT the recurrence's roundings in the restatement misses by an order of magnitude more, and so does the
-    restatement with the OTHER number of W_m planes: the kernel really multiplies bf16(m) with W_m held as hi + lo bf16 planes (17
-    bits; the default) or as one plane (EESEN_BF16_REC_WPLANES=1), and nothing else is rounded."""
+    restatement with W_m as ONE bf16 plane (round 4's arm, removed from the library in round 5): the kernel really multiplies bf16(m)
+    with W_m held as hi + lo bf16 planes (17 bits), and nothing else is rounded."""
     cfg = dict(kind="BiLstmParallel", layers=1, H=H, D=40, K=30, S=S, T=T, seed=1234 + H)
     layers = synth.make_model(**cfg)[:1]
     batch = synth.make_batch(**cfg)
     vm = valid_mask(batch.lens, batch.T, batch.S)
-    for wp in (2, 1):
-        net, out, ri = _forward(layers, batch, 1, wp, monkeypatch)
+    for wp in (2,):
+        net, out, ri = _forward(layers, batch, 1)
         assert ri["fwd_persistent"] == ri["lstm_layers"] == 1 and net.Bf16RecurrenceLayers() == 1, ri
         with_r = bf.forward(layers, batch.feats, batch.lens, T, S, bf16_gemm=True, bf16_rec=True, teacher=out, w_planes=wp)
         other = bf.forward(layers, batch.feats, batch.lens, T, S, bf16_gemm=True, bf16_rec=True, teacher=out, w_planes=3 - wp)
