@@ -10,7 +10,11 @@
 // launch: lane l owns the PL consecutive lattice positions [l*PL, (l+1)*PL), so the j-1 / j-2 (alpha) and
 // j+1 / j+2 (beta) neighbours are in-register except at the chunk edge, where two wave shuffles
 // (__shfl_up / __shfl_down) fetch them -- no LDS, no barrier on the 2T-step dependency chain.  The alpha
-// and beta sweeps of all S utterances run concurrently (2S wavefronts).  The next step's log-probability
+// and beta sweeps of all S utterances run concurrently (2S wavefronts).  Lattices of more than 1024 positions
+// (the reference takes any label length, ctc-loss.cc:116-129: character targets on a 35 s utterance) are
+// walked by NW wavefronts of one workgroup: wave w owns positions [w*64*PL, (w+1)*64*PL), and the two values
+// that cross a wave boundary per step travel through a double-buffered LDS slot behind ONE workgroup barrier
+// per step (round 5).  The arithmetic per position is the same whatever (PL, NW) covers it: bit-identical.  The next step's log-probability
 // gather is issued one step ahead so its latency sits under the current step's log-add-exp.  alpha/beta
 // rows are written utterance-major [S][T][64*PL] so every store is one coalesced line-aligned row.
 // The per-frame gradient is then a bulk pass (one wavefront per frame) that stages alpha+beta in LDS, reduces the
@@ -103,16 +107,28 @@ __device__ __forceinline__ void store_row(float* __restrict__ dst, const float (
 }
 
 // ---- alpha / beta sweeps: grid (S, 2), one wavefront each -------------------------------------------
-template <int PL, bool is_beta>
+template <int PL, int NW, bool is_beta>
 __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld, int T, int S, const int* __restrict__ labx,
                                           const int* __restrict__ lens, const int* __restrict__ lablens,
                                           float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ pzx,
-                                          float* last) {
-  constexpr int Lpad = 64 * PL;
-  const int s = blockIdx.x, lane = threadIdx.x;
+                                          float* last, float (*edge)[NW][2]) {
+  static_assert(NW == 1 || PL >= 2, "a wave boundary hands over TWO positions of the neighbouring lane");
+  constexpr int Lpad = 64 * PL * NW;
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int len = lens[s], ll = lablens[s];
   const int* lab = labx + (size_t)s * Lpad;
-  const int j0 = lane * PL;
+  const int j0 = (int)threadIdx.x * PL;
+  // the lane whose chunk ends at a wave boundary publishes its two edge positions after every step; the lane on the other side
+  // of the boundary takes them instead of the (wrapped) shuffle result
+  const bool pub = NW > 1 && (is_beta ? (lane == 0 && wave > 0) : (lane == 63 && wave < NW - 1));
+  const bool take = NW > 1 && (is_beta ? (lane == 63 && wave < NW - 1) : (lane == 0 && wave > 0));
+  const int src = is_beta ? wave + 1 : wave - 1;
+  auto publish = [&](int k, const float (&v)[PL]) {   // after step k (row 0: k = 0); ONE barrier per step, two slots by step parity
+    if constexpr (NW > 1) {
+      if (pub) { edge[k & 1][wave][0] = is_beta ? v[0] : v[PL - 1]; edge[k & 1][wave][1] = is_beta ? v[PL >= 2 ? 1 : 0] : v[PL >= 2 ? PL - 2 : 0]; }
+      __syncthreads();
+    }
+  };
 
   // Everything per-position that does not change over time is decided once: the class to gather (0 for the -1 padding: a
   // valid address whose value is never used), and which neighbours take part.  A neighbour that does not take part enters
@@ -135,8 +151,8 @@ __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld
       use2[i] = valid[i] && j < ll - 2 && (j & 1) && lab[j + 2] != c;           // :1532
     }
   }
-  if (len <= 0) {
-    if (!is_beta && lane == 0) pzx[s] = kLogZero;
+  if (len <= 0) {   // (uniform over the workgroup: len belongs to the lattice)
+    if (!is_beta && threadIdx.x == 0) pzx[s] = kLogZero;
     return;
   }
   float* out = (is_beta ? beta : alpha) + (size_t)s * T * Lpad + j0;
@@ -159,6 +175,7 @@ __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld
       cur[i] = on ? v : kLogZero;
     }
     store_row<PL>(out + (size_t)t_first * Lpad, cur);
+    publish(0, cur);
   }
   float P[DEPTH][PL];
 #pragma unroll
@@ -180,9 +197,12 @@ __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld
       const int k = base + u;
       if (k < len) {  // wave-uniform
         // the two neighbours beyond this lane's chunk: alpha looks down (j-1, j-2), beta up (j+1, j+2)
-        const float e1 = is_beta ? __shfl_down(cur[0], 1) : __shfl_up(cur[PL - 1], 1);
-        const float e2 = is_beta ? (PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2))
-                                 : (PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2));
+        float e1 = is_beta ? __shfl_down(cur[0], 1) : __shfl_up(cur[PL - 1], 1);
+        float e2 = is_beta ? (PL >= 2 ? __shfl_down(cur[PL >= 2 ? 1 : 0], 1) : __shfl_down(cur[0], 2))
+                           : (PL >= 2 ? __shfl_up(cur[PL >= 2 ? PL - 2 : 0], 1) : __shfl_up(cur[0], 2));
+        if constexpr (NW > 1) {
+          if (take) { e1 = edge[(k - 1) & 1][src][0]; e2 = edge[(k - 1) & 1][src][1]; }
+        }
         float nxt[PL];
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
@@ -201,6 +221,7 @@ __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld
 #pragma unroll
         for (int i = 0; i < PL; ++i) cur[i] = nxt[i];
         store_row<PL>(out + (size_t)(t_first + dt * k) * Lpad, cur);
+        publish(k, cur);
       }
     }
 #pragma unroll
@@ -213,22 +234,23 @@ __device__ __forceinline__ void ctc_sweep(const float* __restrict__ logp, int ld
 #pragma unroll
     for (int i = 0; i < PL; ++i) last[j0 + i] = cur[i];
     __syncthreads();
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       const float tmp1 = last[ll - 1], tmp2 = ll >= 2 ? last[ll - 2] : kLogZero;
       pzx[s] = tmp1 + logf(1.f + ExpA(tmp2 - tmp1));
     }
   }
 }
 
-template <int PL>
-__global__ __launch_bounds__(64) void ctc_alpha_beta_kernel(const float* __restrict__ logp, int ld, int T, int S,
-                                                            const int* __restrict__ labx, const int* __restrict__ lens,
-                                                            const int* __restrict__ lablens, float* __restrict__ alpha,
-                                                            float* __restrict__ beta, float* __restrict__ pzx) {
-  __shared__ float last[64 * PL];
+template <int PL, int NW>
+__global__ __launch_bounds__(64 * NW) void ctc_alpha_beta_kernel(const float* __restrict__ logp, int ld, int T, int S,
+                                                                 const int* __restrict__ labx, const int* __restrict__ lens,
+                                                                 const int* __restrict__ lablens, float* __restrict__ alpha,
+                                                                 float* __restrict__ beta, float* __restrict__ pzx) {
+  __shared__ float last[64 * PL * NW];
+  __shared__ float edge[2][NW][2];
   // the sweep direction is a template parameter so that every register-array index in the step is a compile-time constant
-  if (blockIdx.y == 1) ctc_sweep<PL, true>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last);
-  else ctc_sweep<PL, false>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last);
+  if (blockIdx.y == 1) ctc_sweep<PL, NW, true>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last, edge);
+  else ctc_sweep<PL, NW, false>(logp, ld, T, S, labx, lens, lablens, alpha, beta, pzx, last, edge);
 }
 
 // ---- error kernel (:1603-1627) + softmax Jacobian (ctc-loss.cc:160-168): one wavefront per 8 frames of an utterance -----
@@ -411,21 +433,41 @@ void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int
   check_launch("log_rows");
 }
 
+// Waves per lattice for a padded row of Lpad positions: one up to 1024 positions (PL = Lpad / 64 positions per lane; no barrier on the
+// chain), then 16 positions per lane and 2 / 4 waves.  `waves` > 0 asks for that many instead where such an instantiation exists
+// (EESEN_CTC_WAVES, read when a Ctc is created: tests hold the multi-wave kernels bit for bit against the one-wave kernel where
+// both exist; tuning.h).
+static bool ctc_sweep_has(int pl, int nw) {   // the instantiations of ctc_alpha_beta below
+  if (nw == 1) return pl == 1 || pl == 2 || pl == 4 || pl == 8 || pl == 16;
+  const int lpad = 64 * pl * nw;
+  return pl >= 2 && pl <= 16 && nw <= 16 && (pl & (pl - 1)) == 0 && (nw & (nw - 1)) == 0 && lpad >= 512 && lpad <= 4096 && (pl >= 4 || lpad <= 1024);
+}
+int ctc_sweep_waves(int Lpad, int waves) {
+  if (waves > 0 && Lpad % (64 * waves) == 0 && ctc_sweep_has(Lpad / (64 * waves), waves)) return waves;
+  int nw = 1;
+  while (nw * 64 * 16 < Lpad) nw *= 2;
+  return nw;
+}
+
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
-                    const int* lablens, float* alpha, float* beta, float* pzx) {
-  dim3 grid(S, 2), block(64);
-#define EESEN_AB(PL)                                                                                               \
-  hipLaunchKernelGGL((ctc_alpha_beta_kernel<PL>), grid, block, 0, st, logp, ld, T, S, labx, lens, lablens, alpha, \
-                     beta, pzx)
-  switch (Lpad / 64) {
-    case 1: EESEN_AB(1); break;
-    case 2: EESEN_AB(2); break;
-    case 4: EESEN_AB(4); break;
-    case 8: EESEN_AB(8); break;
-    case 16: EESEN_AB(16); break;
-    default: throw Error(EESEN_ERR_INVALID, "ctc: expanded label length above 1024 is not supported");
+                    const int* lablens, float* alpha, float* beta, float* pzx, int waves) {
+  const int nw = ctc_sweep_waves(Lpad, waves);
+  const int pl = Lpad / (64 * nw);
+  dim3 grid(S, 2), block(64 * nw);
+  bool launched = false;
+#define EESEN_AB(PL, NW)                                                                                                 \
+  if (!launched && pl == PL && nw == NW) {                                                                               \
+    hipLaunchKernelGGL((ctc_alpha_beta_kernel<PL, NW>), grid, block, 0, st, logp, ld, T, S, labx, lens, lablens, alpha, \
+                       beta, pzx);                                                                                       \
+    launched = true;                                                                                                     \
   }
+  EESEN_AB(1, 1) EESEN_AB(2, 1) EESEN_AB(4, 1) EESEN_AB(8, 1) EESEN_AB(16, 1)          // <= 1024 positions, one wave
+  EESEN_AB(4, 2) EESEN_AB(2, 4)                                                        // 512 positions as 2 / 4 waves
+  EESEN_AB(8, 2) EESEN_AB(4, 4) EESEN_AB(2, 8)                                         // 1024 positions as 2 / 4 / 8 waves
+  EESEN_AB(16, 2) EESEN_AB(8, 4) EESEN_AB(4, 8)                                        // 2048 positions
+  EESEN_AB(16, 4) EESEN_AB(8, 8) EESEN_AB(4, 16)                                       // 4096 positions
 #undef EESEN_AB
+  if (!launched) throw Error(EESEN_ERR_INVALID, "ctc: no lattice kernel for this padded label length / wave count (at most 4096 positions)");
   check_launch("ctc_alpha_beta");
 }
 
@@ -449,8 +491,8 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
     hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
                        beta, pzx, diff, ldd, frames);
   };
-  static size_t granted[6] = {0, 0, 0, 0, 0, 0};
-  EESEN_REQUIRE(Lpad <= 1024, EESEN_ERR_INVALID, "ctc: expanded label length above 1024");
+  static size_t granted[10] = {0};
+  EESEN_REQUIRE(Lpad <= 4096, EESEN_ERR_INVALID, "ctc: expanded label length above 4096");
   // positions per lane: the smallest even count that covers the longest lattice of the minibatch (Lmax = max 2 U_s + 1 <= Lpad)
   EESEN_REQUIRE(Lmax >= 1 && Lmax <= Lpad, EESEN_ERR_INVALID, "ctc: lattice length outside the padded row");
   if (Lmax <= 128) launch(ctc_error_diff_kernel<2>, granted[0]);
@@ -458,7 +500,11 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
   else if (Lmax <= 384) launch(ctc_error_diff_kernel<6>, granted[2]);
   else if (Lmax <= 512) launch(ctc_error_diff_kernel<8>, granted[3]);
   else if (Lmax <= 768) launch(ctc_error_diff_kernel<12>, granted[4]);
-  else launch(ctc_error_diff_kernel<16>, granted[5]);
+  else if (Lmax <= 1024) launch(ctc_error_diff_kernel<16>, granted[5]);
+  else if (Lmax <= 1536) launch(ctc_error_diff_kernel<24>, granted[6]);
+  else if (Lmax <= 2048) launch(ctc_error_diff_kernel<32>, granted[7]);
+  else if (Lmax <= 3072) launch(ctc_error_diff_kernel<48>, granted[8]);
+  else launch(ctc_error_diff_kernel<64>, granted[9]);
   check_launch("ctc_error_diff");
 }
 

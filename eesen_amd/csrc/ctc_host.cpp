@@ -20,6 +20,7 @@ Ctc::Ctc(int dev, void* stream) : device(dev) {
   EESEN_REQUIRE(dev >= 0 && dev < n, EESEN_ERR_INVALID, "device index out of range");
   EESEN_HIP_CHECK(hipSetDevice(dev));
   st = reinterpret_cast<hipStream_t>(stream);  // NULL = the device's default stream (shared with the Net)
+  if (const char* e = getenv("EESEN_CTC_WAVES"); e && *e) sweep_waves = atoi(e);
   for (auto& x : ev) EESEN_HIP_CHECK(hipEventCreate(&x));
 }
 
@@ -106,7 +107,7 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   const int Lprime = 2 * maxU + 1;  // ctc-loss.cc:118
   int PL = 1;
   while (64 * PL < Lprime) PL *= 2;
-  EESEN_REQUIRE(PL <= 16, EESEN_ERR_INVALID, "expanded label length above 1024 is not supported");
+  EESEN_REQUIRE(PL <= 64, EESEN_ERR_INVALID, "expanded label length above 4096 (2047 labels per utterance) is not supported");
   const int Lpad = 64 * PL;
 
   // label expansion (ctc-loss.cc:116-129), sequence and expanded-label lengths: one staging vector
@@ -150,7 +151,7 @@ void Ctc::eval_parallel(const int* frame_num_utt, int S, const float* net_out, i
   if (acc) sp0 = timer.begin(st, 0); else EESEN_HIP_CHECK(hipEventRecord(ev[0], st));
   log_rows(st, net_out, ld, logp.p, K, rows, K);                                               // ctc-loss.cc:132-133
   if (acc) { timer.end(st, sp0); sp1 = timer.begin(st, 1); } else EESEN_HIP_CHECK(hipEventRecord(ev[1], st));
-  ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p);  // :136-153
+  ctc_alpha_beta(st, logp.p, K, T, S, Lpad, labx_d, lens_dd, ll_d, alpha.p, beta.p, pzx_d.p, sweep_waves);  // :136-153
   if (acc) { timer.end(st, sp1); sp2 = timer.begin(st, 2); } else EESEN_HIP_CHECK(hipEventRecord(ev[2], st));
   ctc_error_diff(st, net_out, ld, T, S, K, Lpad, Lprime, lens_dd, ll_d, labx_d, alpha.p, beta.p, pzx_d.p, diff, ldd);  // :156-168
   if (acc) timer.end(st, sp2); else EESEN_HIP_CHECK(hipEventRecord(ev[3], st));

@@ -141,11 +141,12 @@ size_t col_sums_ws_floats(int rows, int cols);
 void softmax_rows(hipStream_t st, const float* x, int ldx, float* y, int ldy, int rows, int K);
 // out = log(in) elementwise on a [rows x K] matrix (CuMatrixBase::ApplyLog, ctc-loss.cc:132-133)
 void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int rows, int K);
-// alpha and beta lattice sweeps for all S sequences (2*S single-wave workgroups).
+// alpha and beta lattice sweeps for all S sequences (2*S workgroups: one wave each up to Lpad = 1024, ctc_sweep_waves(Lpad) above).
 // logp: [T*S x K] (ld), labx: [S x Lpad] expanded labels (-1 padded), lens/lablens: [S]
-// alpha/beta: [S][T][Lpad] (utterance-major), pzx: [S]
+// alpha/beta: [S][T][Lpad] (utterance-major), pzx: [S].  Lpad in {64, 128, ..., 4096}.  waves: 0 = the default for Lpad.
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
-                    const int* lablens, float* alpha, float* beta, float* pzx);
+                    const int* lablens, float* alpha, float* beta, float* pzx, int waves = 0);
+int ctc_sweep_waves(int Lpad, int waves = 0);
 // diff[t*S+s][k] = y*rowsum(e) - gamma ... (error kernel + softmax Jacobian, ctc-loss.cc:156-168)
 // labx [S x Lpad]: the expanded labels (blank 0 at even positions), lablens [S] = 2 U_s + 1
 void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, int K, int Lpad, int Lmax, const int* lens,

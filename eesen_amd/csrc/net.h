@@ -204,6 +204,7 @@ struct Ctc {
   DevBuf<int> labx, lens_d, lablens_d, cls_off, cls_pos, ids_d;
   std::vector<int> last_lens;
   int last_T = 0, last_S = 0, last_Lpad = 0, last_Lprime = 0;
+  int sweep_waves = 0;   // EESEN_CTC_WAVES when this object was created (tuning.h): 0 = the default number of waves per lattice
   double obj_sum = 0;
   long sequences = 0, frames = 0, err_tokens = 0, ref_tokens = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

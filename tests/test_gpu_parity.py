@@ -656,8 +656,84 @@ def test_ctc_edge_cases(gpu):
     assert ctc.pzx[0] < -1e29 and want["pzx"][0] < -1e29
     assert rel_err(ctc.pzx[1:], want["pzx"][1:]) < 1e-6
     assert np.all(np.isfinite(diff)) and rel_err(diff, want["diff"]) < TOL
-    with pytest.raises(EesenError, match="above 1024"):
-        ctc.EvalParallel([1300], CuMatrix(1300, K), [np.ones(600, np.int32)])
+    with pytest.raises(EesenError, match="above 4096"):
+        ctc.EvalParallel([4200], CuMatrix(4200, K), [np.ones(2100, np.int32)])
+
+
+def _long_label_case(S, T, K, U, seed):
+    """Character-style targets on long utterances: the LAST sequence has exactly U labels on T frames (the lattice the padded row is
+    sized for), the others fewer labels on shorter utterances; ~15 % adjacent repeats."""
+    rng = np.random.default_rng(seed)
+    lens = np.sort(rng.integers(int(0.85 * T), T + 1, size=S)).astype(np.int32)
+    lens[-1] = T
+    logits = rng.standard_normal((T * S, K)).astype(np.float32) * 1.5
+    probs = np.exp(logits - logits.max(1, keepdims=True)); probs /= probs.sum(1, keepdims=True)
+    labels = []
+    for s in range(S):
+        u = U if s == S - 1 else int(rng.integers(U // 2, int(0.8 * U)))      # (feasible on the shorter utterances, repeats included)
+        lab = rng.integers(1, K, size=u).astype(np.int32)
+        for i in range(1, u):
+            if rng.random() < 0.15: lab[i] = lab[i - 1]
+        labels.append(lab)
+    return lens, probs.astype(np.float32), labels
+
+
+@pytest.mark.parametrize("S,T,K,U", [(3, 3000, 30, 600), (3, 3000, 30, 1000), (2, 3400, 12, 1600), (2, 2900, 8, 2047)])
+def test_ctc_lattices_above_1024_positions(gpu, S, T, K, U):
+    """The reference takes any label length (ctc-loss.cc:116-129; launch shape cuda-matrix.cc:868-898): character targets on a 35 s
+    utterance exceed 511 labels.  Lattices of 1025 .. 4096 positions run as 2 / 4 wavefronts of one workgroup per lattice, the two
+    values that cross a wave boundary handed over through LDS every step (csrc/ctc.hip): held against the oracle exactly like the
+    one-wave lattices of test_ctc_vs_oracle -- the -1e30 sentinel pattern exact, the values to fp32 round-off (|alpha| reaches 1e4
+    here: a relative bar), ln p, the gradient against the fp32 oracle and the fp64 arbiter with the oracle's own fp32 floor."""
+    from eesen_amd.api import CuMatrix, Ctc
+    from oracle import net as onet
+    lens, probs, labels = _long_label_case(S, T, K, U, seed=U)
+    ids = np.concatenate(labels); off = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
+    want = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f32")
+    ctc = Ctc()
+    dprob = CuMatrix.from_numpy(probs)
+    diff = ctc.EvalParallel(lens, dprob, labels).numpy()
+    ctc._rows = T * S
+    a, b = ctc.alpha_beta()
+    assert a.shape[1] == 2 * U + 1 > 1024
+    for got, ref in ((a, want["alpha"]), (b, want["beta"])):
+        assert np.array_equal(got == -1e30, ref == -1e30)
+        m = ref != -1e30
+        assert np.max(np.abs(got[m] - ref[m]) / np.maximum(1.0, np.abs(ref[m]))) < 5e-6
+    assert np.all(np.isfinite(ctc.pzx)) and rel_err(ctc.pzx, want["pzx"]) < 2e-6
+    arb = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f64")
+    floor = rel_err(want["diff"], arb["diff"])
+    assert rel_err(diff, want["diff"]) < max(TOL, 3 * floor) and rel_err(diff, arb["diff"]) < max(TOL, 3 * floor)
+    assert np.all(diff[~valid_mask(lens, T, S)] == 0)
+    ne, nr = ctc.ErrorRateMSeq(lens, dprob, labels)
+    assert (ne, nr) == onet.ctc_error_rate_mseq(probs, T, S, lens, ids, off)
+
+
+@pytest.mark.parametrize("S,T,K,U,waves", [(4, 700, 20, 200, (2, 4)), (3, 900, 25, 450, (2, 4, 8)), (2, 1500, 16, 700, (4, 8)),
+                                           (2, 2400, 10, 1100, (8, 16))])
+def test_ctc_multi_wave_sweep_is_bit_identical(gpu, S, T, K, U, waves, monkeypatch):
+    """The arithmetic of a lattice position does not depend on which lane of which wavefront owns it: the sweep as n wavefronts per
+    lattice (EESEN_CTC_WAVES=n, read when the Ctc is created) must reproduce the default kernel's alpha, beta, ln p and gradient BIT
+    FOR BIT -- at 512 and 1024 positions against the one-wave kernel, above against the default two / four-wave one."""
+    from eesen_amd.api import CuMatrix, Ctc
+    lens, probs, labels = _long_label_case(S, T, K, U, seed=7 * U)
+    dprob = CuMatrix.from_numpy(probs)
+
+    def run():
+        ctc = Ctc()
+        diff = ctc.EvalParallel(lens, dprob, labels).numpy()
+        ctc._rows = T * S
+        a, b = ctc.alpha_beta()
+        return a, b, ctc.pzx.copy(), diff
+
+    base = run()
+    assert np.all(np.isfinite(base[2])) and np.abs(base[3]).max() > 0
+    for w in waves:
+        monkeypatch.setenv("EESEN_CTC_WAVES", str(w))
+        got = run()
+        monkeypatch.delenv("EESEN_CTC_WAVES")
+        for g, r in zip(got, base):
+            assert np.array_equal(g, r), w
 
 
 def test_recovery_from_a_timed_out_persistent_kernel(gpu, monkeypatch, capfd):
