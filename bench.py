@@ -8,12 +8,16 @@
   exactly one JSON line.
 
 A "step" is one pass of train-ctc-parallel's inner loop (/root/reference/src/netbin/train-ctc-parallel.cc:195-207)
-over one synthetic utterance mini-batch per GPU: SetSeqLengths -> Propagate -> Ctc::EvalParallel -> Ctc::ErrorRateMSeq ->
-Backpropagate (+ per-layer RCCL gradient all-reduce when N > 1, issued by the library under the backward pass) -> Update.  Workload at N = 1 = BASELINE.json configs[1]:
+over one synthetic utterance mini-batch per GPU, as SURVEY.md section 8(d) defines it -- H2D -> forward -> CTC -> backward ->
+[all-reduce] -> update: the minibatch's S HOST matrices go through the device feeder (pinned pack, one PCIe copy, time-major
+interleave on the device: what train-ctc-parallel.cc:186-198 does on the host every minibatch) -> SetSeqLengths -> Propagate ->
+Ctc::EvalParallel -> Ctc::ErrorRateMSeq -> Backpropagate (+ per-layer RCCL gradient all-reduce when N > 1, issued by the library
+under the backward pass) -> Update.  Workload at N = 1 = BASELINE.json configs[1]:
 4 x BiLSTM (512 cells/direction), 40-d input, 46 classes, 32 utterances, T_max = 1000, fp32.
 Weak scaling: every rank runs its own 32-utterance shard (global batch 32 N = configs[2] at N = 8).
 `value` = padded frames/s of the whole job (the reference's own fps counts padded frames,
-train-ctc-parallel.cc:215,247-252), inputs resident in HBM when the timed region starts.
+train-ctc-parallel.cc:215,247-252) with the per-step H2D INSIDE the timed step (round 5; the copy of step n + 1 travels under
+step n's backward pass); `config.device_resident_frames_per_s` is the same loop with the features already resident in HBM.
 
 Rank 0 prints ONE JSON line (see the task contract) with `roofline` (dominant kernel, live HIP-event timing)
 and, at N = 1, `cpu_baseline` (the reference's own CPU code from oracle/_ref when present, else the C port).
@@ -91,6 +95,36 @@ def pipe_bound(cfg, split_gemm: bool = True, fwd_products: int = 0) -> dict:
         sec = (rec_f32 + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
     return {"f32_pipe_flops_per_frame": rec_f32 + (0.0 if split_gemm else gemm), "gemm_flops_per_frame_fp32_equivalent": gemm,
             "bf16_pipe_executed_flops_per_frame": bf16, "forward_recurrence_bf16_products": fwd_products, "bound_us_per_frame": 1e6 * sec}
+
+
+def ctc_block(cfg, batch, ctc_ph: dict, K: int) -> dict:
+    """CTC against the HBM roofline.  Whole CTC: 4 * (3K + 2L') algorithmic bytes per padded frame.  Per part as
+    well: the lattice sweep is a 2T-step dependency chain of S independent lattices (not bandwidth-shaped); the bulk pass (gamma,
+    softmax Jacobian: reads alpha_t, beta_t and y_t, writes diff_t) is -- quoted on its algorithmic bytes (the utterance's own L'_s
+    positions) AND on the bytes it actually moves: the kernel reads whole padded lane slots (64 x positions-per-lane of the longest
+    lattice), of real frames only."""
+    T, S, Kc = batch.T, batch.S, cfg["K"]
+    Lp = 2 * max(len(l) for l in batch.labels) + 1
+    ctc_bytes = 4.0 * (3 * Kc + 2 * Lp) * T * S
+    ctc_s = (ctc_ph["alpha_beta"] + ctc_ph["error_diff"] + ctc_ph["log"]) / K
+    bulk_bytes = 4.0 * sum(int(batch.lens[s]) * (2 * (2 * len(batch.labels[s]) + 1) + 2 * Kc) for s in range(S))
+    maxp = next(m for m in (2, 4, 6, 8, 12, 16, 24, 32, 48, 64) if 64 * m >= Lp)      # ctc.hip: ctc_error_diff's positions per lane
+    lpad = 64
+    while lpad < Lp:
+        lpad *= 2
+    moved = 4.0 * float(np.sum(batch.lens)) * (2 * 64 * maxp + 2 * Kc)
+    bulk_s = ctc_ph["error_diff"] / K
+    sweep_s = ctc_ph["alpha_beta"] / K
+    sweep_moved = 4.0 * float(np.sum(batch.lens)) * (2 * lpad + 2 * Kc)   # alpha + beta rows written at the padded width; the frame's log-probability row read once per direction
+    return {"bound": "hbm", "achieved": ctc_bytes / ctc_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ctc_bytes / ctc_s / 1e9 / PEAK_HBM_GBS, "ms": 1e3 * ctc_s, "bytes": ctc_bytes, "bytes_per_frame": 4.0 * (3 * Kc + 2 * Lp),
+            "lattice_positions": Lp, "padded_row": lpad,
+            "sweep": {"ms": 1e3 * sweep_s, "us_per_lattice_step": 1e6 * sweep_s / T, "bytes_moved": sweep_moved, "moved_GBps": sweep_moved / sweep_s / 1e9,
+                      "note": "bounded by the T-step dependency chain (alpha and beta sweeps of all S lattices run concurrently: 2S workgroups), not by HBM (SURVEY.md 8d caveat)"},
+            "bulk": {"ms": 1e3 * bulk_s, "bytes": bulk_bytes, "achieved": bulk_bytes / bulk_s / 1e9, "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": bulk_bytes / bulk_s / 1e9 / PEAK_HBM_GBS,
+                     "bytes_moved": moved, "moved_GBps": moved / bulk_s / 1e9, "moved_frac": moved / bulk_s / 1e9 / PEAK_HBM_GBS,
+                     "positions_per_lane": maxp}}
 
 
 def cpu_baseline(cfg, seconds_budget: float = 25.0) -> dict:
@@ -208,12 +242,15 @@ def frontend_leg(dev: int, S: int = 32, T: int = 1000, D: int = 40, iters: int =
     return out
 
 
-def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_bf16=False) -> dict:
+def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_bf16=False, reps: int = 3, over=None) -> dict:
     """Not the headline: one of the other single-GPU BASELINE.json configurations (configs[3] = cfg4: 5x1024 BiLSTM + 512-d
-    projections; configs[4] = cfg5: 6x1024, S = 64 per GPU, T = 3000), the same loop body, `steps` timed steps, so that the driver's
-    record holds a driver-timed number for every configuration."""
+    projections; configs[4] = cfg5: 6x1024, S = 64 per GPU, T = 3000; cfg2 at --num-sequence 64), the same loop body on features
+    resident in HBM, `reps` repetitions of `steps` timed steps (ms_per_step = the median repetition; min / max beside it), so that
+    the driver's record holds a driver-timed number for every configuration -- and the CTC against its HBM roofline at the
+    configuration BASELINE.json says it binds at (configs[4])."""
     from eesen_amd.api import Net, Ctc, CuMatrix
     cfg = synth.config(name)
+    cfg.update(over or {})
     layers = synth.make_model(max_grad=50.0, **cfg)
     batch = synth.make_batch(**cfg)
     net = Net.from_layers(layers, device=dev)
@@ -233,18 +270,30 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     for _ in range(warmup):
         step()
     net.Synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    net.Synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    ctc.SetProfiling(True)
+    net.SetProfiling(True, accumulate=True)
+    dts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        net.Synchronize()
+        dts.append((time.perf_counter() - t0) / steps)
+    ctc_ph = ctc.PhaseTimes()
+    phases = net.PhaseTimes()
+    ctc.SetProfiling(False)
+    net.SetProfiling(False)
+    dt = float(np.median(dts))
     info = net.RecurrenceInfo()
     fpf = flops_per_frame(cfg)
     frames = float(batch.T * batch.S)
     nd = 2 if cfg["kind"].startswith("BiLstm") else 1
     return {"workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
                         f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
-            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt, "frames_per_s": frames / dt,
+            "steps": steps, "warmup": warmup, "repetitions": reps, "ms_per_step": 1e3 * dt, "ms_per_step_min_median_max": [1e3 * min(dts), 1e3 * dt, 1e3 * max(dts)],
+            "frames_per_s": frames / dt, "input": "device-resident",
+            "phase_ms_per_step": {k: 1e3 * v / (reps * steps) for k, v in phases.items()},
+            "ctc": ctc_block(cfg, batch, ctc_ph, reps * steps),
             "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
             "bf16_recurrence_layers": net.Bf16RecurrenceLayers(),
             "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
@@ -253,7 +302,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
 
 
-def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int = 25000) -> dict:
+def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int = 25000, reps: int = 3) -> dict:
     """Not the headline: the reference's OWN recipe shape -- 4 x 320 BiLSTM on 120-d features (40 fbanks + deltas), ~45 phone
     targets, --num-sequence 10 (20 as the second point) --frame-num-limit 25000, utterances of a length-sorted list with WSJ-like
     durations (asr_egs/wsj/run_ctc_phn.sh:65-85, steps/train_ctc_parallel.sh:13-21) -- through the trainer's own path: greedy
@@ -294,14 +343,19 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int 
         net.Synchronize()
         return pers
     epoch()                                   # warm-up: allocations, every distinct shape once
-    t0 = time.perf_counter()
-    pers = epoch()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        pers = epoch()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
     padded = float(sum(g.T * g.S for g in groups)); real = float(sum(int(g.lens.sum()) for g in groups))
     fpf = flops_per_frame(cfg)
     return {"workload": f"4x320 BiLSTM, D=120, K=46, --num-sequence {num_sequence} --frame-num-limit {frame_limit}, {n_utts} length-sorted utterances "
                         f"of {int(lens.min())}-{int(lens.max())} frames in {len(groups)} minibatches (S = {min(g.S for g in groups)}-{max(g.S for g in groups)})",
-            "minibatches": len(groups), "ms_per_minibatch": 1e3 * dt / len(groups), "padded_frames_per_s": padded / dt, "real_frames_per_s": real / dt,
+            "minibatches": len(groups), "repetitions": reps, "ms_per_minibatch": 1e3 * dt / len(groups),
+            "ms_per_minibatch_min_median_max": [1e3 * min(dts) / len(groups), 1e3 * dt / len(groups), 1e3 * max(dts) / len(groups)],
+            "padded_frames_per_s": padded / dt, "real_frames_per_s": real / dt,
             "whole_step_tflops_fp32_equivalent": fpf * padded / dt / 1e12, "flops_per_frame": fpf,
             "persistent_layer_passes": {"fwd": pers[0], "bwd": pers[1], "of": pers[2]}, "recoveries": net.recoveries}
 
@@ -395,14 +449,31 @@ def main():
 
     net = make_net(attach=False)      # the probing step below runs WITHOUT the exchange: a rank that fails must not strand the others in a collective
     ctc = Ctc(device=dev)
-    feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # inputs resident in HBM before the timed region
+    feats_dev = CuMatrix.from_numpy(batch.feats, dev)             # the device-resident comparison loop's input
     diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
+    # the minibatch as the trainer holds it: S host matrices [T_s x D] (train-ctc-parallel.cc:149-193 reads them from the table)
+    from eesen_amd.api import Feeder
+    f3 = batch.feats.reshape(batch.T, batch.S, cfg["D"])
+    mats = [np.ascontiguousarray(f3[: batch.lens[s], s, :]) for s in range(batch.S)]
+    feeder = Feeder(dev, slots=2)
+    pending = [feeder.submit(mats)]
 
-    def step():   # the reference trainer's loop body, train-ctc-parallel.cc:195-207
+    def step():   # the reference trainer's loop body, train-ctc-parallel.cc:186-207, the H2D of :198 included
+        slot = pending.pop()
         net.SetSeqLengths(batch.lens)
-        out = net.Propagate(feats_dev)
+        out = net.Propagate(feeder.acquire(slot))                               # :198 net.Propagate(CuMatrix<BaseFloat>(feat_mat_host), ...)
+        feeder.release(slot)
         ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)   # like the reference's call: accumulates the objective
         ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)        # :202: greedy decode + edit distance, every minibatch
+        net.Backpropagate(diff)
+        pending.append(feeder.submit(mats))     # the NEXT minibatch: packed, copied and interleaved while this one's backward pass runs
+        return out
+
+    def step_resident():   # the same loop body on features that are already in HBM (config.device_resident_*)
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(feats_dev)
+        ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
+        ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)
         net.Backpropagate(diff)
         return out
 
@@ -473,27 +544,21 @@ def main():
         finally:
             _lib.check(lib.eesen_set_gemm_mode(-1))
 
-    # Not the headline: the same K steps with the features handed over as HOST matrices each step (what the trainer does):
-    # packed into the feeder's pinned slot, copied and interleaved on its own stream while the previous step trains.
-    pcie_fps = None
+    # Not the headline: the same K steps with the features already RESIDENT in HBM (what rounds 1-4 reported as `value`): what the
+    # per-step H2D costs the step is the difference (the copy and the interleave of minibatch n + 1 run on the feeder's stream under
+    # step n's backward pass; what is left is the host's pack into the pinned slot on the enqueueing thread -- hidden while the host
+    # runs ahead of the device -- and the interleave kernel's share of the chip).  Same warm-up, same process, same Net.
+    resident = None
     if world == 1 and not args.main_only:
-        from eesen_amd.api import Feeder
-        f3 = batch.feats.reshape(batch.T, batch.S, cfg["D"])
-        mats = [np.ascontiguousarray(f3[: batch.lens[s], s, :]) for s in range(batch.S)]
-        feeder = Feeder(dev, slots=2)
-        slot = feeder.submit(mats)
-        net.Synchronize()
+        for _ in range(max(2, args.warmup)):
+            step_resident()
+        barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            net.SetSeqLengths(batch.lens)
-            out = net.Propagate(feeder.acquire(slot))
-            feeder.release(slot)
-            ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
-            ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)
-            net.Backpropagate(diff)
-            slot = feeder.submit(mats)      # next batch: staged while this one's backward pass runs
-        net.Synchronize()
-        pcie_fps = float(batch.T * batch.S) * args.steps / (time.perf_counter() - t1)
+            step_resident()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        resident = {"ms_per_step": 1e3 * dt1 / args.steps, "frames_per_s": float(batch.T * batch.S) * args.steps / dt1}
 
     if rank == 0:
         K = args.steps
@@ -554,7 +619,10 @@ def main():
                 traffic = pt["bytes_per_launch"].get(dom)
                 mfma_busy = pt.get("mfma_busy", {}).get(dom)
                 # where the counters come from: the tables, the commit they were collected at, and the switches of that run
+                from eesen_amd.build import csrc_digest
+                # stale: the library's sources are not the ones the counters were collected on (sha1 over csrc/ + include/: the GPU box has no .git)
                 traffic_source = {"file": "profiles/pmc_traffic.json", "tables": pt.get("source"), "commit": pt.get("commit"),
+                                  "csrc_sha": pt.get("csrc_sha"), "stale": pt.get("csrc_sha") != csrc_digest(),
                                   "switches": pt.get("switches"), "kernel": pt.get("kernels", {}).get(dom)}
         except Exception:
             pass
@@ -622,21 +690,7 @@ def main():
             del A_, B_, C_
         except Exception as e:  # noqa: BLE001
             roofline["gate_gemm_standalone"] = {"error": str(e)}
-        # CTC against the HBM roofline.  Whole CTC: 4*(3K + 2L') algorithmic bytes per frame.  Reported per
-        # part as well: the lattice sweep is a 2T-step dependency chain of S independent lattices (not bandwidth-shaped); the bulk
-        # pass (gamma, softmax Jacobian: reads alpha_t, beta_t over the utterance's own L'_s positions and y_t, writes diff_t) is.
-        Lp = 2 * max(len(l) for l in batch.labels) + 1
-        ctc_bytes = 4.0 * (3 * cfg["K"] + 2 * Lp) * T * S
-        ctc_s = (ctc_ph["alpha_beta"] + ctc_ph["error_diff"] + ctc_ph["log"]) / K
-        bulk_bytes = 4.0 * sum(int(batch.lens[s]) * (2 * (2 * len(batch.labels[s]) + 1) + 2 * cfg["K"]) for s in range(S))
-        bulk_s = ctc_ph["error_diff"] / K
-        sweep_s = ctc_ph["alpha_beta"] / K
-        roofline["ctc"] = {"bound": "hbm", "achieved": ctc_bytes / ctc_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": ctc_bytes / ctc_s / 1e9 / PEAK_HBM_GBS, "ms": 1e3 * ctc_s,
-                           "sweep": {"ms": 1e3 * sweep_s, "us_per_lattice_step": 1e6 * sweep_s / T,
-                                     "note": "bounded by the T-step dependency chain (alpha and beta sweeps of all S lattices run concurrently), not by HBM (SURVEY.md 8d caveat)"},
-                           "bulk": {"ms": 1e3 * bulk_s, "bytes": bulk_bytes, "achieved": bulk_bytes / bulk_s / 1e9, "peak": PEAK_HBM_GBS,
-                                    "unit": "GB/s", "frac": bulk_bytes / bulk_s / 1e9 / PEAK_HBM_GBS}}
+        roofline["ctc"] = ctc_block(cfg, batch, ctc_ph, K)
         line = {
             "metric": "CTC training frames/sec (whole node), 4x512 BiLSTM",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -650,7 +704,9 @@ def main():
                                               "bulk": "one RCCL all-reduce of the whole gradient buffer after the backward pass (libeesen_hip.so)",
                                               "torch": "one torch.distributed all-reduce of the whole gradient buffer"}[args.comm]),
                        "real_frames_per_s": real * K / dt, "padded_frames_per_step": padded, "real_frames_per_step": real,
-                       "pcie_inclusive_frames_per_s": pcie_fps,
+                       "h2d": "inside the timed step: S host matrices -> pinned slot -> one PCIe copy -> time-major interleave on the device (feeder), double-buffered",
+                       "device_resident_frames_per_s": resident["frames_per_s"] if resident else None,
+                       "device_resident_ms_per_step": resident["ms_per_step"] if resident else None,
                        "gemm_arithmetic": ("f32-input MFMA (exact fp32 fmaf chain)" if os.environ.get("EESEN_GEMM_MODE") in ("f32", "0") else
                                            "fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross products on v_mfma_f32_32x32x16_bf16 with fp32 "
                                            "accumulation (error <= 2^-23 |ab| per product = one fp32 rounding; measured against fp64 equal to the fp32 chain, "
@@ -696,12 +752,13 @@ def main():
                 line["frontend"] = {"error": str(e)}
         if world == 1 and not args.main_only and not args.no_secondary and args.config == "cfg2" and not (args.T or args.H or args.S or args.layers):
             # the other single-GPU BASELINE configurations and the reference's own recipe shape, driver-timed in the same run
-            del net, feats_dev, diff
+            del net, feats_dev, diff, feeder
             sec = {}
             # (10 / 5 timed steps: three were inside the box-to-box noise for comparing the cfg4 legs with each other)
-            for name, fn in (("cfg4", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2)),
+            for name, fn in (("cfg2_S64", lambda: secondary_leg("cfg2", dev, steps=10, warmup=2, over=dict(S=64))),
+                             ("cfg4", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2)),
                              ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2, forward_bf16=True)),
-                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=5, warmup=1)),
+                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=4, warmup=1)),
                              ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20)),
                              # the same shape with the minibatch this part wants (INTEGRATION.md "Which --num-sequence"): the frame limit raised
                              # so that --num-sequence is what bounds a minibatch

@@ -23,6 +23,21 @@ BINDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin")
 TOOLS = {"train-ctc-parallel": "train_ctc_parallel.cc", "net-output-extract": "net_output_extract.cc"}
 
 
+def csrc_digest() -> str:
+    """sha1 over the library's sources (csrc/*, include/*.h): what the committed measurement records (profiles/pmc_traffic.json,
+    profiles/parity_cfg*.json) are stamped with, so that a reader -- bench.py, on a GPU box that has no .git -- can tell whether
+    they were taken on the tree that is running."""
+    import hashlib
+    h = hashlib.sha1()
+    files = []
+    for d in (CSRC, os.path.join(CSRC, "tools"), os.path.join(_DIR, "..", "include")):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".cpp", ".h", ".cc", ".map"))]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

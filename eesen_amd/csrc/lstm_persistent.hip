@@ -1618,6 +1618,13 @@ static int gpu_share() {
   static const int n = [] { const char* e = getenv("EESEN_GPU_SHARE"); const int v = e && *e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
   return n;
 }
+// the CUs this process sizes its tiles and grids against: the device's, divided by EESEN_GPU_SHARE
+static int share_of_cus() {
+  int ncu = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  return std::max(1, ncu / gpu_share());
+}
 template <class K>
 bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
@@ -1691,9 +1698,7 @@ float handoff_flight_ns() {
 struct FwdTile { int mt, nt; };
 static FwdTile fwd_tile(const LstmLayerDev& L) {
   const int need = ((L.H + 31) / 32 + NW - 1) / NW;
-  int ncu = 256, dev = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = share_of_cus();
   // (wide layers take the 16-sequence tile at ANY batch size: their 32 x 4 tile would need H/4 x ndir workgroups -- 512 at H = 1024 --
   // and a batch of <= 16 sequences fell back to the per-step kernels: seen at S = 16, T = 3000 with the six-layer cfg5 stack, round 4)
   const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2);
@@ -1903,9 +1908,7 @@ void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsign
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;
-  int ncu = 256, dev = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = share_of_cus();
   const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
   if (2 * blocks16 <= ncu && L.S > 8) return 0;   // the 8-sequence / 4 x 32 tiles are taken there
   // the largest window the launcher may pick is the whole batch
@@ -1921,9 +1924,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   // Sequences per workgroup: 16 fills the MFMA rows; 8 wastes half of them but halves the 128 KB of DG_next each workgroup
   // must fetch per step, which is what bounds the step (measured: 3.75 us of fetch at ~34 GB/s per CU vs 1.8 us of MFMA).
   // Take 8 whenever 16 would leave half of the chip's CUs without a workgroup.
-  int ncu = 256, dev = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = share_of_cus();
   const long blocks16 = (long)cdiv(L0.H, 16) * L0.ndir * cdiv(L0.S, 16);
   const int stile = 2 * blocks16 <= ncu && L0.S > 8 ? 8 : 16;
   // 32-bit buffer offsets: the kernel re-bases its DG resource every `chunk` steps; a chunk touches chunk + 1 row blocks

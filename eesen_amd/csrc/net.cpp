@@ -523,11 +523,29 @@ void Net::get_layer_dropout(int layer, float* nine) const {
   for (int k = 0; k < 9; ++k) nine[k] = layers[layer].drop[k];
 }
 
+// The masks cross the boundary at the width of the MODEL FILE's layer, ndir * Hf columns (what eesen_net_layer_info reports and
+// include/eesen_hip.h documents), whatever the library pads the cell count to inside (a multiple of 4: Layer::H): the file's columns
+// are scattered into / gathered out of the internal rows here, as forward_pass does for the layer output (a C caller
+// sizing its buffers by the model's own H overflowed its heap on get and was refused on set).
+static void widen_mask(const Layer& L, const float* src, long n, std::vector<float>& dst, const char* what) {
+  dst.clear();
+  if (!src) return;
+  const long wf = (long)L.ndir * L.Hf, wi = (long)L.ndir * L.H;
+  EESEN_REQUIRE(n > 0 && n % wf == 0, EESEN_ERR_INVALID, std::string(what) + ": the float count is not a multiple of the layer's ndir * H columns");
+  if (wf == wi) { dst.assign(src, src + n); return; }
+  const long rows = n / wf;
+  dst.assign((size_t)rows * wi, 0.f);     // the padded cells are zero cells (zero weights, zero state): their mask never matters
+  for (long r = 0; r < rows; ++r)
+    for (int d = 0; d < L.ndir; ++d)
+      std::copy(src + r * wf + (long)d * L.Hf, src + r * wf + (long)(d + 1) * L.Hf, dst.begin() + r * wi + (long)d * L.H);
+}
+
 void Net::set_dropout_masks(int layer, const float* fwd, long fwd_n, const float* rec, int rec_rows, long rec_n, int coin) {
   EESEN_REQUIRE(layer >= 0 && layer < (int)layers.size() && layers[layer].is_lstm(), EESEN_ERR_INVALID, "not an LSTM layer");
   Layer& L = layers[layer];
-  L.inj_fmask.assign(fwd, fwd + (fwd ? fwd_n : 0));
-  L.inj_rmask.assign(rec, rec + (rec ? rec_n : 0));
+  if (rec) EESEN_REQUIRE(rec_rows > 0 && rec_n == (long)rec_rows * L.ndir * L.Hf, EESEN_ERR_INVALID, "recurrent mask: rec_floats must be rec_rows x ndir * H");
+  widen_mask(L, fwd, fwd ? fwd_n : 0, L.inj_fmask, "forward mask");
+  widen_mask(L, rec, rec ? rec_n : 0, L.inj_rmask, "recurrent mask");
   L.inj_rmask_rows = rec ? rec_rows : 0;
   L.inj_coin = coin;
 }
@@ -538,12 +556,18 @@ void Net::get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* in
   Layer& L = layers[layer];
   EESEN_HIP_CHECK(hipSetDevice(device));
   sync();
-  const size_t ldY = (size_t)L.ndir * L.H;
-  if (fwd_host && L.cur_fwd_drop)
-    EESEN_HIP_CHECK(hipMemcpy(fwd_host, L.fmask.p, (size_t)rows * ldY * sizeof(float), hipMemcpyDeviceToHost));
-  if (rec_host && L.cur_drop_mode)
-    EESEN_HIP_CHECK(hipMemcpy(rec_host, L.rmask.p, (size_t)(T + 2) * S * ldY * sizeof(float), hipMemcpyDeviceToHost));
-  if (info4) { info4[0] = L.cur_fwd_drop; info4[1] = L.cur_drop_mode; info4[2] = L.cur_twiddle_coin; info4[3] = (int)ldY; }
+  const size_t ldY = (size_t)L.ndir * L.H, wf = (size_t)L.ndir * L.Hf;
+  auto fetch = [&](float* host, const float* dev, size_t nrows) {   // the file's columns of an internal [nrows x ndir * H] mask
+    if (wf == ldY) { EESEN_HIP_CHECK(hipMemcpy(host, dev, nrows * ldY * sizeof(float), hipMemcpyDeviceToHost)); return; }
+    std::vector<float> tmp(nrows * ldY);
+    EESEN_HIP_CHECK(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < nrows; ++r)
+      for (int d = 0; d < L.ndir; ++d)
+        std::copy(tmp.begin() + r * ldY + (size_t)d * L.H, tmp.begin() + r * ldY + (size_t)d * L.H + L.Hf, host + r * wf + (size_t)d * L.Hf);
+  };
+  if (fwd_host && L.cur_fwd_drop) fetch(fwd_host, L.fmask.p, (size_t)rows);
+  if (rec_host && L.cur_drop_mode) fetch(rec_host, L.rmask.p, (size_t)(T + 2) * S);
+  if (info4) { info4[0] = L.cur_fwd_drop; info4[1] = L.cur_drop_mode; info4[2] = L.cur_twiddle_coin; info4[3] = (int)wf; }
 }
 
 // Decides what this Propagate applies to layer L and puts the masks in HBM: injected ones if the caller supplied them

@@ -62,7 +62,7 @@ std::string fmt_g(double v) {  // what operator<< prints for a float/double by d
 // ---------------------------------------------------------------------------------------------------- options
 struct Options {  // train-ctc-parallel.cc:45-80, NetTrainOptions train-opts.h:29-62
   float learn_rate = 0.008f, momentum = 0.f, adagrad_epsilon = 1e-6f, rms_prop_rho = 0.9f;
-  bool binary = true, cross_validate = false, shard_shared_list = false;
+  bool binary = true, cross_validate = false, shard_shared_list = false, allow_identical_lists = false;
   int num_sequence = 5, report_step = 100, num_jobs = 1, job_id = 1, utts_per_avg = 500, verbose = 0, device = -1;
   int comm_port = 0, comm_timeout = 300;
   double frame_limit = 100000;
@@ -101,6 +101,7 @@ Options parse_options(int argc, char** argv, eesen_tools::ParseOptions* po) {
   po->Register("comm-port", &o.comm_port, "Rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)");
   po->Register("comm-timeout", &o.comm_timeout, "Seconds to wait for the other jobs at the rendezvous");
   po->Register("shard-shared-list", &o.shard_shared_list, "All jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it");
+  po->Register("allow-identical-lists", &o.allow_identical_lists, "The jobs' feature rspecifiers read the same but name DIFFERENT data (node-local shards under one path): do not refuse them");
   po->Read(argc, argv);
   o.verbose = po->Verbose();
   for (int i = 1; i <= po->NumArgs(); ++i) o.args.push_back(po->GetArg(i));
@@ -159,20 +160,27 @@ int main(int argc, char** argv) {
                                                  : getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + 17 : 29517;
       ck(eesen_comm_create_tcp(device, addr.c_str(), port, rank, world, o.comm_timeout, &comm));
       log_line("LOG", "job " + std::to_string(o.job_id) + " of " + std::to_string(world) + " joined the RCCL communicator on GPU " + std::to_string(device));
-      if (own_list) {
+      {
         // Every job trains the WHOLE list it was given (reference semantics: the recipes hand job J its own feats_tr.J.scp).  A launcher
         // that hands all ranks the same command line without a JOB to substitute would make N jobs train identical minibatches and
         // sum N copies of the same gradient -- silently, an N times larger step on duplicated data.  The jobs compare
-        // their rspecifiers: identical on every job = one shared list, refused unless --shard-shared-list=true deals it out.
-        unsigned long long h = 1469598103934665603ull;   // FNV-1a
+        // their rspecifiers: identical on every job = one shared list, refused unless --shard-shared-list=true deals it out or
+        // --allow-identical-lists=true says the same words name different data on every node (node-local shards).
+        // EVERY job enters this collective, whatever its options, and the two switches travel with the hash: jobs that disagree
+        // on them get a message instead of a hang in a collective only some of them entered.  FNV-1a, the same in both trainers.
+        unsigned long long h = 1469598103934665603ull;
         for (unsigned char c : feature_rspecifier) { h ^= c; h *= 1099511628211ull; }
         const double hv = (double)(h >> 16);             // 48 bits: exact in a double
-        double mm[2] = {hv, -hv};
-        ck(eesen_comm_allreduce_host(comm, mm, 2, /*max*/ 1));
-        if (mm[0] == -mm[1])
+        const double sh = o.shard_shared_list ? 1.0 : 0.0, al = o.allow_identical_lists ? 1.0 : 0.0;
+        double mm[6] = {hv, -hv, sh, -sh, al, -al};
+        ck(eesen_comm_allreduce_host(comm, mm, 6, /*max*/ 1));
+        if (mm[2] != -mm[3]) throw std::runtime_error("the jobs disagree on --shard-shared-list: pass the same value to every job");
+        if (mm[4] != -mm[5]) throw std::runtime_error("the jobs disagree on --allow-identical-lists: pass the same value to every job");
+        if (own_list && !o.allow_identical_lists && mm[0] == -mm[1])
           throw std::runtime_error("all " + std::to_string(world) + " jobs were given the same feature rspecifier '" + feature_rspecifier +
                                    "': each job trains its whole list, so they would all train the same minibatches.  Hand every job its "
-                                   "own list (feats.JOB.scp: a JOB that stands alone is replaced by the job id) or pass --shard-shared-list=true");
+                                   "own list (feats.JOB.scp: a JOB that stands alone is replaced by the job id), pass --shard-shared-list=true "
+                                   "to deal ONE shared list out, or --allow-identical-lists=true if the path names different data on every node");
       }
     }
     ck(eesen_net_create(device, nullptr, &net));

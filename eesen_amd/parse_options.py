@@ -9,9 +9,50 @@ return 255 (the reference's -1, train-ctc-parallel.cc:259-263).
 """
 from __future__ import annotations
 
+import re
 import sys
 from types import SimpleNamespace
 from typing import List, Optional
+
+
+# The reference converts option values with strtol(base 0) / strtod and only checks that SOME prefix parsed (parse-options.cc:561-
+# 656; csrc/tools/parse_options.h does the same): leading white space, the longest valid numeric prefix, trailing garbage ignored,
+# a leading 0 means octal.  int() / float() are stricter in some places ("010", "12abc", "1.5x") and laxer in others ("1_0"), so the
+# Python trainer parses the way the C library does.
+_INT_RE = re.compile(r"\s*([+-]?)(0[xX][0-9a-fA-F]+|0[0-7]*|[1-9][0-9]*)")
+_FLT_RE = re.compile(r"\s*([+-]?(?:0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?[0-9]+)?|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?|inf(?:inity)?|nan(?:\([0-9a-zA-Z_]*\))?))", re.I)
+
+
+def _strtol0(text: str):
+    m = _INT_RE.match(text)
+    if not m:
+        return None
+    sign, digits = m.group(1), m.group(2)
+    if digits[:2].lower() == "0x":
+        v = int(digits, 16)
+    elif digits.startswith("0"):
+        v = int(digits, 8) if len(digits) > 1 else 0
+    else:
+        v = int(digits)
+    v = -v if sign == "-" else v
+    v = max(-(1 << 63), min((1 << 63) - 1, v))                 # strtol saturates at LONG_MIN / LONG_MAX ...
+    return ((v + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)          # ... and the (int32) cast of the reference wraps
+
+
+def _strtod(text: str):
+    m = _FLT_RE.match(text)
+    if not m:
+        return None
+    tok = m.group(1)
+    low = tok.lower().lstrip("+-")
+    try:
+        if low.startswith("0x"):
+            return float.fromhex(tok)
+        if low.startswith("nan"):
+            return float("nan")
+        return float(tok)
+    except (ValueError, OverflowError):
+        return float("inf") if not tok.startswith("-") else float("-inf")
 
 
 class ParseError(RuntimeError):
@@ -101,15 +142,15 @@ class ParseOptions:
             else:
                 self._bad("Invalid format for boolean argument [expected true or false]: " + value)
         elif kind == "int":
-            try:
-                o[2] = int(value, 0)
-            except ValueError:
+            v = _strtol0(value)
+            if v is None:
                 self._bad(f'Invalid integer option "{value}"')
+            o[2] = v
         elif kind in ("float", "double"):
-            try:
-                o[2] = float(value)
-            except ValueError:
+            v = _strtod(value)
+            if v is None:
                 self._bad(f'Invalid floating-point option "{value}"')
+            o[2] = v
         else:
             if not eq:
                 raise ParseError(f"Invalid option --{key}")

@@ -90,6 +90,7 @@ def build_parser():
     po.register("comm-port", 0, "Rendezvous port (default $EESEN_COMM_PORT, else $MASTER_PORT + 17)")
     po.register("comm-timeout", 300, "Seconds to wait for the other jobs at the rendezvous")
     po.register("shard-shared-list", False, "All jobs were handed the SAME feature list: job J trains minibatches J-1, J-1+N, ... of it")
+    po.register("allow-identical-lists", False, "The jobs' feature rspecifiers read the same but name DIFFERENT data (node-local shards under one path): do not refuse them")
     return po
 
 
@@ -159,16 +160,27 @@ def main(argv=None) -> int:
             if o.shard_shared_list:
                 raise EesenError(-1, "--shard-shared-list with a per-job (JOB) feature list")
         feature_rspecifier = mine
-        if comm is not None and not o.shard_shared_list:
+        if comm is not None:
             # every job trains the WHOLE list it was given; the same list on every job would be N copies of the same gradient, silently
-            # (ADVICE r3): the jobs compare their rspecifiers and refuse a shared one unless --shard-shared-list=true deals it out
-            import zlib
-            hv = float(zlib.crc32(feature_rspecifier.encode()) * 65536 + (zlib.adler32(feature_rspecifier.encode()) & 0xFFFF))
-            mx = comm.allreduce([hv, -hv], op=1)
-            if mx[0] == -mx[1]:
+            # (ADVICE r3): the jobs compare their rspecifiers and refuse a shared one unless --shard-shared-list=true deals it out or
+            # --allow-identical-lists=true says the same words name different data on every node.  EVERY job enters the collective and
+            # the two switches travel with the hash (jobs that disagree get a message, not a hang); FNV-1a as in the native trainer, so a
+            # mixed run compares like with like.
+            h = 1469598103934665603
+            for c in feature_rspecifier.encode():
+                h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            hv = float(h >> 16)
+            sh, al = float(bool(o.shard_shared_list)), float(bool(o.allow_identical_lists))
+            mx = comm.allreduce([hv, -hv, sh, -sh, al, -al], op=1)
+            if mx[2] != -mx[3]:
+                raise EesenError(-1, "the jobs disagree on --shard-shared-list: pass the same value to every job")
+            if mx[4] != -mx[5]:
+                raise EesenError(-1, "the jobs disagree on --allow-identical-lists: pass the same value to every job")
+            if not o.shard_shared_list and not o.allow_identical_lists and mx[0] == -mx[1]:
                 raise EesenError(-1, f"all {world} jobs were given the same feature rspecifier '{feature_rspecifier}': each job trains its "
                                      "whole list, so they would all train the same minibatches.  Hand every job its own list (feats.JOB.scp: a "
-                                     "JOB that stands alone is replaced by the job id) or pass --shard-shared-list=true")
+                                     "JOB that stands alone is replaced by the job id), pass --shard-shared-list=true to deal ONE shared list "
+                                     "out, or --allow-identical-lists=true if the path names different data on every node")
         feeder = Feeder(dev, slots=2)
         # a feature rspecifier that is a pipe of the reference's own filters (apply-cmvn | splice-feats | subsample-feats |
         # add-deltas, train_ctc_parallel.sh:95-110): read the raw table here and run the filters on the device

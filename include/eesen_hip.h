@@ -302,7 +302,9 @@ int eesen_ctc_get_phase_times(eesen_ctc_t* ctc, float* out3);
  * host RNG and copies them over (:50-62).  For parity tests the masks of the NEXT eesen_net_propagate can be supplied:
  *   fwd_mask  [T*S x 2H] or NULL;  rec_mask [rec_rows x 2H] with rec_rows = (T+2)*S (time-step masks, row t*S+s as in the
  *   reference's buffers) or S (sequence masks), columns = forward-direction H then backward-direction H, or NULL;
- *   twiddle_coin: 0 / 1 = value of the TwiddleForward coin, -1 = draw it. */
+ *   twiddle_coin: 0 / 1 = value of the TwiddleForward coin, -1 = draw it.
+ * H is the cell count per direction of the MODEL FILE's layer (eesen_net_layer_info's output dimension / ndir): when the library
+ * pads a cell count that is not a multiple of 4 inside, these two accessors gather / scatter the file's columns. */
 int eesen_net_set_train_mode(eesen_net_t* net, int train);
 int eesen_net_set_dropout_seed(eesen_net_t* net, unsigned long long seed);
 int eesen_net_set_layer_dropout(eesen_net_t* net, int layer, const float* nine);

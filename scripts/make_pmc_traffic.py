@@ -12,6 +12,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from eesen_amd.build import csrc_digest  # noqa: E402
 
 
 def table(path):
@@ -39,7 +41,7 @@ def main(tag, commit, switches):
         return max(hits, key=lambda kv: kv[1].get("avg us (profiled)", 0) * kv[1].get("dispatches", 0)) if hits else (None, None)
 
     out = {"source": f"profiles/{tag}_pmc_fetch_write.md, profiles/{tag}_pmc_sq.md (rocprofv3 --pmc, FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes, cfg2, T=1000, S=32)",
-           "commit": commit, "switches": switches,
+           "commit": commit, "csrc_sha": csrc_digest(), "switches": switches,
            "correction": "recurrence kernels: traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (16-B-per-lane full-line reads are tallied at half, "
                          "MI355X_MICROARCH.md); GEMM: (1.59*FETCH_SIZE + WRITE_SIZE) per the FETCH calibration run of the same collection",
            "config": {"config": "cfg2", "T": 1000, "S": 32}, "bytes_per_launch": {}, "mfma_busy": {}, "kernels": {},

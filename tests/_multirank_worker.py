@@ -113,6 +113,36 @@ def main():
             res["seconds"] = np.array(time.time() - t0)
             np.savez(out, **res)
             os._exit(0)     # the communicator is dead: no orderly teardown through it
+    elif mode == "persist":
+        # the PRODUCT configuration at N > 1: persistent recurrence kernels in EVERY rank's process + the communicator's per-layer
+        # buckets under the backward pass -- two processes on one GPU, each sizing its grids against half of it (EESEN_GPU_SHARE=2).
+        # 3 steps whose result goes to the arbiters, then a soak of `soak` more steps: per-step time, recoveries, the exchange's spans.
+        mine = shard_batch(full, rank, world)
+        for _ in range(steps):
+            real_step(mine)
+        net.Synchronize()
+        res["params_steps"] = net.GetParams()
+        res["recurrence_steps"] = np.array(list(net.RecurrenceInfo().values()))
+        nsoak = int(opt.get("soak", 0))
+        if nsoak:
+            comm.barrier()
+            net.SetProfiling(True, accumulate=True)
+            t1 = time.perf_counter()
+            for _ in range(nsoak):
+                real_step(mine)
+            net.Synchronize()
+            comm.barrier()
+            res["soak_ms_per_step"] = np.array(1e3 * (time.perf_counter() - t1) / nsoak)
+            spans = net.PhaseSpans()
+            net.PhaseTimes()
+            net.SetProfiling(False)
+            for nm in ("recurrence_fwd", "recurrence_bwd", "allreduce", "allreduce_exposed"):
+                res["soak_ms_" + nm] = np.array(1e3 * sum(sec for n_, sec in spans if n_ == nm) / nsoak)
+            res["soak_steps"] = np.array(nsoak)
+        res["error"] = np.array("")
+        net.RecurrenceInfo()
+        res["recoveries"] = np.array(net.recoveries)
+        res["dropped"] = np.array(ctc.Dropped())
     elif mode == "uneven":
         # rank r holds steps - r minibatches (each a different one): the others keep going, r drains with zero gradients
         n_mine = max(0, steps - rank * int(opt.get("fewer", 1)))

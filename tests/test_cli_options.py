@@ -102,3 +102,37 @@ def test_native_extractor_follows_the_same_conventions():
     assert rc == 255 and "Invalid option --nope=1" in err
     rc, err = _run([sys.executable, "-m", "eesen_amd.net_output_extract"], "--nope=1", "m", "ark:a", "ark:b")
     assert rc == 255 and "Invalid option --nope=1" in err
+
+
+def test_python_numbers_parse_the_way_strtol_and_strtod_do():
+    """The reference converts option values with strtol(base 0) / strtod and accepts any value with a numeric PREFIX
+    (parse-options.cc:561-656; csrc/tools/parse_options.h does the same): the Python hosts must take and refuse the same strings
+    and read the same values -- held here against the C library itself."""
+    import ctypes
+    import math
+    from eesen_amd.parse_options import _strtol0, _strtod
+    libc = ctypes.CDLL(None)
+    libc.strtol.restype = ctypes.c_long
+    libc.strtol.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    libc.strtod.restype = ctypes.c_double
+    libc.strtod.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p)]
+
+    def c_long(text):
+        buf = ctypes.create_string_buffer(text.encode())
+        end = ctypes.c_char_p()
+        v = libc.strtol(buf, ctypes.byref(end), 0)
+        consumed = ctypes.cast(end, ctypes.c_void_p).value - ctypes.addressof(buf)
+        return None if consumed == 0 else ctypes.c_int32(v & 0xFFFFFFFF).value
+
+    def c_double(text):
+        buf = ctypes.create_string_buffer(text.encode())
+        end = ctypes.c_char_p()
+        v = libc.strtod(buf, ctypes.byref(end))
+        consumed = ctypes.cast(end, ctypes.c_void_p).value - ctypes.addressof(buf)
+        return None if consumed == 0 else v
+
+    for t in ["10", "010", "08", "0x1F", "0X1f", "12abc", " 42", "+7", "-7", "abc", "", "-", "0", "1_0", "0x", "4294967297", "99999999999999999999"]:
+        assert _strtol0(t) == c_long(t), (t, _strtol0(t), c_long(t))
+    for t in ["1.5", "1.5x", "1_0", "1e-3", ".5", "5.", "abc", "", "-inf", "INF", "0x1p3", "1e", "1e+", "-.5e2z", ".", "+", "1e400"]:
+        a, b = _strtod(t), c_double(t)
+        assert (a is None) == (b is None) and (a is None or a == b or (math.isnan(a) and math.isnan(b))), (t, a, b)

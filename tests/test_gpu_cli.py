@@ -322,15 +322,22 @@ def test_shared_list_dealing_is_opt_in(gpu, tmp_path):
     per_job = "scp:" + str(tmp_path / "feats.JOB.scp")
     m_in = str(tmp_path / "nnet.init"); nnet_io.write_nnet(m_in, synth.make_model(**cfg), binary=True)
     for cmd in ([os.path.join(ROOT, "eesen_amd", "bin", "train-ctc-parallel")], [sys.executable, "-m", "eesen_amd.train_ctc_parallel"]):
-        for extra, rspec, want in (([], per_job, (12, 12)), (["--shard-shared-list=true"], "scp:" + scp, (6, 6)), ([], "scp:" + scp, None)):
+        # (extra options of job 1, of job 2, rspecifier, utterances done per job | the message both jobs must die with)
+        for extra1, extra2, rspec, want in (([], [], per_job, (12, 12)), (["--shard-shared-list=true"], ["--shard-shared-list=true"], "scp:" + scp, (6, 6)),
+                                            ([], [], "scp:" + scp, "were given the same feature rspecifier"),
+                                            # the same words, different data on every node (node-local shards): the explicit override
+                                            (["--allow-identical-lists=true"], ["--allow-identical-lists=true"], "scp:" + scp, (12, 12)),
+                                            # jobs that disagree on a switch meet in the SAME collective and get a message, not a hang
+                                            (["--shard-shared-list=true"], [], "scp:" + scp, "disagree on --shard-shared-list")):
             s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
             env = dict(os.environ, EESEN_RCCL_LIBRARY=fake_rccl_path(), EESEN_PERSISTENT="0", FAKE_RCCL_QUIET="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            ps = [subprocess.Popen(cmd + ["--device=0", "--cross-validate=true", "--num-sequence=2", "--num-jobs=2", f"--job-id={j}"] + extra +
+            ps = [subprocess.Popen(cmd + ["--device=0", "--cross-validate=true", "--num-sequence=2", "--num-jobs=2", f"--job-id={j}"] + (extra1 if j == 1 else extra2) +
                                    [rspec, "ark:" + lab, m_in], env=env, stderr=subprocess.PIPE, text=True, cwd=ROOT) for j in (1, 2)]
             errs = [p.communicate(timeout=600)[1] for p in ps]
-            if want is None:
+            extra = extra1
+            if isinstance(want, str):
                 assert [p.returncode for p in ps] == [255, 255], errs
-                assert all("were given the same feature rspecifier" in e and "--shard-shared-list=true" in e for e in errs), errs
+                assert all(want in e for e in errs), errs
                 continue
             assert [p.returncode for p in ps] == [0, 0], errs
             got = tuple(int(re.search(r"Done (\d+) files", e).group(1)) for e in errs)

@@ -152,6 +152,46 @@ def test_generated_masks_end_to_end_against_oracle(gpu):
     assert rel_err(net.GetParams(), ora.get_params()) < TOL
 
 
+def test_masks_cross_the_boundary_at_the_models_own_width(gpu):
+    """A cell count the library pads inside (10 -> 12 per direction): the two mask accessors speak the MODEL's columns, [rows x 2 * 10],
+    as include/eesen_hip.h documents them -- injected masks of that width give the oracle's result on the unpadded model, the masks
+    read back have that width (and the values that were applied), and a buffer of the padded width is refused (a C caller
+    sizing by the model's own H used to overflow its heap on get)."""
+    from eesen_amd.api import Net, Ctc, EesenError
+    from oracle import net as onet
+    cfg = synth.config("small_bi"); cfg.update(T=24, S=6, H=10)
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    layers[0]["dropout"] = dict(forward=0.25, fw_step=True, recurrent=0.25, rec_step=True, nml=True)
+    layers[1]["dropout"] = dict(recurrent=0.3, rec_seq=True, rnndrop=True)
+    T, S, H = batch.T, batch.S, cfg["H"]
+    rng = np.random.default_rng(9)
+    net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
+    ora = onet.OracleNet(layers, "f32"); ora.set_train_options(1.0, 0.0)
+    sent = {}
+    for li in (0, 1):
+        fwd, rec = _masks_for(rng, layers[li]["dropout"], T, S, H, False)
+        sent[li] = (fwd, rec)
+        net.SetDropoutMasks(li, fwd=fwd, rec=rec)
+        ora.set_dropout_masks(li, fwd=fwd, rec_fw=rec[:, :H], rec_bw=rec[:, H:])
+    o = onet.train_step(ora, batch, "f32")
+    net.SetSeqLengths(batch.lens)
+    out = net.Propagate(batch.feats)
+    for li in (0, 1):
+        m = net.GetDropoutMasks(li, T, S)
+        fwd, rec = sent[li]
+        assert m["rec"].shape == ((T + 2) * S, 2 * H)
+        assert np.array_equal(m["rec"], rec if rec.shape[0] == (T + 2) * S else np.tile(rec, (T + 2, 1)))
+        if fwd is not None:
+            assert m["fwd"].shape == (T * S, 2 * H) and np.array_equal(m["fwd"], fwd)
+    diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+    net.Backpropagate(diff)
+    vm = valid_mask(batch.lens, T, S)
+    assert rel_err(out.numpy()[vm], o["net_out"][vm]) < TOL and rel_err(diff.numpy(), o["diff"]) < TOL
+    assert rel_err(net.GetParams(), ora.get_params()) < TOL
+    with pytest.raises(EesenError, match="rec_rows x ndir"):
+        net.SetDropoutMasks(0, rec=np.ones(((T + 2) * S, 2 * 12), np.float32))
+
+
 def test_test_mode_model_files_and_errors(gpu, tmp_path):
     from eesen_amd import nnet_io
     from eesen_amd.api import Net, Ctc, EesenError

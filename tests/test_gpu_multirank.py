@@ -10,8 +10,10 @@ itself via EESEN_RCCL_LIBRARY; its all-reduce is a real kernel on the stream it 
   (iv)  one process, PERSISTENT recurrence kernels on, the stand-in's all-reduce kernels (32 workgroups x 512 threads, 25 MB
         buckets through PCIe) running on the communication stream under every backward recurrence, 200 steps at cfg2: no spin
         time-out, and what the overlap costs per step.
-Two processes on one GPU cannot both hold a cooperative recurrence grid (each wants every CU), so the multi-process cases
-run the one-launch-per-step kernels (EESEN_PERSISTENT=0); (iv) is where the co-residency hazard is exercised.
+  (v)   (round 5) TWO ranks, each holding persistent grids: a shape whose grids are co-resident (H = 256, S = 32 per rank), every
+        process sizing against half the device (EESEN_GPU_SHARE=2) -- the product's N > 1 configuration.
+The other multi-process cases run the one-launch-per-step kernels (EESEN_PERSISTENT=0: at their shapes two processes' grids
+would each want every CU); (iv) and (v) are where the co-residency hazard is exercised.
 """
 import json
 import os
@@ -128,6 +130,60 @@ def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(gpu, tmp_path
     # the merged statistics (what comm_touch_done sums over the done-files, communicator.h:121-170)
     assert abs(float(res[0]["obj_sum"]) - st["obj_sum"]) < 1e-5 * abs(st["obj_sum"])
     assert int(res[0]["ref"]) == st["ref_tokens"] and abs(int(res[0]["err"]) - st["err_tokens"]) <= 1 and int(res[0]["frames"]) == st["frames"]
+
+
+def test_two_ranks_each_holding_persistent_grids_on_one_gpu(gpu, tmp_path):
+    """The product's N > 1 configuration -- PERSISTENT recurrence kernels in every rank + the communicator's per-layer buckets under the
+    backward pass -- with two ranks, before an 8-GPU box runs it first.  Shape chosen so that both processes'
+    grids are co-resident on the one GPU: 2 x BiLSTM of 256 cells, S = 32 per rank (forward 32 x 2 x 2 = 128, backward 8 x 2 x 8 = 128
+    workgroups per process, 256 CUs), every process sizing its grids against HALF the device (EESEN_GPU_SHARE=2: fits() and the tile
+    choices divide the CU count instead of relying on the spin time-outs).  Asserted: both ranks really ran every layer pass on the
+    persistent kernels; 2 x 32 == ONE process x 64 over 3 steps with momentum 0.9 and <MaxGrad> -- against this library in one process
+    AND against the reference's own Net (oracle/_ref, `--num-sequence 64`: SURVEY.md section 8e's parity statement) --; the ranks hold
+    the same model bit for bit, also after a soak of further steps with zero recoveries; what the exchange cost goes on record."""
+    from oracle import refbind
+    from eesen_amd import nnet_io
+    nsoak = int(os.environ.get("EESEN_SOAK_STEPS", "200"))
+    over = dict(S=64, T=80, H=256, layers=2)
+    cfg = synth.config("cfg2"); cfg.update(over)
+    res, rcs, errs = launch("persist", 2, tmp_path, dict(cfg="cfg2", steps=3, soak=nsoak, **over),
+                            env_extra={"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2"}, timeout=600)
+    assert rcs == [0, 0] and all(r is not None for r in res), [e[-2000:] for e in errs]
+    for r in res:
+        assert not str(r["error"]), r["error"]
+        assert list(r["recurrence_steps"]) == [2, 2, 2] and list(r["recurrence"]) == [2, 2, 2], (r["recurrence_steps"], r["recurrence"])   # {LSTM layers, fwd persistent, bwd persistent}
+        assert int(r["recoveries"]) == 0 and int(r["dropped"]) == 0
+    assert np.array_equal(res[0]["params_steps"], res[1]["params_steps"]) and np.array_equal(res[0]["params"], res[1]["params"])
+    layers = synth.make_model(max_grad=0.05, **cfg)
+    full = synth.make_batch(**cfg)
+    want, _ = _single_process(cfg, [full] * 3, persistent="1")     # one process, S = 64, the whole device
+    from eesen_amd.api import Net
+    p0 = Net.from_layers(layers).GetParams()
+    got = res[0]["params_steps"]
+    rep = dict(config="2 x BiLSTM(256) + affine + softmax + CTC, S = 32 per rank x 2 ranks on ONE GPU, T = 80, EESEN_GPU_SHARE=2, persistent kernels, stand-in collective",
+               params_vs_one_process=rel_err(got, want), update_vs_one_process=rel_err(got - p0, want - p0))
+    assert rep["params_vs_one_process"] < 1e-5 and rep["update_vs_one_process"] < 5e-3, rep
+    if refbind.available():   # the reference itself as ONE process with --num-sequence 64
+        path = str(tmp_path / "m.nnet")
+        nnet_io.write_nnet(path, layers, binary=True)
+        ref = refbind.RefNet(path)
+        ref.set_train_options(1e-3, 0.9)
+        for _ in range(3):
+            ref.set_seq_lengths(full.lens)
+            o = ref.propagate(full.feats)
+            c = refbind.cuda_ctc_eval_parallel(o, full.T, full.S, full.lens, full.label_ids, full.label_off)
+            ref.backpropagate(c["diff"], False)
+        rp = ref.get_params()
+        rep.update(params_vs_reference=rel_err(got, rp), update_vs_reference=rel_err(got - p0, rp - p0))
+        assert rep["params_vs_reference"] < 1e-5 and rep["update_vs_reference"] < 5e-3, rep
+    if nsoak:
+        rep.update(soak_steps=nsoak, ms_per_step=[float(r["soak_ms_per_step"]) for r in res],
+                   recurrence_fwd_ms=[float(r["soak_ms_recurrence_fwd"]) for r in res], recurrence_bwd_ms=[float(r["soak_ms_recurrence_bwd"]) for r in res],
+                   allreduce_ms=[float(r["soak_ms_allreduce"]) for r in res], allreduce_exposed_ms=[float(r["soak_ms_allreduce_exposed"]) for r in res],
+                   recoveries=[int(r["recoveries"]) for r in res])
+    out_dir = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump(rep, open(os.path.join(out_dir, "multirank_persistent.json"), "w"), indent=1)
 
 
 def test_three_ranks_and_odd_shard_sizes(gpu, tmp_path):
