@@ -2,8 +2,9 @@
 """What does a weight-gradient-sized GEMM cost a FORWARD recurrence that runs beside it, and what does the recurrence cost the GEMM?
 (The side stream of the backward pass is known: GEMMs at a third of their rate, +1.0 ms per backward launch -- DESIGN.md section 5.)
 Decides whether moving weight-gradient work from under the backward recurrences to under the NEXT step's forward recurrences can
-pay (DESIGN.md section 10 "Deferred weight gradients").  cfg2; the GEMM is the W_x-gradient shape (4096 x 1024 x 32000, TN) on its
-own non-blocking stream, launched back to back by a second host thread while the main thread times whole forward passes."""
+pay (DESIGN.md section 10 "Deferred weight gradients").  cfg2 (default) or `--config cfg4 [--forward-bf16]`; the GEMM is the
+W_x- / W_m-gradient shape (4096 x 1024 x 32000, TN: one direction's W_m gradient at H = 1024, both directions' W_x gradient at H = 512)
+on its own non-blocking stream, launched back to back by a second host thread while the main thread times whole forward passes."""
 import ctypes as C
 import json
 import sys
@@ -18,7 +19,13 @@ from eesen_amd.api import Net, Ctc, CuMatrix, check   # noqa: E402
 
 lib = _lib.load()
 hip = C.CDLL("libamdhip64.so")
-cfg = synth.config("cfg2")
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="cfg2")
+ap.add_argument("--forward-bf16", action="store_true")
+ap.add_argument("--caps", default="48,16,0")
+args = ap.parse_args()
+cfg = synth.config(args.config)
 layers = synth.make_model(max_grad=50.0, **cfg); batch = synth.make_batch(**cfg)
 feats = CuMatrix.from_numpy(batch.feats)
 diff = CuMatrix(batch.T * batch.S, cfg["K"])
@@ -36,6 +43,7 @@ assert hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) == 0
 sg = C.c_void_p()
 assert hip.hipStreamCreateWithPriority(C.byref(sg), 1, lo.value) == 0   # the foreign GEMMs: lowest priority, like the library's side stream
 net = Net.from_layers(layers, stream=st.value); net.SetTrainOptions(4e-5, 0.9)
+net.SetForwardPrecision(1 if args.forward_bf16 else 0)
 ctc = Ctc(stream=st.value)
 WS = CuMatrix(1, 16 << 20, zero=False)    # split-K slabs
 
@@ -97,17 +105,18 @@ def beside(fn, cap_kb, seconds=0.6):
 
 for _ in range(3):
     bwd(fwd())
-res = {"gemm": "W_x-gradient shape 4096 x 1024 x 32000 (TN), %.0f GFLOP" % (2.0 * M * N * K / 1e9)}
+res = {"config": args.config, "forward": "bf16" if args.forward_bf16 else "f32",
+       "gemm": "weight-gradient shape %d x %d x %d (TN), %.0f GFLOP" % (M, N, K, 2.0 * M * N * K / 1e9)}
 res["fwd_alone_ms"] = timed(fwd, 10)
 out = fwd()
 res["bwd_alone_ms"] = timed(lambda: bwd(out), 5)
-for cap in (48, 16, 0):      # extra LDS > 0 selects the 128 x 128 flavour and caps its workgroups per CU: 48 KB = one (the side stream's setting), 16 KB = two; 0 = the 256 x 256 flavour, uncapped
+for cap in [int(c) for c in args.caps.split(",")]:      # extra LDS > 0 selects the 128 x 128 flavour and caps its workgroups per CU: 48 KB = one (the side stream's setting), 16 KB = two; 0 = the 256 x 256 flavour, uncapped
     r = {"gemm_alone_ms": gemm_alone(cap)}
     for k, fn in (("fwd", fwd), ("bwd", lambda: bwd(out))):
         pass_ms, gemm_ms, per_pass = beside(fn, cap)
         r[k] = {"pass_ms": pass_ms, "gemm_ms": gemm_ms, "gemms_per_pass": per_pass,
                 "growth_per_ms_of_standalone_gemm_hidden": (pass_ms - res[f"{k}_alone_ms"]) / max(1e-9, per_pass * r["gemm_alone_ms"])}
     res[f"cap_{cap}KB"] = r
-res["note"] = ("forward pass = 4 recurrences + input GEMMs of cfg2; backward = CTC + 4 recurrences + all gradient GEMMs, its own side stream "
+res["note"] = ("forward pass = the recurrences + input GEMMs of the configuration; backward = CTC + the recurrences + all gradient GEMMs, its own side stream "
                "included; the foreign GEMMs run on a third, lowest-priority stream, at most two queued")
 print(json.dumps(res))
