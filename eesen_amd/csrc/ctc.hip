@@ -10,11 +10,12 @@
 // launch: lane l owns the PL consecutive lattice positions [l*PL, (l+1)*PL), so the j-1 / j-2 (alpha) and
 // j+1 / j+2 (beta) neighbours are in-register except at the chunk edge, where two wave shuffles
 // (__shfl_up / __shfl_down) fetch them -- no LDS, no barrier on the 2T-step dependency chain.  The alpha
-// and beta sweeps of all S utterances run concurrently (2S wavefronts).  Lattices of more than 1024 positions
-// (the reference takes any label length, ctc-loss.cc:116-129: character targets on a 35 s utterance) are
-// walked by NW wavefronts of one workgroup: wave w owns positions [w*64*PL, (w+1)*64*PL), and the two values
-// that cross a wave boundary per step travel through a double-buffered LDS slot behind ONE workgroup barrier
-// per step (round 5).  The arithmetic per position is the same whatever (PL, NW) covers it: bit-identical.  The next step's log-probability
+// and beta sweeps of all S utterances run concurrently (2S workgroups).  Lattices of more than 256 positions
+// -- up to 4096; the reference takes any label length, ctc-loss.cc:116-129: character targets on a 35 s
+// utterance -- are walked by NW wavefronts of one workgroup: wave w owns positions [w*64*PL, (w+1)*64*PL), and
+// the two values that cross a wave boundary per step travel through a double-buffered LDS slot behind ONE
+// workgroup barrier per step (round 5; measured faster than more positions per lane on one wave, see
+// ctc_sweep_waves).  The arithmetic per position is the same whatever (PL, NW) covers it: bit-identical.  The next step's log-probability
 // gather is issued one step ahead so its latency sits under the current step's log-add-exp.  alpha/beta
 // rows are written utterance-major [S][T][64*PL] so every store is one coalesced line-aligned row.
 // The per-frame gradient is then a bulk pass (one wavefront per frame) that stages alpha+beta in LDS, reduces the
@@ -433,20 +434,23 @@ void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int
   check_launch("log_rows");
 }
 
-// Waves per lattice for a padded row of Lpad positions: one up to 1024 positions (PL = Lpad / 64 positions per lane; no barrier on the
-// chain), then 16 positions per lane and 2 / 4 waves.  `waves` > 0 asks for that many instead where such an instantiation exists
+// Waves per lattice for a padded row of Lpad positions (default: see the measurements in ctc_sweep_waves).  `waves` > 0 asks for that
+// many instead where such an instantiation exists
 // (EESEN_CTC_WAVES, read when a Ctc is created: tests hold the multi-wave kernels bit for bit against the one-wave kernel where
 // both exist; tuning.h).
 static bool ctc_sweep_has(int pl, int nw) {   // the instantiations of ctc_alpha_beta below
   if (nw == 1) return pl == 1 || pl == 2 || pl == 4 || pl == 8 || pl == 16;
   const int lpad = 64 * pl * nw;
-  return pl >= 2 && pl <= 16 && nw <= 16 && (pl & (pl - 1)) == 0 && (nw & (nw - 1)) == 0 && lpad >= 512 && lpad <= 4096 && (pl >= 4 || lpad <= 1024);
+  if (pl == 2 && nw == 2) return true;   // 256 positions as 2 x 2 (an A/B arm: measured against the one-wave default)
+  return pl >= 2 && pl <= 16 && nw <= 16 && (pl & (pl - 1)) == 0 && (nw & (nw - 1)) == 0 && lpad >= 512 && lpad <= 4096 && (pl >= 4 || lpad <= 2048);
 }
 int ctc_sweep_waves(int Lpad, int waves) {
   if (waves > 0 && Lpad % (64 * waves) == 0 && ctc_sweep_has(Lpad / (64 * waves), waves)) return waves;
-  int nw = 1;
-  while (nw * 64 * 16 < Lpad) nw *= 2;
-  return nw;
+  // Measured (MI355X, profiles/r05_ctc_waves.json; us per lattice step): a lane's positions are worked through one after the other,
+  // so above 256 positions FEWER positions per lane on MORE waves win although every step then crosses a workgroup barrier --
+  // 512 positions: 0.62 (8 x 1 wave), 0.45 (4 x 2), 0.35 (2 x 4); 1024: 1.25 (16 x 1), 0.75, 0.50, 0.45 (2 x 8); 2048: 1.36 (16 x 2),
+  // 0.83 (8 x 4), 0.72 (4 x 8).  Up to 256 positions (4 per lane: 0.33) one wave, no barrier.
+  return Lpad <= 256 ? 1 : Lpad == 512 ? 4 : Lpad <= 2048 ? 8 : 16;
 }
 
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,
@@ -462,9 +466,10 @@ void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int
     launched = true;                                                                                                     \
   }
   EESEN_AB(1, 1) EESEN_AB(2, 1) EESEN_AB(4, 1) EESEN_AB(8, 1) EESEN_AB(16, 1)          // <= 1024 positions, one wave
+  EESEN_AB(2, 2)                                                                       // 256 positions as 2 waves
   EESEN_AB(4, 2) EESEN_AB(2, 4)                                                        // 512 positions as 2 / 4 waves
   EESEN_AB(8, 2) EESEN_AB(4, 4) EESEN_AB(2, 8)                                         // 1024 positions as 2 / 4 / 8 waves
-  EESEN_AB(16, 2) EESEN_AB(8, 4) EESEN_AB(4, 8)                                        // 2048 positions
+  EESEN_AB(16, 2) EESEN_AB(8, 4) EESEN_AB(4, 8) EESEN_AB(2, 16)                        // 2048 positions
   EESEN_AB(16, 4) EESEN_AB(8, 8) EESEN_AB(4, 16)                                       // 4096 positions
 #undef EESEN_AB
   if (!launched) throw Error(EESEN_ERR_INVALID, "ctc: no lattice kernel for this padded label length / wave count (at most 4096 positions)");

@@ -141,7 +141,7 @@ size_t col_sums_ws_floats(int rows, int cols);
 void softmax_rows(hipStream_t st, const float* x, int ldx, float* y, int ldy, int rows, int K);
 // out = log(in) elementwise on a [rows x K] matrix (CuMatrixBase::ApplyLog, ctc-loss.cc:132-133)
 void log_rows(hipStream_t st, const float* in, int ldi, float* out, int ldo, int rows, int K);
-// alpha and beta lattice sweeps for all S sequences (2*S workgroups: one wave each up to Lpad = 1024, ctc_sweep_waves(Lpad) above).
+// alpha and beta lattice sweeps for all S sequences (2*S workgroups of ctc_sweep_waves(Lpad) wavefronts: one up to Lpad = 256).
 // logp: [T*S x K] (ld), labx: [S x Lpad] expanded labels (-1 padded), lens/lablens: [S]
 // alpha/beta: [S][T][Lpad] (utterance-major), pzx: [S].  Lpad in {64, 128, ..., 4096}.  waves: 0 = the default for Lpad.
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,

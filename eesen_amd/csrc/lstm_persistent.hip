@@ -1643,7 +1643,10 @@ bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE la
     nb = it->second;
   }
   // the occupancy query can over-report by one workgroup per CU (CDNA4 guide): keep a margin of one
-  const long cap = (long)ncu * std::max(1, nb - 1) / gpu_share();
+  // (EESEN_OCC_MARGIN=0, an experiment switch of round 5: trust the query -- two workgroups of the narrow forward tile per CU at
+  // --num-sequence 64; a grid that then turns out not to be co-resident costs one minibatch and ends on the per-step kernels)
+  static const int margin = [] { const char* e = getenv("EESEN_OCC_MARGIN"); return e && *e ? atoi(e) : 1; }();
+  const long cap = (long)ncu * std::max(1, nb - margin) / gpu_share();
   return (long)grid.x * grid.y * grid.z <= cap;
 }
 
@@ -1702,7 +1705,10 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   // (wide layers take the 16-sequence tile at ANY batch size: their 32 x 4 tile would need H/4 x ndir workgroups -- 512 at H = 1024 --
   // and a batch of <= 16 sequences fell back to the per-step kernels: seen at S = 16, T = 3000 with the six-layer cfg5 stack, round 4)
   const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2);
-  if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > ncu)) return {1, 4};
+  // (EESEN_FWD_NARROW2=1, experiment switch of round 5: keep the narrow 16 x 8 tile up to TWO workgroups per CU -- with
+  // EESEN_OCC_MARGIN=0 the bf16-pipe kernel then takes --num-sequence 64 at H = 512 as ONE grid of 512 workgroups)
+  static const int narrow2 = [] { const char* e = getenv("EESEN_FWD_NARROW2"); return e && *e ? atoi(e) : 0; }();
+  if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > (long)ncu * (narrow2 ? 2 : 1))) return {1, 4};
   if (t16_ok && need <= 2) return {1, 2};
   return {2, 1};
 }

@@ -25,7 +25,8 @@
 //                                    the 3-way bf16 split of both operands (fp32-class: six products, one fp32 rounding per product)
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_CTC_WAVES         0        n: the CTC lattice sweep as n wavefronts per lattice where that instantiation exists (read when a
-//                                    Ctc is created; 0: one wave up to 1024 lattice positions, 2 / 4 above; bit-identical)
+//                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 8 / 16 for rows of 512 / 1024 /
+//                                    2048 / 4096; bit-identical)
 //   EESEN_GPU_SHARE         1        n: the persistent grids are sized against 1/n of the device's CUs (n processes on one GPU)
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eesen_amd.api import Ctc, CuMatrix   # noqa: E402
 
 res = {}
-for name, (S, T, K, U) in {"cfg5_ctc": (64, 3000, 51, 300), "L401": (64, 2000, 46, 200), "L1201": (32, 3000, 46, 600)}.items():
+for name, (S, T, K, U) in {"cfg2_ctc": (32, 1000, 46, 100), "cfg5_ctc": (64, 3000, 51, 300), "L401": (64, 2000, 46, 200), "L1201": (32, 3000, 46, 600), "L2401": (16, 3200, 30, 1200)}.items():
     rng = np.random.default_rng(5)
     lens = np.sort(rng.integers(int(0.8 * T), T + 1, size=S)).astype(np.int32); lens[-1] = T
     x = rng.standard_normal((T * S, K)).astype(np.float32)
@@ -22,7 +22,7 @@ for name, (S, T, K, U) in {"cfg5_ctc": (64, 3000, 51, 300), "L401": (64, 2000, 4
     diff = CuMatrix(T * S, K)
     res[name] = {"S": S, "T": T, "K": K, "Lprime": 2 * U + 1}
     base = None
-    for w in (0, 2, 4, 8, 16):
+    for w in (0, 1, 2, 4, 8, 16):
         if w:
             os.environ["EESEN_CTC_WAVES"] = str(w)
         else:
