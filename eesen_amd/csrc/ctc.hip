@@ -450,7 +450,9 @@ int ctc_sweep_waves(int Lpad, int waves) {
   // so above 256 positions FEWER positions per lane on MORE waves win although every step then crosses a workgroup barrier --
   // 512 positions: 0.62 (8 x 1 wave), 0.45 (4 x 2), 0.35 (2 x 4); 1024: 1.25 (16 x 1), 0.75, 0.50, 0.45 (2 x 8); 2048: 1.36 (16 x 2),
   // 0.83 (8 x 4), 0.72 (4 x 8).  Up to 256 positions (4 per lane: 0.33) one wave, no barrier.
-  return Lpad <= 256 ? 1 : Lpad == 512 ? 4 : Lpad <= 2048 ? 8 : 16;
+  // (second collection, profiles/r05b_ctc_waves.json: 2048 as 2 x 16 0.67 against 0.72 as 4 x 8; 4096 as 4 x 16 1.18, 8 x 8 1.28, 16 x 4 1.55;
+  // 256 as 2 x 2 0.323 against 0.336 on one wave: not worth a barrier on the headline's chain)
+  return Lpad <= 256 ? 1 : Lpad == 512 ? 4 : Lpad == 1024 ? 8 : 16;
 }
 
 void ctc_alpha_beta(hipStream_t st, const float* logp, int ld, int T, int S, int Lpad, const int* labx, const int* lens,

@@ -84,6 +84,7 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
+  int bwd_q4_st8 = 1;   // the 4 x 32 backward tile with TWO 4-sequence tiles per workgroup where one does not fit (tuning.h: EESEN_BWD_Q4_ST8)
   // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on bf16 operands with
   // fp32 accumulation (lstm_fwd_persistent_bf_kernel<.., AP = 1, WP = 2>): m_t as ONE bf16 plane in the exchange buffer X, W_m as
   // hi + lo planes
@@ -124,6 +125,10 @@ bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L);
 // the forward tile this layer takes leaves room on a CU for a 128 x 128 GEMM workgroup (net.cpp: "the middle first")
 bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L);
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L);
+// true when this layer's backward recurrence takes one of the SMALL tiles (4 or 8 sequences per workgroup: every CU holds one
+// workgroup of <= 168 registers), beside which a side-stream GEMM workgroup still runs at a third of its rate; the 16-sequence
+// tiles (S = 64 at H = 512: 179 registers, 128 KB of operands per workgroup and step) leave it a seventh (net.cpp: overlap)
+bool lstm_bwd_small_tile(const LstmLayerDev& L);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

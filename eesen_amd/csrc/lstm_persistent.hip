@@ -1025,19 +1025,24 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 //   instruction (pair, r, ABID) takes component r: class ks covers k = pair*64 + ks*32 + ABID*4 + r;
 //   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
 // Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
+// ST = 8 (round 5): TWO 4-sequence tiles per workgroup against the same resident W_m^T -- for batches whose 4-sequence grid needs
+// more workgroups than there are CUs (S = 64 at H = 512: 512), where the alternative was the 16 x 16 tile and its 128 KB of
+// operands per workgroup and step.  The MFMA chain doubles (1.8 us), the operand fetch is 64 KB, the hand-off, the drain and the
+// cell phase (now on four waves) are paid once for eight sequences.
 // ------------------------------------------------------------------------------------------------
 // (Round 4 measured an arm that requests the cell operands of a step at the TOP of that step instead of at the end of the step
 // before, and bumps the counter from a wave nobody waits on: bit-identical, 7140 ticks per step either way -- the stall it removed
 // sat under the peers' own increment flight.  DESIGN.md section 4 "The cell operands at the top of the step" keeps the timeline;
 // the arm is gone.)
-template <int CPW>
+template <int CPW, int ST>   // ST = 4 or 8 sequences per workgroup (8: two 4-sequence A tiles against the same resident weights)
 __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
                                                                          float* __restrict__ DG, unsigned* cnt, unsigned* err,
                                                                          int spin_limit, unsigned long long* trace, Role R) {
-  constexpr int ST = 4, UW = 32, P = CPW / 2;         // sequences, units per workgroup; (load, 64-float) pairs per wave
+  static_assert(ST == 4 || ST == 8, "one or two 4-sequence tiles");
+  constexpr int HS = ST / 4, UW = 32, P = CPW / 2;    // 4-sequence tiles, units per workgroup; (load, 64-float) pairs per wave
   constexpr int LDSP = CPW == 8 ? 1 : 0, REGP = P - LDSP;   // pairs whose B values live in LDS / registers
   __shared__ __attribute__((aligned(16))) float4 bl[LDSP ? LDSP : 1][8][LDSP ? NW * 64 : 1];   // [pair][ABID][thread]
-  __shared__ float red[NW][8][UW + 1];               // [wave][k class (2) x sequence (4)][unit]
+  __shared__ float red[NW][HS * 8][UW + 1];          // [wave][4-sequence tile x k class (2) x sequence (4)][unit]
   __shared__ int s_go;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1093,8 +1098,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
   for (int step = 0; step < T; ++step) {
     const int t = dir == 0 ? T - 1 - step : step;
     const int tn = dir == 0 ? t + 1 : t - 1;
-    f32x4 ac[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 a4[P];
+    f32x4 ac[HS][2];
+#pragma unroll
+    for (int hs = 0; hs < HS; ++hs) { ac[hs][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[hs][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 a4[HS][P];
     // the cell operands of THIS step: requested at the end of the step before, behind the publish
     const float4 gtc = gt;
     const float dyc = dy, ctc = c_t, cpc = c_p;
@@ -1107,12 +1114,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
       __syncthreads();
       if (!s_go) return;
       EESEN_STAMP(1);
-      const unsigned arow = (unsigned)(((size_t)(tn * S + s0 + x) * ldG + (size_t)dir * K4) * 4);
-      const bool rok = s0 + x < S;
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int k = (wave + p * NW) * 64 + (ks * 8 + ab) * 4;
-        a4[p] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow + (unsigned)k * 4u : 0x80000000u, 0, 0);
+      for (int hs = 0; hs < HS; ++hs) {
+        const unsigned arow = (unsigned)(((size_t)(tn * S + s0 + hs * 4 + x) * ldG + (size_t)dir * K4) * 4);
+        const bool rok = s0 + hs * 4 + x < S;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int k = (wave + p * NW) * 64 + (ks * 8 + ab) * 4;
+          a4[hs][p] = __builtin_amdgcn_raw_buffer_load_b128(rDG, (rok && k < K4) ? arow + (unsigned)k * 4u : 0x80000000u, 0, 0);
+        }
       }
     }
     if (step > 0) {
@@ -1132,24 +1142,31 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
             w0[0] = v0.x; w0[1] = v0.y; w0[2] = v0.z; w0[3] = v0.w;
             w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
           }
+          // (ST = 8: the second 4-sequence tile's chain goes through the SAME weight registers -- per tile the same instructions in the
+          // same order as ST = 4, so its gate gradients are bit-identical to the 4-sequence kernel's)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (h == 0)      { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 0, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 1, 0); }
-            else if (h == 1) { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 2, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 3, 0); }
-            else if (h == 2) { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 4, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 5, 0); }
-            else             { ac[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w0[r], ac[0], 3, 6, 0); ac[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[p][r], w1[r], ac[1], 3, 7, 0); }
+          for (int hs = 0; hs < HS; ++hs) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (h == 0)      { ac[hs][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w0[r], ac[hs][0], 3, 0, 0); ac[hs][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w1[r], ac[hs][1], 3, 1, 0); }
+              else if (h == 1) { ac[hs][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w0[r], ac[hs][0], 3, 2, 0); ac[hs][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w1[r], ac[hs][1], 3, 3, 0); }
+              else if (h == 2) { ac[hs][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w0[r], ac[hs][0], 3, 4, 0); ac[hs][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w1[r], ac[hs][1], 3, 5, 0); }
+              else             { ac[hs][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w0[r], ac[hs][0], 3, 6, 0); ac[hs][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[hs][p][r], w1[r], ac[hs][1], 3, 7, 0); }
+            }
           }
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][ks * 4 + i][ab * 4 + x] = ac[0][i] + ac[1][i];
+    for (int hs = 0; hs < HS; ++hs)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave][hs * 8 + ks * 4 + i][ab * 4 + x] = ac[hs][0][i] + ac[hs][1][i];
     EESEN_STAMP(2);
     __syncthreads();
     if (e_ok) {
       float dm = dyc;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) dm += red[w][es][eu] + red[w][4 + es][eu];
+      for (int w = 0; w < NW; ++w) dm += red[w][(es >> 2) * 8 + (es & 3)][eu] + red[w][(es >> 2) * 8 + 4 + (es & 3)][eu];
       const float g = gtc.x, i = gtc.y, f = gtc.z, o = gtc.w;
       const float h = tanhf_(ctc);
       const float dh = (1.f - h * h) * (dm * o);
@@ -1911,6 +1928,11 @@ void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsign
   check_launch("wait_for_word");
 }
 
+bool lstm_bwd_small_tile(const LstmLayerDev& L) {
+  const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
+  return 2 * blocks16 <= share_of_cus() && L.S > 8;     // lstm_bwd_persistent: stile == 8 (and the 4 x 32 tile, which needs it)
+}
+
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;
@@ -1939,13 +1961,20 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   if (max_blocks < 3) return false;
   int chunk = (int)std::min<long>(L0.T, max_blocks - 1);
   if (chunk < L0.T) { int p2 = 1; while (p2 * 2 <= chunk) p2 *= 2; chunk = p2; }   // a power of two keeps `step % chunk` cheap
-  // The 4-sequence x 32-unit tile (lstm_bwd_persistent_q4_kernel): wherever the 8-sequence tile would be taken and the shape allows
-  if (L0.bwd_q4 && stile == 8 && !L0.drop_mode && L0.H % 128 == 0 && L0.H / 64 <= 8 && L0.S % 4 == 0 && chunk >= L0.T) {
+  // The 4-sequence x 32-unit tile (lstm_bwd_persistent_q4_kernel<., 4>): wherever the 8-sequence tile would be taken and the shape
+  // allows; with TWO 4-sequence tiles per workgroup (<., 8>, round 5) where that grid does not fit but half as many workgroups do
+  // (S = 64 at H = 512) -- LstmLayerDev::bwd_q4_st8: 0 = never (the 16 x 16 tile there, as before round 5), 2 = wherever it applies,
+  // before the one-tile form (the tests' A/B arm: same gate gradients bit for bit)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int stq = (L0.bwd_q4_st8 == 2) == (pass == 0) ? 8 : 4;
+    if (!L0.bwd_q4 || L0.drop_mode || L0.H % 128 != 0 || L0.H / 64 > 8 || chunk < L0.T) break;
+    if (stq == 4 && !(stile == 8 && L0.S % 4 == 0)) continue;
+    if (stq == 8 && !(L0.bwd_q4_st8 && L0.S % 8 == 0 && L0.S > 8)) continue;
     const int cpw = L0.H / 64;   // 2, 4 or 8
-    dim3 grid(L0.H / 32, L0.ndir, L0.S / 4), block(NW * 64);
+    dim3 grid(L0.H / 32, L0.ndir, L0.S / stq), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
     bool fit = false;
-#define EESEN_Q4(CPW) fits(lstm_bwd_persistent_q4_kernel<CPW>, grid, NW * 64)
+#define EESEN_Q4(CPW) (stq == 8 ? fits(lstm_bwd_persistent_q4_kernel<CPW, 8>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, 4>, grid, NW * 64))
     if (cpw == 8) fit = EESEN_Q4(8);
     else if (cpw == 4) fit = EESEN_Q4(4);
     else if (cpw == 2) fit = EESEN_Q4(2);
@@ -1956,7 +1985,11 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       const dim3 grid1(grid.x * grid.y * grid.z);
       const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
-#define EESEN_Q4(CPW) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role)
+#define EESEN_Q4(CPW)                                                                                                                    \
+  do {                                                                                                                                   \
+    if (stq == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, 8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
+    else coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, 4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role);         \
+  } while (0)
       if (cpw == 8) EESEN_Q4(8);
       else if (cpw == 4) EESEN_Q4(4);
       else EESEN_Q4(2);

@@ -12,12 +12,16 @@
 //   ---- fallbacks ---------------------------------------------------------------------------------------------------------
 //   EESEN_PERSISTENT        1        0: one launch per recurrence step (lstm.hip) instead of one persistent launch per layer pass
 //   EESEN_OVERLAP           auto     weight-gradient GEMMs on a side stream under the next recurrence (auto: on with persistent
-//                                    kernels)
+//                                    kernels on layers of <= 512 cells whose backward pass takes a 4- / 8-sequence tile; off beside
+//                                    the 16-sequence tiles, e.g. --num-sequence 64 at 512 cells)
 //   EESEN_SPIN_LIMIT        400000   bound of the in-kernel hand-off spins (x10 with a communicator attached); 0 in tests forces a time-out
 //   EESEN_GEMM_MODE         split    f32: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain) instead of the 3-way bf16 split
 //   EESEN_HOST_FEATURE_PIPES unset   (trainers) run recognised feature pipes as host processes instead of on the device
 //   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
 //   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
+//   EESEN_BWD_Q4_ST8        1        0: the 16 x 16 backward tile instead of the 4 x 32 tile with TWO 4-sequence tiles per workgroup where
+//                                    the one-tile grid does not fit (H <= 512 at --num-sequence 64); 2: the two-tile form wherever it
+//                                    applies (bit-identical to the one-tile form: the tests' arm)
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
@@ -25,8 +29,12 @@
 //                                    the 3-way bf16 split of both operands (fp32-class: six products, one fp32 rounding per product)
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_CTC_WAVES         0        n: the CTC lattice sweep as n wavefronts per lattice where that instantiation exists (read when a
-//                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 8 / 16 for rows of 512 / 1024 /
+//                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 16 / 16 for rows of 512 / 1024 /
 //                                    2048 / 4096; bit-identical)
+//   ---- experiment switches of round 5 (measured, not defaults) -------------------------------------------
+//   EESEN_OCC_MARGIN        1        0: fits() trusts the occupancy query instead of keeping one workgroup per CU of margin
+//   EESEN_FWD_NARROW2       0        1: the narrow 16 x 8 forward tile up to TWO workgroups per CU (with EESEN_OCC_MARGIN=0: cfg2 at
+//                                    --num-sequence 64 as ONE grid of 512 workgroups of the bf16-pipe kernel)
 //   EESEN_GPU_SHARE         1        n: the persistent grids are sized against 1/n of the device's CUs (n processes on one GPU)
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
@@ -50,7 +58,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
+  int bwd_q4 = 1, bwd_q4_st8 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -69,6 +77,7 @@ struct Tuning {
     t.spin_limit_set = getenv("EESEN_SPIN_LIMIT") != nullptr;
     t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
     t.bwd_q4 = num("EESEN_BWD_Q4", 1);
+    t.bwd_q4_st8 = num("EESEN_BWD_Q4_ST8", 1);
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);

@@ -475,6 +475,43 @@ def test_backward_tiles_agree_and_are_deterministic(gpu, monkeypatch):
             assert np.array_equal(r[0], res[mode][0][0]) and np.array_equal(r[1], res[mode][0][1])
     assert rel_err(res["1"][0][0], res["0"][0][0]) < 1e-5 and rel_err(res["1"][0][1], res["0"][0][1]) < 1e-5
 
+@pytest.mark.parametrize("over", [dict(T=40, layers=2), dict(T=33, layers=1, H=256, S=24), dict(T=36, layers=2, S=64)])
+def test_two_sequence_tiles_per_backward_workgroup(gpu, over, monkeypatch):
+    """lstm_bwd_persistent_q4_kernel<., 8> (round 5): two 4-sequence tiles per workgroup against the same resident W_m^T -- what a
+    narrow layer takes at --num-sequence 64, where the one-tile grid needs 512 workgroups.  Per tile the same instructions in the
+    same order: forced on shapes where the one-tile form runs too (EESEN_BWD_Q4_ST8=2) the input gradient and every parameter
+    gradient must be BIT-identical to it, run after run; at S = 64 (the default there) it is held against the 16 x 16 tile it replaces
+    (EESEN_BWD_Q4_ST8=0) up to the summation order."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config("cfg2"); cfg.update(over)
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    res = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("EESEN_BWD_Q4_ST8", mode)
+        net = Net.from_layers(layers); ctc = Ctc()
+        runs = []
+        for _ in range(3):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            idf = CuMatrix(batch.T * batch.S, cfg["D"])
+            net.BackpropagateNoUpdate(diff, idf)
+            runs.append((idf.numpy(), net.GetGrads()))
+        info = net.RecurrenceInfo()
+        assert info["bwd_persistent"] == info["lstm_layers"] and net.recoveries == 0, (mode, info)
+        for r in runs:
+            assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]), mode
+        res[mode] = runs[0]
+    assert np.isfinite(res["1"][1]).all() and np.abs(res["1"][1]).max() > 0
+    if cfg["S"] <= 32:    # default = the one-tile form: the forced two-tile form must reproduce it bit for bit
+        assert np.array_equal(res["2"][0], res["1"][0]) and np.array_equal(res["2"][1], res["1"][1])
+        assert np.array_equal(res["0"][0], res["1"][0])       # (the switch's value 0 changes nothing where one tile fits)
+    else:                 # default = the two-tile form; 0 = the 16 x 16 tile
+        assert np.array_equal(res["2"][0], res["1"][0]) and np.array_equal(res["2"][1], res["1"][1])
+        assert not np.array_equal(res["0"][1], res["1"][1])   # another kernel really ran
+        assert rel_err(res["1"][0], res["0"][0]) < 1e-5 and rel_err(res["1"][1], res["0"][1]) < 1e-5
+
+
 def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, capfd):
     """A hand-off that cannot complete (here: a spin bound of zero polls) must surface at the next synchronisation point --
     never as a hang or as silently wrong numbers: a WARNING on stderr and a fall-back to the per-step kernels (an exception
