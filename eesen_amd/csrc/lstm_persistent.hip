@@ -411,6 +411,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf_kernel(LstmLay
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
+  if (T < 0) {   // residency census (census_ok): every workgroup checks in and waits, bounded on the wall clock, until the whole grid has
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      bool all = false;
+      while (!(all = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) && wall_clock64() - t0 < 500000ull)   // 5 ms
+        __builtin_amdgcn_s_sleep(8);
+      if (!all) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const int ldY = L.ndir * H, ldG = L.ndir * 4 * H;
   const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
   const int u0 = bx * UB, s0 = L.s_begin + bz * ST;
@@ -1642,8 +1653,9 @@ static int share_of_cus() {
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   return std::max(1, ncu / gpu_share());
 }
-template <class K>
-bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE launch (one sequence window)
+// census: optional -- `bool(int wgs)`: have `wgs` workgroups of this very kernel been SEEN co-resident on this device (run once, cached)?
+template <class K, class C = bool (*)(int)>
+bool fits(K kernel, dim3 grid, int threads, C census = nullptr) {  // grid: the workgroups of ONE launch (one sequence window)
   int dev = 0, ncu = 0, nb = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -1659,12 +1671,11 @@ bool fits(K kernel, dim3 grid, int threads) {  // grid: the workgroups of ONE la
     }
     nb = it->second;
   }
-  // the occupancy query can over-report by one workgroup per CU (CDNA4 guide): keep a margin of one
-  // (EESEN_OCC_MARGIN=0, an experiment switch of round 5: trust the query -- two workgroups of the narrow forward tile per CU at
-  // --num-sequence 64; a grid that then turns out not to be co-resident costs one minibatch and ends on the per-step kernels)
-  static const int margin = [] { const char* e = getenv("EESEN_OCC_MARGIN"); return e && *e ? atoi(e) : 1; }();
-  const long cap = (long)ncu * std::max(1, nb - margin) / gpu_share();
-  return (long)grid.x * grid.y * grid.z <= cap;
+  // the occupancy query can over-report by one workgroup per CU (MI355X guide: SGPR-heavy kernels): keep a margin of one -- unless the
+  // caller has a residency CENSUS for this instantiation (below), which settles whether the query's own number is real
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  if (wgs <= (long)ncu * std::max(1, nb - 1) / gpu_share()) return true;
+  return census && wgs <= (long)ncu * nb / gpu_share() && census((int)wgs);
 }
 
 // The persistent grids are launched as ORDINARY kernels: hipLaunchCooperativeKernel costs ~40 us more per launch (its dedicated
@@ -1716,16 +1727,20 @@ float handoff_flight_ns() {
 //   16 x 16 <MT=1, NT=4>: for wide layers (H = 1024: 16 x 8 would need 512 co-resident workgroups); 64 gate rows of W_m
 //                         (256 KB at H = 1024) live in the registers of one workgroup
 struct FwdTile { int mt, nt; };
+static bool narrow2_ok(const LstmLayerDev& L, int need);
 static FwdTile fwd_tile(const LstmLayerDev& L) {
   const int need = ((L.H + 31) / 32 + NW - 1) / NW;
   const int ncu = share_of_cus();
   // (wide layers take the 16-sequence tile at ANY batch size: their 32 x 4 tile would need H/4 x ndir workgroups -- 512 at H = 1024 --
   // and a batch of <= 16 sequences fell back to the per-step kernels: seen at S = 16, T = 3000 with the six-layer cfg5 stack, round 4)
   const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2);
-  // (EESEN_FWD_NARROW2=1, experiment switch of round 5: keep the narrow 16 x 8 tile up to TWO workgroups per CU -- with
-  // EESEN_OCC_MARGIN=0 the bf16-pipe kernel then takes --num-sequence 64 at H = 512 as ONE grid of 512 workgroups)
-  static const int narrow2 = [] { const char* e = getenv("EESEN_FWD_NARROW2"); return e && *e ? atoi(e) : 0; }();
-  if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || (long)(L.H / 8) * L.ndir * cdiv(L.S, 16) > (long)ncu * (narrow2 ? 2 : 1))) return {1, 4};
+  // The narrow 16 x 8 tile needs H/8 x ndir x S/16 workgroups: one per CU up to S = 32 at H = 512.  Beyond that, up to TWO per CU
+  // (round 5; S = 64 at H = 512: 512 workgroups of the bf16-pipe kernel, 108 registers) where a residency census has SEEN that many
+  // co-resident (narrow2_ok) -- two chains per CU interleaved by the hardware: 3.5 us per step for 64 sequences against 4.2 on the
+  // wide tile; otherwise the wide 16 x 16 tile.
+  const long narrow_wgs = (long)(L.H / 8) * L.ndir * cdiv(L.S, 16);
+  const bool narrow_full = narrow_wgs > ncu && !(narrow_wgs <= 2L * ncu && need <= 2 && narrow2_ok(L, need));
+  if (t16_ok && L.H % 16 == 0 && need <= 4 && (need > 2 || narrow_full)) return {1, 4};
   if (t16_ok && need <= 2) return {1, 2};
   return {2, 1};
 }
@@ -1772,12 +1787,46 @@ static BfPlan bf_plan_shape(const LstmLayerDev& L) {
     if ((P).nt == 2) { if ((P).cpw <= 1) F(1, 2, 3, 3); else F(2, 2, 3, 3); }                              \
     else { switch ((P).cpw) { case 1: F(1, 4, 1, 2); break; case 2: F(2, 4, 1, 2); break; case 3: F(3, 4, 1, 2); break; default: F(4, 4, 1, 2); } } \
   } while (0)
+// Residency census of one instantiation of the bf16-pipe kernel: `wgs` workgroups launched in its census mode (T < 0) on the idle
+// device must all check in within 5 ms.  Once per (device, workgroup count) and process, ~1 ms; the occupancy query's own number is
+// only trusted where this has seen it (the MI355X guide: the query over-reports by one block per CU for SGPR-heavy kernels).
+template <int C, int N, int A, int W>
+static bool bf_census(int wgs) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, bool> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, wgs);
+  if (auto it = seen.find(key); it != seen.end()) return it->second;
+  bool ok = false;
+  unsigned* w = nullptr;
+  if (hipDeviceSynchronize() == hipSuccess && hipMalloc(reinterpret_cast<void**>(&w), 2 * sizeof(unsigned)) == hipSuccess) {
+    if (hipMemset(w, 0, 2 * sizeof(unsigned)) == hipSuccess) {
+      LstmLayerDev L{};
+      L.T = -1;
+      hipLaunchKernelGGL((lstm_fwd_persistent_bf_kernel<C, N, A, W>), dim3(wgs), dim3(NW * 64), 0, nullptr, L, w, w + 1, 0,
+                         static_cast<unsigned long long*>(nullptr), Role{1, 1, 1, 0});
+      unsigned e = 1;
+      ok = hipMemcpy(&e, w + 1, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && e == 0;
+    }
+    (void)hipFree(w);
+  }
+  seen[key] = ok;
+  return ok;
+}
 static bool bf_fits(const LstmLayerDev& L, const BfPlan& P, int Sw) {
   dim3 grid(L.H / (4 * P.nt), L.ndir, cdiv(Sw, 16));
-#define EESEN_BF_FITS(C, N, A, W) return fits(lstm_fwd_persistent_bf_kernel<C, N, A, W>, grid, NW * 64)
+#define EESEN_BF_FITS(C, N, A, W) return fits(lstm_fwd_persistent_bf_kernel<C, N, A, W>, grid, NW * 64, &bf_census<C, N, A, W>)
   EESEN_BF_DISPATCH(P, EESEN_BF_FITS);
 #undef EESEN_BF_FITS
   return false;
+}
+// the narrow bf16-pipe tile as up to two workgroups per CU (fwd_tile): the plan's own shape conditions, and the grid seen co-resident
+static bool narrow2_ok(const LstmLayerDev& L, int need) {
+  if (!L.fwd_narrow2 || !L.fwd_split || L.fwd_bf16 || L.X == nullptr || L.drop_mode || L.T < 2 || L.H % 32 != 0) return false;
+  if ((size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 1024 * 3 >= ((size_t)1 << 31)) return false;
+  return bf_fits(L, BfPlan{true, need, 2, 3, 3}, L.S);
 }
 static BfPlan bf_plan(const LstmLayerDev& L) {
   BfPlan P = bf_plan_shape(L);
@@ -1804,7 +1853,8 @@ bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return L.fwd_bf16 && b
 // early middle part of the next layer's input GEMM, net.cpp): the narrow tiles (<= 8 units, <= 131 VGPRs); the wide fp32 tile
 // (206 VGPRs) does not
 bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L) {
-  if (const BfPlan P = bf_plan(L); P.on) return P.nt <= 2;   // (the bf16 forward's successor in BASELINE config 4 is a projection, not an LSTM layer)
+  // (the bf16 forward's successor in BASELINE config 4 is a projection, not an LSTM layer; two narrow workgroups per CU leave no room)
+  if (const BfPlan P = bf_plan(L); P.on) return P.nt <= 2 && (long)(L.H / (4 * P.nt)) * L.ndir * cdiv(L.S, 16) <= share_of_cus();
   const FwdTile ft = fwd_tile(L);
   return 4 * ft.nt <= 8;
 }

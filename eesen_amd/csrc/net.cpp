@@ -503,7 +503,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.drop_mode = L.cur_drop_mode;
   d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
   d.fwd_split = net.tn.fwd_split;
-  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
+  d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.fwd_narrow2 = net.tn.fwd_narrow2; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
 
@@ -876,11 +876,13 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   // small backward tiles (cfg2 at S = 32: 1.6 of 22.8 ms) and COSTS beside the 16-sequence tile a narrow layer takes at
   // --num-sequence 64 -- measured (round 5, cfg2 shape at S = 64, `profiles/r05_s64_step_timeline.txt`): the W_x-gradient GEMM ran
   // 14.1 ms beside the recurrence (3.8 alone) and, through the gate-gradient buffer it holds, stalled the main stream 3.5 ms per
-  // layer: 79.8 ms per step overlapped, 71.4 not.  EESEN_OVERLAP=1 forces it.
+  // layer: 79.8 ms per step overlapped, 71.4 not (with the two-tile 4 x 32 kernel there: 77.2 / 67.2).  At the recipes' 320 cells the
+  // gradient GEMMs are 0.39 x the work and overlapping still pays at S = 64 (47.7 against 49.8 ms per minibatch): the rule stops at
+  // H > 320.  EESEN_OVERLAP=1 forces it.
   bool overlap = this->overlap;
   if (overlap && tn.overlap < 0 && persistent)
     for (const Layer& L : layers)
-      if (L.is_lstm() && L.H <= 512 && S > 32 && !lstm_bwd_small_tile(lstm_view(*this, L))) overlap = false;
+      if (L.is_lstm() && L.H > 320 && L.H <= 512 && S > 32 && !lstm_bwd_small_tile(lstm_view(*this, L))) overlap = false;
   bucket_log.clear();
   info_bwd_persistent = 0;
   live_valid = comm != nullptr;

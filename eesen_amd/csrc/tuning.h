@@ -31,10 +31,9 @@
 //   EESEN_CTC_WAVES         0        n: the CTC lattice sweep as n wavefronts per lattice where that instantiation exists (read when a
 //                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 16 / 16 for rows of 512 / 1024 /
 //                                    2048 / 4096; bit-identical)
-//   ---- experiment switches of round 5 (measured, not defaults) -------------------------------------------
-//   EESEN_OCC_MARGIN        1        0: fits() trusts the occupancy query instead of keeping one workgroup per CU of margin
-//   EESEN_FWD_NARROW2       0        1: the narrow 16 x 8 forward tile up to TWO workgroups per CU (with EESEN_OCC_MARGIN=0: cfg2 at
-//                                    --num-sequence 64 as ONE grid of 512 workgroups of the bf16-pipe kernel)
+//   EESEN_FWD_NARROW2       1        0: the wide 16 x 16 forward tile instead of TWO workgroups of the narrow bf16-pipe tile per CU where
+//                                    the one-per-CU grid is full (--num-sequence 64 at 512 cells: 512 workgroups, seen co-resident
+//                                    by a one-time census)
 //   EESEN_GPU_SHARE         1        n: the persistent grids are sized against 1/n of the device's CUs (n processes on one GPU)
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
@@ -58,7 +57,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_q4_st8 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
+  int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -78,6 +77,7 @@ struct Tuning {
     t.spin_limit = num("EESEN_SPIN_LIMIT", 400000);
     t.bwd_q4 = num("EESEN_BWD_Q4", 1);
     t.bwd_q4_st8 = num("EESEN_BWD_Q4_ST8", 1);
+    t.fwd_narrow2 = num("EESEN_FWD_NARROW2", 1);
     t.bwd_ksplit = num("EESEN_BWD_KSPLIT", 1);
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);

@@ -16,8 +16,8 @@ one default A=1
 one overlap1 EESEN_OVERLAP=1
 one st8off EESEN_BWD_Q4_ST8=0
 one st8off_overlap1 EESEN_BWD_Q4_ST8=0 EESEN_OVERLAP=1
-one narrow2_m0_nomid EESEN_FWD_NARROW2=1 EESEN_OCC_MARGIN=0 EESEN_FWD_MID=0
-one narrow2_m0_nomid_ov1 EESEN_FWD_NARROW2=1 EESEN_OCC_MARGIN=0 EESEN_FWD_MID=0 EESEN_OVERLAP=1
+one narrow2off EESEN_FWD_NARROW2=0
+one narrow2off_st8off EESEN_FWD_NARROW2=0 EESEN_BWD_Q4_ST8=0
 cat $O/s64.log
 rec() { local label=$1; shift
   ( timeout 200 env "$@" python -c "

@@ -392,6 +392,39 @@ def test_forward_recurrence_arms_agree_with_the_default(gpu, arm, monkeypatch):
     assert rel_err(got[0], base[0]) < 2e-6 and rel_err(got[1], base[1]) < 1e-4
 
 
+@pytest.mark.parametrize("over", [dict(S=64, T=48, layers=2), dict(S=64, T=40, layers=2, H=320, D=120), dict(S=48, T=40, layers=1)])
+def test_two_narrow_forward_workgroups_per_cu(gpu, over, monkeypatch):
+    """--num-sequence 64 on narrow layers (round 5): the bf16-pipe forward tile as ONE grid of up to two workgroups per CU (512 at
+    H = 512) where a one-time residency census has seen that many co-resident, instead of the wide 16 x 16 fp32 tile
+    (EESEN_FWD_NARROW2=0).  Same arithmetic up to the order of an fp32 sum: softmax outputs within 2e-6, gradients within 1e-4, bit-
+    identical run to run, every layer pass persistent, no recovery."""
+    from eesen_amd.api import Net, Ctc
+    cfg = synth.config("cfg2"); cfg.update(over)
+    layers = synth.make_model(**cfg)
+    batch = synth.make_batch(**cfg)
+
+    def run():
+        net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+        res = []
+        for _ in range(3):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            d = ctc.EvalParallel(batch.lens, out, batch.labels)
+            net.BackpropagateNoUpdate(d)
+            res.append((out.numpy(), net.GetGrads()))
+        ri = net.RecurrenceInfo()
+        assert ri["fwd_persistent"] == ri["bwd_persistent"] == ri["lstm_layers"] == cfg["layers"] and net.recoveries == 0, ri
+        for r in res:
+            assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
+        return res[0]
+
+    base = run()
+    monkeypatch.setenv("EESEN_FWD_NARROW2", "0")
+    wide = run()
+    assert not np.array_equal(wide[0], base[0])          # another kernel really ran
+    assert rel_err(base[0], wide[0]) < 2e-6 and rel_err(base[1], wide[1]) < 1e-4
+
+
 @pytest.mark.parametrize("over", [dict(T=200, S=16, H=64, layers=3), dict(T=130, S=20, H=96, layers=2, min_frac=0.3)])
 def test_middle_first_input_gemm_is_bit_identical(gpu, over, monkeypatch):
     """net.cpp "the middle first": the middle rows of the next layer's input GEMM start on the side stream when both chains of the
