@@ -1035,7 +1035,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_kernel(LstmLayerD
 //   A: lane (ks, ab, x) loads 16 bytes of sequence x at k = pair*64 + (ks*8 + ab)*4: per sequence and load two whole lines;
 //   instruction (pair, r, ABID) takes component r: class ks covers k = pair*64 + ks*32 + ABID*4 + r;
 //   B: lane (ks, cb = ab, x) holds W_m^T[unit cb*4 + x][that k]; D: vgpr i, lane (ks, cb, x) -> out[sequence i][unit cb*4 + x].
-// Shapes: H % 32 == 0, K = 4H split over the 8 waves in pairs of chunks (CPW even), no dropout, gate gradients below 2 GB.
+// Shapes: H % 32 == 0 up to 512 cells (K = 4H split over the 8 waves in CPW / 2 pairs of 64-float chunks, CPW = 2 ceil(H / 128); chunks
+// beyond 4H read as zero -- the recipes' 320 cells run as CPW = 6 since round 5), no dropout, gate gradients below 2 GB.
 // ST = 8 (round 5): TWO 4-sequence tiles per workgroup against the same resident W_m^T -- for batches whose 4-sequence grid needs
 // more workgroups than there are CUs (S = 64 at H = 512: 512), where the alternative was the 16 x 16 tile and its 128 KB of
 // operands per workgroup and step.  The MFMA chain doubles (1.8 us), the operand fetch is 64 KB, the hand-off, the drain and the
@@ -2017,15 +2018,18 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
   // before the one-tile form (the tests' A/B arm: same gate gradients bit for bit)
   for (int pass = 0; pass < 2; ++pass) {
     const int stq = (L0.bwd_q4_st8 == 2) == (pass == 0) ? 8 : 4;
-    if (!L0.bwd_q4 || L0.drop_mode || L0.H % 128 != 0 || L0.H / 64 > 8 || chunk < L0.T) break;
+    // (round 5: any whole number of 32-unit workgroups up to 512 cells -- the recipes' 320 among them: the waves' k chunks beyond 4H read
+    // as zero and their weights ARE zero, so K = 4H need not fill the 8 waves x CPW / 2 pairs exactly)
+    if (!L0.bwd_q4 || L0.drop_mode || L0.H % 32 != 0 || L0.H > 512 || chunk < L0.T) break;
     if (stq == 4 && !(stile == 8 && L0.S % 4 == 0)) continue;
     if (stq == 8 && !(L0.bwd_q4_st8 && L0.S % 8 == 0 && L0.S > 8)) continue;
-    const int cpw = L0.H / 64;   // 2, 4 or 8
+    const int cpw = 2 * ((L0.H + 127) / 128);   // 2, 4, 6 or 8 chunks of 32 floats per wave: K = 4H in 8 waves x (cpw / 2) pairs of 64
     dim3 grid(L0.H / 32, L0.ndir, L0.S / stq), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
     bool fit = false;
 #define EESEN_Q4(CPW) (stq == 8 ? fits(lstm_bwd_persistent_q4_kernel<CPW, 8>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, 4>, grid, NW * 64))
     if (cpw == 8) fit = EESEN_Q4(8);
+    else if (cpw == 6) fit = EESEN_Q4(6);
     else if (cpw == 4) fit = EESEN_Q4(4);
     else if (cpw == 2) fit = EESEN_Q4(2);
 #undef EESEN_Q4
@@ -2041,6 +2045,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     else coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, 4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role);         \
   } while (0)
       if (cpw == 8) EESEN_Q4(8);
+      else if (cpw == 6) EESEN_Q4(6);
       else if (cpw == 4) EESEN_Q4(4);
       else EESEN_Q4(2);
 #undef EESEN_Q4

@@ -16,7 +16,7 @@ GEMM_BENCH_ONLY="one tile" timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace
 unset EESEN_FWD_MID
 cd $R
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_calib -name "*.db") > $O/${TAG}_pmc_fetch_calibration.md
-timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 python scripts/rocpd_summary.py $(find $O/prof_$TAG -name "*_results.db" | head -1) > $O/${TAG}_kernel_stats.md
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_FETCH_SIZE $O/pmc_${TAG}_WRITE_SIZE -name "*.db") > $O/${TAG}_pmc_fetch_write.md
 python scripts/rocpd_pmc_summary.py $(find $O/pmc_${TAG}_SQ -name "*.db") > $O/${TAG}_pmc_sq.md

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round 5, GPU call 5: the 4 x 32 backward tile at cell counts that are not multiples of 128 (the recipes' 320: CPW = 6), A/B on one box.
+mkdir -p gpurun_out/r5e; O=gpurun_out/r5e
+export TMPDIR=/tmp
+( timeout 400 python -m pytest -x -q tests/test_gpu_parity.py -k "backward_tiles or two_sequence_tiles or recipe_shape or odd_shapes or unaligned or train_step_parity" 2>&1 | tail -8 ) > $O/tests_new.log 2>&1; cat $O/tests_new.log
+rec() { local label=$1; shift
+  ( timeout 200 env "$@" python -c "
+import json, bench
+for S, n, lim in ((10, 120, 25000), (20, 120, 25000), (32, 256, 100000), (64, 256, 100000)):
+    r = bench.recipe_leg(0, S, n, lim)
+    print('$label recipe S', S, round(r['ms_per_minibatch'], 2), 'ms/minibatch', round(r['padded_frames_per_s']), 'padded fps', r['persistent_layer_passes'], flush=True)
+" 2>/dev/null ) >> $O/recipe.log 2>&1; }
+rec default A=1
+rec q4off EESEN_BWD_Q4=0
+rec default_overlap0 EESEN_OVERLAP=0
+rec st8off EESEN_BWD_Q4_ST8=0
+cat $O/recipe.log

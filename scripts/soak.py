@@ -9,6 +9,8 @@ from eesen_amd.api import Net, Ctc, CuMatrix
 cfg_name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 cfg = synth.config(cfg_name)
+if len(sys.argv) > 3:
+    cfg["S"] = int(sys.argv[3])      # e.g. `soak.py cfg2 300 64`: --num-sequence 64 (two forward workgroups per CU, two-tile backward kernel)
 layers = synth.make_model(max_grad=50.0, **cfg); batch = synth.make_batch(**cfg)
 net = Net.from_layers(layers); net.SetTrainOptions(4e-5, 0.9)
 ctc = Ctc()
