@@ -306,8 +306,9 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int 
     """Not the headline: the reference's OWN recipe shape -- 4 x 320 BiLSTM on 120-d features (40 fbanks + deltas), ~45 phone
     targets, --num-sequence 10 (20 as the second point) --frame-num-limit 25000, utterances of a length-sorted list with WSJ-like
     durations (asr_egs/wsj/run_ctc_phn.sh:65-85, steps/train_ctc_parallel.sh:13-21) -- through the trainer's own path: greedy
-    grouping, device feeder (every minibatch has its own T and S), Propagate / CTC / Backpropagate.  H = 320 is not a multiple of
-    128, so the backward pass cannot take the 4 x 32 tile: this leg measures the fallbacks instead of assuming them."""
+    grouping, device feeder (every minibatch has its own T and S), Propagate / CTC / Backpropagate.  (H = 320 is not a multiple of
+    128: up to round 4 the backward pass fell to the 8-sequence tile here; since round 5 it takes the 4 x 32 tile with K = 4H not
+    filling the waves' chunk pairs -- lstm_bwd_persistent_q4_kernel<6, .> -- wherever S is a multiple of 4.)"""
     from eesen_amd.api import Net, Ctc, CuMatrix, Feeder
     from eesen_amd.batching import assemble
     cfg = dict(kind="BiLstmParallel", layers=4, H=320, D=120, K=46)
