@@ -84,6 +84,7 @@ struct LstmLayerDev {
   // kernel selection switches (tuning.h; all 1 in production): XCD-aware role map, time-multiplexed forward kernel, 4 x 32 and
   // K-split backward tiles
   int xcd_map = 1, fwd_mux = 1, bwd_q4 = 1, bwd_ksplit = 1, bwd_mux = 1;
+  int fwd_t16_small = 1; // batches of <= 16 sequences on narrow layers: the 16 x 8 tile (bf16-pipe kernel) instead of the 32 x 4 fp32 tile (tuning.h: EESEN_FWD_T16_SMALL)
   int fwd_narrow2 = 1;  // the narrow bf16-pipe forward tile as up to two workgroups per CU where a census has seen them resident (tuning.h: EESEN_FWD_NARROW2)
   int bwd_q4_st8 = 1;   // the 4 x 32 backward tile with TWO 4-sequence tiles per workgroup where one does not fit (tuning.h: EESEN_BWD_Q4_ST8)
   // eesen_net_set_forward_precision(1): the recurrent product m_{t-1} W_m^T of the persistent forward kernel on bf16 operands with

@@ -1734,7 +1734,9 @@ static FwdTile fwd_tile(const LstmLayerDev& L) {
   const int ncu = share_of_cus();
   // (wide layers take the 16-sequence tile at ANY batch size: their 32 x 4 tile would need H/4 x ndir workgroups -- 512 at H = 1024 --
   // and a batch of <= 16 sequences fell back to the per-step kernels: seen at S = 16, T = 3000 with the six-layer cfg5 stack, round 4)
-  const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2);
+  // (S <= 16 on narrow layers: the 32 x 4 tile has twice the workgroups of the 16 x 8 tile -- but only the latter has the bf16-pipe
+  // kernel; LstmLayerDev::fwd_t16_small takes it there too where that kernel applies)
+  const bool t16_ok = L.H % 8 == 0 && (L.S > 16 || need > 2 || (L.fwd_t16_small && L.fwd_split && !L.drop_mode && L.X && L.H % 32 == 0));
   // The narrow 16 x 8 tile needs H/8 x ndir x S/16 workgroups: one per CU up to S = 32 at H = 512.  Beyond that, up to TWO per CU
   // (round 5; S = 64 at H = 512: 512 workgroups of the bf16-pipe kernel, 108 registers) where a residency census has SEEN that many
   // co-resident (narrow2_ok) -- two chains per CU interleaved by the hardware: 3.5 us per step for 64 sequences against 4.2 on the
@@ -2021,10 +2023,12 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     // (round 5: any whole number of 32-unit workgroups up to 512 cells -- the recipes' 320 among them: the waves' k chunks beyond 4H read
     // as zero and their weights ARE zero, so K = 4H need not fill the 8 waves x CPW / 2 pairs exactly)
     if (!L0.bwd_q4 || L0.drop_mode || L0.H % 32 != 0 || L0.H > 512 || chunk < L0.T) break;
-    if (stq == 4 && !(stile == 8 && L0.S % 4 == 0)) continue;
-    if (stq == 8 && !(L0.bwd_q4_st8 && L0.S % 8 == 0 && L0.S > 8)) continue;
+    // (a ragged last tile is masked in the kernel -- operand rows and cells beyond S -- so S need not be a multiple of the tile: the
+    // recipes' default --num-sequence 10 takes this tile too)
+    if (stq == 4 && stile != 8) continue;
+    if (stq == 8 && !(L0.bwd_q4_st8 && L0.S > 8)) continue;
     const int cpw = 2 * ((L0.H + 127) / 128);   // 2, 4, 6 or 8 chunks of 32 floats per wave: K = 4H in 8 waves x (cpw / 2) pairs of 64
-    dim3 grid(L0.H / 32, L0.ndir, L0.S / stq), block(NW * 64);
+    dim3 grid(L0.H / 32, L0.ndir, cdiv(L0.S, stq)), block(NW * 64);
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
     bool fit = false;
 #define EESEN_Q4(CPW) (stq == 8 ? fits(lstm_bwd_persistent_q4_kernel<CPW, 8>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, 4>, grid, NW * 64))

@@ -482,12 +482,14 @@ def test_adaptive_update_rules(gpu, rule, tmp_path):
         net.SetUpdateAlgorithm("Adam")
 
 
-@pytest.mark.parametrize("over", [dict(T=40, layers=2), dict(T=40, layers=2, H=320, D=120), dict(T=30, layers=1, H=192, S=16), dict(T=30, layers=1, H=448)])
+@pytest.mark.parametrize("over", [dict(T=40, layers=2), dict(T=40, layers=2, H=320, D=120), dict(T=30, layers=1, H=192, S=16), dict(T=30, layers=1, H=448),
+                                  dict(T=30, layers=2, H=320, D=120, S=10), dict(T=30, layers=1, S=22), dict(T=30, layers=1, S=13, H=256)])
 def test_backward_tiles_agree_and_are_deterministic(gpu, over, monkeypatch):
     """The 4-sequence x 32-unit backward tile (default where the shape allows) and the 8-sequence tile it replaced
     (EESEN_BWD_Q4=0: v_mfma_f32_4x4x1 with CBSZ = 2, part of W_m^T in LDS) on the same inputs: each bit-identical run after
     run (the in-kernel hand-off leaves no room for a race), and equal to each other up to the summation order.  Since round 5 also
-    at cell counts that are not multiples of 128 (the recipes' 320; 192; 448): K = 4H then does not fill the waves' chunk pairs."""
+    at cell counts that are not multiples of 128 (the recipes' 320; 192; 448): K = 4H then does not fill the waves' chunk pairs -- and
+    at sequence counts that are not multiples of 4 (the recipes' default --num-sequence 10): the last tile is ragged."""
     from eesen_amd.api import Net, Ctc, CuMatrix
     cfg = synth.config("cfg2"); cfg.update(over)      # S = 32, bidirectional
     layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
@@ -512,7 +514,7 @@ def test_backward_tiles_agree_and_are_deterministic(gpu, over, monkeypatch):
     assert rel_err(res["1"][0][0], res["0"][0][0]) < 1e-5 and rel_err(res["1"][0][1], res["0"][0][1]) < 1e-5
 
 @pytest.mark.parametrize("over", [dict(T=40, layers=2), dict(T=33, layers=1, H=256, S=24), dict(T=36, layers=2, S=64),
-                                  dict(T=33, layers=2, H=320, D=120, S=32), dict(T=33, layers=2, H=320, D=120, S=64)])
+                                  dict(T=33, layers=2, H=320, D=120, S=32), dict(T=33, layers=2, H=320, D=120, S=64), dict(T=33, layers=1, S=52)])
 def test_two_sequence_tiles_per_backward_workgroup(gpu, over, monkeypatch):
     """lstm_bwd_persistent_q4_kernel<., 8> (round 5): two 4-sequence tiles per workgroup against the same resident W_m^T -- what a
     narrow layer takes at --num-sequence 64, where the one-tile grid needs 512 workgroups.  Per tile the same instructions in the
