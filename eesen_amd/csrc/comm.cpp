@@ -386,6 +386,23 @@ void Net::bucket_allreduce(int li, hipStream_t producer) {
   if (!comm || !layers[li].p_n) return;
   bucket_log.push_back(li);
   EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], producer));
+  if (tn.comm_defer) { deferred_buckets.push_back(li); return; }   // issued by flush_deferred_buckets, in this order
+  issue_bucket(li);
+}
+
+// Deferred mode (EESEN_COMM_DEFER=1): every bucket of this backward pass, in the order the layers completed, once the main stream's
+// last recurrence and input-gradient GEMM have run -- the collectives then meet only the side stream's finite GEMMs on the chip, never
+// a persistent grid that needs every CU.  Same buckets, same order, same sums as the overlapped mode; update() waits bucket by bucket.
+void Net::flush_deferred_buckets() {
+  if (!comm || deferred_buckets.empty()) return;
+  if (!ev_bwd_done) EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_bwd_done, hipEventDisableTiming));
+  EESEN_HIP_CHECK(hipEventRecord(ev_bwd_done, st));
+  EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_bwd_done, 0));
+  for (int li : deferred_buckets) issue_bucket(li);
+  deferred_buckets.clear();
+}
+
+void Net::issue_bucket(int li) {
   EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_ready[li], 0));
   const bool top = li == top_trainable();  // its block ends at P: the liveness word (4 floats of padding) rides along
   // phase 6 of the profiling spans (eesen_net_get_phase_spans): this bucket's collective on the communicator's stream, from the
@@ -418,8 +435,10 @@ void Net::backpropagate_zero() {
   EESEN_HIP_CHECK(hipSetDevice(device));
   if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, (P + kLiveWords) * sizeof(float), st));
   bucket_log.clear();
+  deferred_buckets.clear();
   live_valid = comm != nullptr;
   for (int li = (int)layers.size() - 1; li >= 0; --li) bucket_allreduce(li, st);
+  flush_deferred_buckets();
 }
 
 // How many ranks had a minibatch in the step whose top bucket was issued last (the sum of the liveness words).  For a

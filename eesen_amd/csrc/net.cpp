@@ -211,6 +211,7 @@ Net::~Net() {
   if (ev_gate_done) (void)hipEventDestroy(ev_gate_done);
   for (auto& e : ev_ready) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_bucket) if (e) (void)hipEventDestroy(e);
+  if (ev_bwd_done) (void)hipEventDestroy(ev_bwd_done);
   if (own_stream) (void)hipStreamDestroy(st);
 }
 
@@ -872,6 +873,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   ws2.reserve(need_ws);
   int dg_slot = 0;
   bool side_pending[2] = {false, false};
+  deferred_buckets.clear();
   // Weight-gradient GEMMs on the side stream, under the next-lower layer's recurrence: decided per minibatch.  It pays beside the
   // small backward tiles (cfg2 at S = 32: 1.6 of 22.8 ms) and COSTS beside the 16-sequence tile a narrow layer takes at
   // --num-sequence 64 -- measured (round 5, cfg2 shape at S = 64, `profiles/r05_s64_step_timeline.txt`): the W_x-gradient GEMM ran
@@ -1012,6 +1014,7 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
     }
   }
   if (in_diff) copy2d(st, d, ld_d, in_diff, ldi, rows, layers[0].din);
+  flush_deferred_buckets();   // EESEN_COMM_DEFER=1: the exchange starts here, behind the last recurrence (comm.cpp)
   // the gradient buffer is complete only when the side stream has drained: make the caller's stream wait for it
   for (int k = 0; k < 2; ++k)
     if (side_pending[k]) EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_grad[k], 0));

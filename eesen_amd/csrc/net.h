@@ -161,6 +161,12 @@ struct Net {
   Comm* comm = nullptr;                       // not owned
   std::vector<hipEvent_t> ev_ready, ev_bucket;
   std::vector<char> bucket_pending;
+  // EESEN_COMM_DEFER=1 (tuning.h): the buckets of a backward pass are issued when its last recurrence has run instead of as each
+  // layer's gradients are enqueued -- no all-reduce kernel then competes with a persistent grid for CUs (comm.cpp)
+  std::vector<int> deferred_buckets;
+  hipEvent_t ev_bwd_done = nullptr;
+  void issue_bucket(int li);
+  void flush_deferred_buckets();
   std::vector<struct Ctc*> guards;   // the Ctc objects guarding on this Net's error word (eesen_ctc_set_guard): unhooked in ~Net
   bool grads_sanitized = false;   // this step's gradients went through an all-reduce that zeroed them on a raised error word: update() must apply
   bool live_valid = false;        // the liveness word behind the gradient buffer was written for THIS step (backpropagate / backpropagate_zero)
@@ -169,7 +175,7 @@ struct Net {
   void set_comm(Comm* c);
   int top_trainable() const;
   int live_ranks();
-  void bucket_allreduce(int li, hipStream_t producer);
+  void bucket_allreduce(int li, hipStream_t producer);   // (deferred with EESEN_COMM_DEFER=1: see flush_deferred_buckets)
   void wait_buckets_host();
   void backpropagate_zero();
   void allreduce_grads(Comm* c);

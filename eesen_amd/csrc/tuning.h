@@ -48,6 +48,12 @@
 //   ---- data-parallel exchange (comm.cpp) ----------------------------------------------------------------------------------
 //   EESEN_RCCL_LIBRARY      librccl.so.1   library to dlopen for the nccl* entry points (tests: the stand-in)
 //   EESEN_COMM_TIMEOUT_S    600      watchdog: seconds after which an unfinished collective aborts the communicator
+//   EESEN_COMM_DEFER        0        1: a backward pass's gradient buckets are all-reduced when its LAST recurrence has run (top-down, one
+//                                    after the other on the communication stream) instead of each as soon as its layer's gradients
+//                                    are enqueued: RCCL's kernels (248-256 VGPRs) cannot be resident beside any backward tile of a
+//                                    BASELINE shape, so "overlapped" buckets run in the gaps between recurrences and may hold CUs the
+//                                    next recurrence wants while a peer is late; deferred, the exchange is serial and bounded by the
+//                                    ring time.  For the first real multi-GPU run to choose by measurement
 //   EESEN_COMM_PORT         MASTER_PORT+17  rendezvous port of the hosts that create the communicator from the environment
 #pragma once
 #include <cstdlib>
@@ -60,6 +66,7 @@ struct Tuning {
   int spin_limit = 400000;
   bool spin_limit_set = false;
   int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
+  int comm_defer = 0;
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -86,6 +93,7 @@ struct Tuning {
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
     t.fwd_split = num("EESEN_FWD_SPLIT", 1);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
+    t.comm_defer = num("EESEN_COMM_DEFER", 0);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;
     t.poll_ns = getenv("EESEN_POLL_NS");

@@ -48,12 +48,16 @@ def test_host_scalars_and_barrier(comm):
     comm.barrier()
 
 
+@pytest.mark.parametrize("defer", ["0", "1"])
 @pytest.mark.parametrize("cfg_name,over", [("small_bi", {}), ("cfg2", dict(T=40, S=16, layers=3)), ("tiny_bi", dict(layers=3, proj=12, H=12, T=20, S=4))])
-def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name, over):
+def test_bucketed_bulk_and_detached_paths_are_bit_identical(gpu, comm, cfg_name, over, defer, monkeypatch):
+    """defer = "1": EESEN_COMM_DEFER (round 5) -- the same buckets in the same order, issued when the backward pass's last recurrence
+    has run instead of as each layer's gradients are enqueued: bit-identical to every other path, the zero-gradient protocol included."""
     from eesen_amd.api import Net, Ctc
     cfg = synth.config(cfg_name); cfg.update(over)
     layers = synth.make_model(max_grad=0.5, **cfg)
     batch = synth.make_batch(**cfg)
+    monkeypatch.setenv("EESEN_COMM_DEFER", defer)     # read when a Net is created
 
     def run(mode):
         net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()

@@ -118,9 +118,11 @@ def _merge(batches):
     return synth.Batch(feats=feats.reshape(T * S, D), lens=lens, labels=labels, T=T, S=S)
 
 
-def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(gpu, tmp_path):
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(gpu, tmp_path, defer):
+    """(defer = "1": EESEN_COMM_DEFER -- the buckets issued behind the backward pass's last recurrence; same sums.)"""
     cfg = synth.config("small_bi"); cfg.update(S=32, T=60)
-    res, rcs, errs = launch("parity", 2, tmp_path, dict(cfg="small_bi", S=32, T=60, steps=3))
+    res, rcs, errs = launch("parity", 2, tmp_path, dict(cfg="small_bi", S=32, T=60, steps=3), env_extra={"EESEN_COMM_DEFER": defer})
     assert rcs == [0, 0] and all(r is not None for r in res), errs
     assert not str(res[0]["error"]) and not str(res[1]["error"]), (res[0]["error"], res[1]["error"])
     assert np.array_equal(res[0]["params"], res[1]["params"])            # the ranks hold the same model, bit for bit
@@ -145,6 +147,11 @@ def test_two_ranks_each_holding_persistent_grids_on_one_gpu(gpu, tmp_path):
     from eesen_amd import nnet_io
     nsoak = int(os.environ.get("EESEN_SOAK_STEPS", "200"))
     over = dict(S=64, T=80, H=256, layers=2)
+    # first the same run with the buckets DEFERRED behind the backward pass (EESEN_COMM_DEFER=1), no soak: same model bit for bit
+    (tmp_path / "defer").mkdir()
+    res_d, rcs_d, errs_d = launch("persist", 2, tmp_path / "defer", dict(cfg="cfg2", steps=3, soak=0, **over),
+                                  env_extra={"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2", "EESEN_COMM_DEFER": "1"}, timeout=300)
+    assert rcs_d == [0, 0] and all(r is not None and not str(r["error"]) for r in res_d), [e[-2000:] for e in errs_d]
     cfg = synth.config("cfg2"); cfg.update(over)
     res, rcs, errs = launch("persist", 2, tmp_path, dict(cfg="cfg2", steps=3, soak=nsoak, **over),
                             env_extra={"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2"}, timeout=600)
@@ -154,6 +161,7 @@ def test_two_ranks_each_holding_persistent_grids_on_one_gpu(gpu, tmp_path):
         assert list(r["recurrence_steps"]) == [2, 2, 2] and list(r["recurrence"]) == [2, 2, 2], (r["recurrence_steps"], r["recurrence"])   # {LSTM layers, fwd persistent, bwd persistent}
         assert int(r["recoveries"]) == 0 and int(r["dropped"]) == 0
     assert np.array_equal(res[0]["params_steps"], res[1]["params_steps"]) and np.array_equal(res[0]["params"], res[1]["params"])
+    assert np.array_equal(res_d[0]["params_steps"], res[0]["params_steps"]) and np.array_equal(res_d[1]["params_steps"], res[0]["params_steps"])
     layers = synth.make_model(max_grad=0.05, **cfg)
     full = synth.make_batch(**cfg)
     want, _ = _single_process(cfg, [full] * 3, persistent="1")     # one process, S = 64, the whole device
@@ -196,10 +204,11 @@ def test_three_ranks_and_odd_shard_sizes(gpu, tmp_path):
     assert rel_err(res[0]["params"], want) < 1e-5
 
 
-def test_uneven_shards_zero_gradient_protocol(gpu, tmp_path):
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_uneven_shards_zero_gradient_protocol(gpu, tmp_path, defer):
     cfg = synth.config("small_bi"); cfg.update(S=6, T=40)
     steps, world = 4, 2
-    res, rcs, errs = launch("uneven", world, tmp_path, dict(cfg="small_bi", S=6, T=40, steps=steps, fewer=2))
+    res, rcs, errs = launch("uneven", world, tmp_path, dict(cfg="small_bi", S=6, T=40, steps=steps, fewer=2), env_extra={"EESEN_COMM_DEFER": defer})
     assert rcs == [0, 0] and all(r is not None for r in res), errs
     # rank 0 trained 4 minibatches, rank 1 only 2 and then followed with zero gradients for exactly the 2 steps it lacked
     assert [int(r["real_steps"]) for r in res] == [4, 2] and [int(r["zero_steps"]) for r in res] == [0, 2]
