@@ -704,6 +704,9 @@ def main():
                                              {"native": "RCCL all-reduce(sum, fp32) per layer bucket on a communication stream, issued by libeesen_hip.so as each layer's weight-gradient kernels are enqueued",
                                               "bulk": "one RCCL all-reduce of the whole gradient buffer after the backward pass (libeesen_hip.so)",
                                               "torch": "one torch.distributed all-reduce of the whole gradient buffer"}[args.comm]),
+                       "exchange_schedule": (None if not multi else ("deferred: every bucket behind the backward pass's last recurrence (EESEN_COMM_DEFER=1)"
+                                                                       if os.environ.get("EESEN_COMM_DEFER", "0") not in ("", "0") else
+                                                                       "overlapped: each bucket as soon as its layer's gradients are enqueued (default; EESEN_COMM_DEFER=1 is the other one)")),
                        "real_frames_per_s": real * K / dt, "padded_frames_per_step": padded, "real_frames_per_step": real,
                        "h2d": "inside the timed step: S host matrices -> pinned slot -> one PCIe copy -> time-major interleave on the device (feeder), double-buffered",
                        "device_resident_frames_per_s": resident["frames_per_s"] if resident else None,

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf_kernel(LstmLay
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
-  if (T < 0) {   // residency census (census_ok): every workgroup checks in and waits, bounded on the wall clock, until the whole grid has
+  if (T < 0) {   // residency census (bf_census): every workgroup checks in and waits -- at most 5 ms of wall clock -- until the whole grid has checked in
     if (tid == 0) {
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long t0 = wall_clock64();
