@@ -148,6 +148,13 @@ def test_python_trainer_treats_its_list_as_its_own_shard(monkeypatch, tmp_path):
     o = t.build_parser().read(["--print-args=false", "--num-jobs=4", "--job-id=3", "scp:feats_tr.3.scp", "ark:l", "m", "o"])
     assert o.shard_shared_list is False and o.num_jobs == 4 and o.job_id == 3 and o.args == ["scp:feats_tr.3.scp", "ark:l", "m", "o"]
     assert t.build_parser().read(["--print-args=false", "--shard-shared-list=true", "a", "b", "c", "d"]).shard_shared_list is True
+    # node-local shards under one path are not "the same list": the explicit override, off by default; the check's collective
+    # is entered by EVERY job whatever its switches (they travel with the hash), and both trainers hash with FNV-1a
+    assert o.allow_identical_lists is False
+    assert t.build_parser().read(["--print-args=false", "--allow-identical-lists=true", "a", "b", "c", "d"]).allow_identical_lists is True
+    assert "1469598103934665603" in src and "if comm is not None:" in src and "crc32" not in src
+    native = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eesen_amd", "csrc", "tools", "train_ctc_parallel.cc")).read()
+    assert "1469598103934665603ull" in native and "allow-identical-lists" in native
 
 
 def test_rendezvous_survives_stray_and_half_open_peers():
