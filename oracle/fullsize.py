@@ -48,10 +48,16 @@ CASES = {
     #   _s16: the full SIX-layer stack at S = 16 (how six 1024-cell layers carry the 3000-frame lattice's round-off down).
     "full_cfg5_b3000_l2": ("cfg5", dict(layers=2)),
     "full_cfg5_b3000_s16": ("cfg5", dict(S=16)),
+    # round 5: the kernels narrow layers take at --num-sequence 64 (two forward workgroups per CU, two 4-sequence tiles per backward
+    # workgroup, no side stream) -- BASELINE configs[1]'s net on 64 utterances ...
+    "full_cfg2_s64": ("cfg2", dict(S=64)),
+    # ... and the recipes' own width (asr_egs/wsj/utils/model_topo.py: 320 cells per direction on 120-d features) at full length:
+    # the 4 x 32 backward tile where K = 4H does not fill the waves' chunk pairs (lstm_bwd_persistent_q4_kernel<6, 4>)
+    "full_recipe320": ("cfg2", dict(H=320, D=120)),
 }
 # cases whose reference step is too long to repeat inside the default GPU suite: the committed fixture (made by this script from
 # the reference) is the arbiter unless EESEN_FULLSIZE_LIVE=1
-FIXTURE_FIRST = {"full_cfg5_b1000", "full_cfg5_b3000_l2", "full_cfg5_b3000_s16", "full_cfg3"}
+FIXTURE_FIRST = {"full_cfg5_b1000", "full_cfg5_b3000_l2", "full_cfg5_b3000_s16", "full_cfg3", "full_cfg2_s64", "full_recipe320"}
 # cases that only fit the host's memory with the layer-by-layer backward of ref_driver.cc (ref_net_backpropagate_lowmem: the
 # reference's own per-layer Backpropagate + Update in Net::Backpropagate's order, each layer's state buffers released after use)
 LOWMEM = {"full_cfg5_b3000_l2", "full_cfg5_b3000_s16", "full_cfg3"}

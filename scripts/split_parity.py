@@ -10,7 +10,7 @@ reps = json.load(open(sys.argv[1]))
 commit = sys.argv[2] if len(sys.argv) > 2 else ""
 sys.path.insert(0, ROOT)
 from eesen_amd.build import csrc_digest  # noqa: E402
-groups = {"cfg2": [], "cfg3": [], "cfg4": [], "cfg5": []}
+groups = {"cfg2": [], "cfg3": [], "cfg4": [], "cfg5": [], "recipe320": []}
 for r in reps:
     for k in groups:
         if ("full_" + k) in r["case"]:

@@ -291,6 +291,19 @@ def test_cfg2_full_length_per_step_kernels_against_reference(gpu, record):
     _check("full_cfg2", False, record)
 
 
+def test_cfg2_net_at_num_sequence_64_against_reference(gpu, record):
+    """Round 5: what narrow layers run at --num-sequence 64 -- the bf16-pipe forward tile as two workgroups per CU (census-backed),
+    lstm_bwd_persistent_q4_kernel<8, 8>, gradient GEMMs off the side stream -- against the reference's own step on the same 64
+    utterances of 1000 frames (fixture made by oracle/fullsize.py from the reference; EESEN_FULLSIZE_LIVE=1 repeats it live)."""
+    _check("full_cfg2_s64", True, record)
+
+
+def test_recipe_width_320_cells_full_length_against_reference(gpu, record):
+    """Round 5: the recipes' own width, 4 x 320 cells on 120-d features, S = 32, T = 1000 -- the 4 x 32 backward tile with K = 4H not
+    filling the waves' chunk pairs (lstm_bwd_persistent_q4_kernel<6, 4>), the narrow bf16-pipe forward tile at H = 320."""
+    _check("full_recipe320", True, record)
+
+
 def test_cfg4_wide_layer_full_length_against_reference(gpu, record):
     _check("full_cfg4_layer", True, record)
 
