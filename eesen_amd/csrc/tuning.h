@@ -36,7 +36,8 @@
 //   EESEN_FWD_NARROW2       1        0: the wide 16 x 16 forward tile instead of TWO workgroups of the narrow bf16-pipe tile per CU where
 //                                    the one-per-CU grid is full (--num-sequence 64 at 512 cells: 512 workgroups, seen co-resident
 //                                    by a one-time census)
-//   EESEN_GPU_SHARE         1        n: the persistent grids are sized against 1/n of the device's CUs (n processes on one GPU)
+//   EESEN_GPU_SHARE         1        n: the persistent grids are sized against 1/n of the device's CUs (n processes on one GPU); read once
+//                                    per PROCESS
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
 //                                    what counter-collecting runs (rocprofv3 --pmc lets ONE kernel run at a time) must set
