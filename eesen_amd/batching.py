@@ -22,12 +22,15 @@ class Minibatch:
     mats: List[np.ndarray] = None    # the S utterance matrices [T_s x D] (kept only with interleaved=False)
 
 
+MAX_LABELS = 2047   # include/eesen_hip.h, eesen_ctc_eval_parallel: lattices of up to 4096 positions (511 / 1024 up to round 4)
+
+
 @dataclass
 class AssemblyStats:
     num_no_tgt_mat: int = 0      # utterances without targets (train-ctc-parallel.cc:152-156)
     num_too_long: int = 0        # utterances above the frame limit (:161-164)
     num_other_error: int = 0     # utterances the CTC cannot take: empty transcript (the reference reads alpha column -1 there,
-                                 # ctc-loss.cc:151) or more than 511 labels (expanded length above the 1024 lattice positions of a sweep)
+                                 # ctc-loss.cc:151) or more than 2047 labels (expanded length above the 4096 lattice positions a sweep holds)
     warnings: List[str] = field(default_factory=list)
 
 
@@ -70,9 +73,9 @@ def assemble(features: Iterable[Tuple[str, np.ndarray]], targets: Dict[str, np.n
                 pending = None
                 continue
             n_lab = len(targets[utt])
-            if n_lab == 0 or n_lab > 511:
+            if n_lab == 0 or n_lab > MAX_LABELS:
                 stats.num_other_error += 1
-                stats.warnings.append(f"{utt}, {'empty transcript' if n_lab == 0 else f'{n_lab} labels exceed the 511 a lattice sweep holds'}; ignoring")
+                stats.warnings.append(f"{utt}, {'empty transcript' if n_lab == 0 else f'{n_lab} labels exceed the {MAX_LABELS} a lattice sweep holds'}; ignoring")
                 pending = None
                 continue
             if mat.shape[0] > frame_limit:

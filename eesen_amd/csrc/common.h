@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -55,11 +56,20 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
-  // returns true when a new allocation was made (contents undefined then)
+  // returns true when a new allocation was made (contents undefined then; `cap` elements, possibly more than n).
+  // The FIRST allocation is exact (a fixed-shape workload pays for what it uses); a buffer that has to GROW takes half as much again:
+  // the recipes sort their lists by length (train_ctc_parallel.sh:84-89), so T grows from minibatch to minibatch through a whole
+  // epoch, and exact growth meant a hipFree -- which drains the device -- and a hipMalloc of every activation buffer on EVERY
+  // minibatch (round 5, measured through the trainer binaries: 331 k padded frames/s end to end where the same loop on warm buffers
+  // does 1.1 M).
   bool reserve(size_t n) {
     if (n <= cap) return false;
+    const size_t want = cap ? std::max(n, cap + cap / 2) : n;
     release();
-    EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+    if (hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)) == hipSuccess) { cap = want; return true; }
+    p = nullptr;
+    (void)hipGetLastError();
+    EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));   // (no room for the margin: exactly what is needed)
     cap = n;
     return true;
   }

@@ -808,7 +808,7 @@ void Net::forward_pass() {
       ldx = ldY;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       const int ldo = pad4(L.dout);
-      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, L.out.cap * sizeof(float), st));   // (the whole allocation: pad columns of rows a later, longer minibatch uses)
       { const int ti_ = timer.begin(st, 2);
       gemm_f32(st, true, true, rows, L.dout, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, L.out.p, ldo,
                params.p + L.p_off + L.off_b, nullptr, 0, 0, fwd_bf16);
@@ -817,7 +817,7 @@ void Net::forward_pass() {
       ldx = ldo;
     } else if (L.is_activation()) {  // sigmoid-layer.h:44-46, tanh-layer.h:44-46
       const int ldo = pad4(L.dout);
-      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, L.out.cap * sizeof(float), st));   // (the whole allocation: pad columns of rows a later, longer minibatch uses)
       { const int ti_ = timer.begin(st, 2);
       activation_rows(st, L.kind == EESEN_LAYER_TANH, x, ldx, L.out.p, ldo, rows, L.dout);
       timer.end(st, ti_); }
@@ -825,7 +825,7 @@ void Net::forward_pass() {
       ldx = ldo;
     } else {  // Softmax
       const int ldo = pad4(L.dout);
-      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, (size_t)rows * ldo * sizeof(float), st));
+      if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, L.out.cap * sizeof(float), st));   // (the whole allocation: pad columns of rows a later, longer minibatch uses)
       { const int ti_ = timer.begin(st, 2);
       softmax_rows(st, x, ldx, L.out.p, ldo, rows, L.dout);
       timer.end(st, ti_); }
@@ -838,7 +838,7 @@ void Net::forward_pass() {
   out_ld = ldx;
   if (const Layer& Lb = layers.back(); Lb.out_nb) {   // a padded LSTM layer (or a Tanh over one) is the net's last layer (Seam 2: the only
     const int ldo = pad4(Lb.dout_f);                  // one): the caller gets the file's columns, run by run
-    if (out_f.reserve((size_t)rows * ldo) && ldo != Lb.dout_f) EESEN_HIP_CHECK(hipMemsetAsync(out_f.p, 0, (size_t)rows * ldo * sizeof(float), st));
+    if (out_f.reserve((size_t)rows * ldo) && ldo != Lb.dout_f) EESEN_HIP_CHECK(hipMemsetAsync(out_f.p, 0, out_f.cap * sizeof(float), st));
     for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, x + (size_t)b * Lb.out_hi, ldx, out_f.p + (size_t)b * Lb.out_hf, ldo, rows, Lb.out_hf);
     out_ptr = out_f.p; out_cols = Lb.dout_f; out_ld = ldo;
   }
@@ -862,7 +862,8 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   }
   need_ws = std::max(need_ws, (size_t)16 << 20);  // 64 MB of split-K slabs
   ws.reserve(need_ws);
-  ws_floats = ws.cap;
+  ws_floats = need_ws;   // (what this minibatch asked for, not the allocation: the GEMMs' split-K factor follows the workspace size, and
+                         // an allocation that grew by half for an earlier, longer minibatch must not change this one's summation order)
   dA.reserve((size_t)rows * maxdim);
   dB.reserve((size_t)rows * maxdim);
   if (max_g) {
@@ -993,13 +994,13 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
-      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, ws2.cap, side_lds);
+      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, need_ws, side_lds);
       // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
       for (int dir = 0; dir < nd; ++dir)
         gemm_f32(sg, false, false, 4 * H, H, rows, 1.f, DGl + (size_t)dir * 4 * H, ldG,
                  L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
-                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, ws2.cap, side_lds);
-      lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, ws2.cap);
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, need_ws, side_lds);
+      lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, need_ws);
       timer.end(sg, ti_); }
       bucket_allreduce(li, sg);  // this layer's gradients are complete: sum them over the ranks under the lower layers' backward pass
       if (overlap) {

@@ -23,6 +23,7 @@
 // src/cpucompute/matrix.cc:968-994, compressed-matrix.cc:437-520) and the labels (int32 vectors, binary or text --
 // src/util/kaldi-holder-inl.h:190-260).
 #include <cctype>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -234,8 +235,8 @@ int main(int argc, char** argv) {
           ++num_no_tgt_mat;
           continue;
         }
-        if (tg->second.empty() || tg->second.size() > 511) {  // what the CTC cannot take (the reference reads alpha column -1 for an empty transcript, ctc-loss.cc:151)
-          warnings.push_back(utt + (tg->second.empty() ? ", empty transcript; ignoring" : ", more labels than the 511 a lattice sweep holds; ignoring"));
+        if (tg->second.empty() || tg->second.size() > 2047) {   // (include/eesen_hip.h, eesen_ctc_eval_parallel: lattices of up to 4096 positions)  // what the CTC cannot take (the reference reads alpha column -1 for an empty transcript, ctc-loss.cc:151)
+          warnings.push_back(utt + (tg->second.empty() ? ", empty transcript; ignoring" : ", more labels than the 2047 a lattice sweep holds; ignoring"));
           ++num_other_error;
           continue;
         }
@@ -326,9 +327,9 @@ int main(int argc, char** argv) {
       ck(eesen_feeder_release(feeder, slot));
       std::vector<int> ids, off(1, 0);
       for (const auto& l : cur.labels) { ids.insert(ids.end(), l.begin(), l.end()); off.push_back((int)ids.size()); }
-      if ((long)T * S * out_ld > diff_cap) {
+      if ((long)T * S * out_ld > diff_cap) {   // (grows by half: the list is sorted by length, T rises from minibatch to minibatch)
         if (diff) { ck(eesen_net_synchronize(net)); ck(eesen_dev_free(device, diff)); }
-        diff_cap = (long)T * S * out_ld;
+        diff_cap = std::max((long)T * S * out_ld, diff_cap + diff_cap / 2);
         ck(eesen_dev_alloc(device, diff_cap * 4, reinterpret_cast<void**>(&diff)));
       }
       // Neither call waits for the device: ln p and the decoded ids come back through pinned slots and join the statistics when

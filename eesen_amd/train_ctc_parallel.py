@@ -199,7 +199,7 @@ def main(argv=None) -> int:
             b = next(batches, None)
             return (b, feeder.submit(b.mats)) if b is not None else (None, -1)
 
-        diff = None
+        diff = diff_buf = None
         staged = stage()
         zero_steps = 0
         while True:
@@ -220,9 +220,12 @@ def main(argv=None) -> int:
             net.SetSeqLengths(mb.lens)
             net_out = net.Propagate(feeder.acquire(slot))
             feeder.release(slot)
-            if diff is None or diff.rows != net_out.rows:
+            if diff_buf is None or diff_buf.rows < net_out.rows or diff_buf.cols != net_out.cols:
                 net.Synchronize()                # the old matrix may still be read by queued kernels
-                diff = CuMatrix(net_out.rows, net_out.cols, dev, zero=False)
+                # (grows by half: the list is sorted by length, so T rises from minibatch to minibatch -- a new matrix and a drained
+                # device per minibatch otherwise)
+                diff_buf = CuMatrix(max(net_out.rows, 0 if diff_buf is None else diff_buf.rows * 3 // 2), net_out.cols, dev, zero=False)
+            diff = CuMatrix.view(diff_buf.ptr, net_out.rows, net_out.cols, diff_buf.stride, dev, keepalive=diff_buf)
             # neither call waits for the device (the reference's calls return nothing and only accumulate, ctc-loss.cc:171-192)
             ctc.EvalParallel(mb.lens, net_out, mb.labels, diff, want_pzx=False)
             ctc.ErrorRateMSeq(mb.lens, net_out, mb.labels, deferred=True)

@@ -147,17 +147,19 @@ def test_compressed_feature_archive_against_reference(tmp_path):
 
 
 def test_assembly_skips_utterances_the_ctc_cannot_take():
-    """Empty transcripts (the reference reads alpha column -1 there, ctc-loss.cc:151) and transcripts beyond 511 labels are dropped
-    with a warning and counted as `other errors` instead of aborting the run."""
+    """Empty transcripts (the reference reads alpha column -1 there, ctc-loss.cc:151) and transcripts beyond the 2047 labels a lattice of
+    4096 positions holds are dropped with a warning and counted as `other errors` instead of aborting the run; 600 labels -- beyond
+    the 511 of rounds 1-4 -- train."""
     from eesen_amd.batching import assemble, AssemblyStats
     rng = np.random.default_rng(3)
     feats = [(f"u{i}", rng.standard_normal((10 + i, 4)).astype(np.float32)) for i in range(5)]
     targets = {"u0": np.array([1, 2], np.int32), "u1": np.zeros(0, np.int32), "u2": np.array([3], np.int32),
-               "u3": np.ones(600, np.int32), "u4": np.array([2, 2], np.int32)}
+               "u3": np.ones(2100, np.int32), "u4": np.array([2, 2], np.int32), "u5": np.ones(600, np.int32)}
+    feats.append(("u5", rng.standard_normal((16, 4)).astype(np.float32)))
     st = AssemblyStats()
     got = list(assemble(iter(feats), targets, 2, 1e5, 4, st))
-    assert [k for mb in got for k in mb.keys] == ["u0", "u2", "u4"]
-    assert st.num_other_error == 2 and any("empty transcript" in w for w in st.warnings) and any("511" in w for w in st.warnings)
+    assert [k for mb in got for k in mb.keys] == ["u0", "u2", "u4", "u5"]
+    assert st.num_other_error == 2 and any("empty transcript" in w for w in st.warnings) and any("2047" in w for w in st.warnings)
 
 
 def test_pipe_and_stdin_specifiers(tmp_path):
