@@ -26,6 +26,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--num-sequence", type=int, default=32)
 ap.add_argument("--frame-limit", type=int, default=100000)
 ap.add_argument("--utts", type=int, default=512)
+ap.add_argument("--extract", action="store_true", help="also time net-output-extract over the table (--num-sequence 1 and 32)")
 args = ap.parse_args()
 cfg = dict(kind="BiLstmParallel", layers=4, H=320, D=120, K=46)
 rng = np.random.default_rng(777)
@@ -52,4 +53,16 @@ with tempfile.TemporaryDirectory() as tmp:
         pad = re.search(r"\[TRAINING, ([0-9.e+-]+) min", r.stderr)
         res[name] = {"rc": r.returncode, "wall_s": wall, "logged_fps": float(m.group(1)) if m else None, "files": int(done.group(1)) if done else None,
                      "tail": r.stderr.strip().splitlines()[-2:] if r.returncode else None}
+    # the step AFTER the path: net-output-extract over the same table, one utterance at a time (the reference's way,
+    # the tool's default) and 32 together (--num-sequence, an extension: padding is masked, every utterance's output is its own)
+    if args.extract:
+        exe = os.path.join(ROOT, "eesen_amd", "bin", "net-output-extract")
+        for ns in (1, 32):
+            for rep in range(2):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "--apply-log=true", f"--num-sequence={ns}", os.path.join(tmp, "nnet.native"), "scp:" + scp, "ark:/dev/null"],
+                                   capture_output=True, text=True, cwd=ROOT)
+                wall = time.perf_counter() - t0
+            res[f"extract_num_sequence_{ns}"] = {"rc": r.returncode, "wall_s": wall, "real_frames_per_s": float(lens.sum()) / wall,
+                                                 "tail": r.stderr.strip().splitlines()[-2:] if r.returncode else None}
 print(json.dumps(res))
