@@ -713,6 +713,39 @@ def test_recipe_shape_on_the_persistent_kernels(gpu, S):
         assert rel_err(g, w) < TOL, f"layer {li} {name}: gradient rel err {rel_err(g, w):.2e}"
 
 
+def test_results_do_not_depend_on_the_allocation_history(gpu):
+    """The recipes sort their lists by length, so the minibatches of an epoch grow; device buffers grow by half when they have to
+    (round 5: exact growth freed and re-allocated every buffer on every minibatch) and stay when a shorter minibatch follows.  What a
+    minibatch computes must not depend on what the handle saw before: pad columns of over-allocated matrices are zero, boundary row
+    blocks are re-zeroed at the new T, and the GEMMs' split-K factor follows the minibatch's own workspace request, not the
+    allocation -- gradients of the SAME minibatch are bit-identical on a fresh handle, after a longer one, and after a run of
+    growing ones."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config("cfg2"); cfg.update(layers=2, H=64, K=30)     # K = 30: the output matrices have pad columns (ld 32)
+    layers = synth.make_model(**cfg)
+    shapes = [(16, 30), (20, 44), (32, 60), (32, 90), (24, 140)]     # (S, T): growing, as in a length-sorted epoch
+    batches = [synth.make_batch(**{**cfg, "S": S, "T": T, "seed": 100 + i}) for i, (S, T) in enumerate(shapes)]
+
+    def grads_of(net, ctc, b):
+        net.SetSeqLengths(b.lens)
+        out = net.Propagate(b.feats)
+        d = ctc.EvalParallel(b.lens, out, b.labels)
+        idf = CuMatrix(b.T * b.S, cfg["D"])
+        net.BackpropagateNoUpdate(d, idf)
+        return out.numpy(), idf.numpy(), net.GetGrads()
+
+    fresh = []
+    for b in batches:
+        net = Net.from_layers(layers); ctc = Ctc()
+        fresh.append(grads_of(net, ctc, b))
+    net = Net.from_layers(layers); ctc = Ctc()
+    order = [0, 1, 2, 3, 4, 1, 0, 3, 2]       # growing, then back to shorter ones on the grown buffers
+    for i in order:
+        got = grads_of(net, ctc, batches[i])
+        for g, f in zip(got, fresh[i]):
+            assert np.array_equal(g, f), (i, shapes[i])
+
+
 def test_ctc_edge_cases(gpu):
     """Infeasible alignment (fewer frames than the labels need: ln p ~ -1e30 in the reference), a
     one-label utterance, and the expanded-label limit."""
