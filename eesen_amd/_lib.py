@@ -68,6 +68,8 @@ SIGNATURES = {
     "eesen_comm_create_tcp": (_i, [_i, C.c_char_p, _i, _i, _i, _i, C.POINTER(_vp)]),
     "eesen_comm_destroy": (_i, [_vp]),
     "eesen_comm_info": (_i, [_vp, _pi, _pi]),
+    "eesen_comm_describe": (_i, [_vp, C.c_char_p, _i]),
+    "eesen_net_plan_string": (_i, [_vp, C.c_char_p, _i]),
     "eesen_comm_allreduce_host": (_i, [_vp, _pd, _i, _i]),
     "eesen_net_set_comm": (_i, [_vp, _vp]),
     "eesen_net_allreduce_grads": (_i, [_vp, _vp]),

@@ -128,6 +128,14 @@ class Comm:
     def barrier(self):
         self.allreduce([0.0])
 
+    def Describe(self) -> dict:
+        """COLLECTIVE (every rank calls it): the library the linker resolved, its version, whether it is the tests' stand-in, the
+        ranks and device the library itself reports, every rank's PCI bus id, distinct_devices (eesen_comm_describe)."""
+        import json
+        buf = C.create_string_buffer(16384)
+        check(self.lib.eesen_comm_describe(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
 
 class Net:
     """eesen::Net for BiLstmParallel / LstmParallel / AffineTransform / Softmax stacks."""
@@ -388,6 +396,14 @@ class Net:
         check(self.lib.eesen_net_recurrence_info(self.h, a))
         self.recoveries = a[3]
         return dict(lstm_layers=a[0], fwd_persistent=a[1], bwd_persistent=a[2])
+
+    def Plan(self) -> dict:
+        """What will run the current minibatch shape (after SetSeqLengths): the recurrence plans of every LSTM layer -- the very ones
+        the launchers execute -- and the schedule decisions read from them (eesen_net_plan_string)."""
+        import json
+        buf = C.create_string_buffer(32768)
+        check(self.lib.eesen_net_plan_string(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def _raise_error_word(self, value: int):
         """Test hook: what a recurrence kernel (1) / the milestone waiter (2) stores when it gives up."""

@@ -196,6 +196,14 @@ int eesen_net_set_forward_precision(eesen_net_t* net, int bf16) {
 int eesen_net_bf16_recurrence_layers(eesen_net_t* net, int* layers) {
   return guard([&] { REQ_PTR(net); REQ_PTR(layers); *layers = net->info_fwd_bf16; });
 }
+int eesen_net_plan_string(eesen_net_t* net, char* json, int cap) {
+  return guard([&] {
+    REQ_PTR(net); REQ_PTR(json);
+    const std::string s = net->plan_string();
+    EESEN_REQUIRE(cap > (int)s.size(), EESEN_ERR_INVALID, "eesen_net_plan_string: buffer too small (" + std::to_string(s.size() + 1) + " bytes needed)");
+    std::memcpy(json, s.c_str(), s.size() + 1);
+  });
+}
 int eesen_net_recurrence_info(eesen_net_t* net, int* out3) {  // four ints
   return guard([&] {
     REQ_PTR(net); REQ_PTR(out3);

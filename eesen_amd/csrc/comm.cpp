@@ -32,6 +32,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -58,6 +59,13 @@ struct RcclApi {
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional: only for eesen_comm_describe (what the bench line says about the library that really ran)
+  ncclResult_t (*GetVersion)(int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  std::string path;        // where the dynamic linker found the library (dladdr of ncclAllReduce)
+  bool stand_in = false;   // it exports fake_rccl_error_word: tests/native/libfake_rccl.so, not RCCL
 };
 
 RcclApi& rccl() {
@@ -81,6 +89,13 @@ RcclApi& rccl() {
   api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.dl, "ncclCommAbort"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.dl, "ncclGetVersion"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.dl, "ncclCommCount"));
+  api.CommCuDevice = reinterpret_cast<decltype(api.CommCuDevice)>(dlsym(api.dl, "ncclCommCuDevice"));
+  api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.dl, "ncclCommUserRank"));
+  api.stand_in = dlsym(api.dl, "fake_rccl_error_word") != nullptr;
+  Dl_info di{};
+  if (dladdr(reinterpret_cast<void*>(api.AllReduce), &di) && di.dli_fname) api.path = di.dli_fname;
   return api;
 }
 
@@ -343,6 +358,64 @@ struct Comm {
     check_alive();
     std::memcpy(v, scratch_h, n * sizeof(double));
   }
+  // What this communicator really is, as JSON -- COLLECTIVE (every rank calls it; it gathers one word per rank): the library the
+  // dynamic linker resolved and its version, whether it is the tests' stand-in, the ranks the library itself counts, and the
+  // PCI bus id of every rank's device, so that a reader of a bench line can tell "N ranks on N distinct GPUs through RCCL" from
+  // "N ranks sharing one GPU through a stand-in" without trusting the launcher.
+  std::string describe() {
+    check_alive();
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    int version = 0, seen = -1, nccl_dev = -1, nccl_rank = -1;
+    if (rccl().GetVersion) (void)rccl().GetVersion(&version);
+    if (rccl().CommCount) (void)rccl().CommCount(comm, &seen);
+    if (rccl().CommCuDevice) (void)rccl().CommCuDevice(comm, &nccl_dev);
+    if (rccl().CommUserRank) (void)rccl().CommUserRank(comm, &nccl_rank);
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    (void)sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f);
+    char host[256] = "";
+    (void)gethostname(host, sizeof(host) - 1);
+    unsigned hh = 2166136261u;   // FNV-1a of the host name, 20 bits: ranks of different hosts never look like one device
+    for (const char* c = host; *c; ++c) hh = (hh ^ (unsigned char)*c) * 16777619u;
+    // host hash (20 bits) | domain (16) | bus (8) | device (5) | function (3) = 52 bits: exact in a double
+    const double mine = (double)(((unsigned long long)(hh & 0xfffffu) << 32) | ((unsigned long long)(dom & 0xffffu) << 16) | ((b & 0xffu) << 8) | ((d & 0x1fu) << 3) | (f & 7u)) + 1.0;
+    std::vector<double> ids;
+    for (int base = 0; base < world; base += kScratch) {   // gather = sum of vectors that are zero except at the own rank
+      const int n = std::min(kScratch, world - base);
+      double v[kScratch] = {0};
+      if (rank >= base && rank < base + n) v[rank - base] = mine;
+      allreduce_host(v, n, 0);
+      ids.insert(ids.end(), v, v + n);
+    }
+    std::vector<double> uniq(ids);
+    std::sort(uniq.begin(), uniq.end());
+    const int distinct = (int)(std::unique(uniq.begin(), uniq.end()) - uniq.begin());
+    std::string o = "{\"library\": \"" + rccl().path + "\", \"rccl_version\": " + std::to_string(version) + ", \"stand_in\": " + (rccl().stand_in ? "true" : "false") +
+                    ", \"rank\": " + std::to_string(rank) + ", \"world\": " + std::to_string(world) + ", \"world_seen\": " + std::to_string(seen) +
+                    ", \"rank_seen\": " + std::to_string(nccl_rank) + ", \"device\": " + std::to_string(device) + ", \"device_seen\": " + std::to_string(nccl_dev) + ", \"devices\": [";
+    for (int r = 0; r < world; ++r) {
+      const unsigned long long u = (unsigned long long)(ids[r] - 1.0);
+      char t[64];
+      snprintf(t, sizeof(t), "%s\"%05x/%04x:%02x:%02x.%x\"", r ? ", " : "", (unsigned)((u >> 32) & 0xfffffu), (unsigned)((u >> 16) & 0xffffu), (unsigned)((u >> 8) & 0xffu),
+               (unsigned)((u >> 3) & 0x1fu), (unsigned)(u & 7u));
+      o += t;
+    }
+    o += "], \"distinct_devices\": " + std::to_string(distinct) + ", \"ranks_share_devices\": " + (distinct < world ? "true" : "false") + "}";
+    return o;
+  }
+  // a rank that cannot keep the collective sequence (Net::fail_step_buckets could not issue what the peers will wait for)
+  void abort_now(const std::string& why) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (dead.load()) return;
+    dead_msg = "data-parallel exchange aborted on rank " + std::to_string(rank) + ": " + why;
+    fprintf(stderr, "ERROR (eesen_hip) %s\n", dead_msg.c_str());
+    dead.store(true, std::memory_order_release);
+    ncclComm_t c = comm;
+    comm = nullptr;
+    lk.unlock();
+    if (rccl().CommAbort && c) (void)rccl().CommAbort(c);
+  }
 };
 
 void comm_check_alive(const Comm* c) {
@@ -386,7 +459,7 @@ void Net::bucket_allreduce(int li, hipStream_t producer) {
   if (!comm || !layers[li].p_n) return;
   bucket_log.push_back(li);
   EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], producer));
-  if (tn.comm_defer) { deferred_buckets.push_back(li); return; }   // issued by flush_deferred_buckets, in this order
+  if (exchange_deferred) { deferred_buckets.push_back(li); return; }   // issued by flush_deferred_buckets, in this order
   issue_bucket(li);
 }
 
@@ -420,6 +493,41 @@ void Net::issue_bucket(int li) {
   bucket_pending[li] = 1;
 }
 
+// Backpropagate threw half-way (a refused option, a HIP error in a lower layer) on a rank whose peers are in the same step: they
+// will issue EVERY bucket of it, in the order of the layers.  The overlapped schedule has issued the upper layers' buckets by
+// then, the deferred one none: in both cases the peers would spin until the watchdog's EESEN_COMM_TIMEOUT_S.  So the
+// failing rank completes the sequence before the exception leaves the library: buckets whose gradients are complete go as they
+// are, the others as ZEROS (liveness 0 with the top bucket) -- the ranks' models stay identical, the step loses this rank's
+// share -- and if even that cannot be enqueued the communicator is aborted so that this process, at least, stops at once.
+void Net::fail_step_buckets() noexcept {
+  if (!comm) return;
+  try {
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    std::vector<char> logged(layers.size(), 0);
+    for (int li : bucket_log) logged[li] = 1;
+    flush_deferred_buckets();                    // complete gradients, recorded but not yet issued
+    if (!ev_bwd_done) EESEN_HIP_CHECK(hipEventCreateWithFlags(&ev_bwd_done, hipEventDisableTiming));
+    for (hipStream_t s : {st, st2}) {            // whatever was enqueued before the failure may still write the gradient buffer
+      if (!s) continue;
+      EESEN_HIP_CHECK(hipEventRecord(ev_bwd_done, s));
+      EESEN_HIP_CHECK(hipStreamWaitEvent(comm->st, ev_bwd_done, 0));
+    }
+    const int top = top_trainable();
+    for (int li = (int)layers.size() - 1; li >= 0; --li) {
+      if (!layers[li].p_n || logged[li]) continue;
+      const size_t n = layers[li].p_n + (li == top ? kLiveWords : 0);
+      EESEN_HIP_CHECK(hipMemsetAsync(fresh.p + layers[li].p_off, 0, n * sizeof(float), comm->st));
+      bucket_log.push_back(li);
+      EESEN_HIP_CHECK(hipEventRecord(ev_ready[li], comm->st));
+      issue_bucket(li);
+    }
+    fprintf(stderr, "WARNING (eesen_hip) Backpropagate failed on this rank in a data-parallel step: its unfinished gradient buckets were "
+                    "all-reduced as zeros so that the other ranks are not left waiting\n");
+  } catch (...) {
+    try { comm->abort_now("Backpropagate failed and the step's remaining gradient buckets could not be issued"); } catch (...) {}
+  }
+}
+
 void Net::wait_buckets_host() {
   if (!comm) return;
   bool any = false;
@@ -436,6 +544,7 @@ void Net::backpropagate_zero() {
   if (P) EESEN_HIP_CHECK(hipMemsetAsync(fresh.p, 0, (P + kLiveWords) * sizeof(float), st));
   bucket_log.clear();
   deferred_buckets.clear();
+  exchange_deferred = false;   // no recurrence runs in this step: nothing to defer behind
   live_valid = comm != nullptr;
   for (int li = (int)layers.size() - 1; li >= 0; --li) bucket_allreduce(li, st);
   flush_deferred_buckets();
@@ -505,6 +614,14 @@ int eesen_comm_destroy(eesen_comm_t* comm) {
 }
 int eesen_comm_info(eesen_comm_t* comm, int* rank, int* world) {
   return guard([&] { REQ_PTR(comm); if (rank) *rank = comm->rank; if (world) *world = comm->world; });
+}
+int eesen_comm_describe(eesen_comm_t* comm, char* json, int cap) {
+  return guard([&] {
+    REQ_PTR(comm); REQ_PTR(json);
+    const std::string s = comm->describe();
+    EESEN_REQUIRE(cap > (int)s.size(), EESEN_ERR_INVALID, "eesen_comm_describe: buffer too small (" + std::to_string(s.size() + 1) + " bytes needed)");
+    std::memcpy(json, s.c_str(), s.size() + 1);
+  });
 }
 int eesen_comm_allreduce_host(eesen_comm_t* comm, double* values, int n, int op) {
   return guard([&] { REQ_PTR(comm); REQ_PTR(values); comm->allreduce_host(values, n, op); });

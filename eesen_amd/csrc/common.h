@@ -64,7 +64,16 @@ struct DevBuf {
   // does 1.1 M).
   bool reserve(size_t n) {
     if (n <= cap) return false;
-    const size_t want = cap ? std::max(n, cap + cap / 2) : n;
+    // The margin is bounded (round 6): at most 1 GiB per buffer, and none when the device could not hold the margin twice
+    // over -- a near-capacity shape that fits with exact sizing must not fail because EARLIER buffers kept slack.  Peak footprint on a
+    // length-sorted list: the exact footprint of the longest minibatch + at most min(50 %, 1 GiB) per buffer.
+    size_t want = cap ? std::max(n, cap + cap / 2) : n;
+    if (want > n) {
+      want = std::min(want, n + ((size_t)1 << 30) / sizeof(T));
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); want = n; }
+      else if (fr + cap * sizeof(T) < n * sizeof(T) + 2 * (want - n) * sizeof(T)) want = n;
+    }
     release();
     if (hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T)) == hipSuccess) { cap = want; return true; }
     p = nullptr;

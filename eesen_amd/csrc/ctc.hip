@@ -490,28 +490,27 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
   if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
     EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (8 K floats of LDS per workgroup exceed 160 KB)");
   }
-  auto launch = [&](auto kern, size_t& granted) {
-    if (smem > 64 * 1024 && smem > granted) {
+  auto launch = [&](auto kern) {
+    // (asked for on every such launch: the grant is per device and per kernel, a process-wide "already granted" table was neither
+    // -- a second device skipped the call and its launch failed; the call is a host-side table update, microseconds)
+    if (smem > 64 * 1024)
       EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      granted = smem;
-    }
     hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
                        beta, pzx, diff, ldd, frames);
   };
-  static size_t granted[10] = {0};
   EESEN_REQUIRE(Lpad <= 4096, EESEN_ERR_INVALID, "ctc: expanded label length above 4096");
   // positions per lane: the smallest even count that covers the longest lattice of the minibatch (Lmax = max 2 U_s + 1 <= Lpad)
   EESEN_REQUIRE(Lmax >= 1 && Lmax <= Lpad, EESEN_ERR_INVALID, "ctc: lattice length outside the padded row");
-  if (Lmax <= 128) launch(ctc_error_diff_kernel<2>, granted[0]);
-  else if (Lmax <= 256) launch(ctc_error_diff_kernel<4>, granted[1]);
-  else if (Lmax <= 384) launch(ctc_error_diff_kernel<6>, granted[2]);
-  else if (Lmax <= 512) launch(ctc_error_diff_kernel<8>, granted[3]);
-  else if (Lmax <= 768) launch(ctc_error_diff_kernel<12>, granted[4]);
-  else if (Lmax <= 1024) launch(ctc_error_diff_kernel<16>, granted[5]);
-  else if (Lmax <= 1536) launch(ctc_error_diff_kernel<24>, granted[6]);
-  else if (Lmax <= 2048) launch(ctc_error_diff_kernel<32>, granted[7]);
-  else if (Lmax <= 3072) launch(ctc_error_diff_kernel<48>, granted[8]);
-  else launch(ctc_error_diff_kernel<64>, granted[9]);
+  if (Lmax <= 128) launch(ctc_error_diff_kernel<2>);
+  else if (Lmax <= 256) launch(ctc_error_diff_kernel<4>);
+  else if (Lmax <= 384) launch(ctc_error_diff_kernel<6>);
+  else if (Lmax <= 512) launch(ctc_error_diff_kernel<8>);
+  else if (Lmax <= 768) launch(ctc_error_diff_kernel<12>);
+  else if (Lmax <= 1024) launch(ctc_error_diff_kernel<16>);
+  else if (Lmax <= 1536) launch(ctc_error_diff_kernel<24>);
+  else if (Lmax <= 2048) launch(ctc_error_diff_kernel<32>);
+  else if (Lmax <= 3072) launch(ctc_error_diff_kernel<48>);
+  else launch(ctc_error_diff_kernel<64>);
   check_launch("ctc_error_diff");
 }
 

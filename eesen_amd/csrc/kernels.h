@@ -127,10 +127,32 @@ bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L);
 // the forward tile this layer takes leaves room on a CU for a 128 x 128 GEMM workgroup (net.cpp: "the middle first")
 bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L);
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L);
-// true when this layer's backward recurrence takes one of the SMALL tiles (4 or 8 sequences per workgroup: every CU holds one
-// workgroup of <= 168 registers), beside which a side-stream GEMM workgroup still runs at a third of its rate; the 16-sequence
-// tiles (S = 64 at H = 512: 179 registers, 128 KB of operands per workgroup and step) leave it a seventh (net.cpp: overlap)
-bool lstm_bwd_small_tile(const LstmLayerDev& L);
+// What runs a layer's time recurrence.  ONE selection function per pass (lstm_fwd_plan / lstm_bwd_plan, lstm_persistent.hip) decides
+// the instantiation; the launchers execute the plan, and everything else that has to know -- the per-minibatch side-stream rule of
+// Net::backpropagate, the exchange-schedule rule of the data-parallel path (comm.cpp), eesen_net_plan_string, the tests -- reads the
+// SAME plan, so a rule can no longer drift away from what the launcher picks.
+enum { kRecNone = 0, kRecFwdBf = 1, kRecFwdMux = 2, kRecFwdF32 = 3, kRecBwdQ4 = 4, kRecBwdKsplit = 5, kRecBwdKsplitMux = 6, kRecBwdGeneric = 7 };
+struct RecPlan {
+  int kind = kRecNone;        // kRecNone: no persistent tile fits this shape -- the one-launch-per-step kernels of lstm.hip
+  char kernel[80] = "";       // the instantiation, e.g. "lstm_bwd_persistent_q4_kernel<8,4>"
+  int seq_tile = 0;           // sequences per workgroup
+  int units = 0;              // hidden units per workgroup
+  int windows = 0;            // launches per layer pass (sequence windows, one after the other)
+  int grid[3] = {0, 0, 0};    // (unit blocks, directions, sequence groups) of ONE launch; launched as a 1-D grid of their product
+  int wgs = 0;                // workgroups per launch
+  int wgs_per_cu = 0;         // ... per CU of this process's share of the device (EESEN_GPU_SHARE)
+  int vgprs = 0, lds = 0;     // registers per lane / static LDS bytes of the instantiation (hipFuncGetAttributes = the code object's
+                              // .vgpr_count / .group_segment_fixed_size: pinned by tests/test_kernel_resources.py); 0: not known
+  int free_vgprs = -1;        // registers per SIMD lane this grid leaves on a CU it occupies: 512 - waves per SIMD x allocated (-1: not known)
+  bool light = false;         // backward: the 4- / 8-sequence tiles, beside which a side-stream GEMM workgroup keeps a third of its rate
+  // for the launcher
+  int cpw = 0, stq = 0, chunk = 0, xchg = 0;
+  const void* fn = nullptr;
+};
+RecPlan lstm_fwd_plan(const LstmLayerDev& L);
+// assume_px: plan as if the caller will hand over the K-split kernels' exchange buffer (LstmLayerDev::PX) -- Net::backpropagate does
+// whenever lstm_bwd_ksplit_px_floats asks for one; the launcher itself plans with the buffer it was really given
+RecPlan lstm_bwd_plan(const LstmLayerDev& L, bool assume_px);
 bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L, const float* dY, int lddy, float* DG, unsigned* cnt,
                          unsigned* err, int spin_limit, unsigned long long* trace = nullptr);
 // bias_grad[ndir*4H] = column sums of DG; peep_grad[ndir][3][H] = the diag(D^T C) products of

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void handoff_pingpong_kernel(unsigned* flags, u
 // (unsigned* err: this kernel may RAISE the error word too)
 __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word, unsigned target, unsigned* err, unsigned long long limit_ticks) {
   if (threadIdx.x != 0) return;
-  // ~1 us per poll, bounded on the WALL CLOCK (limit_ticks of 10 ns; the host scales it with the recurrence it waits on and with the
+  // ~7 us per poll, bounded on the WALL CLOCK (limit_ticks of 10 ns; the host scales it with the recurrence it waits on and with the
   // spin limit, which a communicator raises tenfold: wait_for_word): orders of magnitude above any recurrence this waits on, and the
   // producer's stream raises the word itself behind that kernel.  A wait that does give up must not let the consumer behind it pass
   // for a success: it raises the error word (value 2), the step is dropped like one whose recurrence kernel gave up (in a
@@ -186,11 +186,14 @@ __global__ __launch_bounds__(64) void wait_for_word_kernel(const unsigned* word,
   const unsigned long long t0 = wall_clock64();
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
-    if ((spins & 15) == 15) {
+    if ((spins & 7) == 7) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
       if (wall_clock64() - t0 > limit_ticks) break;
     }
-    __builtin_amdgcn_s_sleep(32);
+    // ~7 us asleep per poll (round 6; round 5: ~1 us): the waiter is off the critical path -- what it releases is a GEMM that runs
+    // UNDER the rest of the recurrence -- and it sits on a CU whose issue slots the recurrence wants for 2 ms, three times a step
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
   }
   __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 2: "the milestone wait gave up" (net.cpp: check_device_error)
 }
@@ -1683,12 +1686,7 @@ bool fits(K kernel, dim3 grid, int threads, C census = nullptr) {  // grid: the 
 // queue; 0.3 ms per cfg2 step over eight launches, measured) and guarantees nothing that fits() has not checked already -- the
 // runtime does not gang-schedule a cooperative grid either (the side-stream GEMMs co-run with it), it only refuses grids above the
 // occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at once
-// are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp).
-template <class K, class... Args>
-void coop_launch(hipStream_t st, K kernel, dim3 grid, dim3 block, Args... args) {
-  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
-}
-
+// are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp).  (plan_launch below.)
 }  // namespace
 
 // One-way flight of an agent-scope increment between two CUs of the current device, in nanoseconds (measured once per device and
@@ -1799,13 +1797,20 @@ static bool bf_census(int wgs) {
   static std::map<std::pair<int, int>, bool> seen;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
+  // A device this process SHARES (EESEN_GPU_SHARE > 1: peers' grids come and go) has no idle moment to take a census in, and its
+  // answer would differ from rank to rank and run to run -- and with it the forward tile, whose two candidates are not bit-identical
+  // (ADVICE r5): there the occupancy query's margin decides alone, the same way in every process.
+  if (gpu_share() > 1) return false;
   std::lock_guard<std::mutex> lock(mu);
   const auto key = std::make_pair(dev, wgs);
   if (auto it = seen.find(key); it != seen.end()) return it->second;
   bool ok = false;
   unsigned* w = nullptr;
   if (hipDeviceSynchronize() == hipSuccess && hipMalloc(reinterpret_cast<void**>(&w), 2 * sizeof(unsigned)) == hipSuccess) {
-    if (hipMemset(w, 0, 2 * sizeof(unsigned)) == hipSuccess) {
+    // up to three takes: a grid that fits an idle device is seen at once; one transient occupant (another stream's kernel retiring)
+    // must not decide the tile for the life of the process
+    for (int take = 0; take < 3 && !ok; ++take) {
+      if (hipMemset(w, 0, 2 * sizeof(unsigned)) != hipSuccess) break;
       LstmLayerDev L{};
       L.T = -1;
       hipLaunchKernelGGL((lstm_fwd_persistent_bf_kernel<C, N, A, W>), dim3(wgs), dim3(NW * 64), 0, nullptr, L, w, w + 1, 0,
@@ -1816,6 +1821,7 @@ static bool bf_census(int wgs) {
     (void)hipFree(w);
   }
   seen[key] = ok;
+  if (getenv("EESEN_PRINT_PLAN")) fprintf(stderr, "LOG (eesen_hip) residency census: %d workgroups of lstm_fwd_persistent_bf_kernel<%d,%d,%d,%d> on device %d: %s\n", wgs, C, N, A, W, dev, ok ? "seen co-resident" : "NOT seen");
   return ok;
 }
 static bool bf_fits(const LstmLayerDev& L, const BfPlan& P, int Sw) {
@@ -1849,9 +1855,6 @@ void lstm_fwd_persistent_geometry(const LstmLayerDev& L, int* nblk, int* nz, int
   if (units_per_wg) *units_per_wg = 4 * ft.nt;
 }
 
-int lstm_fwd_persistent_windows(const LstmLayerDev& L);
-
-bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return L.fwd_bf16 && bf_plan(L).on && lstm_fwd_persistent_windows(L) > 0; }
 // true when the forward tile this layer takes leaves register and LDS room for a 128 x 128 GEMM workgroup on the same CU (the
 // early middle part of the next layer's input GEMM, net.cpp): the narrow tiles (<= 8 units, <= 131 VGPRs); the wide fp32 tile
 // (206 VGPRs) does not
@@ -1862,95 +1865,83 @@ bool lstm_fwd_persistent_leaves_room(const LstmLayerDev& L) {
   return 4 * ft.nt <= 8;
 }
 
-bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, unsigned* err, int spin_limit,
-                         unsigned long long* trace, hipEvent_t after_reset) {
-  const int nch = (L0.H + 31) / 32;
-  const int need = (nch + NW - 1) / NW;
-  const FwdTile ft = fwd_tile(L0);
-  if (need > 4 || (ft.nt == 2 && need > 2) || L0.H % (4 * ft.nt) != 0 || L0.T < 2) return false;
-  // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
-  // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
-  // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
-  // and is read back stale one step later (seen at S = 17, H = 20).  Such shapes use the per-step kernels.
-  if (((size_t)L0.S * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;
-  if ((size_t)(L0.T + 2) * L0.S * L0.ndir * L0.H * sizeof(float) >= ((size_t)1 << 31)) return false;  // 32-bit buffer offsets over all of Y
-  const int nwin = lstm_fwd_persistent_windows(L0);
-  if (nwin == 0) return false;
-  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return false;  // a window's rows start on a line too
-  if (const BfPlan P = bf_plan(L0); P.on) {   // on the bf16 matrix pipe: config 4's bf16 forward, or the fp32-class 3-way split (lstm_fwd_persistent_bf_kernel)
-    for (int w = 0; w < nwin; ++w) {
-      LstmLayerDev L = L0;
-      L.s_count = L0.S / nwin;
-      L.s_begin = w * L.s_count;
-      dim3 grid(L.H / (4 * P.nt), L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
-      const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-      if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
-      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
-      if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));
-#define EESEN_BF_LAUNCH(C, N, A, W) coop_launch(st, lstm_fwd_persistent_bf_kernel<C, N, A, W>, grid1, block, L, cnt, err, spin_limit, trace, role)
-      EESEN_BF_DISPATCH(P, EESEN_BF_LAUNCH);
-#undef EESEN_BF_LAUNCH
-    }
-    return true;
+// ---- the instantiations, by address: a plan carries the host stub of the kernel it chose; occupancy query, resource query and
+// launch all go through that one pointer (hipOccupancyMaxActiveBlocksPerMultiprocessor / hipFuncGetAttributes / hipLaunchKernel)
+template <int CPW, int MT, int NT>
+static const void* fwd_f32_fn(bool drop, bool xchg) {
+  if (drop) return reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<CPW, MT, NT, true>);
+  if constexpr (MT == 1) {
+    if (xchg) return reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<CPW, 1, NT, false, true>);
   }
-  // Two windows of the wide tile: one launch that time-multiplexes the two sequence tiles of every workgroup instead
-  // (lstm_fwd_persistent_mux_kernel).  LstmLayerDev::fwd_mux = 0 (EESEN_FWD_MUX=0): the two launches, one after the other.
-  if (L0.fwd_mux && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
-    const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
-    const bool xchg = L0.X != nullptr && (size_t)L0.T * L0.ndir * nz * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31);
-    dim3 grid(L0.H / 16, L0.ndir, ng), block(NW * 64);
-    const bool fit = xchg ? fits(lstm_fwd_persistent_mux_kernel<4, 4, true>, grid, NW * 64) : fits(lstm_fwd_persistent_mux_kernel<4, 4, false>, grid, NW * 64);
-    if (fit && (size_t)L0.ndir * nz * kShards * kShardStride <= (size_t)kCtlHalf) {
-      LstmLayerDev L = L0;
-      L.s_begin = 0; L.s_count = 0;
-      const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * nz * kShards * kShardStride, st));
-      if (xchg) coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, true>, grid1, block, L, cnt, err, spin_limit, role);
-      else coop_launch(st, lstm_fwd_persistent_mux_kernel<4, 4, false>, grid1, block, L, cnt, err, spin_limit, role);
-      return true;
-    }
+  return reinterpret_cast<const void*>(&lstm_fwd_persistent_kernel<CPW, MT, NT, false>);
+}
+static const void* fwd_f32_fn(const FwdTile& ft, int need, bool drop, bool xchg) {
+  if (ft.nt == 4) return need <= 1 ? fwd_f32_fn<1, 1, 4>(drop, xchg) : need <= 2 ? fwd_f32_fn<2, 1, 4>(drop, xchg) : fwd_f32_fn<4, 1, 4>(drop, xchg);
+  if (ft.nt == 2) return need <= 1 ? fwd_f32_fn<1, 1, 2>(drop, xchg) : fwd_f32_fn<2, 1, 2>(drop, xchg);
+  return need <= 1 ? fwd_f32_fn<1, 2, 1>(drop, false) : need <= 2 ? fwd_f32_fn<2, 2, 1>(drop, false) : fwd_f32_fn<4, 2, 1>(drop, false);
+}
+static int fwd_f32_cpw(const FwdTile& ft, int need) { return ft.nt == 2 ? (need <= 1 ? 1 : 2) : (need <= 1 ? 1 : need <= 2 ? 2 : 4); }
+static const void* fwd_bf_fn(const BfPlan& B) {
+#define EESEN_BF_FN(C, N, A, W) return reinterpret_cast<const void*>(&lstm_fwd_persistent_bf_kernel<C, N, A, W>)
+  EESEN_BF_DISPATCH(B, EESEN_BF_FN);
+#undef EESEN_BF_FN
+  return nullptr;
+}
+static const void* bwd_q4_fn(int cpw, int stq) {
+#define EESEN_Q4_FN(CPW) (stq == 8 ? reinterpret_cast<const void*>(&lstm_bwd_persistent_q4_kernel<CPW, 8>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_q4_kernel<CPW, 4>))
+  switch (cpw) { case 8: return EESEN_Q4_FN(8); case 6: return EESEN_Q4_FN(6); case 4: return EESEN_Q4_FN(4); default: return EESEN_Q4_FN(2); }
+#undef EESEN_Q4_FN
+}
+static const void* bwd_ksplit_fn(int cpw, bool mux) {
+  switch (cpw) {
+    case 4: return mux ? reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_mux_kernel<4>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_kernel<4>);
+    case 3: return mux ? reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_mux_kernel<3>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_kernel<3>);
+    case 2: return mux ? reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_mux_kernel<2>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_kernel<2>);
+    default: return nullptr;
   }
-  for (int w = 0; w < nwin; ++w) {
-    LstmLayerDev L = L0;
-    L.s_count = L0.S / nwin;
-    L.s_begin = w * L.s_count;
-    dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(L.s_count, 16 * ft.mt)), block(NW * 64);
-    const dim3 grid1(grid.x * grid.y * grid.z);
-    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-    if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
-    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
-    if (after_reset && nwin == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
-    // exchange-layout operand fetch: 16-sequence tiles, whole 32-unit chunks, block offsets within 32 bits
-    const bool xchg = L.X != nullptr && ft.mt == 1 && L.H % 32 == 0 && !L.drop_mode &&
-                      (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 32) * 2048 < ((size_t)1 << 31);
-#define EESEN_FP(CPW, MT, NT)                                                                          \
-  do {                                                                                                  \
-    if (L.drop_mode) coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
-    else coop_launch(st, lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid1, block, L, cnt, err, spin_limit, trace, role); \
-  } while (0)
-#define EESEN_FPX(CPW, NT)                                                                             \
-  do {                                                                                                  \
-    if (xchg) coop_launch(st, lstm_fwd_persistent_kernel<CPW, 1, NT, false, true>, grid1, block, L, cnt, err, spin_limit, trace, role); \
-    else EESEN_FP(CPW, 1, NT);                                                                          \
-  } while (0)
-    if (ft.nt == 4) {
-      if (need <= 1) EESEN_FPX(1, 4);
-      else if (need <= 2) EESEN_FPX(2, 4);
-      else EESEN_FPX(4, 4);
-    } else if (ft.nt == 2) {
-      if (need <= 1) EESEN_FPX(1, 2);
-      else EESEN_FPX(2, 2);
-    } else {
-      if (need <= 1) EESEN_FP(1, 2, 1);
-      else if (need <= 2) EESEN_FP(2, 2, 1);
-      else EESEN_FP(4, 2, 1);
-    }
-#undef EESEN_FPX
-#undef EESEN_FP
+}
+template <int CPW>
+static const void* bwd_generic_fn(int stile, bool drop) {
+  if (stile == 8) return drop ? reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<CPW, 8, true>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<CPW, 8, false>);
+  return drop ? reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<CPW, 16, true>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_kernel<CPW, 16, false>);
+}
+static int bwd_generic_cpw(int need) { return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16; }
+static const void* bwd_generic_fn(int need, int stile, bool drop) {
+  switch (bwd_generic_cpw(need)) {
+    case 1: return bwd_generic_fn<1>(stile, drop);
+    case 2: return bwd_generic_fn<2>(stile, drop);
+    case 4: return bwd_generic_fn<4>(stile, drop);
+    case 8: return bwd_generic_fn<8>(stile, drop);
+    default: return bwd_generic_fn<16>(stile, drop);
   }
-  return true;
+}
+
+// registers and LDS of the chosen instantiation, and what its grid leaves free on a CU (RecPlan::free_vgprs): a SIMD has 512
+// registers per lane, allocated in blocks of 8; a 512-thread workgroup is two waves per SIMD
+static void plan_resources(RecPlan& P, const dim3& grid) {
+  P.grid[0] = (int)grid.x; P.grid[1] = (int)grid.y; P.grid[2] = (int)grid.z;
+  P.wgs = (int)(grid.x * grid.y * grid.z);
+  P.wgs_per_cu = std::max(1, cdiv(P.wgs, share_of_cus()));
+  if (!P.fn) return;
+  static std::mutex mu;
+  static std::map<const void*, std::pair<int, int>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(P.fn);
+  if (it == cache.end()) {
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, P.fn) != hipSuccess) { (void)hipGetLastError(); return; }
+    it = cache.emplace(P.fn, std::make_pair((int)a.numRegs, (int)a.sharedSizeBytes)).first;
+  }
+  P.vgprs = it->second.first;
+  P.lds = it->second.second;
+  if (P.vgprs > 0) P.free_vgprs = 512 - P.wgs_per_cu * (NW / 4) * ((P.vgprs + 7) & ~7);
+}
+
+// (see "The persistent grids are launched as ORDINARY kernels" above)
+template <class... Args>
+static void plan_launch(hipStream_t st, const RecPlan& P, const dim3& grid, Args... args) {
+  void* argv[] = {static_cast<void*>(&args)...};
+  EESEN_HIP_CHECK(hipLaunchKernel(P.fn, dim3(grid.x * grid.y * grid.z), dim3(NW * 64), argv, 0, st));
 }
 
 // number of sequence windows the forward pass of this layer takes (0: no persistent tile fits; 1: the whole batch at once)
@@ -1961,31 +1952,98 @@ int lstm_fwd_persistent_windows(const LstmLayerDev& L) {
   const FwdTile ft = fwd_tile(L);
   auto fits_with = [&](int Sw) {
     dim3 grid(L.H / (4 * ft.nt), L.ndir, cdiv(Sw, 16 * ft.mt));
-#define EESEN_FF(CPW, MT, NT) return L.drop_mode ? fits(lstm_fwd_persistent_kernel<CPW, MT, NT, true>, grid, NW * 64) \
-                                                 : fits(lstm_fwd_persistent_kernel<CPW, MT, NT, false>, grid, NW * 64)
-    if (ft.nt == 4) { if (need <= 1) EESEN_FF(1, 1, 4); else if (need <= 2) EESEN_FF(2, 1, 4); else EESEN_FF(4, 1, 4); }
-    else if (ft.nt == 2) { if (need <= 1) EESEN_FF(1, 1, 2); else EESEN_FF(2, 1, 2); }
-    else { if (need <= 1) EESEN_FF(1, 2, 1); else if (need <= 2) EESEN_FF(2, 2, 1); else EESEN_FF(4, 2, 1); }
-#undef EESEN_FF
+    return fits(fwd_f32_fn(ft, need, L.drop_mode != 0, false), grid, NW * 64);
   };
   return pick_windows(L.S, 16 * ft.mt, fits_with);
 }
 
-// Floats of partial-sum exchange space the K-split backward kernels need for this layer shape: per (direction, 16-sequence tile)
-// group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
-// 0 = the kernel does not apply (narrow layers take the 4 x 32
-// tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
+// ---- forward ----------------------------------------------------------------------------------------------------------------
+RecPlan lstm_fwd_plan(const LstmLayerDev& L0) {
+  RecPlan P;
+  const int nch = (L0.H + 31) / 32;
+  const int need = (nch + NW - 1) / NW;
+  const FwdTile ft = fwd_tile(L0);
+  if (need > 4 || (ft.nt == 2 && need > 2) || L0.H % (4 * ft.nt) != 0 || L0.T < 2) return P;
+  // The hand-off relies on every step reading cache lines nobody has touched before in this launch.  That holds only if
+  // a time step's row block [S x ndir*H] of Y starts on a 128-byte line: otherwise the last line of block t also carries
+  // the first bytes of block t+1, gets cached (L1 and the XCD's non-coherent L2) while block t+1 is still unwritten,
+  // and is read back stale one step later (seen at S = 17, H = 20).  Such shapes use the per-step kernels.
+  if (((size_t)L0.S * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return P;
+  if ((size_t)(L0.T + 2) * L0.S * L0.ndir * L0.H * sizeof(float) >= ((size_t)1 << 31)) return P;  // 32-bit buffer offsets over all of Y
+  const int nwin = lstm_fwd_persistent_windows(L0);
+  if (nwin == 0) return P;
+  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * L0.H * sizeof(float)) % 128 != 0) return P;  // a window's rows start on a line too
+  if (const BfPlan B = bf_plan(L0); B.on) {   // on the bf16 matrix pipe: config 4's bf16 forward, or the fp32-class 3-way split (lstm_fwd_persistent_bf_kernel)
+    const dim3 grid(L0.H / (4 * B.nt), L0.ndir, cdiv(L0.S / nwin, 16));
+    if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return P;
+    P.kind = kRecFwdBf; P.fn = fwd_bf_fn(B); P.cpw = B.cpw; P.seq_tile = 16; P.units = 4 * B.nt; P.windows = nwin;
+    snprintf(P.kernel, sizeof(P.kernel), "lstm_fwd_persistent_bf_kernel<%d,%d,%d,%d>", B.nt == 2 ? (B.cpw <= 1 ? 1 : 2) : std::min(4, std::max(1, B.cpw)), B.nt, B.ap, B.wp);
+    plan_resources(P, grid);
+    return P;
+  }
+  // Two windows of the wide tile: one launch that time-multiplexes the two sequence tiles of every workgroup instead
+  // (lstm_fwd_persistent_mux_kernel).  LstmLayerDev::fwd_mux = 0 (EESEN_FWD_MUX=0): the two launches, one after the other.
+  if (L0.fwd_mux && nwin == 2 && ft.mt == 1 && ft.nt == 4 && need > 2 && need <= 4 && !L0.drop_mode && L0.H % 32 == 0) {
+    const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
+    const bool xchg = L0.X != nullptr && (size_t)L0.T * L0.ndir * nz * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31);
+    const dim3 grid(L0.H / 16, L0.ndir, ng);
+    const void* fn = xchg ? reinterpret_cast<const void*>(&lstm_fwd_persistent_mux_kernel<4, 4, true>) : reinterpret_cast<const void*>(&lstm_fwd_persistent_mux_kernel<4, 4, false>);
+    if (fits(fn, grid, NW * 64) && (size_t)L0.ndir * nz * kShards * kShardStride <= (size_t)kCtlHalf) {
+      P.kind = kRecFwdMux; P.fn = fn; P.cpw = 4; P.seq_tile = 32; P.units = 16; P.windows = 1; P.xchg = xchg;
+      snprintf(P.kernel, sizeof(P.kernel), "lstm_fwd_persistent_mux_kernel<4,4,%s>", xchg ? "true" : "false");
+      plan_resources(P, grid);
+      return P;
+    }
+  }
+  const dim3 grid(L0.H / (4 * ft.nt), L0.ndir, cdiv(L0.S / nwin, 16 * ft.mt));
+  if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return P;
+  // exchange-layout operand fetch: 16-sequence tiles, whole 32-unit chunks, block offsets within 32 bits
+  const bool xchg = L0.X != nullptr && ft.mt == 1 && L0.H % 32 == 0 && !L0.drop_mode &&
+                    (size_t)L0.T * L0.ndir * cdiv(L0.S, 16) * (size_t)(L0.H / 32) * 2048 < ((size_t)1 << 31);
+  P.kind = kRecFwdF32; P.fn = fwd_f32_fn(ft, need, L0.drop_mode != 0, xchg); P.cpw = fwd_f32_cpw(ft, need);
+  P.seq_tile = 16 * ft.mt; P.units = 4 * ft.nt; P.windows = nwin; P.xchg = xchg;
+  snprintf(P.kernel, sizeof(P.kernel), "lstm_fwd_persistent_kernel<%d,%d,%d,%s,%s>", P.cpw, ft.mt, ft.nt, L0.drop_mode ? "true" : "false", xchg && !L0.drop_mode ? "true" : "false");
+  plan_resources(P, grid);
+  return P;
+}
+
+bool lstm_fwd_persistent_is_bf16(const LstmLayerDev& L) { return L.fwd_bf16 && lstm_fwd_plan(L).kind == kRecFwdBf; }
+
+bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, unsigned* err, int spin_limit,
+                         unsigned long long* trace, hipEvent_t after_reset) {
+  const RecPlan P = lstm_fwd_plan(L0);
+  if (P.kind == kRecNone) return false;
+  const dim3 grid(P.grid[0], P.grid[1], P.grid[2]);
+  const Role role{P.grid[0], P.grid[1], P.grid[2], L0.xcd_map};
+  if (P.kind == kRecFwdMux) {
+    LstmLayerDev L = L0;
+    L.s_begin = 0; L.s_count = 0;
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * L0.ndir * cdiv(L0.S, 16) * kShards * kShardStride, st));
+    plan_launch(st, P, grid, L, cnt, err, spin_limit, role);
+    return true;
+  }
+  for (int w = 0; w < P.windows; ++w) {
+    LstmLayerDev L = L0;
+    L.s_count = L0.S / P.windows;
+    L.s_begin = w * L.s_count;
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+    if (after_reset && P.windows == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
+    plan_launch(st, P, grid, L, cnt, err, spin_limit, trace, role);
+  }
+  return true;
+}
+
 void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err, double limit_s) {
   const unsigned long long ticks = (unsigned long long)(std::max(0.05, limit_s) * 1e8);   // wall_clock64: 100 MHz
   hipLaunchKernelGGL(wait_for_word_kernel, dim3(1), dim3(64), 0, st, word, target, err, ticks);
   check_launch("wait_for_word");
 }
 
-bool lstm_bwd_small_tile(const LstmLayerDev& L) {
-  const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
-  return 2 * blocks16 <= share_of_cus() && L.S > 8;     // lstm_bwd_persistent: stile == 8 (and the 4 x 32 tile, which needs it)
-}
-
+// ---- backward ---------------------------------------------------------------------------------------------------------------
+// Floats of partial-sum exchange space the K-split backward kernels need for this layer shape: per (direction, 16-sequence tile)
+// group and 64-unit block 16 blocks of 16 x 16 words of 8 bytes (value, step), two slots by step parity (px_put / px_take);
+// 0 = the kernel does not apply (narrow layers take the 4 x 32
+// tile, dropout layers and odd shapes the generic one).  LstmLayerDev::bwd_ksplit = 0 (EESEN_BWD_KSPLIT=0) switches it off.
 size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   if (!L.bwd_ksplit) return 0;
   if (L.drop_mode || L.H % 256 != 0 || L.H < 768 || L.H > 1024 || L.T < 2) return 0;
@@ -1996,24 +2054,26 @@ size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   return (size_t)2 * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096 * 2;
 }
 
-bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY, int lddy, float* DG, unsigned* cnt,
-                         unsigned* err, int spin_limit, unsigned long long* trace) {
+RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
+  RecPlan P;
   const int nch = (4 * L0.H + 31) / 32;
   const int need = (nch + NW - 1) / NW;
-  if (need > 16 || L0.T < 2) return false;
-  if (((size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return false;      // line-aligned DG row blocks (see forward)
   // Sequences per workgroup: 16 fills the MFMA rows; 8 wastes half of them but halves the 128 KB of DG_next each workgroup
   // must fetch per step, which is what bounds the step (measured: 3.75 us of fetch at ~34 GB/s per CU vs 1.8 us of MFMA).
   // Take 8 whenever 16 would leave half of the chip's CUs without a workgroup.
   const int ncu = share_of_cus();
   const long blocks16 = (long)cdiv(L0.H, 16) * L0.ndir * cdiv(L0.S, 16);
   const int stile = 2 * blocks16 <= ncu && L0.S > 8 ? 8 : 16;
+  P.light = stile == 8;   // (a property of the SHAPE: it also holds for the per-step kernels a shape without a persistent tile takes)
+  if (need > 16 || L0.T < 2) return P;
+  if (((size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return P;      // line-aligned DG row blocks (see forward)
   // 32-bit buffer offsets: the kernel re-bases its DG resource every `chunk` steps; a chunk touches chunk + 1 row blocks
   const size_t blk_bytes = (size_t)L0.S * L0.ndir * 4 * L0.H * sizeof(float);
   const long max_blocks = (long)((((size_t)1 << 31) - 1) / blk_bytes);
-  if (max_blocks < 3) return false;
+  if (max_blocks < 3) return P;
   int chunk = (int)std::min<long>(L0.T, max_blocks - 1);
   if (chunk < L0.T) { int p2 = 1; while (p2 * 2 <= chunk) p2 *= 2; chunk = p2; }   // a power of two keeps `step % chunk` cheap
+  P.chunk = chunk;
   // The 4-sequence x 32-unit tile (lstm_bwd_persistent_q4_kernel<., 4>): wherever the 8-sequence tile would be taken and the shape
   // allows; with TWO 4-sequence tiles per workgroup (<., 8>, round 5) where that grid does not fit but half as many workgroups do
   // (S = 64 at H = 512) -- LstmLayerDev::bwd_q4_st8: 0 = never (the 16 x 16 tile there, as before round 5), 2 = wherever it applies,
@@ -2028,129 +2088,103 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
     if (stq == 4 && stile != 8) continue;
     if (stq == 8 && !(L0.bwd_q4_st8 && L0.S > 8)) continue;
     const int cpw = 2 * ((L0.H + 127) / 128);   // 2, 4, 6 or 8 chunks of 32 floats per wave: K = 4H in 8 waves x (cpw / 2) pairs of 64
-    dim3 grid(L0.H / 32, L0.ndir, cdiv(L0.S, stq)), block(NW * 64);
+    const dim3 grid(L0.H / 32, L0.ndir, cdiv(L0.S, stq));
     const size_t cwords = (size_t)grid.y * grid.z * kShards * kShardStride;
-    bool fit = false;
-#define EESEN_Q4(CPW) (stq == 8 ? fits(lstm_bwd_persistent_q4_kernel<CPW, 8>, grid, NW * 64) : fits(lstm_bwd_persistent_q4_kernel<CPW, 4>, grid, NW * 64))
-    if (cpw == 8) fit = EESEN_Q4(8);
-    else if (cpw == 6) fit = EESEN_Q4(6);
-    else if (cpw == 4) fit = EESEN_Q4(4);
-    else if (cpw == 2) fit = EESEN_Q4(2);
-#undef EESEN_Q4
-    if (fit && cwords <= (size_t)kCtlHalf) {
-      LstmLayerDev L = L0;
-      L.s_begin = 0; L.s_count = 0;
-      const dim3 grid1(grid.x * grid.y * grid.z);
-      const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cwords, st));
-#define EESEN_Q4(CPW)                                                                                                                    \
-  do {                                                                                                                                   \
-    if (stq == 8) coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, 8>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role); \
-    else coop_launch(st, lstm_bwd_persistent_q4_kernel<CPW, 4>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role);         \
-  } while (0)
-      if (cpw == 8) EESEN_Q4(8);
-      else if (cpw == 6) EESEN_Q4(6);
-      else if (cpw == 4) EESEN_Q4(4);
-      else EESEN_Q4(2);
-#undef EESEN_Q4
-      return true;
+    const void* fn = bwd_q4_fn(cpw, stq);
+    if (fits(fn, grid, NW * 64) && cwords <= (size_t)kCtlHalf) {
+      P.kind = kRecBwdQ4; P.fn = fn; P.cpw = cpw; P.stq = stq; P.seq_tile = stq; P.units = 32; P.windows = 1;
+      snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_q4_kernel<%d,%d>", cpw, stq);
+      plan_resources(P, grid);
+      return P;
     }
   }
   // Wide layers: K split four ways (lstm_bwd_persistent_ksplit_kernel) wherever the 16-sequence tile would be taken and the caller
   // handed over the partial-sum exchange buffer (lstm_bwd_ksplit_px_floats)
-  if (const size_t px_need = stile == 16 && L0.PX ? lstm_bwd_ksplit_px_floats(L0) : 0; px_need && L0.px_floats >= px_need) {
+  const size_t px_need = stile == 16 && (L0.PX || assume_px) ? lstm_bwd_ksplit_px_floats(L0) : 0;
+  if (px_need && (L0.PX ? L0.px_floats >= px_need : assume_px)) {
     const int cpw = (4 * L0.H / 4) / (32 * NW);
     auto kfits = [&](int Sw) {
       dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(Sw, 16));
       const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
       if (c1 > (size_t)kCtlHalf) return false;
-      switch (cpw) {
-        case 4: return fits(lstm_bwd_persistent_ksplit_kernel<4>, grid, NW * 64);
-        case 3: return fits(lstm_bwd_persistent_ksplit_kernel<3>, grid, NW * 64);
-        case 2: return fits(lstm_bwd_persistent_ksplit_kernel<2>, grid, NW * 64);
-        default: return false;
-      }
+      const void* fn = bwd_ksplit_fn(cpw, false);
+      return fn != nullptr && fits(fn, grid, NW * 64);
     };
     const int nwin = pick_windows(L0.S, 16, kfits);
     // Two windows: one launch that time-multiplexes two sequence tiles per workgroup instead (lstm_bwd_persistent_ksplit_mux_kernel;
     // LstmLayerDev::bwd_mux = 0 / EESEN_BWD_MUX=0: the two launches, one after the other)
     if (nwin == 2 && L0.bwd_mux && cpw >= 2 && cpw <= 4) {
       const int nz = cdiv(L0.S, 16), ng = cdiv(nz, 2);
-      dim3 grid(L0.H / 64 * 4, L0.ndir, ng), block(NW * 64);
+      const dim3 grid(L0.H / 64 * 4, L0.ndir, ng);
       const size_t c1 = (size_t)L0.ndir * nz * 4 * kShards * kShardStride;
-      bool fit = c1 <= (size_t)kCtlHalf;
-      if (fit) fit = cpw == 4 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<4>, grid, NW * 64)
-                   : cpw == 3 ? fits(lstm_bwd_persistent_ksplit_mux_kernel<3>, grid, NW * 64) : fits(lstm_bwd_persistent_ksplit_mux_kernel<2>, grid, NW * 64);
-      if (fit) {
-        LstmLayerDev L = L0;
-        L.s_begin = 0; L.s_count = 0;
-        const dim3 grid1(grid.x * grid.y * grid.z);
-        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
-        EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
-        unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
-        if (cpw == 4) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
-        else if (cpw == 3) coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
-        else coop_launch(st, lstm_bwd_persistent_ksplit_mux_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
-        return true;
+      const void* fn = bwd_ksplit_fn(cpw, true);
+      if (c1 <= (size_t)kCtlHalf && fits(fn, grid, NW * 64)) {
+        P.kind = kRecBwdKsplitMux; P.fn = fn; P.cpw = cpw; P.seq_tile = 32; P.units = 64; P.windows = 1;
+        snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_mux_kernel<%d>", cpw);
+        plan_resources(P, grid);
+        return P;
       }
     }
     if (nwin > 0 && (nwin == 1 || ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
-      for (int w = 0; w < nwin; ++w) {
-        LstmLayerDev L = L0;
-        L.s_count = L0.S / nwin;
-        L.s_begin = w * L.s_count;
-        dim3 grid(L.H / 64 * 4, L.ndir, cdiv(L.s_count, 16)), block(NW * 64);
-        const dim3 grid1(grid.x * grid.y * grid.z);
-        const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L0.xcd_map};
-        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
-        EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
-        EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
-        unsigned long long* px = reinterpret_cast<unsigned long long*>(L.PX);
-        switch (cpw) {
-          case 4: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<4>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
-          case 3: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<3>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
-          default: coop_launch(st, lstm_bwd_persistent_ksplit_kernel<2>, grid1, block, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace); break;
-        }
-      }
-      return true;
+      const dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(L0.S / nwin, 16));
+      P.kind = kRecBwdKsplit; P.fn = bwd_ksplit_fn(cpw, false); P.cpw = cpw; P.seq_tile = 16; P.units = 64; P.windows = nwin;
+      snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_kernel<%d>", cpw);
+      plan_resources(P, grid);
+      return P;
     }
   }
-  auto launch = [&](const LstmLayerDev& L, bool dry) -> bool {
-    const int Sw = L.s_count ? L.s_count : L.S;
-    dim3 grid(cdiv(L.H, 16), L.ndir, cdiv(Sw, stile)), block(NW * 64);
-    const dim3 grid1(grid.x * grid.y * grid.z);
-    const Role role{(int)grid.x, (int)grid.y, (int)grid.z, L.xcd_map};
+  const void* fn = bwd_generic_fn(need, stile, L0.drop_mode != 0);
+  auto gfits = [&](int Sw) {
+    dim3 grid(cdiv(L0.H, 16), L0.ndir, cdiv(Sw, stile));
     if ((size_t)grid.y * grid.z * kShards * kShardStride > (size_t)kCtlHalf) return false;
-    if (!dry) EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride), st));
-#define EESEN_BP2(CPW, STV)                                                                                       \
-  do {                                                                                                            \
-    if (L.drop_mode) {                                                                                            \
-      if (dry) return fits(lstm_bwd_persistent_kernel<CPW, STV, true>, grid, NW * 64);                            \
-      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, true>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role, chunk); \
-    } else {                                                                                                      \
-      if (dry) return fits(lstm_bwd_persistent_kernel<CPW, STV, false>, grid, NW * 64);                           \
-      coop_launch(st, lstm_bwd_persistent_kernel<CPW, STV, false>, grid1, block, L, dY, lddy, DG, cnt, err, spin_limit, trace, role, chunk); \
-    }                                                                                                             \
-  } while (0)
-#define EESEN_BP(CPW) do { if (stile == 8) EESEN_BP2(CPW, 8); else EESEN_BP2(CPW, 16); } while (0)
-    if (need <= 1) EESEN_BP(1);
-    else if (need <= 2) EESEN_BP(2);
-    else if (need <= 4) EESEN_BP(4);
-    else if (need <= 8) EESEN_BP(8);
-    else EESEN_BP(16);
-#undef EESEN_BP2
-#undef EESEN_BP
-    return true;
+    return fits(fn, grid, NW * 64);
   };
-  const int nwin = pick_windows(L0.S, stile, [&](int Sw) { LstmLayerDev L = L0; L.s_count = Sw; return launch(L, true); });
-  if (nwin == 0) return false;
-  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return false;
-  for (int w = 0; w < nwin; ++w) {
+  const int nwin = pick_windows(L0.S, stile, gfits);
+  if (nwin == 0) return P;
+  if (nwin > 1 && ((size_t)(L0.S / nwin) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 != 0) return P;
+  const dim3 grid(cdiv(L0.H, 16), L0.ndir, cdiv(L0.S / nwin, stile));
+  P.kind = kRecBwdGeneric; P.fn = fn; P.cpw = bwd_generic_cpw(need); P.seq_tile = stile; P.units = 16; P.windows = nwin;
+  snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_kernel<%d,%d,%s>", P.cpw, stile, L0.drop_mode ? "true" : "false");
+  plan_resources(P, grid);
+  return P;
+}
+
+bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY, int lddy, float* DG, unsigned* cnt,
+                         unsigned* err, int spin_limit, unsigned long long* trace) {
+  const RecPlan P = lstm_bwd_plan(L0, false);
+  if (P.kind == kRecNone) return false;
+  const dim3 grid(P.grid[0], P.grid[1], P.grid[2]);
+  const Role role{P.grid[0], P.grid[1], P.grid[2], L0.xcd_map};
+  int chunk = P.chunk;
+  if (P.kind == kRecBwdQ4) {
     LstmLayerDev L = L0;
-    L.s_count = L0.S / nwin;
+    L.s_begin = 0; L.s_count = 0;
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
+    plan_launch(st, P, grid, L, dY, lddy, DG, cnt, err, spin_limit, trace, role);
+    return true;
+  }
+  if (P.kind == kRecBwdKsplitMux || P.kind == kRecBwdKsplit) {
+    const size_t px_need = lstm_bwd_ksplit_px_floats(L0);
+    unsigned long long* px = reinterpret_cast<unsigned long long*>(L0.PX);
+    for (int w = 0; w < P.windows; ++w) {
+      LstmLayerDev L = L0;
+      if (P.kind == kRecBwdKsplitMux) { L.s_begin = 0; L.s_count = 0; }
+      else { L.s_count = L0.S / P.windows; L.s_begin = w * L.s_count; }
+      // counters: one set per (direction, 16-sequence tile) and K quarter -- the multiplexed launch covers every tile of the batch
+      const size_t c1 = (size_t)L0.ndir * (P.kind == kRecBwdKsplitMux ? cdiv(L0.S, 16) : (int)grid.z) * 4 * kShards * kShardStride;
+      EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
+      EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
+      if (P.kind == kRecBwdKsplitMux) plan_launch(st, P, grid, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);
+      else plan_launch(st, P, grid, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk, trace);
+    }
+    return true;
+  }
+  for (int w = 0; w < P.windows; ++w) {
+    LstmLayerDev L = L0;
+    L.s_count = L0.S / P.windows;
     L.s_begin = w * L.s_count;
-    if (!launch(L, false)) return false;
+    EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * (grid.y * grid.z * kShards * kShardStride), st));
+    plan_launch(st, P, grid, L, dY, lddy, DG, cnt, err, spin_limit, trace, role, chunk);
   }
   return true;
 }

@@ -847,6 +847,17 @@ void Net::forward_pass() {
 }
 
 void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi) {
+  bucket_log.clear();
+  deferred_buckets.clear();
+  try {
+    backpropagate_impl(out_diff, ldd, in_diff, ldi);
+  } catch (...) {
+    fail_step_buckets();   // with a communicator: the peers are in this step and wait for every one of its buckets (comm.cpp)
+    throw;
+  }
+}
+
+void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int ldi) {
   EESEN_REQUIRE(propagated, EESEN_ERR_STATE, "Backpropagate needs a preceding Propagate");
   EESEN_HIP_CHECK(hipSetDevice(device));
   int maxdim = 0, max_g = 0, max_y = 0;
@@ -882,10 +893,8 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   // layer: 79.8 ms per step overlapped, 71.4 not (with the two-tile 4 x 32 kernel there: 77.2 / 67.2).  At the recipes' 320 cells the
   // gradient GEMMs are 0.39 x the work and overlapping still pays at S = 64 (47.7 against 49.8 ms per minibatch): the rule stops at
   // H > 320.  EESEN_OVERLAP=1 forces it.
-  bool overlap = this->overlap;
-  if (overlap && tn.overlap < 0 && persistent)
-    for (const Layer& L : layers)
-      if (L.is_lstm() && L.H > 320 && L.H <= 512 && S > 32 && !lstm_bwd_small_tile(lstm_view(*this, L))) overlap = false;
+  const bool overlap = overlap_for_minibatch();
+  exchange_deferred = comm && exchange_deferred_for_minibatch();
   bucket_log.clear();
   info_bwd_persistent = 0;
   live_valid = comm != nullptr;
@@ -1019,6 +1028,73 @@ void Net::backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi)
   // the gradient buffer is complete only when the side stream has drained: make the caller's stream wait for it
   for (int k = 0; k < 2; ++k)
     if (side_pending[k]) EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_grad[k], 0));
+}
+
+// The two per-minibatch schedule decisions of the backward pass, both read from the plan the launcher itself will execute
+// (lstm_bwd_plan: one selection function).
+//   * side stream: the weight-gradient GEMMs under the next-lower recurrence, unless a narrow layer (320 < H <= 512) at more than 32
+//     sequences takes a tile that is not "light" (see the measurements at the call site);
+//   * exchange (comm.cpp): deferred behind the last recurrence whenever some layer's persistent backward grid leaves fewer than 256
+//     registers per SIMD lane free on the CUs it occupies -- an RCCL all-reduce workgroup (ncclDevKernel_Generic_*: 512 threads,
+//     248-256 registers per lane, profiles/r05_rccl_kernel_descriptors.md) then cannot become resident beside it, would run in the
+//     gaps between recurrences and, while it waits for a late peer, hold CUs the next recurrence needs.  Every BASELINE shape is in
+//     that class; narrow layers of <= 256 cells are not.  EESEN_COMM_DEFER=0|1 overrides.
+bool Net::overlap_for_minibatch() const {
+  bool ov = overlap;
+  if (ov && tn.overlap < 0 && persistent)
+    for (const Layer& L : layers)
+      if (L.is_lstm() && L.H > 320 && L.H <= 512 && S > 32 && !lstm_bwd_plan(lstm_view(*this, L), true).light) ov = false;
+  return ov;
+}
+bool Net::exchange_deferred_for_minibatch() const {
+  if (tn.comm_defer >= 0) return tn.comm_defer != 0;
+  if (!persistent) return false;    // no persistent grid: an all-reduce kernel only ever meets finite kernels
+  for (const Layer& L : layers)
+    if (L.is_lstm()) {
+      const RecPlan bp = lstm_bwd_plan(lstm_view(*this, L), true);
+      if (bp.kind != kRecNone && bp.free_vgprs < kRcclVgprsPerSimdLane) return true;   // (unknown register count: -1, deferred)
+    }
+  return false;
+}
+
+// eesen_net_plan_string: what runs the CURRENT minibatch shape (after eesen_net_set_seq_lengths; T from the last Propagate or the
+// longest sequence), as JSON -- per LSTM layer the forward and backward recurrence plans (instantiation, tile, grid, windows,
+// registers, LDS, what the grid leaves free on a CU), and the schedule decisions that follow from them.
+std::string Net::plan_string() const {
+  EESEN_REQUIRE(finalized, EESEN_ERR_STATE, "net not finalized");
+  EESEN_REQUIRE(S > 0, EESEN_ERR_STATE, "call eesen_net_set_seq_lengths first: the plan depends on the minibatch shape");
+  EESEN_HIP_CHECK(hipSetDevice(device));
+  Net& self = const_cast<Net&>(*this);   // lstm_view reads T: plan for the shape the next Propagate will see
+  const int T_saved = T;
+  if (!propagated) { int tm = 0; for (int v : lens) tm = std::max(tm, v); self.T = tm; }
+  auto one = [](const RecPlan& P) {
+    char b[512];
+    if (P.kind == kRecNone) { snprintf(b, sizeof(b), "{\"kernel\": \"per-step kernels (lstm.hip)\", \"persistent\": false}"); return std::string(b); }
+    snprintf(b, sizeof(b), "{\"kernel\": \"%s\", \"persistent\": true, \"sequences_per_workgroup\": %d, \"units_per_workgroup\": %d, \"grid\": [%d, %d, %d], "
+             "\"workgroups\": %d, \"workgroups_per_cu\": %d, \"launches\": %d, \"vgprs\": %d, \"lds_bytes\": %d, \"free_vgprs_per_simd_lane\": %d}",
+             P.kernel, P.seq_tile, P.units, P.grid[0], P.grid[1], P.grid[2], P.wgs, P.wgs_per_cu, P.windows, P.vgprs, P.lds, P.free_vgprs);
+    return std::string(b);
+  };
+  std::string o = "{\"T\": " + std::to_string(T) + ", \"S\": " + std::to_string(S) + ", \"persistent\": " + (persistent ? "true" : "false") + ", \"layers\": [";
+  bool first = true;
+  for (size_t li = 0; li < layers.size(); ++li) {
+    const Layer& L = layers[li];
+    if (!L.is_lstm()) continue;
+    LstmLayerDev v = lstm_view(*this, L);
+    const RecPlan fp = persistent && T >= 1 ? lstm_fwd_plan(v) : RecPlan{}, bp = persistent && T >= 1 ? lstm_bwd_plan(v, true) : RecPlan{};
+    o += std::string(first ? "" : ", ") + "{\"layer\": " + std::to_string(li) + ", \"cells\": " + std::to_string(L.H) + ", \"directions\": " + std::to_string(L.ndir) +
+         ", \"forward\": " + one(fp) + ", \"backward\": " + one(bp) + "}";
+    first = false;
+  }
+  const bool ov = overlap_for_minibatch();
+  o += std::string("], \"weight_gradient_gemms\": \"") + (ov ? "side stream, under the next-lower recurrence" : "main stream, serial") + "\"";
+  o += std::string(", \"gemm_arithmetic\": \"") + (gemm_mode() == 1 ? "3-way bf16 split (fp32-class)" : "f32-input MFMA") + "\"";
+  o += std::string(", \"exchange\": ") + (comm ? (exchange_deferred_for_minibatch() ? "\"deferred: every bucket behind the backward pass's last recurrence\""
+                                                                                      : "\"overlapped: each bucket as soon as its layer's gradients are enqueued\"") : "null");
+  o += std::string(", \"exchange_rule\": \"") + (tn.comm_defer >= 0 ? "EESEN_COMM_DEFER" : "auto: deferred when a persistent backward grid leaves < 256 registers per SIMD lane") + "\"";
+  o += ", \"gpu_share\": " + std::to_string(std::max(1, atoi(getenv("EESEN_GPU_SHARE") ? getenv("EESEN_GPU_SHARE") : "1"))) + "}";
+  self.T = T_saved;
+  return o;
 }
 
 void Net::update() {

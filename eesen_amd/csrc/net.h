@@ -84,6 +84,10 @@ class PhaseTimer {
 struct Comm;  // comm.cpp: RCCL communicator (one rank per GPU)
 void comm_check_alive(const Comm* c);  // throws EESEN_ERR_COMM once the communicator's watchdog has aborted it (null: no-op)
 constexpr size_t kLiveWords = 4;       // floats behind the gradient buffer: [0] = the data-parallel liveness word (comm.cpp)
+// registers per SIMD lane one RCCL all-reduce workgroup needs to become resident on a CU: ncclDevKernel_Generic_{1,2,4} are 512-thread
+// workgroups (two waves per SIMD) of 248-256 registers per lane -- at 256 threads per block one wave per SIMD: 256
+// (profiles/r05_rccl_kernel_descriptors.md, read from librccl's gfx950 code object)
+constexpr int kRcclVgprsPerSimdLane = 256;
 
 struct Net {
   int device = 0;
@@ -164,8 +168,13 @@ struct Net {
   // EESEN_COMM_DEFER=1 (tuning.h): the buckets of a backward pass are issued when its last recurrence has run instead of as each
   // layer's gradients are enqueued -- no all-reduce kernel then competes with a persistent grid for CUs (comm.cpp)
   std::vector<int> deferred_buckets;
+  bool exchange_deferred = false;             // this backward pass's schedule (decided per minibatch: exchange_deferred_for_minibatch)
+  bool overlap_for_minibatch() const;         // weight-gradient GEMMs on the side stream for the current shape (net.cpp)
+  bool exchange_deferred_for_minibatch() const;
+  std::string plan_string() const;            // eesen_net_plan_string
   hipEvent_t ev_bwd_done = nullptr;
   void issue_bucket(int li);
+  void fail_step_buckets() noexcept;          // Backpropagate threw with peers waiting: complete the step's collective sequence (comm.cpp)
   void flush_deferred_buckets();
   std::vector<struct Ctc*> guards;   // the Ctc objects guarding on this Net's error word (eesen_ctc_set_guard): unhooked in ~Net
   bool grads_sanitized = false;   // this step's gradients went through an all-reduce that zeroed them on a raised error word: update() must apply
@@ -191,6 +200,7 @@ struct Net {
   void propagate(const float* in, int rows, int ld, bool is_device);
   void forward_pass();
   void backpropagate(const float* out_diff, int ldd, float* in_diff, int ldi);
+  void backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int ldi);
   void update();
   void refresh_derived();  // W_m^T copies
   // MomentStatistics (utils-functions.h:50-82) of the tensors of one layer in the reference's Info() / InfoGradient() order

@@ -49,12 +49,13 @@
 //   ---- data-parallel exchange (comm.cpp) ----------------------------------------------------------------------------------
 //   EESEN_RCCL_LIBRARY      librccl.so.1   library to dlopen for the nccl* entry points (tests: the stand-in)
 //   EESEN_COMM_TIMEOUT_S    600      watchdog: seconds after which an unfinished collective aborts the communicator
-//   EESEN_COMM_DEFER        0        1: a backward pass's gradient buckets are all-reduced when its LAST recurrence has run (top-down, one
-//                                    after the other on the communication stream) instead of each as soon as its layer's gradients
-//                                    are enqueued: RCCL's kernels (248-256 VGPRs) cannot be resident beside any backward tile of a
-//                                    BASELINE shape, so "overlapped" buckets run in the gaps between recurrences and may hold CUs the
-//                                    next recurrence wants while a peer is late; deferred, the exchange is serial and bounded by the
-//                                    ring time.  For the first real multi-GPU run to choose by measurement
+//   EESEN_COMM_DEFER        auto     a backward pass's gradient buckets all-reduced when its LAST recurrence has run (1: top-down, one after
+//                                    the other on the communication stream) or each as soon as its layer's gradients are enqueued (0).
+//                                    auto (round 6): deferred whenever some layer's persistent backward grid leaves < 256 registers per
+//                                    SIMD lane on its CUs -- RCCL's all-reduce workgroups (248-256 VGPRs x 512 threads) then cannot be
+//                                    resident beside it, would run in the gaps between recurrences and hold CUs the next recurrence
+//                                    wants while a peer is late (measured beside an RCCL-shaped stand-in: profiles/r06_rccl_shaped_soak.json).
+//                                    Every BASELINE shape is deferred; layers of <= 256 cells overlap.  Same buckets, order and sums.
 //   EESEN_COMM_PORT         MASTER_PORT+17  rendezvous port of the hosts that create the communicator from the environment
 #pragma once
 #include <cstdlib>
@@ -67,7 +68,7 @@ struct Tuning {
   int spin_limit = 400000;
   bool spin_limit_set = false;
   int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
-  int comm_defer = 0;
+  int comm_defer = -1;   // -1: decided per minibatch from the backward plans (Net::exchange_deferred_for_minibatch)
   int trace = 0;
   bool print_flight = false;
   const char* poll_ns = nullptr;
@@ -94,7 +95,7 @@ struct Tuning {
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
     t.fwd_split = num("EESEN_FWD_SPLIT", 1);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
-    t.comm_defer = num("EESEN_COMM_DEFER", 0);
+    t.comm_defer = num("EESEN_COMM_DEFER", -1);
     t.trace = num("EESEN_TRACE", 0);
     t.print_flight = getenv("EESEN_PRINT_FLIGHT") != nullptr;
     t.poll_ns = getenv("EESEN_POLL_NS");

@@ -173,6 +173,13 @@ int eesen_net_bf16_recurrence_layers(eesen_net_t* net, int* layers);
  * gradients then enter the all-reduce as zeros (decided on the device) and it applies the same summed update, so the ranks' models
  * stay identical and the run only loses that rank's share of the minibatches in flight. */
 int eesen_net_recurrence_info(eesen_net_t* net, int* out4);
+/* What WILL run the current minibatch shape (call after eesen_net_set_seq_lengths), as one JSON object: per LSTM layer the forward
+ * and backward recurrence plans -- kernel instantiation, sequences / units per workgroup, grid, launches per pass, registers per
+ * lane and LDS bytes of the instantiation, registers per SIMD lane its grid leaves free on a CU -- and the schedule decisions that
+ * follow from them: weight-gradient GEMMs on the side stream or not, the exchange schedule with a communicator attached.  The
+ * launchers execute exactly these plans (one selection function per pass, lstm_persistent.hip: lstm_fwd_plan / lstm_bwd_plan).
+ * Diagnostic; the reference has no counterpart (its kernels are chosen at compile time, src/gpucompute/cuda-kernels.cu). */
+int eesen_net_plan_string(eesen_net_t* net, char* json, int cap);
 /* Test hook: stores `value` into that device word on the handle's stream, as a kernel that gave up would (1: a recurrence
  * kernel's bounded spin, 2: the side stream's wait for a forward milestone), so that the recovery paths can be exercised. */
 int eesen_net_debug_set_error_word(eesen_net_t* net, unsigned value);
@@ -212,6 +219,13 @@ int eesen_comm_create(int device, const char* id128, int rank, int world, eesen_
 int eesen_comm_create_tcp(int device, const char* addr, int port, int rank, int world, int timeout_s, eesen_comm_t** out);
 int eesen_comm_destroy(eesen_comm_t* comm);
 int eesen_comm_info(eesen_comm_t* comm, int* rank, int* world);
+/* What the communicator really is, as one JSON object -- COLLECTIVE: every rank calls it (it gathers one word per rank).
+ * {library: path the dynamic linker resolved, rccl_version: ncclGetVersion, stand_in: the tests' stand-in and not RCCL,
+ *  rank / world: as created, world_seen / rank_seen / device_seen: ncclCommCount / ncclCommUserRank / ncclCommCuDevice,
+ *  devices: [hosthash/PCI bus id of every rank's GPU], distinct_devices, ranks_share_devices}.
+ * The reference's multi-job mode has no such thing (its jobs only meet through files, src/net/communicator.h:39-170); a
+ * collective-based exchange owes its operator the answer to "did N ranks on N distinct GPUs really meet". */
+int eesen_comm_describe(eesen_comm_t* comm, char* json, int cap);
 /* Sum (op 0) or max (op 1) of n <= 64 host doubles over the ranks, in place; blocks.  Carries the statistics the
  * reference merges through done-files (sum ln p, error / reference tokens, frames), "does any rank still have a
  * minibatch", and doubles as a barrier. */

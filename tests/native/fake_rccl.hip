@@ -13,6 +13,11 @@
 //     that never issues the collective leaves the kernel spinning until ncclCommAbort raises the communicator's abort flag
 //     (as RCCL's kernels poll theirs); a hard bound (FAKE_RCCL_SPIN_SECONDS, default 60) keeps a bug from hanging the box;
 //   * every rank ends with bit-identical sums (fixed rank order).
+//   * FAKE_RCCL_SHAPE=rccl (round 6): the kernel takes the FOOTPRINT of the real ncclDevKernel_Generic_* of RCCL 2.27.7's gfx950 code
+//     object (profiles/r05_rccl_kernel_descriptors.md): 512-thread launch bound, 256 VGPRs per lane (the whole register file of
+//     every SIMD of the CU it lands on), 37 664 bytes of static LDS -- so that what becomes resident beside which persistent
+//     recurrence tile, and what waits for what when a peer is late, is what it will be under RCCL; the plain flavour (~30 VGPRs,
+//     a few bytes of LDS) fits beside every tile and exercised a residency real RCCL will not have.
 //
 // Transport: one POSIX shared-memory segment named by the 128-byte unique id, mapped by every rank and registered with HIP
 // (hipHostRegister: fine-grained, system-coherent).  Per collective chunk `seq` (<= FAKE_RCCL_CHUNK_MB, default 8):
@@ -79,6 +84,9 @@ struct FakeComm {
   unsigned* abort_h = nullptr;  // pinned, device-visible: [0] abort flag, [1] error word raised by a kernel
   unsigned* abort_d = nullptr;
   unsigned spin_seconds = 60;
+  bool rccl_shape = false;  // FAKE_RCCL_SHAPE=rccl
+  int threads = kThreads;   // FAKE_RCCL_THREADS: 512 (the kernels' launch bound, default) or 256
+  int device = 0;
 };
 
 __device__ __forceinline__ unsigned ld_acquire_sys(const unsigned* p) {
@@ -115,11 +123,11 @@ __device__ bool wait_all(const unsigned* flag, int world, int b, unsigned target
 }
 
 template <typename T, int OP>  // OP 0 sum, 1 max
-__global__ __launch_bounds__(kThreads) void fake_allreduce_kernel(const T* __restrict__ send, T* __restrict__ recv, size_t n,
-                                                                  char* slots, unsigned* arrive, unsigned* done,
-                                                                  const unsigned* abort_flag, unsigned* err, int rank, int world,
-                                                                  unsigned seq, size_t slot_stride, unsigned long long spin_ticks) {
-  __shared__ int s_bail;
+__device__ __forceinline__ void fake_allreduce_body(const T* __restrict__ send, T* __restrict__ recv, size_t n,
+                                                    char* slots, unsigned* arrive, unsigned* done,
+                                                    const unsigned* abort_flag, unsigned* err, int rank, int world,
+                                                    unsigned seq, size_t slot_stride, unsigned long long spin_ticks, int* s_bail_p) {
+  int& s_bail = *s_bail_p;
   const int b = blockIdx.x, nb = gridDim.x;
   const unsigned long long deadline = wall_clock64() + spin_ticks;
   // this block's contiguous range of 16-byte vectors (the tail elements go to the last block)
@@ -131,13 +139,13 @@ __global__ __launch_bounds__(kThreads) void fake_allreduce_kernel(const T* __res
   T* mine = reinterpret_cast<T*>(par + (size_t)rank * slot_stride);
 
   if (seq >= 3 && !wait_all(done, world, b, seq - 2, abort_flag, err, deadline, &s_bail)) return;
-  for (size_t i = e0 + threadIdx.x; i < e1; i += kThreads) mine[i] = send[i];
+  for (size_t i = e0 + threadIdx.x; i < e1; i += blockDim.x) mine[i] = send[i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // every wave: its stores are visible at system scope ...
   __syncthreads();
   if (threadIdx.x == 0) st_release_sys(arrive + (size_t)rank * kMaxBlocks + b, seq);  // ... before the flag is
 
   if (!wait_all(arrive, world, b, seq, abort_flag, err, deadline, &s_bail)) return;
-  for (size_t i = e0 + threadIdx.x; i < e1; i += kThreads) {
+  for (size_t i = e0 + threadIdx.x; i < e1; i += blockDim.x) {
     T acc = reinterpret_cast<const T*>(par)[i];
     for (int r = 1; r < world; ++r) {
       const T v = reinterpret_cast<const T*>(par + (size_t)r * slot_stride)[i];
@@ -147,6 +155,33 @@ __global__ __launch_bounds__(kThreads) void fake_allreduce_kernel(const T* __res
   }
   __syncthreads();
   if (threadIdx.x == 0) st_release_sys(done + (size_t)rank * kMaxBlocks + b, seq);
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(kThreads) void fake_allreduce_kernel(const T* __restrict__ send, T* __restrict__ recv, size_t n,
+                                                                  char* slots, unsigned* arrive, unsigned* done,
+                                                                  const unsigned* abort_flag, unsigned* err, int rank, int world,
+                                                                  unsigned seq, size_t slot_stride, unsigned long long spin_ticks) {
+  __shared__ int s_bail;
+  fake_allreduce_body<T, OP>(send, recv, n, slots, arrive, done, abort_flag, err, rank, world, seq, slot_stride, spin_ticks, &s_bail);
+}
+
+// The same collective with RCCL's residency footprint (FAKE_RCCL_SHAPE=rccl): ncclDevKernel_Generic_4 of librccl 2.27.7 for gfx950
+// reports .max_flat_workgroup_size 512, .vgpr_count 256, .group_segment_fixed_size 37664.  The registers are claimed by naming the
+// last one of the budget in an asm clobber (the allocation is the highest register a kernel touches), the LDS by a static array
+// that is really written and read; tests/test_kernel_resources.py reads both back from the built code object.
+constexpr int kRcclLdsBytes = 37664;
+template <typename T, int OP>
+__global__ __launch_bounds__(kThreads) void fake_allreduce_rccl_shaped_kernel(const T* __restrict__ send, T* __restrict__ recv, size_t n,
+                                                                              char* slots, unsigned* arrive, unsigned* done,
+                                                                              const unsigned* abort_flag, unsigned* err, int rank, int world,
+                                                                              unsigned seq, size_t slot_stride, unsigned long long spin_ticks) {
+  __shared__ int lds[kRcclLdsBytes / sizeof(int)];
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");
+  for (int i = threadIdx.x + 1; i < (int)(kRcclLdsBytes / sizeof(int)); i += blockDim.x) lds[i] = (int)seq;
+  __syncthreads();
+  fake_allreduce_body<T, OP>(send, recv, n, slots, arrive, done, abort_flag, err, rank, world, seq, slot_stride, spin_ticks, &lds[0]);
+  if (lds[1 + (seq % 1024u)] != (int)seq) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (never: keeps the array alive)
 }
 
 const char* kErr[] = {"no error", "unhandled HIP error", "unhandled system error", "internal error", "invalid argument",
@@ -174,6 +209,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   c->nblocks = std::min(kMaxBlocks, std::max(1, env_int("FAKE_RCCL_BLOCKS", 32)));
   c->chunk_bytes = (size_t)std::max(1, env_int("FAKE_RCCL_CHUNK_MB", 8)) << 20;
   c->spin_seconds = (unsigned)std::max(1, env_int("FAKE_RCCL_SPIN_SECONDS", 60));
+  { const char* sh = getenv("FAKE_RCCL_SHAPE"); c->rccl_shape = sh && std::strcmp(sh, "rccl") == 0; }
+  (void)hipGetDevice(&c->device);
+  c->threads = env_int("FAKE_RCCL_THREADS", kThreads) <= 256 ? 256 : kThreads;
   c->lay = layout(nranks, c->nblocks, c->chunk_bytes);
   id.internal[sizeof(id.internal) - 1] = 0;
   const int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
@@ -210,8 +248,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   c->abort_d = static_cast<unsigned*>(d);
   *comm = reinterpret_cast<ncclComm_t>(c);
   if (rank == 0 && !getenv("FAKE_RCCL_QUIET"))
-    fprintf(stderr, "fake_rccl (TEST STAND-IN, not RCCL): %d rank(s), %d x %d-thread workgroups per all-reduce, %zu MB chunks through host memory\n",
-            nranks, c->nblocks, kThreads, c->chunk_bytes >> 20);
+    fprintf(stderr, "fake_rccl (TEST STAND-IN, not RCCL): %d rank(s), %d x %d-thread workgroups per all-reduce%s, %zu MB chunks through host memory\n",
+            nranks, c->nblocks, c->threads, c->rccl_shape ? " with RCCL's footprint (256 VGPRs, 37.7 KB LDS)" : "", c->chunk_bytes >> 20);
   return ncclSuccess;
 }
 
@@ -230,19 +268,20 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
   for (size_t off = 0; off < count; off += per_chunk) {
     const size_t n = std::min(per_chunk, count - off);
     const unsigned seq = ++c->seq;
-    const dim3 grid(c->nblocks), block(kThreads);
-    if (datatype == ncclFloat32)
-      hipLaunchKernelGGL((fake_allreduce_kernel<float, 0>), grid, block, 0, stream, static_cast<const float*>(sendbuff) + off,
-                         static_cast<float*>(recvbuff) + off, n, slots, arrive, done, c->abort_d, c->abort_d + 1, c->rank, c->world, seq,
-                         c->lay.slot_stride, ticks);
-    else if (op == ncclSum)
-      hipLaunchKernelGGL((fake_allreduce_kernel<double, 0>), grid, block, 0, stream, static_cast<const double*>(sendbuff) + off,
-                         static_cast<double*>(recvbuff) + off, n, slots, arrive, done, c->abort_d, c->abort_d + 1, c->rank, c->world, seq,
-                         c->lay.slot_stride, ticks);
-    else
-      hipLaunchKernelGGL((fake_allreduce_kernel<double, 1>), grid, block, 0, stream, static_cast<const double*>(sendbuff) + off,
-                         static_cast<double*>(recvbuff) + off, n, slots, arrive, done, c->abort_d, c->abort_d + 1, c->rank, c->world, seq,
-                         c->lay.slot_stride, ticks);
+    const dim3 grid(c->nblocks), block(c->threads);
+#define FAKE_LAUNCH(KERN, TYPE, OPV)                                                                                              \
+  hipLaunchKernelGGL((KERN<TYPE, OPV>), grid, block, 0, stream, static_cast<const TYPE*>(sendbuff) + off, static_cast<TYPE*>(recvbuff) + off, \
+                     n, slots, arrive, done, c->abort_d, c->abort_d + 1, c->rank, c->world, seq, c->lay.slot_stride, ticks)
+    if (c->rccl_shape) {
+      if (datatype == ncclFloat32) FAKE_LAUNCH(fake_allreduce_rccl_shaped_kernel, float, 0);
+      else if (op == ncclSum) FAKE_LAUNCH(fake_allreduce_rccl_shaped_kernel, double, 0);
+      else FAKE_LAUNCH(fake_allreduce_rccl_shaped_kernel, double, 1);
+    } else {
+      if (datatype == ncclFloat32) FAKE_LAUNCH(fake_allreduce_kernel, float, 0);
+      else if (op == ncclSum) FAKE_LAUNCH(fake_allreduce_kernel, double, 0);
+      else FAKE_LAUNCH(fake_allreduce_kernel, double, 1);
+    }
+#undef FAKE_LAUNCH
     if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
   }
   return ncclSuccess;
@@ -266,6 +305,24 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   if (c->abort_h) (void)hipHostFree(c->abort_h);
   delete c;
   return ncclSuccess;
+}
+
+// what eesen_comm_describe asks the library about itself: version 0 = "not RCCL"
+ncclResult_t ncclGetVersion(int* v) { if (!v) return ncclInvalidArgument; *v = 0; return ncclSuccess; }
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* n) {
+  const FakeComm* c = reinterpret_cast<const FakeComm*>(comm);
+  if (!c || !n) return ncclInvalidArgument;
+  *n = c->world; return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* r) {
+  const FakeComm* c = reinterpret_cast<const FakeComm*>(comm);
+  if (!c || !r) return ncclInvalidArgument;
+  *r = c->rank; return ncclSuccess;
+}
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* d) {
+  const FakeComm* c = reinterpret_cast<const FakeComm*>(comm);
+  if (!c || !d) return ncclInvalidArgument;
+  *d = c->device; return ncclSuccess;
 }
 
 const char* ncclGetErrorString(ncclResult_t r) { return (int)r >= 0 && (int)r < 8 ? kErr[(int)r] : "unknown result code"; }
