@@ -248,7 +248,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     resident in HBM, `reps` repetitions of `steps` timed steps (ms_per_step = the median repetition; min / max beside it), so that
     the driver's record holds a driver-timed number for every configuration -- and the CTC against its HBM roofline at the
     configuration BASELINE.json says it binds at (configs[4])."""
-    from eesen_amd.api import Net, Ctc, CuMatrix
+    from eesen_amd.api import Net, Ctc, CuMatrix, Feeder
     cfg = synth.config(name)
     cfg.update(over or {})
     layers = synth.make_model(max_grad=50.0, **cfg)
@@ -260,8 +260,24 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     ctc.SetGuard(net)
     feats = CuMatrix.from_numpy(batch.feats, dev)
     diff = CuMatrix(batch.T * batch.S, cfg["K"], dev)
+    # round 6: like the headline, the timed step INCLUDES the minibatch's H2D (S host matrices -> pinned slot -> one PCIe copy ->
+    # interleave on the device, double-buffered under the previous step's backward pass); the device-resident loop is kept beside it
+    f3 = batch.feats.reshape(batch.T, batch.S, cfg["D"])
+    mats = [np.ascontiguousarray(f3[: batch.lens[s], s, :]) for s in range(batch.S)]
+    feeder = Feeder(dev, slots=2)
+    pending = [feeder.submit(mats)]
 
     def step():
+        slot = pending.pop()
+        net.SetSeqLengths(batch.lens)
+        out = net.Propagate(feeder.acquire(slot))
+        feeder.release(slot)
+        ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
+        ctc.ErrorRateMSeq(batch.lens, out, batch.labels, deferred=True)
+        net.Backpropagate(diff)
+        pending.append(feeder.submit(mats))
+
+    def step_resident():
         net.SetSeqLengths(batch.lens)
         out = net.Propagate(feats)
         ctc.EvalParallel(batch.lens, out, batch.labels, diff, want_pzx=False)
@@ -270,6 +286,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     for _ in range(warmup):
         step()
     net.Synchronize()
+    plan = net.Plan()
     ctc.SetProfiling(True)
     net.SetProfiling(True, accumulate=True)
     dts = []
@@ -283,6 +300,13 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     phases = net.PhaseTimes()
     ctc.SetProfiling(False)
     net.SetProfiling(False)
+    step_resident()
+    net.Synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_resident()
+    net.Synchronize()
+    dt_res = (time.perf_counter() - t0) / steps
     dt = float(np.median(dts))
     info = net.RecurrenceInfo()
     fpf = flops_per_frame(cfg)
@@ -291,7 +315,9 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     return {"workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
                         f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
             "steps": steps, "warmup": warmup, "repetitions": reps, "ms_per_step": 1e3 * dt, "ms_per_step_min_median_max": [1e3 * min(dts), 1e3 * dt, 1e3 * max(dts)],
-            "frames_per_s": frames / dt, "input": "device-resident",
+            "frames_per_s": frames / dt, "input": "host matrices through the feeder, H2D inside the timed step (like the headline)",
+            "device_resident_ms_per_step": 1e3 * dt_res, "device_resident_frames_per_s": frames / dt_res,
+            "kernels": plan_summary(plan),
             "phase_ms_per_step": {k: 1e3 * v / (reps * steps) for k, v in phases.items()},
             "ctc": ctc_block(cfg, batch, ctc_ph, reps * steps),
             "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
@@ -300,6 +326,21 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
             "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, True, fwd_rec_products(cfg, batch.S, int(forward_bf16)))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
+
+
+def plan_summary(plan: dict) -> dict:
+    """eesen_net_plan_string boiled down to what a bench leg should say about itself: the recurrence instantiations the library's
+    one selection function chose for this shape (the launchers execute exactly these), and the schedule decisions."""
+    fw = sorted({L["forward"]["kernel"] for L in plan["layers"]})
+    bw = sorted({L["backward"]["kernel"] for L in plan["layers"]})
+    one = plan["layers"][-1] if plan["layers"] else None
+    out = {"forward": fw, "backward": bw, "weight_gradient_gemms": plan["weight_gradient_gemms"], "exchange": plan["exchange"]}
+    if one and one["backward"].get("persistent"):
+        b, f = one["backward"], one["forward"]
+        out["backward_tile"] = {k: b[k] for k in ("sequences_per_workgroup", "units_per_workgroup", "workgroups", "launches", "vgprs", "lds_bytes", "free_vgprs_per_simd_lane")}
+        if f.get("persistent"):
+            out["forward_tile"] = {k: f[k] for k in ("sequences_per_workgroup", "units_per_workgroup", "workgroups", "workgroups_per_cu", "launches", "vgprs", "lds_bytes")}
+    return out
 
 
 def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int = 25000, reps: int = 3) -> dict:
@@ -361,6 +402,76 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int 
             "persistent_layer_passes": {"fwd": pers[0], "bwd": pers[1], "of": pers[2]}, "recoveries": net.recoveries}
 
 
+def check_full_cfg3(comm, dev: int, rank: int, world: int, all_reduce) -> dict:
+    """--check full_cfg3 (N = 8): SURVEY.md section 8e's parity statement through the REAL exchange.  Rank r runs shard r of the global
+    minibatch of BASELINE configs[2] (256 utterances, T = 1000, 4 x 512; the interleaved deal of eesen_amd.parallel.shard_batch) with
+    lr = 1, momentum 0, no clipping, and the communicator attached; what eesen_net_get_grads returns after Backpropagate is then the
+    all-reduced gradient of the 256 utterances.  It is held against the committed fixture tests/golden/full_cfg3.npz -- ONE process of
+    the reference itself at --num-sequence 256 (its CUDA CTC bodies executed on the CPU; made by oracle/fullsize.py where
+    /root/reference exists) -- on the fixture's sample (every 1009th element + every tensor of <= 8192 elements whole) and its
+    per-tensor sums, at the fixture's own bars: per tensor max(1e-4, 3 x the reference's fp32-vs-fp64-CTC floor).  Data only is read
+    here (the .npz); nothing under oracle/ is imported.  Every rank calls this (collectives inside); rank 0's dict is the result."""
+    from eesen_amd.api import Net, Ctc
+    from eesen_amd.parallel import shard_batch, deal_shards
+    W, STRIDE, SMALL, TOL = 8, 1009, 8192, 1e-4
+    if world != W:
+        return {"skipped": f"needs 8 ranks (the fixture is the 8-shard global minibatch); this run has {world}"}
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "full_cfg3.npz"))
+    cfg = synth.config("cfg2"); cfg["S"] = 256
+    layers = synth.make_model(**cfg)                       # no <MaxGrad>: the delta of an lr = 1 step IS the gradient
+    glob = synth.make_batch(**cfg)
+    sb = shard_batch(glob, rank, W)
+    net = Net.from_layers(layers, device=dev)
+    net.SetTrainOptions(1.0, 0.0)
+    net.SetComm(comm)
+    ctc = Ctc(device=dev)
+    net.SetSeqLengths(sb.lens)
+    out = net.Propagate(sb.feats)
+    diff = ctc.EvalParallel(sb.lens, out, sb.labels)
+    net.BackpropagateNoUpdate(diff)
+    g = net.GetGrads().astype(np.float64)                  # waits for the buckets: the SUM over the eight ranks
+    plan = net.Plan()
+    info = net.RecurrenceInfo()
+    net.SetComm(None)
+    # ln p of this rank's utterances against the fixture's, worst over the ranks
+    mine = deal_shards(glob.S, W)[rank]
+    e_pzx = float(np.max(np.abs(ctc.pzx.astype(np.float64) - fx["pzx"][mine]) / np.maximum(np.abs(fx["pzx"][mine]), 1e-30)))
+    e_pzx = all_reduce([e_pzx], 1)[0]
+    # the fixture's gradient sample and per-tensor statistics, in Net::GetParams order
+    bounds, i = [], 0
+    for L in layers:
+        for prm in L["params"]:
+            bounds.append((i, i + prm.size)); i += prm.size
+    m = np.zeros(i, bool); m[::STRIDE] = True
+    for a, b in bounds:
+        if b - a <= SMALL:
+            m[a:b] = True
+    idx = np.flatnonzero(m)
+    fs, floors = fx["grad_stats"], fx["floor_grads"]
+    worst, worst_ratio, bad = 0.0, 0.0, []
+    for t, (a, b) in enumerate(bounds):
+        gt = g[a:b]
+        e = abs(np.max(np.abs(gt)) - fs[t, 0]) / fs[t, 0]
+        e = max(e, abs(gt.sum() - fs[t, 1]) / fs[t, 2], abs(np.abs(gt).sum() - fs[t, 2]) / fs[t, 2])
+        lo, hi = np.searchsorted(idx, [a, b])
+        if hi > lo:
+            e = max(e, float(np.max(np.abs(g[idx[lo:hi]] - fx["grad_sample"][lo:hi].astype(np.float64))) / fs[t, 0]))
+        bar = max(TOL, 3.0 * float(floors[t]))
+        worst, worst_ratio = max(worst, float(e)), max(worst_ratio, float(e) / bar)
+        if not (e < bar and e < max(3 * TOL, float(floors[t]))):
+            bad.append(t)
+    # every rank must have computed the same verdict from the same summed gradient
+    v = all_reduce([worst, -worst], 1)
+    same = v[0] == -v[1]
+    ok = bool(not bad and e_pzx < TOL and same)
+    return {"ok": ok, "fixture": "tests/golden/full_cfg3.npz: one reference process, --num-sequence 256 (made by oracle/fullsize.py)",
+            "shards": W, "utterances_per_shard": sb.S, "ln_p_worst_rel_err_per_sequence": e_pzx,
+            "summed_gradient_worst_tensor_error": worst, "worst_error_over_its_bar": worst_ratio, "tensors": len(bounds), "tensors_over_bar": bad,
+            "bar": "per tensor max(1e-4, 3 x the reference's own fp32-vs-fp64-CTC floor), as tests/test_gpu_reference_fullsize.py",
+            "every_rank_sees_the_same_sum": bool(same), "exchange": plan["exchange"],
+            "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -383,6 +494,10 @@ def main():
     ap.add_argument("--comm", choices=["native", "bulk", "torch"], default="native",
                     help="gradient exchange: native = the library's RCCL communicator, one bucket per layer overlapped with the backward "
                          "pass (default); bulk = the same communicator, one all-reduce after the backward pass; torch = torch.distributed")
+    ap.add_argument("--check", choices=["full_cfg3"], default=None,
+                    help="N = 8 only: before the timed steps, the eight shards of BASELINE configs[2]'s global minibatch (256 utterances) through the "
+                         "communicator -- the all-reduced gradient against tests/golden/full_cfg3.npz (ONE reference process at --num-sequence "
+                         "256) at the fixture's bars; the result goes into the line as config.check_full_cfg3")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -423,6 +538,30 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX if op == Comm.MAX else dist.ReduceOp.SUM)
             return t.tolist()
         return list(values)
+
+    # What the exchange really is: the library the linker resolved, the ranks and devices IT reports, every
+    # rank's PCI bus id.  n_gpus of the line = the DISTINCT devices the ranks sit on, not the number of processes.
+    comm_desc = None
+    if comm is not None:
+        comm_desc = comm.Describe()                     # collective
+    elif dist is not None:
+        props = torch.cuda.get_device_properties(local)
+        busid = f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', local):02x}:{getattr(props, 'pci_device_id', 0):02x}.0"
+        allb = [None] * dist.get_world_size()
+        dist.all_gather_object(allb, (os.uname().nodename, busid))
+        comm_desc = {"library": "torch.distributed (backend nccl = RCCL on ROCm)", "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
+                     "stand_in": False, "rank": dist.get_rank(), "world": world, "world_seen": dist.get_world_size(),
+                     "devices": [f"{h}/{b}" for h, b in allb], "distinct_devices": len(set(allb)), "ranks_share_devices": len(set(allb)) < dist.get_world_size()}
+
+    check = None
+    if args.check == "full_cfg3":
+        if comm is None:
+            check = {"skipped": "needs the library's communicator (--comm native / bulk) and 8 ranks"}
+        else:
+            try:
+                check = check_full_cfg3(comm, local, rank, world, all_reduce)
+            except Exception as e:   # noqa: BLE001 -- the check must never take the measurement down (it fails on every rank alike or not at all: same code, same data)
+                check = {"ok": False, "error": str(e)}
 
     cfg = synth.config(args.config)
     for k in ("T", "H", "S", "layers"):
@@ -512,6 +651,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     spans = net.PhaseSpans()           # every timed span of the K steps, in record order (before PhaseTimes clears them)
+    main_plan = net.Plan()             # what the library's selection functions chose for this shape -- with the exchange schedule
+    # Do the ranks still hold the SAME model after warm-up + K steps?  Every rank hashes its parameters (48 bits of sha1: exact in the
+    # doubles the communicator's host all-reduce carries); identical iff max == min over the ranks.
+    ranks_identical = None
+    if multi:
+        import hashlib
+        hv = float(int.from_bytes(hashlib.sha1(net.GetParams().tobytes()).digest()[:6], "big"))
+        mx = all_reduce([hv, -hv], Comm.MAX)
+        ranks_identical = bool(mx[0] == -mx[1])
     phases = net.PhaseTimes()
     ctc_ph = ctc.PhaseTimes()
     ctc.SetProfiling(False)
@@ -694,19 +842,31 @@ def main():
         roofline["ctc"] = ctc_block(cfg, batch, ctc_ph, K)
         line = {
             "metric": "CTC training frames/sec (whole node), 4x512 BiLSTM",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": value, "unit": "frames/s", "n_gpus": (comm_desc["distinct_devices"] if comm_desc else world), "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.forward_precision == "f32" else "bf16-fwd/f32", "data": "synthetic (seed 777: N(0,1) 40-d features, lengths U{0.8T..T}, T/10 labels per utterance, U(-0.1,0.1) weights)",
             "config": {"workload": f"{args.config}: {nl}x{H} {'Bi' if nd == 2 else ''}LSTM + affine + softmax + CTC, D={cfg['D']}, K={cfg['K']}, "
                                    f"S={S} utterances/GPU, T_max={T}, SGD lr=4e-5 momentum=0.9 max_grad=50",
-                       "global_batch_utterances": S * world, "parallelism": f"dp{world}",
+                       "global_batch_utterances": S * world, "parallelism": f"dp{world}", "ranks": world,
+                       # flat on purpose (a reader that keeps only scalars still sees them): did N ranks on N distinct GPUs meet through RCCL, and did they stay identical
+                       "ranks_share_devices": (comm_desc["ranks_share_devices"] if comm_desc else None),
+                       "distinct_devices": (comm_desc["distinct_devices"] if comm_desc else None),
+                       "comm_stand_in": (comm_desc["stand_in"] if comm_desc else None),
+                       "comm_library": (comm_desc["library"] if comm_desc else None),
+                       "comm_world_seen": (comm_desc["world_seen"] if comm_desc else None),
+                       "ranks_bit_identical": ranks_identical,
+                       "check_full_cfg3_ok": (check.get("ok") if check else None),
+                       "vs_1gpu": None,     # for the driver to fill: value / (N x the N = 1 value of the same round)
+                       "comm": comm_desc,
+                       "check_full_cfg3": check,
                        "gradient_exchange": (None if not multi else
-                                             {"native": "RCCL all-reduce(sum, fp32) per layer bucket on a communication stream, issued by libeesen_hip.so as each layer's weight-gradient kernels are enqueued",
-                                              "bulk": "one RCCL all-reduce of the whole gradient buffer after the backward pass (libeesen_hip.so)",
+                                             ("TEST STAND-IN (tests/native/libfake_rccl.so, NOT RCCL): " if comm_desc and comm_desc["stand_in"] else "RCCL ") +
+                                             {"native": "all-reduce(sum, fp32) per layer bucket on a communication stream, issued by libeesen_hip.so",
+                                              "bulk": "one all-reduce of the whole gradient buffer after the backward pass (libeesen_hip.so)",
                                               "torch": "one torch.distributed all-reduce of the whole gradient buffer"}[args.comm]),
-                       "exchange_schedule": (None if not multi else ("deferred: every bucket behind the backward pass's last recurrence (EESEN_COMM_DEFER=1)"
-                                                                       if os.environ.get("EESEN_COMM_DEFER", "0") not in ("", "0") else
-                                                                       "overlapped: each bucket as soon as its layer's gradients are enqueued (default; EESEN_COMM_DEFER=1 is the other one)")),
+                       "exchange_schedule": (None if not multi or args.comm != "native" else main_plan["exchange"]),
+                       "exchange_rule": (None if not multi or args.comm != "native" else main_plan["exchange_rule"]),
+                       "kernels": plan_summary(main_plan),
                        "real_frames_per_s": real * K / dt, "padded_frames_per_step": padded, "real_frames_per_step": real,
                        "h2d": "inside the timed step: S host matrices -> pinned slot -> one PCIe copy -> time-major interleave on the device (feeder), double-buffered",
                        "device_resident_frames_per_s": resident["frames_per_s"] if resident else None,
@@ -772,6 +932,15 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     sec[name] = {"error": str(e)}
             line["config"]["secondary"] = sec
+            # every leg's figure twice more, where a truncated or scalars-only copy of the line still has it: flat in config, and as
+            # the LAST object of the line (the driver's stored tail is the last 9 KB)
+            legs = {}
+            for name, r in sec.items():
+                v = r.get("ms_per_step", r.get("ms_per_minibatch")) if isinstance(r, dict) else None
+                legs[name] = v if v is not None else (r.get("error") if isinstance(r, dict) else None)
+                line["config"]["leg_" + name + ("_ms_per_step" if "ms_per_step" in r else "_ms_per_minibatch")] = v
+            line["legs_ms"] = {"headline_cfg2": line["ms_per_step"], **legs,
+                               "note": "ms per step (cfg legs, H2D inside the step) / per minibatch (recipe legs); details in config.secondary"}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if multi:
         all_reduce([0.0])

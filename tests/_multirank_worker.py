@@ -52,16 +52,30 @@ def soak(out, opt):
         ms = 1e3 * (time.perf_counter() - t0) / steps
         info = net.RecurrenceInfo()
         p = net.GetParams()
+        # a second, shorter pass with the library's span timers on: what the exchange itself took and what of it was exposed
+        ex = {}
         if comm is not None:
+            net.SetProfiling(True, accumulate=True)
+            n2 = max(1, min(steps, 50))
+            for _ in range(n2):
+                step()
+            net.Synchronize()
+            spans = net.PhaseSpans(); net.PhaseTimes(); net.SetProfiling(False)
+            for nm in ("recurrence_bwd", "allreduce", "allreduce_exposed"):
+                v = [sec for n_, sec in spans if n_ == nm]
+                ex[nm] = 1e3 * sum(v) / n2
+                ex["max_" + nm] = 1e3 * max(v or [0.0])
+            ex["schedule"] = net.Plan()["exchange"]
+            net.RecurrenceInfo()
             net.SetComm(None)
-        return ms, info, net.recoveries, p, ctc.Dropped()
+        return ms, info, net.recoveries, p, ctc.Dropped(), ex
 
-    ms0, info0, rec0, p0, _ = run(None)
+    ms0, info0, rec0, p0, _, _ = run(None)
     comm = Comm.from_env(device=0, timeout_s=60)
     standin = any("libfake_rccl.so" in l for l in open("/proc/self/maps"))   # not the real RCCL, whose one-rank all-reduce is a no-op
-    ms1, info1, rec1, p1, dropped = run(comm)
+    ms1, info1, rec1, p1, dropped, ex = run(comm)
     np.savez(out, ms0=ms0, ms1=ms1, info0=list(info0.values()), info1=list(info1.values()), rec0=rec0, rec1=rec1, dropped=dropped,
-             identical=np.array_equal(p0, p1), standin=standin, steps=steps)
+             identical=np.array_equal(p0, p1), standin=standin, steps=steps, exchange=np.array(__import__("json").dumps(ex)))
 
 
 def main():
@@ -91,12 +105,25 @@ def main():
     ctc = Ctc()
     ctc.SetGuard(net)
 
-    def real_step(batch):
+    # straggle_ms=3 straggle_rank=1: that rank's host is late by 3 ms EVERY step -- its collectives arrive late, which is when a
+    # resident all-reduce kernel of the punctual rank holds its CUs longest (the straggler case)
+    straggle_s = float(opt.get("straggle_ms", 0)) * 1e-3 if rank == int(opt.get("straggle_rank", -1)) else 0.0
+    captured = {"grads": [], "params": []}
+
+    def real_step(batch, capture=False):
+        if straggle_s:
+            time.sleep(straggle_s)
         net.SetSeqLengths(batch.lens)
         o = net.Propagate(batch.feats)
         d = ctc.EvalParallel(batch.lens, o, batch.labels, want_pzx=False)
         ctc.ErrorRateMSeq(batch.lens, o, batch.labels, deferred=True)
-        net.Backpropagate(d)
+        if capture:   # the exchange's result itself: the all-reduced fresh gradient, read between Backpropagate and Update
+            net.BackpropagateNoUpdate(d)
+            captured["grads"].append(net.GetGrads())     # (eesen_net_get_grads waits for the buckets)
+            net.Update()
+            captured["params"].append(net.GetParams())
+        else:
+            net.Backpropagate(d)
 
     res = {}
     t0 = time.time()
@@ -104,8 +131,10 @@ def main():
         mine = shard_batch(full, rank, world)     # utterance s -> rank s mod N, re-padded to the shard's own T_max
         try:
             for _ in range(steps):
-                real_step(mine)
+                real_step(mine, capture=opt.get("grads") == "1")
             net.Synchronize()
+            if captured["grads"]:
+                res["grads_steps"] = np.stack(captured["grads"]); res["params_each_step"] = np.stack(captured["params"])
             res["error"] = np.array("")
         except EesenError as e:
             res["error"] = np.array(str(e))
@@ -119,8 +148,11 @@ def main():
         # 3 steps whose result goes to the arbiters, then a soak of `soak` more steps: per-step time, recoveries, the exchange's spans.
         mine = shard_batch(full, rank, world)
         for _ in range(steps):
-            real_step(mine)
+            real_step(mine, capture=opt.get("grads") == "1")
         net.Synchronize()
+        if captured["grads"]:
+            res["grads_steps"] = np.stack(captured["grads"]); res["params_each_step"] = np.stack(captured["params"])
+        res["plan"] = np.array(__import__("json").dumps(net.Plan()))
         res["params_steps"] = net.GetParams()
         res["recurrence_steps"] = np.array(list(net.RecurrenceInfo().values()))
         nsoak = int(opt.get("soak", 0))
@@ -138,6 +170,7 @@ def main():
             net.SetProfiling(False)
             for nm in ("recurrence_fwd", "recurrence_bwd", "allreduce", "allreduce_exposed"):
                 res["soak_ms_" + nm] = np.array(1e3 * sum(sec for n_, sec in spans if n_ == nm) / nsoak)
+                res["soak_max_ms_" + nm] = np.array(1e3 * max([sec for n_, sec in spans if n_ == nm] or [0.0]))   # the longest single span: a recurrence held up by a resident all-reduce shows here
             res["soak_steps"] = np.array(nsoak)
         res["error"] = np.array("")
         net.RecurrenceInfo()

@@ -148,3 +148,43 @@ def test_timed_out_recurrence_contributes_zero_in_a_data_parallel_run(gpu, comm,
         assert rel_err(net.GetParams(), want) < 1e-6
         assert net.LiveRanks() == 1
         net.SetComm(None)
+
+
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_backpropagate_that_throws_still_completes_the_steps_collectives(gpu, comm, defer, monkeypatch, capfd):
+    """a Backpropagate that throws half-way (here: a dropout layer asked to backpropagate in test mode,
+    bilstm-parallel-layer.h:425 -- the LOWEST layer, so the upper layers' gradients are already complete) on a rank whose peers are
+    in the same step.  The peers issue every bucket of the step; the failing rank must too, or they spin until the watchdog's
+    EESEN_COMM_TIMEOUT_S -- in the overlapped schedule for the lower buckets, in the deferred one for ALL of them.  The library
+    completes the sequence before the exception leaves it: complete gradients as they are, the rest as zeros.  Seen here at world
+    size 1 through what is observable: the exception still arrives, the bucket log holds every trainable layer top-down, the
+    communicator is alive, and the next (clean) step equals a clean net's."""
+    from eesen_amd.api import Net, Ctc, EesenError
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(max_grad=0.5, **cfg)
+    batch = synth.make_batch(**cfg)
+    monkeypatch.setenv("EESEN_COMM_DEFER", defer)
+    net = Net.from_layers(layers); net.SetTrainOptions(1e-3, 0.9); ctc = Ctc()
+    net.SetComm(comm)
+    trainable = [i for i, L in enumerate(layers) if L["params"]]
+    net.SetLayerDropout(0, {"forward": 0.2})
+    net.SetTestMode()
+    net.SetSeqLengths(batch.lens)
+    o = net.Propagate(batch.feats)
+    d = ctc.EvalParallel(batch.lens, o, batch.labels)
+    before = net.GetParams()
+    with pytest.raises(EesenError, match="test mode"):
+        net.BackpropagateNoUpdate(d)
+    assert net.BucketOrder() == trainable[::-1]                     # the whole sequence went out, in the peers' order
+    assert "all-reduced as zeros" in capfd.readouterr().err
+    g = net.GetGrads()                                              # (waits for the buckets: none is stuck)
+    from tests.util import split_params
+    assert not np.any(split_params(layers, g)[0][2])                # the failed layer's bucket carried zeros
+    assert comm.allreduce([2.0]) == [2.0]                           # the communicator is alive
+    assert np.array_equal(net.GetParams(), before)
+    # the same handle, made sane again, takes a clean step equal to a fresh net's
+    net.SetLayerDropout(0, {})
+    net.SetTrainMode()
+    got = _steps(net, ctc, batch, 1)[-1][1]
+    net.SetComm(None)
+    assert rel_err(got, _steps_reference(layers, batch, 1)) < 1e-6

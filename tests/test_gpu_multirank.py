@@ -100,6 +100,70 @@ def _single_process(cfg, batches, lr=1e-3, momentum=0.9, max_grad=0.05, persiste
     return net.GetParams(), ctc.stats()
 
 
+def _with_params(layers, flat):
+    """The same topology carrying the parameters of a flat Net::GetParams-ordered vector."""
+    out, i = [], 0
+    for L in layers:
+        L = dict(L)
+        ps = []
+        for p in L["params"]:
+            ps.append(np.asarray(flat[i:i + p.size], np.float32).reshape(p.shape)); i += p.size
+        L["params"] = ps
+        out.append(L)
+    assert i == len(flat)
+    return out
+
+
+def _gradient_arbiters(layers, full, params_before, persistent):
+    """The gradient of the WHOLE minibatch at the given parameters, two ways: this library in ONE process, and the reference's own
+    Net (oracle/_ref; an lr = 1, momentum 0, <MaxGrad> 0 step's parameter delta IS the gradient, bilstm-layer.h:846-883).
+    Returns (one_process, reference | None), flat in Net::GetParams order."""
+    from eesen_amd.api import Net, Ctc
+    from eesen_amd import nnet_io
+    from oracle import refbind
+    import tempfile
+    lay = _with_params(layers, params_before)
+    for L in lay:
+        L["max_grad"] = 0.0
+    old = os.environ.get("EESEN_PERSISTENT")
+    os.environ["EESEN_PERSISTENT"] = persistent
+    try:
+        net = Net.from_layers(lay)
+    finally:
+        if old is None:
+            del os.environ["EESEN_PERSISTENT"]
+        else:
+            os.environ["EESEN_PERSISTENT"] = old
+    net.SetTrainOptions(1.0, 0.0)
+    ctc = Ctc()
+    net.SetSeqLengths(full.lens)
+    o = net.Propagate(full.feats)
+    d = ctc.EvalParallel(full.lens, o, full.labels, want_pzx=False)
+    net.BackpropagateNoUpdate(d)
+    one = net.GetGrads()
+    ref = None
+    if refbind.available():
+        path = tempfile.mktemp(suffix=".nnet")
+        nnet_io.write_nnet(path, lay, binary=True)
+        try:
+            rn = refbind.RefNet(path)
+        finally:
+            os.unlink(path)
+        before = rn.get_params().astype(np.float64)
+        rn.set_train_options(1.0, 0.0)
+        rn.set_seq_lengths(full.lens)
+        ro = rn.propagate(full.feats)
+        c = refbind.cuda_ctc_eval_parallel(ro, full.T, full.S, full.lens, full.label_ids, full.label_off)
+        rn.backpropagate(c["diff"], False)
+        ref = (before - rn.get_params().astype(np.float64)).astype(np.float32)
+    return one, ref
+
+
+def _per_tensor(layers, a, b):
+    from tests.util import split_params
+    return {f"L{li}.{nm}": rel_err(x, y) for (li, nm, x), (_, _, y) in zip(split_params(layers, a), split_params(layers, b))}
+
+
 def _merge(batches):
     """One minibatch holding the utterances of several (each re-padded to the longest): what a single process with
     --num-sequence = the sum would have assembled."""
@@ -122,11 +186,25 @@ def _merge(batches):
 def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(gpu, tmp_path, defer):
     """(defer = "1": EESEN_COMM_DEFER -- the buckets issued behind the backward pass's last recurrence; same sums.)"""
     cfg = synth.config("small_bi"); cfg.update(S=32, T=60)
-    res, rcs, errs = launch("parity", 2, tmp_path, dict(cfg="small_bi", S=32, T=60, steps=3), env_extra={"EESEN_COMM_DEFER": defer})
+    res, rcs, errs = launch("parity", 2, tmp_path, dict(cfg="small_bi", S=32, T=60, steps=3, grads=1), env_extra={"EESEN_COMM_DEFER": defer})
     assert rcs == [0, 0] and all(r is not None for r in res), errs
     assert not str(res[0]["error"]) and not str(res[1]["error"]), (res[0]["error"], res[1]["error"])
     assert np.array_equal(res[0]["params"], res[1]["params"])            # the ranks hold the same model, bit for bit
+    assert np.array_equal(res[0]["grads_steps"], res[1]["grads_steps"])  # ... because they applied the same SUM, bit for bit
     full = synth.make_batch(**cfg)
+    # What the exchange delivers, per step: the all-reduced fresh gradient (read between Backpropagate and Update) against the gradient of
+    # the WHOLE minibatch at the very parameters the ranks held -- this library in one process, and the reference's own Net -- per
+    # tensor at north_star's 1e-4 (VERDICT r5 item 5: this, not a clipped three-step update, is the bar of the data-parallel step)
+    layers0 = synth.make_model(max_grad=0.05, **cfg)
+    from eesen_amd.api import Net as _Net
+    before = [_Net.from_layers(layers0).GetParams()] + list(res[0]["params_each_step"][:-1])
+    for k in range(3):
+        one, ref = _gradient_arbiters(layers0, full, before[k], "0")
+        e1 = _per_tensor(layers0, res[0]["grads_steps"][k], one)
+        assert max(e1.values()) < 1e-4, (k, e1)
+        if ref is not None:
+            e2 = _per_tensor(layers0, res[0]["grads_steps"][k], ref)
+            assert max(e2.values()) < 1e-4, (k, e2)
     want, st = _single_process(cfg, [full] * 3)
     assert rel_err(res[0]["params"], want) < 1e-5
     # the merged statistics (what comm_touch_done sums over the done-files, communicator.h:121-170)
@@ -134,61 +212,78 @@ def test_two_ranks_on_one_gpu_equal_one_process_on_the_whole_batch(gpu, tmp_path
     assert int(res[0]["ref"]) == st["ref_tokens"] and abs(int(res[0]["err"]) - st["err_tokens"]) <= 1 and int(res[0]["frames"]) == st["frames"]
 
 
+RCCL_SHAPED = {"FAKE_RCCL_SHAPE": "rccl", "FAKE_RCCL_BLOCKS": "16"}   # two ranks x 16 = the 32 workgroups of ONE RCCL kernel on the device
+
+
 def test_two_ranks_each_holding_persistent_grids_on_one_gpu(gpu, tmp_path):
-    """The product's N > 1 configuration -- PERSISTENT recurrence kernels in every rank + the communicator's per-layer buckets under the
-    backward pass -- with two ranks, before an 8-GPU box runs it first.  Shape chosen so that both processes'
-    grids are co-resident on the one GPU: 2 x BiLSTM of 256 cells, S = 32 per rank (forward 32 x 2 x 2 = 128, backward 8 x 2 x 8 = 128
-    workgroups per process, 256 CUs), every process sizing its grids against HALF the device (EESEN_GPU_SHARE=2: fits() and the tile
-    choices divide the CU count instead of relying on the spin time-outs).  Asserted: both ranks really ran every layer pass on the
-    persistent kernels; 2 x 32 == ONE process x 64 over 3 steps with momentum 0.9 and <MaxGrad> -- against this library in one process
-    AND against the reference's own Net (oracle/_ref, `--num-sequence 64`: SURVEY.md section 8e's parity statement) --; the ranks hold
-    the same model bit for bit, also after a soak of further steps with zero recoveries; what the exchange cost goes on record."""
-    from oracle import refbind
-    from eesen_amd import nnet_io
+    """The product's N > 1 configuration -- PERSISTENT recurrence kernels in every rank + the communicator's per-layer buckets --
+    with two ranks, before an 8-GPU box runs it first.  Shape chosen so that both processes' grids are co-resident on the one GPU:
+    2 x BiLSTM of 256 cells, S = 32 per rank (forward 32 x 2 x 2 = 128, backward 8 x 2 x 8 = 128 workgroups per process, 256 CUs),
+    every process sizing its grids against HALF the device (EESEN_GPU_SHARE=2).  Round 6: the stand-in's all-reduce kernels have
+    RCCL's FOOTPRINT (FAKE_RCCL_SHAPE=rccl: 512 threads x 256 VGPRs, 37.7 KB LDS -- the whole register file of the CU they land on),
+    so what is resident beside what is what it will be under RCCL.  Runs: both schedules (overlapped = what the plan rule picks at
+    256 cells, deferred), and the overlapped one again with rank 1 LATE by 3 ms every step (the straggler case of DESIGN.md section 7).
+    Asserted: every layer pass on the persistent kernels, zero recoveries in all four runs; ranks bit-identical to each other and
+    across schedules; per step the ALL-REDUCED gradient == the gradient of the 64 utterances at the same parameters, per tensor at
+    1e-4, against this library in one process AND the reference's own Net (`--num-sequence 64`: SURVEY.md section 8e's parity
+    statement).  What the exchange cost in each run goes on record (profiles/r06_rccl_shaped_soak.json)."""
     nsoak = int(os.environ.get("EESEN_SOAK_STEPS", "200"))
     over = dict(S=64, T=80, H=256, layers=2)
-    # first the same run with the buckets DEFERRED behind the backward pass (EESEN_COMM_DEFER=1), no soak: same model bit for bit
-    (tmp_path / "defer").mkdir()
-    res_d, rcs_d, errs_d = launch("persist", 2, tmp_path / "defer", dict(cfg="cfg2", steps=3, soak=0, **over),
-                                  env_extra={"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2", "EESEN_COMM_DEFER": "1"}, timeout=300)
-    assert rcs_d == [0, 0] and all(r is not None and not str(r["error"]) for r in res_d), [e[-2000:] for e in errs_d]
     cfg = synth.config("cfg2"); cfg.update(over)
-    res, rcs, errs = launch("persist", 2, tmp_path, dict(cfg="cfg2", steps=3, soak=nsoak, **over),
-                            env_extra={"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2"}, timeout=600)
-    assert rcs == [0, 0] and all(r is not None for r in res), [e[-2000:] for e in errs]
-    for r in res:
-        assert not str(r["error"]), r["error"]
-        assert list(r["recurrence_steps"]) == [2, 2, 2] and list(r["recurrence"]) == [2, 2, 2], (r["recurrence_steps"], r["recurrence"])   # {LSTM layers, fwd persistent, bwd persistent}
-        assert int(r["recoveries"]) == 0 and int(r["dropped"]) == 0
-    assert np.array_equal(res[0]["params_steps"], res[1]["params_steps"]) and np.array_equal(res[0]["params"], res[1]["params"])
-    assert np.array_equal(res_d[0]["params_steps"], res[0]["params_steps"]) and np.array_equal(res_d[1]["params_steps"], res[0]["params_steps"])
+    base = {"EESEN_PERSISTENT": "1", "EESEN_GPU_SHARE": "2", **RCCL_SHAPED}
+    runs = {}
+    for name, extra, opts in (("overlapped", {"EESEN_COMM_DEFER": "0"}, {}), ("deferred", {"EESEN_COMM_DEFER": "1"}, {}),
+                              ("auto", {}, {}),
+                              ("overlapped_straggler_3ms", {"EESEN_COMM_DEFER": "0"}, dict(straggle_ms=3, straggle_rank=1)),
+                              ("deferred_straggler_3ms", {"EESEN_COMM_DEFER": "1"}, dict(straggle_ms=3, straggle_rank=1))):
+        (tmp_path / name).mkdir()
+        res, rcs, errs = launch("persist", 2, tmp_path / name, dict(cfg="cfg2", steps=3, soak=nsoak if name != "auto" else 0, grads=1, **over, **opts),
+                                env_extra={**base, **extra}, timeout=600)
+        assert rcs == [0, 0] and all(r is not None for r in res), (name, [e[-2000:] for e in errs])
+        for r in res:
+            assert not str(r["error"]), (name, r["error"])
+            assert list(r["recurrence_steps"]) == [2, 2, 2] and list(r["recurrence"]) == [2, 2, 2], (name, r["recurrence_steps"], r["recurrence"])   # {LSTM layers, fwd persistent, bwd persistent}
+            assert int(r["recoveries"]) == 0 and int(r["dropped"]) == 0, name
+        assert np.array_equal(res[0]["params_steps"], res[1]["params_steps"]) and np.array_equal(res[0]["params"], res[1]["params"]), name
+        assert np.array_equal(res[0]["grads_steps"], res[1]["grads_steps"]), name
+        runs[name] = res
+    for name in runs:   # the schedule and a late peer change WHEN the buckets travel, never what they sum to
+        assert np.array_equal(runs[name][0]["params_steps"], runs["overlapped"][0]["params_steps"]), name
+    plan = json.loads(str(runs["auto"][0]["plan"]))
+    assert plan["exchange"].startswith("overlapped") and plan["gpu_share"] == 2, plan    # 256 cells: q4<4,4>, 122 registers -> 256 free per SIMD lane
+    assert plan["layers"][0]["backward"]["kernel"] == "lstm_bwd_persistent_q4_kernel<4,4>" and plan["layers"][0]["backward"]["free_vgprs_per_simd_lane"] == 256, plan
+
+    res = runs["overlapped"]
     layers = synth.make_model(max_grad=0.05, **cfg)
     full = synth.make_batch(**cfg)
-    want, _ = _single_process(cfg, [full] * 3, persistent="1")     # one process, S = 64, the whole device
     from eesen_amd.api import Net
     p0 = Net.from_layers(layers).GetParams()
-    got = res[0]["params_steps"]
-    rep = dict(config="2 x BiLSTM(256) + affine + softmax + CTC, S = 32 per rank x 2 ranks on ONE GPU, T = 80, EESEN_GPU_SHARE=2, persistent kernels, stand-in collective",
-               params_vs_one_process=rel_err(got, want), update_vs_one_process=rel_err(got - p0, want - p0))
-    assert rep["params_vs_one_process"] < 1e-5 and rep["update_vs_one_process"] < 5e-3, rep
-    if refbind.available():   # the reference itself as ONE process with --num-sequence 64
-        path = str(tmp_path / "m.nnet")
-        nnet_io.write_nnet(path, layers, binary=True)
-        ref = refbind.RefNet(path)
-        ref.set_train_options(1e-3, 0.9)
-        for _ in range(3):
-            ref.set_seq_lengths(full.lens)
-            o = ref.propagate(full.feats)
-            c = refbind.cuda_ctc_eval_parallel(o, full.T, full.S, full.lens, full.label_ids, full.label_off)
-            ref.backpropagate(c["diff"], False)
-        rp = ref.get_params()
-        rep.update(params_vs_reference=rel_err(got, rp), update_vs_reference=rel_err(got - p0, rp - p0))
-        assert rep["params_vs_reference"] < 1e-5 and rep["update_vs_reference"] < 5e-3, rep
+    before = [p0] + list(res[0]["params_each_step"][:-1])
+    rep = dict(config="2 x BiLSTM(256) + affine + softmax + CTC, S = 32 per rank x 2 ranks on ONE GPU, T = 80, EESEN_GPU_SHARE=2, persistent kernels, "
+                      "stand-in collective in RCCL's footprint (512 threads x 256 VGPRs, 37.7 KB LDS, 2 x 16 workgroups)", steps=[])
+    for k in range(3):
+        one, ref = _gradient_arbiters(layers, full, before[k], "1")
+        e1 = _per_tensor(layers, res[0]["grads_steps"][k], one)
+        st = dict(step=k + 1, summed_gradient_vs_one_process_worst_tensor=max(e1.values()))
+        assert max(e1.values()) < 1e-4, (k, e1)
+        if ref is not None:
+            e2 = _per_tensor(layers, res[0]["grads_steps"][k], ref)
+            st["summed_gradient_vs_reference_worst_tensor"] = max(e2.values())
+            assert max(e2.values()) < 1e-4, (k, e2)
+        rep["steps"].append(st)
+    want, _ = _single_process(cfg, [full] * 3, persistent="1")     # one process, S = 64, the whole device: the parameters after three steps
+    rep["params_vs_one_process"] = rel_err(res[0]["params_steps"], want)
+    assert rep["params_vs_one_process"] < 1e-5, rep
     if nsoak:
-        rep.update(soak_steps=nsoak, ms_per_step=[float(r["soak_ms_per_step"]) for r in res],
-                   recurrence_fwd_ms=[float(r["soak_ms_recurrence_fwd"]) for r in res], recurrence_bwd_ms=[float(r["soak_ms_recurrence_bwd"]) for r in res],
-                   allreduce_ms=[float(r["soak_ms_allreduce"]) for r in res], allreduce_exposed_ms=[float(r["soak_ms_allreduce_exposed"]) for r in res],
-                   recoveries=[int(r["recoveries"]) for r in res])
+        rep["soak_steps"] = nsoak
+        for name, rr in runs.items():
+            if name == "auto":
+                continue
+            rep[name] = dict(ms_per_step=[float(r["soak_ms_per_step"]) for r in rr],
+                             recurrence_bwd_ms=[float(r["soak_ms_recurrence_bwd"]) for r in rr], recurrence_bwd_max_ms=[float(r["soak_max_ms_recurrence_bwd"]) for r in rr],
+                             recurrence_fwd_max_ms=[float(r["soak_max_ms_recurrence_fwd"]) for r in rr],
+                             allreduce_ms=[float(r["soak_ms_allreduce"]) for r in rr], allreduce_max_ms=[float(r["soak_max_ms_allreduce"]) for r in rr],
+                             allreduce_exposed_ms=[float(r["soak_ms_allreduce_exposed"]) for r in rr], recoveries=[int(r["recoveries"]) for r in rr])
     out_dir = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
     os.makedirs(out_dir, exist_ok=True)
     json.dump(rep, open(os.path.join(out_dir, "multirank_persistent.json"), "w"), indent=1)
@@ -233,27 +328,43 @@ def test_a_rank_that_dies_before_the_first_collective_does_not_hang_the_other(gp
     assert took < 90, f"the survivor needed {took:.0f} s to give up"
 
 
-def test_standin_allreduce_under_every_persistent_backward_recurrence(gpu, tmp_path):
-    """(iv): the co-residency hazard.  The persistent recurrence grids need every workgroup resident (one per CU at cfg2); with a
-    communicator attached, the stand-in's all-reduce kernels -- 32 workgroups x 512 threads per 8 MB chunk, four chunks per
-    25 MB bucket, each moving its payload to host memory and back -- run on the high-priority communication stream exactly
-    when the next-lower layer's backward recurrence is on the chip.  200 steps: no spin time-out (a time-out under a
-    communicator is fatal by design), the model stays bit-identical to the run without the exchange (one rank: the sum is the
-    identity), and the per-step cost of the overlap goes on record."""
+@pytest.mark.parametrize("shape", ["plain", "rccl"])
+def test_standin_allreduce_under_every_persistent_backward_recurrence(gpu, tmp_path, shape):
+    """(iv): the co-residency hazard at the HEADLINE shape.  cfg2's persistent grids hold one workgroup on every CU; with a communicator
+    attached the stand-in's all-reduce kernels (32 workgroups x 512 threads per 8 MB chunk, four chunks per 25 MB bucket, payload to
+    host memory and back) run on the high-priority communication stream.
+      shape = "plain": the ~30-register kernel of rounds 3-5, which fits beside every tile -- the overlapped schedule forced
+                       (EESEN_COMM_DEFER=0), as those rounds ran it;
+      shape = "rccl":  RCCL's footprint (256 VGPRs x 512 threads, 37.7 KB LDS: fits beside NO backward tile of cfg2) -- under BOTH
+                       schedules: overlapped (the all-reduce workgroups become resident when a recurrence retires and hold their CUs
+                       against the next one) and deferred, which is what the plan rule picks here (q4<8,4>: 176 registers free < 256).
+    200 steps each: no spin time-out (a time-out under a communicator is fatal by design), the model bit-identical to the run
+    without the exchange (one rank: the sum is the identity), and the per-step cost goes on record (profiles/r06_rccl_shaped_soak.json)."""
     steps = int(os.environ.get("EESEN_SOAK_STEPS", "200"))
-    res, rcs, errs = launch("soak", 1, tmp_path, dict(cfg="cfg2", steps=steps), env_extra={"EESEN_PERSISTENT": "1"}, timeout=600)
-    assert rcs == [0] and res[0] is not None, errs[0][-3000:]
-    r = res[0]
-    assert bool(r["standin"]), "EESEN_RCCL_LIBRARY was not honoured"
-    ms0, ms1 = float(r["ms0"]), float(r["ms1"])
-    # {lstm layers, forward persistent, backward persistent}: every layer pass ran as ONE launch, with and without the exchange
-    assert list(r["info0"]) == [4, 4, 4] and list(r["info1"]) == [4, 4, 4], (r["info0"], r["info1"])
-    assert int(r["rec0"]) == 0 and int(r["rec1"]) == 0 and int(r["dropped"]) == 0, "a persistent recurrence kernel timed out beside the all-reduce kernels"
-    assert bool(r["identical"])       # one rank: the sum is the identity, so the model must not move by a bit
-    rep = dict(config="cfg2", steps=steps, ms_per_step_without_exchange=ms0, ms_per_step_with_standin_allreduce=ms1,
-               overlap_cost_ms=ms1 - ms0, buckets_mb=[0.19, 25.2, 25.2, 25.2, 9.1],
-               standin="tests/native/fake_rccl.hip: 32 workgroups x 512 threads per 8 MB chunk, payload through host memory (PCIe) and back")
+    arms = [("overlapped", "0")] if shape == "plain" else [("overlapped", "0"), ("deferred", "1"), ("auto", None)]
+    rep = dict(config="cfg2", steps=steps, shape=shape, buckets_mb=[0.19, 25.2, 25.2, 25.2, 9.1],
+               standin="tests/native/fake_rccl.hip: 32 workgroups x 512 threads per 8 MB chunk, payload through host memory (PCIe) and back"
+                       + ("; RCCL's footprint: 256 VGPRs per lane, 37 664 B LDS" if shape == "rccl" else "; ~30 VGPRs"))
+    for name, defer in arms:
+        (tmp_path / name).mkdir()
+        env = {"EESEN_PERSISTENT": "1"}
+        if defer is not None:
+            env["EESEN_COMM_DEFER"] = defer
+        if shape == "rccl":
+            env["FAKE_RCCL_SHAPE"] = "rccl"
+        res, rcs, errs = launch("soak", 1, tmp_path / name, dict(cfg="cfg2", steps=steps if name != "auto" else 20), env_extra=env, timeout=600)
+        assert rcs == [0] and res[0] is not None, (name, errs[0][-3000:])
+        r = res[0]
+        assert bool(r["standin"]), "EESEN_RCCL_LIBRARY was not honoured"
+        ms0, ms1 = float(r["ms0"]), float(r["ms1"])
+        ex = json.loads(str(r["exchange"]))
+        # {lstm layers, forward persistent, backward persistent}: every layer pass ran as ONE launch, with and without the exchange
+        assert list(r["info0"]) == [4, 4, 4] and list(r["info1"]) == [4, 4, 4], (name, r["info0"], r["info1"])
+        assert int(r["rec0"]) == 0 and int(r["rec1"]) == 0 and int(r["dropped"]) == 0, f"{name}: a persistent recurrence kernel timed out beside the all-reduce kernels"
+        assert bool(r["identical"]), name       # one rank: the sum is the identity, so the model must not move by a bit
+        assert ex["schedule"].startswith("deferred" if name in ("deferred", "auto") else "overlapped"), (name, ex)
+        rep[name] = dict(ms_per_step_without_exchange=ms0, ms_per_step_with_standin_allreduce=ms1, cost_ms=ms1 - ms0, **ex)
+        assert ms1 < 2.0 * ms0, rep
     out_dir = os.environ.get("EESEN_PARITY_OUT", os.path.join(ROOT, "gpurun_out"))
     os.makedirs(out_dir, exist_ok=True)
-    json.dump(rep, open(os.path.join(out_dir, "multirank_overlap.json"), "w"), indent=1)
-    assert ms1 < 2.0 * ms0, rep
+    json.dump(rep, open(os.path.join(out_dir, f"multirank_overlap_{shape}.json"), "w"), indent=1)

@@ -25,6 +25,62 @@ def test_bench_runs_under_torchrun_with_one_rank(gpu):
     assert r.returncode == 0 and '"metric"' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def _bench(args, env_extra, timeout=900):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "EESEN_RCCL_LIBRARY", "EESEN_PERSISTENT", "EESEN_GPU_SHARE", "EESEN_COMM_DEFER"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_line_describes_the_real_rccl_at_world_size_one(gpu):
+    """The self-describing N > 1 line with the REAL librccl, at the only world size a one-GPU box offers:
+    `config.comm` names the library the linker resolved (not the stand-in), its version, the one rank RCCL itself counts, the
+    device's PCI bus id; n_gpus = distinct devices = 1; the rank-consistency check ran."""
+    d, _ = _bench(["--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--main-only", "--T", "120"], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547"})
+    c = d["config"]["comm"]
+    assert c["stand_in"] is False and "librccl" in c["library"] and c["rccl_version"] >= 20000, c
+    assert c["world"] == 1 and c["world_seen"] == 1 and c["rank_seen"] == 0 and c["device_seen"] == c["device"] == 0, c
+    assert c["distinct_devices"] == 1 and c["ranks_share_devices"] is False and len(c["devices"]) == 1 and ":" in c["devices"][0]
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 1 and d["config"]["ranks_bit_identical"] is True
+    assert d["config"]["comm_stand_in"] is False and d["config"]["gradient_exchange"].startswith("RCCL ")
+    # a full-width cfg2 net, persistent kernels: the schedule is the deferred one, chosen from the backward plan (164 registers: 176 free < 256)
+    assert d["config"]["exchange_schedule"].startswith("deferred") and d["config"]["exchange_rule"].startswith("auto")
+    k = d["config"]["kernels"]
+    assert k["backward"] == ["lstm_bwd_persistent_q4_kernel<8,4>"] and k["backward_tile"]["free_vgprs_per_simd_lane"] < 256, k
+
+
+def test_bench_with_eight_ranks_on_one_gpu_through_the_rccl_shaped_stand_in(gpu):
+    """8-GPU pre-flight: `bench.py --gpus 8` -- self-launch of eight ranks, rendezvous, buckets, closing
+    barrier, rank 0's JSON -- with every rank holding PERSISTENT grids on the one GPU (EESEN_GPU_SHARE=8: each process sizes its
+    grids against 32 CUs; 2 x BiLSTM of 64 cells, S = 16: 8 x (16 + 16) workgroups co-resident) and the stand-in's all-reduce
+    kernels in RCCL's footprint (FAKE_RCCL_SHAPE=rccl: 256 VGPRs x 512 threads, 37.7 KB LDS).  The line must say what it is:
+    eight ranks, ONE device, a stand-in -- and that the eight models are still identical after the steps."""
+    from tests.test_gpu_multirank import fake_rccl_path
+    d, err = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--main-only", "--T", "100", "--H", "64", "--S", "16", "--layers", "2"],
+                    dict(EESEN_RCCL_LIBRARY=fake_rccl_path(), FAKE_RCCL_QUIET="1", FAKE_RCCL_SHAPE="rccl", EESEN_BENCH_SHARE_GPU="0", EESEN_GPU_SHARE="8"), timeout=1200)
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["ranks"] == 8 and c["parallelism"] == "dp8" and c["global_batch_utterances"] == 8 * 16
+    assert c["ranks_share_devices"] is True and c["distinct_devices"] == 1 and c["comm_stand_in"] is True and c["comm_world_seen"] == 8
+    assert len(c["comm"]["devices"]) == 8 and len(set(c["comm"]["devices"])) == 1 and "libfake_rccl" in c["comm"]["library"]
+    assert c["gradient_exchange"].startswith("TEST STAND-IN")
+    assert c["ranks_bit_identical"] is True
+    assert c["padded_frames_per_step"] == 8 * 16 * 100
+    # every rank's layer passes ran on the persistent kernels (rank 0 reports; a rank that failed its probing step makes ALL fall back)
+    assert c["kernels"]["backward"] == ["lstm_bwd_persistent_q4_kernel<2,4>"] and c["kernels"]["forward"][0].startswith("lstm_fwd_persistent"), c["kernels"]
+    # 64 cells: the 4 x 32 tile leaves >= 256 registers per SIMD lane -- the one class of shapes whose buckets stay overlapped
+    assert c["exchange_schedule"].startswith("overlapped")
+    ex = d["roofline"]["exchange"]
+    assert [b["layer"] for b in ex["buckets"]] == [2, 1, 0] and all(b["ms"] > 0 for b in ex["buckets"])
+    assert "persistent path failed" not in err, err[-3000:]
+
+
 def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in(gpu):
     """bench.py's world > 1 path itself -- self-launch, TCP rendezvous, the library's communicator attached to the Net, the
     barrier's all-reduce of dt / padded / real frames over the ranks, rank 0's one JSON line with the exchange report -- executed
@@ -44,7 +100,11 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in(gpu):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch_utterances"] == 64 and d["config"]["parallelism"] == "dp2"
+    # two ranks on ONE device through the stand-in: the line says so itself -- n_gpus counts distinct devices
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 2 and d["config"]["ranks_share_devices"] is True and d["config"]["comm_stand_in"] is True
+    assert d["config"]["comm"]["world_seen"] == 2 and d["config"]["comm"]["distinct_devices"] == 1 and d["config"]["ranks_bit_identical"] is True
+    assert d["config"]["gradient_exchange"].startswith("TEST STAND-IN") and d["config"]["exchange_schedule"].startswith("overlapped")   # per-step kernels: nothing to defer behind
+    assert d["config"]["global_batch_utterances"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["padded_frames_per_step"] == 2 * 32 * 120           # the ranks' frames were summed over the communicator
     assert d["value"] == pytest.approx(d["config"]["padded_frames_per_step"] * 1e3 / d["ms_per_step"], rel=1e-6)
     ex = d["roofline"]["exchange"]
