@@ -312,7 +312,30 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
     fpf = flops_per_frame(cfg)
     frames = float(batch.T * batch.S)
     nd = 2 if cfg["kind"].startswith("BiLstm") else 1
-    return {"workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
+    # the leg's dominant kernel -- the backward recurrence -- against its roofline, live (HIP-event spans of this run) + the committed
+    # counters of the same instantiation where they exist (profiles/pmc_traffic.json "wide", scripts/collect_profiles_wide.sh)
+    leg_roof = None
+    try:
+        nl, n_timed = cfg["layers"], reps * steps
+        rec_flops = 2.0 * batch.S * 4 * cfg["H"] * cfg["H"] * nd * batch.T
+        us = 1e6 * phases["recurrence_bwd"] / (nl * n_timed)
+        bk = sorted({L["backward"]["kernel"] for L in plan["layers"]})
+        leg_roof = {"bound": "mfma", "kernel": bk[0] if len(bk) == 1 else bk, "avg_launch_us": us, "flops_per_launch": rec_flops,
+                    "achieved": rec_flops / (us * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": rec_flops / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "launches_per_layer_pass": plan["layers"][-1]["backward"].get("launches"), "traffic": None, "mfma_busy": None}
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        key = {("cfg4", False): "cfg4", ("cfg4", True): "cfg4_bf16_forward", ("cfg5", False): "cfg5"}.get((name, bool(forward_bf16))) if not over else None
+        w = pt.get("wide", {}).get(key) if key else None
+        if w:
+            from eesen_amd.build import csrc_digest
+            for kn, e in w["kernels"].items():
+                if kn.replace(" ", "") == (bk[0] if len(bk) == 1 else ""):
+                    leg_roof.update(traffic=e["bytes_per_launch"], algorithmic_bytes=e["algorithmic_bytes_per_launch"], traffic_over_algorithmic=e["traffic_over_algorithmic"],
+                                    mfma_busy=e.get("mfma_busy"), traffic_source={"file": "profiles/pmc_traffic.json (wide)", "tables": pt.get("wide_source"),
+                                                                                  "csrc_sha": pt.get("csrc_sha"), "stale": pt.get("csrc_sha") != csrc_digest()})
+    except Exception:   # noqa: BLE001 -- a leg's roofline block never takes the leg down
+        pass
+    return {"roofline": leg_roof, "workload": f"{name}: {cfg['layers']}x{cfg['H']} {'Bi' if nd == 2 else ''}LSTM{' + ' + str(cfg['proj']) + '-d projections' if cfg.get('proj') else ''}, "
                         f"K={cfg['K']}, S={batch.S} utterances/GPU, T_max={batch.T}",
             "steps": steps, "warmup": warmup, "repetitions": reps, "ms_per_step": 1e3 * dt, "ms_per_step_min_median_max": [1e3 * min(dts), 1e3 * dt, 1e3 * max(dts)],
             "frames_per_s": frames / dt, "input": "host matrices through the feeder, H2D inside the timed step (like the headline)",

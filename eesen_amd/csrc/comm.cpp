@@ -267,6 +267,43 @@ struct Comm {
     EESEN_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&scratch_h), kScratch * sizeof(double), hipHostMallocDefault));
     if (const char* e = getenv("EESEN_COMM_TIMEOUT_S")) timeout_s = std::max(0.05, atof(e));
     wd = std::thread([this] { watch(); });
+    share_colocated_device();
+  }
+  // Jobs that were given the SAME device (the reference's own two-jobs-one-GPU test mode; `--num-jobs 2` with one GPU in the box)
+  // must size their persistent grids against their share of it, all of them alike -- or each plans for every CU and they find out
+  // through spin time-outs.  The ranks' device ids are gathered once, here (one 8-byte-per-rank host all-reduce: every rank is in
+  // this constructor), and a process that finds k > 1 ranks on its device sizes against 1/k of it from now on (set_gpu_share),
+  // unless EESEN_GPU_SHARE says otherwise.  Nets created BEFORE the communicator keep the tiles they planned with.
+  void share_colocated_device() {
+    if (world <= 1 || world > kScratch) return;
+    try {
+      const double mine = device_word();
+      double v[kScratch] = {0};
+      v[rank] = mine;
+      allreduce_host(v, world, 0);
+      int here = 0;
+      for (int r = 0; r < world; ++r) here += v[r] == mine;
+      if (here > 1) {
+        if (getenv("EESEN_GPU_SHARE") == nullptr) set_gpu_share(here);
+        if (rank == 0 || here != world)
+          fprintf(stderr, "LOG (eesen_hip) %d of the %d data-parallel ranks share this rank's device: persistent grids are sized against 1/%d of its CUs%s\n",
+                  here, world, gpu_share_value(), getenv("EESEN_GPU_SHARE") ? " (EESEN_GPU_SHARE)" : "");
+      }
+    } catch (const Error& e) {   // never fatal: the explicit EESEN_GPU_SHARE remains
+      fprintf(stderr, "WARNING (eesen_hip) could not find out whether data-parallel ranks share a device (%s)\n", e.what());
+    }
+  }
+  // host hash (20 bits) | PCI domain (16) | bus (8) | device (5) | function (3) of this rank's GPU, + 1: exact in a double, never 0
+  double device_word() const {
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    (void)sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f);
+    char host[256] = "";
+    (void)gethostname(host, sizeof(host) - 1);
+    unsigned hh = 2166136261u;   // FNV-1a of the host name: ranks of different hosts never look like one device
+    for (const char* c = host; *c; ++c) hh = (hh ^ (unsigned char)*c) * 16777619u;
+    return (double)(((unsigned long long)(hh & 0xfffffu) << 32) | ((unsigned long long)(dom & 0xffffu) << 16) | ((b & 0xffu) << 8) | ((d & 0x1fu) << 3) | (f & 7u)) + 1.0;
   }
   ~Comm() {
     {
@@ -370,16 +407,7 @@ struct Comm {
     if (rccl().CommCount) (void)rccl().CommCount(comm, &seen);
     if (rccl().CommCuDevice) (void)rccl().CommCuDevice(comm, &nccl_dev);
     if (rccl().CommUserRank) (void)rccl().CommUserRank(comm, &nccl_rank);
-    char bus[64] = "";
-    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
-    unsigned dom = 0, b = 0, d = 0, f = 0;
-    (void)sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f);
-    char host[256] = "";
-    (void)gethostname(host, sizeof(host) - 1);
-    unsigned hh = 2166136261u;   // FNV-1a of the host name, 20 bits: ranks of different hosts never look like one device
-    for (const char* c = host; *c; ++c) hh = (hh ^ (unsigned char)*c) * 16777619u;
-    // host hash (20 bits) | domain (16) | bus (8) | device (5) | function (3) = 52 bits: exact in a double
-    const double mine = (double)(((unsigned long long)(hh & 0xfffffu) << 32) | ((unsigned long long)(dom & 0xffffu) << 16) | ((b & 0xffu) << 8) | ((d & 0x1fu) << 3) | (f & 7u)) + 1.0;
+    const double mine = device_word();
     std::vector<double> ids;
     for (int base = 0; base < world; base += kScratch) {   // gather = sum of vectors that are zero except at the own rank
       const int n = std::min(kScratch, world - base);

@@ -95,6 +95,10 @@ struct LstmLayerDev {
   int fwd_split = 0;
 };
 float handoff_flight_ns();
+// The share of the device's CUs this PROCESS sizes its persistent grids against: 1/n (EESEN_GPU_SHARE, or set by a communicator
+// that found n of its ranks on this device: comm.cpp).  Process-wide.
+void set_gpu_share(int n);
+int gpu_share_value();
 // one wave that returns once *word >= target (or when the recurrence kernels' error word is raised; it raises that word itself
 // if it ever gives up): puts a stream behind a milestone of a kernel that is still running on another stream
 void wait_for_word(hipStream_t st, const unsigned* word, unsigned target, unsigned* err, double limit_s = 2.0);   // gives up after limit_s seconds of wall clock

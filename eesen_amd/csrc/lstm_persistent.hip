@@ -33,6 +33,7 @@
 // 16-float halves); tests assert exactly that.
 #include "kernels.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -1361,13 +1362,35 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
         ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4), k, KQ, sa < s_end, a[c]);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+      // Costing probes (scripts/build_variant.py -DEESEN_PROBE_KSPLIT=n; never in the product build; results are garbage, only the
+      // step time is read -- DESIGN.md section 9 round 6, the bf16-plane ledger): bit 0 = the MFMA chain shortened to what six
+      // v_mfma_f32_16x16x32_bf16 per 32-wide k block would take (96 x 16 cycles per wave instead of 128 x 32: every fifth MFMA of
+      // the fp32 chain is kept... see EESEN_PROBE_MFMA below); bit 1 = the operand fetch grown by half (three bf16 planes = 6 bytes
+      // per gate gradient instead of 4).
+#ifdef EESEN_PROBE_KSPLIT
+#define EESEN_PROBE_MFMA(c, j) ((EESEN_PROBE_KSPLIT & 1) == 0 || (((c) * 8 + (j)) % 8) < 3)   /* 3 of 8: 48 x 32 = 96 x 16 cycles */
+      if (EESEN_PROBE_KSPLIT & 2) {
+        float extra[CPW / 2 > 0 ? CPW / 2 : 1][8];
+#pragma unroll
+        for (int c = 0; c < CPW / 2; ++c) {
+          const int k = (wave + c * NW) * 32 + kq * 8;
+          ld8_sc1(rDG, (unsigned)(arow + (size_t)k * 4 + (size_t)KQ * 4 * ((ku + 1) % KU - ku)), k, KQ, sa < s_end, extra[c]);   // another quarter's rows: lines nobody else of this workgroup reads
+        }
+#pragma unroll
+        for (int c = 0; c < CPW / 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[c][j] += 1e-30f * extra[c][j];
+      }
+#else
+#define EESEN_PROBE_MFMA(c, j) true
+#endif
       // pass 1: the siblings' three blocks (three accumulators interleaved)
 #pragma unroll
       for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
+          for (int n = 0; n < 3; ++n) if (EESEN_PROBE_MFMA(c, j)) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[n][c][j], acc[n], 0, 0, 0);
       // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
 #pragma unroll
       for (int n = 0; n < 3; ++n)
@@ -1391,7 +1414,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 #pragma unroll
       for (int c = 0; c < CPW / 2; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) if (EESEN_PROBE_MFMA(c, j)) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
       // half way through, the siblings' words are read SPECULATIVELY: the siblings run in lockstep, their stores left when this
       // workgroup's did, and the answer is back by the end of the pass (px_take re-reads in the rare case it was too early)
       __builtin_amdgcn_sched_barrier(0);
@@ -1401,7 +1424,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 #pragma unroll
       for (int c = CPW / 2; c < CPW; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) if (EESEN_PROBE_MFMA(c, j)) acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], b[3][c][j], acc[3], 0, 0, 0);
+#undef EESEN_PROBE_MFMA
 #pragma unroll
       for (int r = 0; r < 4; ++r) red2[wave][4 * kq + r][li] = acc[3][r];
       EESEN_STAMP(2);
@@ -1646,9 +1670,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_mux_kernel
 // EESEN_GPU_SHARE=n (tuning.h): this process may count on 1/n of the device's CUs -- n trainer processes on one GPU (the reference's
 // own two-jobs-one-GPU test mode; tests/test_gpu_multirank.py) each size their persistent grids against their share, so that all
 // of them are co-resident TOGETHER instead of relying on the spin time-outs to find out that they are not.
+// (round 6: a communicator that finds several of its ranks on ONE device sets the share itself -- set_gpu_share, comm.cpp -- so that
+// co-located trainer jobs need no environment variable; an explicit EESEN_GPU_SHARE wins)
+static std::atomic<int> g_share_override{0};
 static int gpu_share() {
-  static const int n = [] { const char* e = getenv("EESEN_GPU_SHARE"); const int v = e && *e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
-  return n;
+  static const int env = [] { const char* e = getenv("EESEN_GPU_SHARE"); const int v = e && *e ? atoi(e) : 0; return v < 1 ? 0 : v; }();
+  if (env) return env;
+  const int o = g_share_override.load(std::memory_order_relaxed);
+  return o > 0 ? o : 1;
 }
 // the CUs this process sizes its tiles and grids against: the device's, divided by EESEN_GPU_SHARE
 static int share_of_cus() {
@@ -1688,6 +1717,9 @@ bool fits(K kernel, dim3 grid, int threads, C census = nullptr) {  // grid: the 
 // occupancy limit, which is the check fits() makes with a workgroup per CU of margin.  Workgroups that are not resident at once
 // are waited for by the others' bounded spins, and a spin that gives up is recovered from (net.cpp).  (plan_launch below.)
 }  // namespace
+
+void set_gpu_share(int n) { g_share_override.store(n < 1 ? 1 : n, std::memory_order_relaxed); }
+int gpu_share_value() { return gpu_share(); }
 
 // One-way flight of an agent-scope increment between two CUs of the current device, in nanoseconds (measured once per device and
 // process, ~3 ms: 2000 round trips, the median of five runs).  The first-poll delays of the recurrence kernels are multiples of it.

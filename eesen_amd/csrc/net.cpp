@@ -1092,7 +1092,7 @@ std::string Net::plan_string() const {
   o += std::string(", \"exchange\": ") + (comm ? (exchange_deferred_for_minibatch() ? "\"deferred: every bucket behind the backward pass's last recurrence\""
                                                                                       : "\"overlapped: each bucket as soon as its layer's gradients are enqueued\"") : "null");
   o += std::string(", \"exchange_rule\": \"") + (tn.comm_defer >= 0 ? "EESEN_COMM_DEFER" : "auto: deferred when a persistent backward grid leaves < 256 registers per SIMD lane") + "\"";
-  o += ", \"gpu_share\": " + std::to_string(std::max(1, atoi(getenv("EESEN_GPU_SHARE") ? getenv("EESEN_GPU_SHARE") : "1"))) + "}";
+  o += ", \"gpu_share\": " + std::to_string(gpu_share_value()) + "}";
   self.T = T_saved;
   return o;
 }

@@ -58,6 +58,35 @@ def main(tag, commit, switches):
             out["mfma_busy"][key] = r["SQ_VALU_MFMA_BUSY_CYCLES"] / (r["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     out["bytes_per_launch"]["lstm_bwd_persistent_kernel"] = out["bytes_per_launch"].get("lstm_bwd_persistent_q4_kernel")
     out["bytes_per_launch"]["gemm_f32_mfma_kernel(input->gates)"] = out["bytes_per_launch"].get("gemm_f32_split_bf16_big_kernel(input->gates)")
+    # the WIDE configurations (round 6: scripts/collect_profiles_wide.sh): per configuration the recurrence kernels' traffic per launch
+    # against their algorithmic bytes, and their matrix-pipe occupancy -- quoted by bench.py's secondary legs
+    wide = {}
+    for name, cfgname, S, T, nl in (("cfg4", "cfg4_f32", 32, 1000, 5), ("cfg4_bf16_forward", "cfg4_bf16", 32, 1000, 5), ("cfg5", "cfg5", 64, 3000, 6)):
+        f1, f2 = os.path.join(ROOT, "profiles", f"{tag}_{cfgname}_pmc_fetch_write.md"), os.path.join(ROOT, "profiles", f"{tag}_{cfgname}_pmc_sq.md")
+        if not (os.path.exists(f1) and os.path.exists(f2)):
+            continue
+        fw2, sq2 = table(f1), table(f2)
+        H, nd = 1024, 2
+        rows = float(T) * S
+        # algorithmic bytes per launch: backward reads G (4H), C (H), dY (H) and writes DG (4H) per frame and direction;
+        # forward reads G (4H) and writes C, Y (H each) [+ the exchange copy of m_t]
+        alg = {"lstm_bwd": rows * nd * (4 * H + H + H + 4 * H) * 4.0, "lstm_fwd": rows * nd * (4 * H + H + H) * 4.0}
+        flops = 2.0 * S * 4 * H * H * nd * T
+        ent = {"config": {"config": name.split("_")[0], "T": T, "S": S}, "kernels": {}}
+        for k, r in fw2.items():
+            if not k.startswith(("lstm_bwd_persistent", "lstm_fwd_persistent")):
+                continue
+            kind = "lstm_bwd" if k.startswith("lstm_bwd") else "lstm_fwd"
+            b = (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
+            e = {"bytes_per_launch": b, "algorithmic_bytes_per_launch": alg[kind], "traffic_over_algorithmic": b / alg[kind],
+                 "profiled_avg_us": r["avg us (profiled)"], "flops_per_launch": flops}
+            q = sq2.get(k)
+            if q and q.get("GRBM_GUI_ACTIVE"):
+                e["mfma_busy"] = q["SQ_VALU_MFMA_BUSY_CYCLES"] / (q["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            ent["kernels"][k] = e
+        wide[name] = ent
+    out["wide"] = wide
+    out["wide_source"] = f"profiles/{tag}_cfg4_f32_*, {tag}_cfg4_bf16_*, {tag}_cfg5_* (scripts/collect_profiles_wide.sh)"
     w = {k: v for k, v in fw.items() if k.startswith("wait_for_word")}
     out["milestone_waiter_rows"] = {k: v.get("avg us (profiled)") for k, v in w.items()}
     json.dump(out, sys.stdout, indent=1)

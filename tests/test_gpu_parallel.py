@@ -58,13 +58,16 @@ def test_bench_line_describes_the_real_rccl_at_world_size_one(gpu):
 
 def test_bench_with_eight_ranks_on_one_gpu_through_the_rccl_shaped_stand_in(gpu):
     """8-GPU pre-flight: `bench.py --gpus 8` -- self-launch of eight ranks, rendezvous, buckets, closing
-    barrier, rank 0's JSON -- with every rank holding PERSISTENT grids on the one GPU (EESEN_GPU_SHARE=8: each process sizes its
-    grids against 32 CUs; 2 x BiLSTM of 64 cells, S = 16: 8 x (16 + 16) workgroups co-resident) and the stand-in's all-reduce
+    barrier, rank 0's JSON -- with every rank holding PERSISTENT grids on the one GPU (each process sizes its grids against 32 CUs:
+    the share the communicator works out itself; 2 x BiLSTM of 64 cells, S = 16: 8 x (16 + 16) workgroups co-resident) and the stand-in's all-reduce
     kernels in RCCL's footprint (FAKE_RCCL_SHAPE=rccl: 256 VGPRs x 512 threads, 37.7 KB LDS).  The line must say what it is:
     eight ranks, ONE device, a stand-in -- and that the eight models are still identical after the steps."""
     from tests.test_gpu_multirank import fake_rccl_path
     d, err = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--main-only", "--T", "100", "--H", "64", "--S", "16", "--layers", "2"],
-                    dict(EESEN_RCCL_LIBRARY=fake_rccl_path(), FAKE_RCCL_QUIET="1", FAKE_RCCL_SHAPE="rccl", EESEN_BENCH_SHARE_GPU="0", EESEN_GPU_SHARE="8"), timeout=1200)
+                    dict(EESEN_RCCL_LIBRARY=fake_rccl_path(), FAKE_RCCL_QUIET="1", FAKE_RCCL_SHAPE="rccl", FAKE_RCCL_BLOCKS="4", EESEN_BENCH_SHARE_GPU="0"), timeout=1200)
+    # (FAKE_RCCL_BLOCKS=4: 8 ranks x 4 = the 32 workgroups of ONE RCCL kernel on the device, each with a whole CU's registers.  No
+    # EESEN_GPU_SHARE: the communicator finds its eight ranks on one device and sizes every process against 1/8 of it -- VERDICT r5 item 8)
+    assert "8 of the 8 data-parallel ranks share this rank's device: persistent grids are sized against 1/8" in err, err[-3000:]
     c = d["config"]
     assert d["n_gpus"] == 1 and c["ranks"] == 8 and c["parallelism"] == "dp8" and c["global_batch_utterances"] == 8 * 16
     assert c["ranks_share_devices"] is True and c["distinct_devices"] == 1 and c["comm_stand_in"] is True and c["comm_world_seen"] == 8
@@ -113,3 +116,20 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in(gpu):
     assert abs(sum(b["MB"] for b in ex["buckets"]) - 84.8) < 0.2                                   # 84.8 MB at cfg2
     assert all(b["ms"] > 0 for b in ex["buckets"]) and ex["ms_per_step"] > 0 and ex["exposed_ms_per_step"] >= 0
     assert d["phase_ms_per_step"]["allreduce"] == pytest.approx(ex["ms_per_step"]) and "allreduce_exposed" in d["phase_ms_per_step"]
+
+
+def test_bench_check_full_cfg3_with_eight_ranks_through_the_stand_in(gpu):
+    """`bench.py --gpus 8 --check full_cfg3` -- what the driver's 8-GPU box can run to hold the REAL exchange against the reference:
+    rank r takes shard r of BASELINE configs[2]'s global minibatch (256 utterances, T = 1000, 4 x 512), the communicator sums the
+    gradients, and the sum is compared with tests/golden/full_cfg3.npz (one reference process at --num-sequence 256) at the
+    fixture's bars.  Here: eight ranks on the one GPU through the stand-in, per-step kernels (eight 256-workgroup persistent grids
+    cannot share a device), so that the check's own control flow and arithmetic have run before the first 8-GPU box sees them."""
+    from tests.test_gpu_multirank import fake_rccl_path
+    d, err = _bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--main-only", "--T", "100", "--check", "full_cfg3"],
+                    dict(EESEN_RCCL_LIBRARY=fake_rccl_path(), FAKE_RCCL_QUIET="1", EESEN_BENCH_SHARE_GPU="0", EESEN_PERSISTENT="0"), timeout=1800)
+    c = d["config"]["check_full_cfg3"]
+    assert c.get("ok") is True, c
+    assert d["config"]["check_full_cfg3_ok"] is True
+    assert c["shards"] == 8 and c["utterances_per_shard"] == 32 and c["every_rank_sees_the_same_sum"] is True and c["tensors"] == 50
+    assert c["ln_p_worst_rel_err_per_sequence"] < 1e-4 and c["worst_error_over_its_bar"] < 1.0, c
+    assert d["config"]["ranks"] == 8 and d["config"]["ranks_bit_identical"] is True and d["config"]["comm_stand_in"] is True
