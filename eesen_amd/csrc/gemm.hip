@@ -17,6 +17,7 @@
 //   * split-K (deterministic two-pass: partial slabs + reduce kernel) for the weight-gradient shapes
 //     whose M x N tile count cannot fill 256 CUs (e.g. 2048 x 512 with K = T*S = 32000).
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "kernels.h"
@@ -46,6 +47,8 @@ struct GemmParams {
   int gm;       // > 0: XCD-aware tile map with row groups of gm tiles (see tile_of); 0: row-major
   int bm, bn;   // output tile of the kernel flavour being launched (128 x 128, or 256 x 256 for the big split kernel)
   int nprod;    // split kernel: 6 = fp32-class (hi/mid/lo cross products), 1 = bf16 x bf16 only (operands rounded to bf16)
+  const float* amax_a;   // two-plane fp16 kernel: device words holding an upper bound of max |A| / max |B| (the operand scales)
+  const float* amax_b;
   GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
 
@@ -142,9 +145,10 @@ __device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const 
 
 // C/D map of the 32x32 MFMA (all input types): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // row_w / col_w: offset of this wave's BMW x BNW blocks inside the workgroup's tile.
-template <int BMW, int BNW>
+// SCALED (two-plane fp16 kernel): the accumulators hold 2^(sa + sb) times the products; ua = 2^-sa, ub = 2^-sb (exact).
+template <int BMW, int BNW, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[BMW][BNW], int m0, int n0, int split, int row_w,
-                                              int col_w, int lr, int lk) {
+                                              int col_w, int lr, int lk, float ua = 1.f, float ub = 1.f) {
   float* C = p.C;
   size_t ldc = p.ldc;
   const bool partial = p.splits > 1;
@@ -164,10 +168,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
         const int row = m0 + row_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= p.M) continue;
         float* dst = C + (size_t)row * ldc + col;
+        const float a = SCALED ? acc[mi][ni][r] * ua * ub : acc[mi][ni][r];
         if (partial) {
-          *dst = acc[mi][ni][r];
+          *dst = a;
         } else {
-          float v = p.alpha * acc[mi][ni][r] + bv;
+          float v = p.alpha * a + bv;
           if (p.beta != 0.f) v += p.beta * *dst;
           *dst = v;
         }
@@ -312,8 +317,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
 // LDS: per operand and stage 3 planes (hi, mid, lo) x 2 k-halves x 128 rows x 8 bf16 (16 B): lane l of an MFMA reads row
 // l & 31, k-half l >> 5 with ONE conflict-free ds_read_b128 (consecutive rows are consecutive 16-byte slots); the k-halves
 // are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
+//
+// Round 6: the same body on TWO fp16 planes ("half" mode, PL = 2).  With round-to-nearest at both levels an fp32 value a is
+// hi + lo to within 2^-24 |a| (hi = fp16(a): 11 bits, |a - hi| <= 2^-12 |a|; lo = fp16(a - hi): |a - hi - lo| <= 2^-24 |a| -- the
+// residual is signed, which is worth one bit per level), so
+//     a*b ~ hi*hi' + (hi*lo' + lo*hi'),   |error| <= ~3 * 2^-24 |a*b|   (dropped lo*lo' <= 2^-24 |ab|; two representation errors)
+// THREE products on v_mfma_f32_32x32x16_f16 instead of six on the bf16 form of the same rate, and two planes to split instead
+// of three.  What fp16 lacks is exponent range (5 bits): every operand is multiplied by a power of two that brings ITS largest
+// magnitude into [2^14, 2^15) (half_scale: from a device word holding max |x| or a bound of it -- amax_abs below, or a bound
+// the caller knows, e.g. 1 for an LSTM output), and the epilogue multiplies the two powers back out -- both exact.  hi is then
+// a normal fp16 number down to 2^-29 of the tensor's largest element, lo down to 2^-17 of it; below that they are fp16
+// DENORMALS, which the gfx950 MFMA multiplies exactly (no flush; asserted on the device by tests/test_gpu_gemm.py), so the
+// absolute error of an element never exceeds 2^-40 of the tensor's largest.  Measured against fp64 the two-plane kernel is as
+// accurate as the three-plane one (profiles/r06_gemm_accuracy.json).
 constexpr int kSplitMinW = 3;   // workgroups per CU of the 128 x 128 split kernel; measured: 171 -> 178 TF with two tiles of prefetch, 189 with three workgroups per CU
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));   // eight 16-bit operand values of one lane, of either type
 
 // Geometry of one split-kernel flavour.  TM x TN output tile, WGM x WGN waves, each wave (TM/WGM) x (TN/WGN) = BMW x BNW MFMA
 // blocks of 32 x 32.  Two flavours are built:
@@ -322,21 +344,34 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   256 x 256, 2 x 4 waves (512 threads, 48 MFMAs per wave and k-tile): the same 16 floats to split per thread for twice the
 //     MFMAs -- the kernel is bound by the SIMD issue port (split instructions), not by the matrix pipe -- one workgroup per
 //     CU: the main-stream GEMMs of large shapes.
-template <int TM_, int TN_, int WGM_, int WGN_>
+template <int TM_, int TN_, int WGM_, int WGN_, int PL_ = 3>
 struct SplitGeo {
   static constexpr int TM = TM_, TN = TN_, WGM = WGM_, WGN = WGN_;
+  static constexpr int PL = PL_;                                       // planes per operand: 3 bf16 (six products) or 2 fp16 (three)
+  static constexpr int NPROD = PL == 3 ? 6 : 3;
   static constexpr int THREADS = WGM * WGN * 64;
   static constexpr int BMW = TM / WGM / 32, BNW = TN / WGN / 32;
   static constexpr int UA = TM * 4 / THREADS, UB = TN * 4 / THREADS;   // (row, k-quad) units per thread and k-tile, per operand
   static constexpr int HS_A = TM * 16 + 64, HS_B = TN * 16 + 64;       // bytes per k-half (rows x 16 B, + 16 banks)
   static constexpr int PS_A = 2 * HS_A, PS_B = 2 * HS_B;               // bytes per plane
-  static constexpr int OP_A = 3 * PS_A, OP_B = 3 * PS_B;               // bytes per operand and stage
+  static constexpr int OP_A = PL * PS_A, OP_B = PL * PS_B;             // bytes per operand and stage
   static constexpr int STAGE = OP_A + OP_B;
-  static constexpr int NMFMA = 6 * BMW * BNW;                          // per wave and k-tile
+  static constexpr int NMFMA = NPROD * BMW * BNW;                      // per wave and k-tile
   static_assert(UA == 2 && UB == 2, "the k loop below is written for two units per thread and operand");
 };
 using GeoSmall = SplitGeo<128, 128, 2, 2>;
 using GeoBig = SplitGeo<256, 256, 2, 4>;
+using GeoSmallH = SplitGeo<128, 128, 2, 2, 2>;
+using GeoBigH = SplitGeo<256, 256, 2, 4, 2>;
+
+// The power of two that brings an operand whose largest magnitude is *amax into [2^14, 2^15), and its inverse (both exact; an
+// all-zero operand gets 2^126 and 2^-126).  Uniform: scalar loads.
+__device__ __forceinline__ void half_scale(const float* amax, float& scale, float& inv) {
+  const int e = (int)((__builtin_bit_cast(unsigned, *amax) >> 23) & 0xffu);   // biased exponent of the bound
+  const int s = min(max(127 + 14 + 127 - e, 1), 253);   // (253: the inverse stays a normal number)
+  scale = __builtin_bit_cast(float, (unsigned)s << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(254 - s) << 23);
+}
 
 // (row, k-quad) units of an operand tile of ROWS rows x 16 k: each thread brings 2 units of 4 consecutive-k floats per k-tile.
 //   KC (k contiguous in HBM):  unit f = tid + THREADS i -> row f >> 2, quad f & 3: one float4
@@ -389,8 +424,16 @@ struct SplitUnit {
 // to its first use, i.e. behind the MFMAs it is meant to hide under.  An empty volatile asm that takes the values as
 // read-write operands is a use at this point, and it keeps its place among the scheduling fences.
 #define EESEN_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
-template <bool KC, bool GUARD, int THREADS, int ROWS>
-__device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int i, int tid, int R, int r0, int k0, int kend) {
+// two floats -> two fp16, round to nearest even, packed (low half = first): v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+// PL = 3: bf16 planes by truncation (scale unused).  PL = 2: fp16 planes by rounding, of the operand times `scale` (half_scale).
+template <int PL, bool KC, bool GUARD, int THREADS, int ROWS>
+__device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int i, int tid, int R, int r0, int k0, int kend, float scale) {
   float x[4] = {v.x, v.y, v.z, v.w};
   if (GUARD) {
     int row, q;
@@ -400,18 +443,35 @@ __device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = (ok && k + j < kend) ? x[j] : 0.f;
   }
-  u.ph[0] = pack_hi16(x[0], x[1]);
-  u.ph[1] = pack_hi16(x[2], x[3]);
+  if (PL == 3) {
+    u.ph[0] = pack_hi16(x[0], x[1]);
+    u.ph[1] = pack_hi16(x[2], x[3]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) u.r[j] = x[j] - trunc_bf16(x[j]);   // exact
+    for (int j = 0; j < 4; ++j) u.r[j] = x[j] - trunc_bf16(x[j]);   // exact
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] *= scale;                      // exact (a power of two)
+    u.ph[0] = pack_f16(x[0], x[1]);
+    u.ph[1] = pack_f16(x[2], x[3]);
+    u.r[0] = x[0] - f16_lo(u.ph[0]);                                // exact: the residual of a rounding to 11 bits has <= 13
+    u.r[1] = x[1] - f16_hi(u.ph[0]);
+    u.r[2] = x[2] - f16_lo(u.ph[1]);
+    u.r[3] = x[3] - f16_hi(u.ph[1]);
+  }
 }
+template <int PL>
 __device__ __forceinline__ void split_stage_b(SplitUnit& u) {
-  u.pm[0] = pack_hi16(u.r[0], u.r[1]);
-  u.pm[1] = pack_hi16(u.r[2], u.r[3]);
+  if (PL == 3) {
+    u.pm[0] = pack_hi16(u.r[0], u.r[1]);
+    u.pm[1] = pack_hi16(u.r[2], u.r[3]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) u.r[j] = u.r[j] - trunc_bf16(u.r[j]);   // exact; the lo plane takes its top 16 bits
+    for (int j = 0; j < 4; ++j) u.r[j] = u.r[j] - trunc_bf16(u.r[j]);   // exact; the lo plane takes its top 16 bits
+  } else {
+    u.pm[0] = pack_f16(u.r[0], u.r[1]);
+    u.pm[1] = pack_f16(u.r[2], u.r[3]);
+  }
 }
-template <bool KC, int THREADS, int ROWS>
+template <int PL, bool KC, int THREADS, int ROWS>
 __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char* base, int i, int tid) {
   constexpr int HS = ROWS * 16 + 64, PS = 2 * HS;
   int row, q;
@@ -419,17 +479,23 @@ __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char*
   unsigned char* dst = base + (q >> 1) * HS + row * 16 + (q & 1) * 8;
   *reinterpret_cast<uint2*>(dst) = make_uint2(u.ph[0], u.ph[1]);
   *reinterpret_cast<uint2*>(dst + PS) = make_uint2(u.pm[0], u.pm[1]);
-  *reinterpret_cast<uint2*>(dst + 2 * PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
+  if (PL == 3) *reinterpret_cast<uint2*>(dst + 2 * PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
 }
-template <bool KC, bool GUARD, int THREADS, int ROWS>
-__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend) {
+template <int PL, bool KC, bool GUARD, int THREADS, int ROWS>
+__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend, float scale) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     SplitUnit u;
-    split_stage_a<KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend);
-    split_stage_b(u);
-    split_stage_c<KC, THREADS, ROWS>(u, base, i, tid);
+    split_stage_a<PL, KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend, scale);
+    split_stage_b<PL>(u);
+    split_stage_c<PL, KC, THREADS, ROWS>(u, base, i, tid);
   }
+}
+// one product of two planes on the matrix pipe: 32 x 32 x 16, fp32 accumulate
+template <int PL>
+__device__ __forceinline__ f32x16 mfma_planes(const frag_t& a, const frag_t& b, const f32x16& c) {
+  if constexpr (PL == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // nprod == 1 ("bf16 forward", BASELINE config 4): both operands rounded to nearest-even bf16, ONE MFMA product, fp32 accumulation.
@@ -459,7 +525,7 @@ __device__ __forceinline__ void bf16_store(unsigned char* base, int tid, const f
 
 template <class G, bool A_KC, bool B_KC, bool GUARD, bool GATED>
 __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
-  constexpr int TM = G::TM, TN = G::TN, TH = G::THREADS, BMW = G::BMW, BNW = G::BNW;
+  constexpr int TM = G::TM, TN = G::TN, TH = G::THREADS, BMW = G::BMW, BNW = G::BNW, PL = G::PL;
   // stage s: A planes at s * STAGE, B planes at s * STAGE + OP_A (indexed as an array, so the accesses stay ds_* ones)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -488,16 +554,18 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     split_load<A_KC, TH, TM>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
     split_load<B_KC, TH, TN>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
   };
+  float sa = 1.f, sb = 1.f, ua = 1.f, ub = 1.f;   // two fp16 planes: the operands' power-of-two scales and their inverses
+  if constexpr (PL == 2) { half_scale(p.amax_a, sa, ua); half_scale(p.amax_b, sb, ub); }
   auto store = [&](int t, const float4 (&ra)[2], const float4 (&rb)[2]) {
     const int st = (t & 1) * G::STAGE;
-    split_store<A_KC, GUARD, TH, TM>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend);
-    split_store<B_KC, GUARD, TH, TN>(&lds[st + G::OP_A], tid, rb, p.N, n0, kbeg + t * SBK, kend);
+    split_store<PL, A_KC, GUARD, TH, TM>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend, sa);
+    split_store<PL, B_KC, GUARD, TH, TN>(&lds[st + G::OP_A], tid, rb, p.N, n0, kbeg + t * SBK, kend, sb);
   };
-  // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi'; the output blocks in turn, so that
-  // dependent MFMAs are BMW * BNW issues apart
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi' (two planes: hi*lo' + lo*hi', then hi*hi');
+  // the output blocks in turn, so that dependent MFMAs are BMW * BNW issues apart
+  constexpr int PA[6] = {0, PL == 3 ? 2 : 1, PL == 3 ? 1 : 0, 0, 1, 0}, PB[6] = {PL == 3 ? 2 : 1, 0, PL == 3 ? 1 : 0, 1, 0, 0};
 
-  if (p.nprod == 1) {   // bf16 x bf16 only: the hi plane, one product
+  if (PL == 3 && p.nprod == 1) {   // bf16 x bf16 only: the hi plane, one product
     float4 ra[2], rb[2];
     if (nk > 0) {
       load(0, ra, rb);
@@ -536,14 +604,14 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   // matrix pipe, was the limit (PMC: matrix pipe 55 % busy, VALU 40 %, summing to ~100 %).
   float4 ra0[2], rb0[2], ra1[2], rb1[2];
   // fragments of tile t: every plane of every block row / column of this wave
-  auto frags = [&](int t, bf16x8 (&a)[BMW][3], bf16x8 (&b)[BNW][3]) {
+  auto frags = [&](int t, frag_t (&a)[BMW][PL], frag_t (&b)[BNW][PL]) {
     const int cur = (t & 1) * G::STAGE;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < PL; ++pl) {
 #pragma unroll
-      for (int i = 0; i < BMW; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * G::PS_A + a_off + i * 32 * 16]);
+      for (int i = 0; i < BMW; ++i) a[i][pl] = *reinterpret_cast<const frag_t*>(&lds[cur + pl * G::PS_A + a_off + i * 32 * 16]);
 #pragma unroll
-      for (int i = 0; i < BNW; ++i) b[i][pl] = *reinterpret_cast<const bf16x8*>(&lds[cur + pl * G::PS_B + b_off + i * 32 * 16]);
+      for (int i = 0; i < BNW; ++i) b[i][pl] = *reinterpret_cast<const frag_t*>(&lds[cur + pl * G::PS_B + b_off + i * 32 * 16]);
     }
   };
   // steady state: MFMAs of tile t with the split of tile t + 1 in their shadow -- per unit  M..M [A]  M..M [B]  M..M [C], every
@@ -551,11 +619,11 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   auto fused = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
     const int nxt = G::STAGE - (t & 1) * G::STAGE;
     const int k1 = kbeg + (t + 1) * SBK;
-    bf16x8 a[BMW][3], b[BNW][3];
+    frag_t a[BMW][PL], b[BNW][PL];
     frags(t, a, b);
     auto mm = [&](int idx) {   // MFMA number idx of the tile: product idx / (BMW * BNW), output block idx % (BMW * BNW)
       const int t6 = idx / (BMW * BNW), blk = idx % (BMW * BNW), mi = blk / BNW, ni = blk % BNW;
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
+      acc[mi][ni] = mfma_planes<PL>(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni]);
     };
     constexpr int PER = G::NMFMA / 12;   // MFMAs next to every split stage
     SplitUnit su;
@@ -570,19 +638,19 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u);
       __builtin_amdgcn_sched_barrier(0);
-      if (u < 2) split_stage_a<A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend);
-      else split_stage_a<B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend);
+      if (u < 2) split_stage_a<PL, A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend, sa);
+      else split_stage_a<PL, B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend, sb);
       EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u + 1);
       __builtin_amdgcn_sched_barrier(0);
-      split_stage_b(su);
+      split_stage_b<PL>(su);
       EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.pm[0], su.pm[1]);
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u + 2);
       __builtin_amdgcn_sched_barrier(0);
-      if (u < 2) split_stage_c<A_KC, TH, TM>(su, &lds[nxt], u, tid);
-      else split_stage_c<B_KC, TH, TN>(su, &lds[nxt + G::OP_A], u - 2, tid);
+      if (u < 2) split_stage_c<PL, A_KC, TH, TM>(su, &lds[nxt], u, tid);
+      else split_stage_c<PL, B_KC, TH, TN>(su, &lds[nxt + G::OP_A], u - 2, tid);
     }
     __builtin_amdgcn_sched_barrier(0);
     load(t + 3, ra, rb);
@@ -590,16 +658,16 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   };
   auto step = [&](int t, float4 (&ra)[2], float4 (&rb)[2], bool do_store, bool do_load) {
     {
-      bf16x8 a[BMW][3], b[BNW][3];
+      frag_t a[BMW][PL], b[BNW][PL];
       frags(t, a, b);
       __builtin_amdgcn_sched_barrier(0);  // global prefetches and fragment reads are issued before the MFMA block
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6)
+      for (int t6 = 0; t6 < G::NPROD; ++t6)
 #pragma unroll
         for (int mi = 0; mi < BMW; ++mi)
 #pragma unroll
           for (int ni = 0; ni < BNW; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = mfma_planes<PL>(a[mi][PA[t6]], b[ni][PB[t6]], acc[mi][ni]);
       __builtin_amdgcn_sched_barrier(0);  // ... and nothing that reads prefetched registers (a vmcnt wait) moves above them
     }
     if (do_store) store(t + 1, ra, rb);
@@ -619,7 +687,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     step(kt, ra0, rb0, kt + 1 < nk, kt + 3 < nk);
     if (kt + 1 < nk) step(kt + 1, ra1, rb1, kt + 2 < nk, kt + 4 < nk);
   }
-  gemm_epilogue<BMW, BNW>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk);
+  gemm_epilogue<BMW, BNW, PL == 2>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk, ua, ub);
 }
 
 template <bool A_KC, bool B_KC, bool GUARD>
@@ -633,6 +701,45 @@ __global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_bf16_gated_ker
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_f32_split_bf16_big_kernel(GemmParams p) {
   gemm_split_body<GeoBig, A_KC, B_KC, false, false>(p);
+}
+
+// the same three kernels on two fp16 planes (three products)
+template <bool A_KC, bool B_KC, bool GUARD>
+__global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_f16_kernel(GemmParams p) {
+  gemm_split_body<GeoSmallH, A_KC, B_KC, GUARD, false>(p);
+}
+__global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_f16_gated_kernel(GemmParams p) {
+  gemm_split_body<GeoSmallH, true, true, false, true>(p);
+}
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_f32_split_f16_big_kernel(GemmParams p) {
+  gemm_split_body<GeoBigH, A_KC, B_KC, false, false>(p);
+}
+
+// max |x| over a [rows x cols] matrix (row stride ld) into *out, which the caller has zeroed: non-negative floats order like their
+// bit patterns, so one unsigned atomic max per wave does it.  NaN / Inf bit patterns win, and the GEMM then produces what an fp32
+// GEMM would: NaN / Inf.
+__global__ __launch_bounds__(256) void amax_abs_kernel(const float* __restrict__ P, long rows, int cols, int ld, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cols == ld) {   // one flat array
+    const long n4 = rows * cols / 4;
+    for (long i = t0; i < n4; i += stride) {
+      const uint4 v = reinterpret_cast<const uint4*>(P)[i];
+      m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+  } else {
+    const int c4 = (cols + 3) / 4;
+    for (long i = t0; i < rows * c4; i += stride) {
+      const long r = i / c4;
+      const int c = (int)(i % c4) * 4;
+      const float* src = P + r * ld + c;
+      for (int j = 0; j < 4 && c + j < cols; ++j) m = max(m, __builtin_bit_cast(unsigned, src[j]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // C = alpha * sum_s ws[s] + beta * C + bias
@@ -653,15 +760,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-// 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1 (default): 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (fp32-class
-// accuracy, 2.67x the matrix rate).  EESEN_GEMM_MODE=f32|split; read per call so that tests can flip it inside one process.
+// 0: v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain); 1: 3-way bf16 split on v_mfma_f32_32x32x16_bf16 (six products, fp32-class
+// accuracy, 2.67x the matrix rate); 2: two fp16 planes on v_mfma_f32_32x32x16_f16 (three products, the same accuracy class, see the
+// comment at kSplitMinW).  EESEN_GEMM_MODE=f32|split|half; read per call so that tests can flip it inside one process.
 static int g_gemm_mode = -1;
 int gemm_mode() {
   if (g_gemm_mode >= 0) return g_gemm_mode;
-  const char* e = getenv("EESEN_GEMM_MODE");   // default: the split kernel
-  return (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : 1;
+  const char* e = getenv("EESEN_GEMM_MODE");
+  if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) return 0;
+  if (e && (!strcmp(e, "split") || !strcmp(e, "1"))) return 1;
+  if (e && (!strcmp(e, "half") || !strcmp(e, "2"))) return 2;
+  return kDefaultGemmMode;
 }
 void set_gemm_mode(int mode) { g_gemm_mode = mode; }
+
+void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float* out) {
+  EESEN_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), st));
+  amax_abs_accumulate(st, P, rows, cols, ld, out);
+}
+void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out) {
+  if (rows <= 0 || cols <= 0) return;
+  const long quads = cols == ld ? rows * cols / 4 : rows * ((cols + 3) / 4);
+  const int blocks = (int)std::max<long>(1, std::min<long>((quads + 1023) / 1024, 2048));   // >= 4 float4 per thread, <= 8 blocks per CU
+  hipLaunchKernelGGL(amax_abs_kernel, dim3(blocks), dim3(256), 0, st, P, rows, cols, ld, reinterpret_cast<unsigned*>(out));
+  check_launch("amax_abs");
+}
+
+// Operand bounds for a two-plane call whose caller passed none: a ring of device words, one pair per call.  A slot is reused after
+// kRing calls, far beyond what any stream of this library has in flight; the Net passes its own slots and never comes here.
+static const float* ring_amax(hipStream_t st, const float* P, long rows, int cols, int ld) {
+  constexpr int kRing = 4096, kDevs = 16;
+  static std::mutex mu;
+  static float* ring[kDevs] = {nullptr};   // never freed: lives as long as the process's HIP context
+  static unsigned next[kDevs] = {0};
+  int dev = 0;
+  EESEN_HIP_CHECK(hipGetDevice(&dev));
+  EESEN_REQUIRE(dev >= 0 && dev < kDevs, EESEN_ERR_INVALID, "gemm: device index beyond the amax ring table");
+  float* slot;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ring[dev]) EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ring[dev]), kRing * sizeof(float)));
+    slot = ring[dev] + (next[dev]++ % kRing);
+  }
+  amax_abs(st, P, rows, cols, ld, slot);
+  return slot;
+}
 
 // Row-group height of the XCD-aware tile map (0 = plain row-major) and the grid it needs.  Groups of 8 tile-rows once
 // every XCD gets at least two of them; fewer rows per group for short grids so that all eight XCDs still get work.
@@ -678,12 +821,18 @@ static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
 
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats,
-              int extra_lds_bytes, bool bf16_operands) {
+              int extra_lds_bytes, bool bf16_operands, const float* amax_a, const float* amax_b) {
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
-  const bool use_split = gemm_mode() == 1 || bf16_operands;
+  const bool use_split = gemm_mode() >= 1 || bf16_operands;
+  const bool half = gemm_mode() == 2 && !bf16_operands;   // two fp16 planes: needs a bound of each operand's largest magnitude
   GemmParams p;
+  p.amax_a = p.amax_b = nullptr;
+  if (half) {
+    p.amax_a = amax_a ? amax_a : ring_amax(st, A, a_kc ? M : K, a_kc ? K : M, lda);
+    p.amax_b = amax_b ? amax_b : ring_amax(st, B, b_kc ? N : K, b_kc ? K : N, ldb);
+  }
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.alpha = alpha; p.beta = beta;
@@ -724,20 +873,27 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     if (guard) hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, true>), grid, block, extra_lds_bytes, st, p); \
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
-  if (big) {   // K and k_chunk are multiples of 16: every split is made of whole k-tiles, every tile is interior
+  if (big && half) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<true, false>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<false, false>), grid, block, 0, st, p);
+  } else if (big) {   // K and k_chunk are multiples of 16: every split is made of whole k-tiles, every tile is interior
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, true>), grid, block, 0, st, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, false>), grid, block, 0, st, p);
     else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<false, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<false, false>), grid, block, 0, st, p);
   } else if (use_split) {
-    // 49.5 KB of LDS per workgroup: the occupancy caps of the callers (unused dynamic LDS) are sized for the 33 KB of the f32
-    // kernel; keep the same workgroups-per-CU they ask for
-    const int extra = extra_lds_bytes > 0 ? std::max(0, extra_lds_bytes + 33792 - 2 * GeoSmall::STAGE) : 0;
+    // 49.5 KB (three bf16 planes) / 33 KB (two fp16 planes) of LDS per workgroup: the occupancy caps of the callers (unused dynamic
+    // LDS) are sized for the 33 KB of the f32 kernel; keep the same workgroups-per-CU they ask for
+    const int extra = extra_lds_bytes > 0 ? std::max(0, extra_lds_bytes + 33792 - 2 * (half ? GeoSmallH::STAGE : GeoSmall::STAGE)) : 0;
     // every tile interior and every split made of whole k-tiles: no clamps, no selects
     const bool sg = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % 16) != 0;
 #define EESEN_SPLIT_LAUNCH(AK, BKC)                                                                                   \
   do {                                                                                                                \
-    if (sg) hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, true>), grid, block, extra, st, p);               \
+    if (half && sg) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, true>), grid, block, extra, st, p);        \
+    else if (half) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, false>), grid, block, extra, st, p);        \
+    else if (sg) hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, true>), grid, block, extra, st, p);          \
     else hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, false>), grid, block, extra, st, p);                 \
   } while (0)
     if (a_kc && b_kc) EESEN_SPLIT_LAUNCH(true, true);
@@ -761,7 +917,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
 }
 
 void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                       int ldc, const float* bias, const GemmGate& gate) {
+                       int ldc, const float* bias, const GemmGate& gate, const float* amax_a, const float* amax_b) {
   EESEN_REQUIRE((M % BM) == 0 && (N % BN) == 0 && (K % BK) == 0, EESEN_ERR_INVALID, "gated GEMM needs whole tiles");
   EESEN_REQUIRE(gate.ndir * gate.nz * kShards <= 64, EESEN_ERR_INVALID, "gated GEMM: too many counter groups");
   GemmParams p;
@@ -771,6 +927,8 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN; p.tiles_m = M / BM;
   p.gate = gate;
   p.nprod = 6;
+  p.amax_a = amax_a; p.amax_b = amax_b;
+  EESEN_REQUIRE(gemm_mode() != 2 || (amax_a && amax_b), EESEN_ERR_INVALID, "gated GEMM on fp16 planes needs both operand bounds (A is still being written)");
   p.bm = p.bn = BM;
   unsigned gx = (unsigned)(p.tiles_m * p.tiles_n);
   p.gm = xcd_group_rows(p.tiles_m, p.tiles_n, &gx);
@@ -779,7 +937,8 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
   constexpr int gate_lds = 26 * 1024;
-  if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmall::STAGE), st, p);
+  if (gemm_mode() == 2) hipLaunchKernelGGL(gemm_f32_split_f16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmallH::STAGE), st, p);
+  else if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmall::STAGE), st, p);
   else hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");
 }

@@ -14,12 +14,19 @@ namespace eesen {
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
               size_t ws_floats, int extra_lds_bytes = 0,   // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
-              bool bf16_operands = false);                 // round both operands to bf16, one bf16 MFMA product, fp32 accumulate
+              bool bf16_operands = false,                  // round both operands to bf16, one bf16 MFMA product, fp32 accumulate
+              // mode 2 only: device words holding (a bound of) max |A| / max |B| over at least the operand; null = measured here
+              // by a pass over the operand (amax_abs) before the launch
+              const float* amax_a = nullptr, const float* amax_b = nullptr);
 
-// Arithmetic of every gemm_f32 / gemm_f32_nt_gated call: 0 = f32-input MFMA, 1 = 3-way bf16 split (gemm.hip); -1 = follow
-// EESEN_GEMM_MODE.  Process-wide.
+// Arithmetic of every gemm_f32 / gemm_f32_nt_gated call: 0 = f32-input MFMA, 1 = 3-way bf16 split (six products), 2 = two fp16
+// planes (three products; gemm.hip); -1 = follow EESEN_GEMM_MODE.  Process-wide.
+constexpr int kDefaultGemmMode = 2;
 int gemm_mode();
 void set_gemm_mode(int mode);
+// *out = max |P[r][c]| over a [rows x cols] matrix with row stride ld (amax_abs zeroes the word first; _accumulate folds into it)
+void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
+void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
 
 // Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
 // shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.
@@ -41,7 +48,7 @@ struct GemmGate {
   int spin_limit;
 };
 void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                       int ldc, const float* bias, const GemmGate& gate);
+                       int ldc, const float* bias, const GemmGate& gate, const float* amax_a = nullptr, const float* amax_b = nullptr);
 
 // ---------------------------------------------------------------------------------------- lstm.hip
 struct LstmLayerDev {
@@ -93,6 +100,10 @@ struct LstmLayerDev {
   int fwd_bf16 = 0;
   // fp32-class forward recurrence on the bf16 matrix pipe (3-way split of both operands, six products; tuning.h: EESEN_FWD_SPLIT)
   int fwd_split = 0;
+  // fp32-class forward recurrence on TWO fp16 planes per operand, three products (round 6; tuning.h: EESEN_FWD_F16): taken where
+  // the 3-way split would be, and on the wide 16 x 16 tile.  wm_amax: device word holding max |W_m| of this layer (both directions).
+  int fwd_f16 = 0;
+  const float* wm_amax = nullptr;
 };
 float handoff_flight_ns();
 // The share of the device's CUs this PROCESS sizes its persistent grids against: 1/n (EESEN_GPU_SHARE, or set by a communicator

@@ -368,9 +368,27 @@ void Net::finalize() {
   if (tn.overlap < 0)
     for (const Layer& L : layers)
       if (L.is_lstm() && L.H > 512) overlap = false;
+  amax.reserve(1 + 4 * layers.size());
+  EESEN_HIP_CHECK(hipMemsetAsync(amax.p, 0, amax.cap * sizeof(float), st));
+  EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(amax.p), 0x3f800000, 1, st));   // word 0 = 1.0f
   finalized = true;
   refresh_derived();
   sync();
+}
+
+// max |W| of every weight matrix a GEMM multiplies with, after a parameter change (mode 2 of gemm.hip only)
+void Net::ensure_weight_amax() {
+  if (wamax_valid) return;
+  EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_W), 0, layers.size() * sizeof(float), st));
+  EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_WM), 0, layers.size() * sizeof(float), st));
+  for (size_t li = 0; li < layers.size(); ++li) {
+    const Layer& L = layers[li];
+    if (L.is_lstm()) {
+      amax_abs_accumulate(st, params.p + L.p_off + L.off_wx, (long)L.ndir * 4 * L.H, pad4(L.din), pad4(L.din), am(li, AM_W));
+      amax_abs_accumulate(st, params.p + L.p_off + L.off_wm, (long)L.ndir * 4 * L.H, L.H, L.H, am(li, AM_WM));
+    } else if (L.kind == EESEN_LAYER_AFFINE) amax_abs_accumulate(st, params.p + L.p_off + L.off_w, L.dout, pad4(L.din), pad4(L.din), am(li, AM_W));
+  }
+  wamax_valid = true;
 }
 
 long Net::num_params() const {
@@ -387,6 +405,7 @@ void Net::init_accu() {  // InitAdaBuffers (bilstm-layer.h:66-100, affine-trans-
 }
 
 void Net::refresh_derived() {
+  wamax_valid = false;
   for (Layer& L : layers)
     if (L.is_lstm())
       for (int dir = 0; dir < L.ndir; ++dir)
@@ -504,6 +523,8 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.drop_mode = L.cur_drop_mode;
   d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
   d.fwd_split = net.tn.fwd_split;
+  d.fwd_f16 = net.tn.fwd_f16 && net.tn.fwd_split;   // (EESEN_FWD_SPLIT=0 is the master switch: the fp32-input MFMA kernels)
+  d.wm_amax = net.amax.p ? const_cast<Net&>(net).am((int)(&L - net.layers.data()), Net::AM_WM) : nullptr;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.fwd_narrow2 = net.tn.fwd_narrow2; d.fwd_t16_small = net.tn.fwd_t16_small; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
@@ -676,7 +697,25 @@ void Net::forward_pass() {
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
   int mid_r0 = 0, mid_r1 = 0;   // rows [mid_r0, mid_r1) of the current layer's input GEMM already ran on the side stream (see plan_mid)
+  // two-plane fp16 GEMMs: the bound of the current activation x (null in the other modes)
+  // (measured also when this pass itself runs on bf16-rounded operands: Backpropagate's GEMMs read the words)
+  const bool half = gemm_mode() == 2;
+  ensure_weight_amax();
+  const float* x_amax = nullptr;
+  amx_valid = half;
+  if (half) {
+    EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_X), 0, layers.size() * sizeof(float), st));
+    amax_abs_accumulate(st, x, rows, layers[0].din, ldx, am(0, AM_X));
+    x_amax = am(0, AM_X);
+  }
   for (Layer& L : layers) {
+    const int li_ = (int)(&L - layers.data());
+    const float* w_amax = half ? am(li_, AM_W) : nullptr;
+    if (half && li_ > 0 && L.trainable()) {   // the input of a GEMM layer: bounded by 1 behind an LSTM layer (|m| = |o tanh c| < 1) or an
+      const Layer& Pv = layers[li_ - 1];      // activation / softmax layer; measured behind an affine layer or forward dropout (mask = 1 / (1 - p))
+      if ((Pv.is_lstm() && !Pv.cur_fwd_drop) || Pv.is_activation() || Pv.kind == EESEN_LAYER_SOFTMAX) x_amax = am_one();
+      else { amax_abs_accumulate(st, x, rows, L.din, ldx, am(li_, AM_X)); x_amax = am(li_, AM_X); }
+    }
     if (L.is_lstm()) {
       const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
       L.G.reserve((size_t)rows * ldG);
@@ -697,7 +736,7 @@ void Net::forward_pass() {
         if (gated_rows < rows) {  // the last, partial row tile (T*S not a multiple of 128): its frames are the last to complete anyway
           const int ti_ = timer.begin(st, 0);
           gemm_f32(st, true, true, rows - gated_rows, ldG, L.din, 1.f, x + (size_t)gated_rows * ldx, ldx, params.p + L.p_off + L.off_wx,
-                   pad4(L.din), 0.f, L.G.p + (size_t)gated_rows * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
+                   pad4(L.din), 0.f, L.G.p + (size_t)gated_rows * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16, x_amax, w_amax);
           timer.end(st, ti_);
         }
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
@@ -708,14 +747,14 @@ void Net::forward_pass() {
         for (const auto& pr : parts)
           if (pr[1] > pr[0])
             gemm_f32(st, true, true, pr[1] - pr[0], ldG, L.din, 1.f, x + (size_t)pr[0] * ldx, ldx, params.p + L.p_off + L.off_wx, pad4(L.din),
-                     0.f, L.G.p + (size_t)pr[0] * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
+                     0.f, L.G.p + (size_t)pr[0] * ldG, ldG, params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16, x_amax, w_amax);
         timer.end(st, ti_);
         EESEN_HIP_CHECK(hipStreamWaitEvent(st, ev_gate_done, 0));
         mid_r0 = mid_r1 = 0;
       } else {
         const int ti_ = timer.begin(st, 0);
         gemm_f32(st, true, true, rows, ldG, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, L.G.p, ldG,
-                 params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16);
+                 params.p + L.p_off + L.off_bias, nullptr, 0, 0, fwd_bf16, x_amax, w_amax);
         timer.end(st, ti_);
       }
       // The NEXT LSTM layer's input GEMM can run on the side stream WHILE this layer's persistent kernel is running:
@@ -772,8 +811,10 @@ void Net::forward_pass() {
         const int tj_ = timer.begin(st2, 0);
         GemmGate gate{ctl.p, ctl.p + kCtlWords - 1, nd, nz, gate_nblk, T, S, spin_limit};
         gated_rows = rows / 128 * 128;
+        // (this layer's output is the operand: no forward dropout here, so it is bounded by 1; the weights' word was written on `st`
+        // before ev_gate_reset, which the side stream has just waited for)
         gemm_f32_nt_gated(st2, gated_rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
-                          nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate);
+                          nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate, half ? am_one() : nullptr, half ? am(li_ + 1, AM_W) : nullptr);
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
         g_gated = true;
@@ -798,7 +839,8 @@ void Net::forward_pass() {
         const int tj_ = timer.begin(st2, 0);
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,
-                 params.p + nxt->p_off + nxt->off_bias, nullptr, 0, /* a token of extra LDS: the 128 x 128 flavour */ 64, fwd_bf16);
+                 params.p + nxt->p_off + nxt->off_bias, nullptr, 0, /* a token of extra LDS: the 128 x 128 flavour */ 64, fwd_bf16,
+                 half ? am_one() : nullptr, half ? am(li_ + 1, AM_W) : nullptr);
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
       } }
@@ -811,7 +853,7 @@ void Net::forward_pass() {
       if (L.out.reserve((size_t)rows * ldo)) EESEN_HIP_CHECK(hipMemsetAsync(L.out.p, 0, L.out.cap * sizeof(float), st));   // (the whole allocation: pad columns of rows a later, longer minibatch uses)
       { const int ti_ = timer.begin(st, 2);
       gemm_f32(st, true, true, rows, L.dout, L.din, 1.f, x, ldx, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, L.out.p, ldo,
-               params.p + L.p_off + L.off_b, nullptr, 0, 0, fwd_bf16);
+               params.p + L.p_off + L.off_b, nullptr, 0, 0, fwd_bf16, x_amax, w_amax);
       timer.end(st, ti_); }
       x = L.out.p;
       ldx = ldo;
@@ -908,6 +950,17 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
   float* d = dA.p;
   int ld_d = pad4(Kout);
   float* dn = dB.p;
+  // two-plane fp16 GEMMs: operand bounds (weights: ensure_weight_amax; layer inputs: the words Propagate left; gradients: measured here)
+  const bool half = gemm_mode() == 2;
+  ensure_weight_amax();
+  if (half) EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_D), 0, layers.size() * sizeof(float), st));
+  auto x_bound = [&](int li) -> const float* {   // as forward_pass chose it
+    if (!half) return nullptr;
+    if (!amx_valid) return nullptr;   // the mode changed between Propagate and here: measured at the call (gemm.hip)
+    if (li == 0) return am(0, AM_X);
+    const Layer& Pv = layers[li - 1];
+    return ((Pv.is_lstm() && !Pv.cur_fwd_drop) || Pv.is_activation() || Pv.kind == EESEN_LAYER_SOFTMAX) ? am_one() : am(li, AM_X);
+  };
   if (const Layer& Lb = layers.back(); Lb.out_nb) {   // the caller's out_diff has the file's columns: the padded cells get zeros
     EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
     for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, out_diff + (size_t)b * Lb.out_hf, ldd, d + (size_t)b * Lb.out_hi, ld_d, rows, Lb.out_hf);
@@ -939,13 +992,16 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
       continue;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       { const int ti_ = timer.begin(st, 4);
+      const float* d_amax = nullptr;
+      if (half) { amax_abs_accumulate(st, d, rows, L.dout, ld_d, am(li, AM_D)); d_amax = am(li, AM_D); }
       if (want_in) {  // in_diff = out_diff * W  (affine-trans-layer.h:171)
         if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
         gemm_f32(st, true, false, rows, L.din, L.dout, 1.f, d, ld_d, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, dn, ld_n,
-                 nullptr, nullptr, 0);
+                 nullptr, nullptr, 0, 0, false, d_amax, half ? am(li, AM_W) : nullptr);
       }
       // gradients (computed inside Update in the reference, affine-trans-layer.h:182-183)
-      gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats);
+      gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats, 0, false,
+               d_amax, x_bound(li));
       col_sums(st, d, rows, L.dout, ld_d, fr + L.off_b, ws.p, ws_floats);
       timer.end(st, ti_); }
       bucket_allreduce(li, st);
@@ -976,12 +1032,14 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
         for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
       check_launch("lstm_bwd");
       timer.end(st, ti_); }
+      const float* dg_amax = nullptr;   // one pass over the gate gradients for the (up to four) GEMMs that multiply them
+      if (half) { const int ti_ = timer.begin(st, 4); amax_abs_accumulate(st, DGl, rows, ldG, ldG, am(li, AM_D)); dg_amax = am(li, AM_D); timer.end(st, ti_); }
       EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
       if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction
         const int ti_ = timer.begin(st, 4);
         if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
         gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DGl, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
-                 nullptr, nullptr, 0);
+                 nullptr, nullptr, 0, 0, false, dg_amax, half ? am(li, AM_W) : nullptr);
         timer.end(st, ti_);
         // The input-gradient GEMM is on the critical path (the next-lower recurrence waits for it), the weight-gradient GEMMs
         // are not: they start behind it instead of beside it (measured: step 44.15 -> 42.97 ms)
@@ -996,19 +1054,20 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
       // with one per CU the side stream itself became the critical path (12 ms of gradient GEMMs per layer against 9 ms of
       // recurrence + input-gradient GEMM); before the recurrence kernels overlapped fetch and MFMA the ranking was the reverse.
       // (with the bf16-split GEMM: one per CU -- 47.6 vs 48.9 ms/step; the gradient GEMMs are short enough not to become the critical path)
-      const int side_lds_env = (tn.side_lds_kb >= 0 ? tn.side_lds_kb : (gemm_mode() == 1 ? 48 : 32)) * 1024;
+      const int side_lds_env = (tn.side_lds_kb >= 0 ? tn.side_lds_kb : (gemm_mode() >= 1 ? 48 : 32)) * 1024;
       bool lstm_below = false;   // the cap protects the NEXT-LOWER recurrence's cooperative launch: the lowest LSTM layer's
       for (int lj = 0; lj < li; ++lj) lstm_below |= layers[lj].is_lstm();   // gradient GEMMs have the chip to themselves
       const int side_lds = overlap && lstm_below ? side_lds_env : 0;  // occupancy cap of the side-stream GEMMs
       if (overlap) EESEN_HIP_CHECK(hipStreamWaitEvent(st2, ev_rec, 0));
       { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
-      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, need_ws, side_lds);
+      gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, need_ws, side_lds, false,
+               dg_amax, x_bound(li));
       // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
       for (int dir = 0; dir < nd; ++dir)
         gemm_f32(sg, false, false, 4 * H, H, rows, 1.f, DGl + (size_t)dir * 4 * H, ldG,
                  L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
-                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, need_ws, side_lds);
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, need_ws, side_lds, false, dg_amax, half ? am_one() : nullptr);
       lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, need_ws);
       timer.end(sg, ti_); }
       bucket_allreduce(li, sg);  // this layer's gradients are complete: sum them over the ranks under the lower layers' backward pass
@@ -1088,7 +1147,7 @@ std::string Net::plan_string() const {
   }
   const bool ov = overlap_for_minibatch();
   o += std::string("], \"weight_gradient_gemms\": \"") + (ov ? "side stream, under the next-lower recurrence" : "main stream, serial") + "\"";
-  o += std::string(", \"gemm_arithmetic\": \"") + (gemm_mode() == 1 ? "3-way bf16 split (fp32-class)" : "f32-input MFMA") + "\"";
+  o += std::string(", \"gemm_arithmetic\": \"") + (gemm_mode() == 2 ? "two fp16 planes, three products (fp32-class)" : gemm_mode() == 1 ? "3-way bf16 split (fp32-class)" : "f32-input MFMA") + "\"";
   o += std::string(", \"exchange\": ") + (comm ? (exchange_deferred_for_minibatch() ? "\"deferred: every bucket behind the backward pass's last recurrence\""
                                                                                       : "\"overlapped: each bucket as soon as its layer's gradients are enqueued\"") : "null");
   o += std::string(", \"exchange_rule\": \"") + (tn.comm_defer >= 0 ? "EESEN_COMM_DEFER" : "auto: deferred when a persistent backward grid leaves < 256 registers per SIMD lane") + "\"";

@@ -158,6 +158,18 @@ struct Net {
   void set_dropout_masks(int layer, const float* fwd, long fwd_n, const float* rec, int rec_rows, long rec_n, int coin);
   void get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* info4);
   size_t ws_floats = 0;
+  // Operand bounds of the two-plane fp16 GEMMs (gemm.hip, mode 2): device words holding max |x| of a tensor, or a bound the
+  // structure gives (word 0 = 1.0: LSTM outputs, sigmoid / tanh / softmax outputs).  Per layer li: [W] the weight matrix its GEMMs
+  // multiply with (W_x / W; measured after every parameter change), [X] its input activation (measured in Propagate when not
+  // bounded by 1, reused by Backpropagate), [D] the gradient it multiplies in Backpropagate (DG of an LSTM layer, out_diff of an affine
+  // one; measured there).  The GEMM of a PART of a tensor takes the whole tensor's word, so results do not depend on how a GEMM is cut.
+  DevBuf<float> amax;
+  bool wamax_valid = false;
+  bool amx_valid = false;     // the [X] words are those of the last Propagate
+  enum { AM_W = 0, AM_X = 1, AM_D = 2, AM_WM = 3 };   // AM_WM: max |W_m| of an LSTM layer (the fp16-plane forward recurrence, lstm_persistent.hip)
+  float* am(int li, int k) { return amax.p + 1 + (size_t)k * layers.size() + li; }
+  const float* am_one() const { return amax.p; }
+  void ensure_weight_amax();
   PhaseTimer timer;
   // data-parallel exchange (comm.cpp): with a communicator attached, Backpropagate sums every layer's fresh gradients
   // over the ranks on the communicator's stream as soon as that layer's weight-gradient kernels are enqueued (the point

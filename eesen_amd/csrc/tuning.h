@@ -67,7 +67,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1;
+  int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1, fwd_f16 = 1;
   int comm_defer = -1;   // -1: decided per minibatch from the backward plans (Net::exchange_deferred_for_minibatch)
   int trace = 0;
   bool print_flight = false;
@@ -94,6 +94,7 @@ struct Tuning {
     t.fwd_mux = num("EESEN_FWD_MUX", 1);
     t.bwd_mux = num("EESEN_BWD_MUX", 1);
     t.fwd_split = num("EESEN_FWD_SPLIT", 1);
+    t.fwd_f16 = num("EESEN_FWD_F16", 1);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.comm_defer = num("EESEN_COMM_DEFER", -1);
     t.trace = num("EESEN_TRACE", 0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Microbenchmark of the GEMM on the shapes of the hot path (cfg2), in both arithmetic modes (f32-input MFMA, 3-way bf16
-split).  Prints fp32-equivalent TFLOP/s (2 M N K / time) per shape."""
+"""Microbenchmark of the GEMM on the shapes of the hot path (cfg2), in the three arithmetic modes (f32-input MFMA, 3-way bf16
+split, two fp16 planes).  Prints fp32-equivalent TFLOP/s (2 M N K / time) per shape."""
 import ctypes as C
 import os
 import sys
@@ -35,7 +35,7 @@ def main():
         A = CuMatrix.from_numpy(rng.uniform(-1, 1, (ar, ac)).astype(np.float32))
         B = CuMatrix.from_numpy(rng.uniform(-1, 1, (br, bc)).astype(np.float32))
         Cm = CuMatrix(M, N)
-        for mode, mname in ((0, "f32-mfma"), (1, "bf16-split")):
+        for mode, mname in ((0, "f32-mfma"), (1, "bf16-split"), (2, "f16-planes")):
             lib.eesen_set_gemm_mode(mode)
             ms = C.c_float()
             _lib.check(lib.eesen_op_gemm_bench(0, akc, bkc, M, N, K, C.c_void_p(A.ptr), A.stride, C.c_void_p(B.ptr), B.stride,

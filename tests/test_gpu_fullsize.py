@@ -161,8 +161,10 @@ def test_cfg5_full_length_layer_persistent_equals_per_step_kernels(gpu, monkeypa
         assert info["fwd_persistent"] == info["bwd_persistent"] == (1 if mode == "1" else 0), info
         res[mode] = (out.numpy(), ctc.pzx.copy(), idf.numpy(), net.GetGrads())
         del net, ctc, out, diff, idf
-    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
-    assert rel_err(res["1"][2], res["0"][2]) < 1e-5
-    assert rel_err(res["1"][3], res["0"][3]) < 1e-5
+    # (round 6: the wide forward tile runs on two fp16 planes per operand -- fp32-class, another summation order: 2e-6 like the narrow
+    # tile's; EESEN_FWD_SPLIT=0 keeps the fp32-input kernel, which is bit-identical to the per-step one)
+    assert rel_err(res["1"][0], res["0"][0]) < 2e-6 and rel_err(res["1"][1], res["0"][1]) < 1e-6
+    assert rel_err(res["1"][2], res["0"][2]) < 1e-4
+    assert rel_err(res["1"][3], res["0"][3]) < 1e-4
     vm = valid_mask(batch.lens, batch.T, batch.S)
     assert np.all(np.isfinite(res["1"][3])) and np.all(res["1"][2][~vm] == 0)

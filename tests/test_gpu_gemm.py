@@ -1,9 +1,11 @@
-"""-m gpu: the two arithmetic modes of the dense GEMM (include/eesen_hip.h `eesen_set_gemm_mode`) against an fp64 product.
+"""-m gpu: the three arithmetic modes of the dense GEMM (include/eesen_hip.h `eesen_set_gemm_mode`) against an fp64 product.
 
 Mode 0 (f32-input MFMA) is an exact fp32 fmaf chain.  Mode 1 splits every fp32 operand into three bf16 terms and runs
 six bf16 MFMA products with fp32 accumulation; its error bound is 2^-23 |a*b| per product, the class of ONE fp32 rounding.
-The test measures both against fp64, normalised by sum_k |a||b| (the quantity round-off scales with), over every operand
-layout, ragged shapes, split-K shapes and the bias / alpha / beta epilogue, and requires the split mode to be as accurate
+Mode 2 (round 6) holds every operand as two fp16 planes (round to nearest at both levels: 2^-24 relative), scaled by a power
+of two so that its largest magnitude sits in fp16's top binades, and runs three fp16 MFMA products: ~3 * 2^-24 |a*b| per product.
+The test measures all three against fp64, normalised by sum_k |a||b| (the quantity round-off scales with), over every operand
+layout, ragged shapes, split-K shapes and the bias / alpha / beta epilogue, and requires the plane modes to be as accurate
 as the fp32 chain."""
 import ctypes as C
 import json
@@ -57,16 +59,49 @@ def test_split_mode_is_as_accurate_as_the_fp32_chain(gpu, report, a_kc, b_kc, M,
     bias = rng.standard_normal(N).astype(np.float32)
     alpha, beta = 0.75, 0.5
     try:
-        got = {m: _run(gpu, m, a_kc, b_kc, A, B, C0, bias, alpha, beta) for m in (0, 1)}
+        got = {m: _run(gpu, m, a_kc, b_kc, A, B, C0, bias, alpha, beta) for m in (0, 1, 2)}
     finally:
         gpu.eesen_set_gemm_mode(-1)
     A64, B64 = A.astype(np.float64), B.astype(np.float64)
     want = alpha * (A64 @ B64) + beta * C0 + bias[None, :]
     scale = alpha * (np.abs(A64) @ np.abs(B64)) + np.abs(beta * C0) + np.abs(bias)[None, :]
-    err = {m: float(np.max(np.abs(got[m] - want) / scale)) for m in (0, 1)}
-    report(dict(a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, err_f32_mfma=err[0], err_bf16_split=err[1]))
+    err = {m: float(np.max(np.abs(got[m] - want) / scale)) for m in (0, 1, 2)}
+    report(dict(a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, err_f32_mfma=err[0], err_bf16_split=err[1], err_f16_planes=err[2]))
     assert err[0] < 4e-6                      # fp32 chain vs fp64, normalised by sum |a||b|: round-off class (grows slowly with K)
     assert err[1] < max(1.5 * err[0], 2.4e-7), f"split {err[1]:.3g} vs fp32 chain {err[0]:.3g}"
+    assert err[2] < max(4.0 * err[0], 4e-7), f"fp16 planes {err[2]:.3g} vs fp32 chain {err[0]:.3g}"
+
+
+def test_fp16_planes_keep_what_fp16_range_would_lose(gpu):
+    """Mode 2's operands are fp16 planes of the operand times a power of two.  What has to hold for "fp32-class": (i) an element 2^-32
+    of its tensor's largest lands in fp16's DENORMAL range (2^-18 after the scale): the MFMA must multiply it exactly, not flush it;
+    (ii) operands whose magnitudes are far outside fp16's range altogether (1e-30, 1e30) come back scaled exactly; (iii) an all-zero
+    operand gives zeros (its scale saturates), and a tensor whose largest element is huge does not overflow an fp16 plane."""
+    K = 64
+    A = np.zeros((128, K), np.float32); B = np.zeros((K, 128), np.float32)
+    A[:, 0] = 1.0                      # the tensor's largest: sets the scale (1 -> 2^14)
+    A[:, 1] = 2.0 ** -32               # 2^-18 after the scale: an fp16 denormal (64 units of 2^-24)
+    A[:, 2] = 1.0 + 2.0 ** -20         # needs the lo plane (hi = 1, lo = 2^-20 -> 2^-6 after the scale)
+    A[:, 3] = 3.0 * 2.0 ** -36         # 3 * 2^-22 after the scale: the denormal range's last bits
+    B[1, 0] = 1.0; B[2, 1] = 1.0; B[3, 2] = 1.0; B[0, 3] = 0.5
+    C0 = np.zeros((128, 128), np.float32); bias = np.zeros(128, np.float32)
+    try:
+        got = _run(gpu, 2, 1, 0, A, B, C0, bias, 1.0, 0.0)
+        assert np.all(got[:, 0] == np.float32(2.0 ** -32)), got[0, :4]      # (i)
+        assert np.all(got[:, 1] == np.float32(1.0 + 2.0 ** -20))
+        assert np.all(got[:, 2] == np.float32(3.0 * 2.0 ** -36))
+        assert np.all(got[:, 3] == 0.5)
+        rng = np.random.default_rng(5)
+        for sa, sb in ((1e-30, 1e30), (1e30, 1e-30), (1e-34, 1.0), (1.0, 1e37 / K)):   # (ii)
+            A2 = (rng.standard_normal((128, K)) * sa).astype(np.float32); B2 = (rng.standard_normal((K, 128)) * sb).astype(np.float32)
+            want = A2.astype(np.float64) @ B2.astype(np.float64)
+            got = _run(gpu, 2, 1, 0, A2, B2, C0, bias, 1.0, 0.0)
+            den = np.abs(A2).astype(np.float64) @ np.abs(B2).astype(np.float64)
+            assert np.all(np.isfinite(got)) and float(np.max(np.abs(got - want) / den)) < 4e-7, (sa, sb)
+        got = _run(gpu, 2, 1, 0, np.zeros_like(A), B, C0, bias, 1.0, 0.0)               # (iii)
+        assert np.all(got == 0.0)
+    finally:
+        gpu.eesen_set_gemm_mode(-1)
 
 
 def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
@@ -83,7 +118,7 @@ def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
     o = onet.train_step(ora, batch, "f32")
     grads = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             gpu.eesen_set_gemm_mode(mode)
             net = Net.from_layers(layers); net.SetTrainOptions(1.0, 0.0); ctc = Ctc()
             net.SetSeqLengths(batch.lens)
@@ -96,6 +131,7 @@ def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
     finally:
         gpu.eesen_set_gemm_mode(-1)
     assert rel_err(grads[1], grads[0]) < 2e-5
+    assert rel_err(grads[2], grads[0]) < 2e-5
 
 
 def test_bf16_forward_variant(gpu):

@@ -37,7 +37,8 @@ def table():
 BUDGETS = {
     # cfg2 (4 x 512, S = 32): backward 4 x 32 tile, forward narrow bf16-pipe tile, the side-stream / early-middle GEMM flavour
     "lstm_bwd_persistent_q4_kernel<8,4>": (168, 74 * 1024),
-    "lstm_fwd_persistent_bf_kernel<2,2,3,3>": (112, 19 * 1024),
+    "lstm_fwd_persistent_bf_kernel<2,2,3,3,false>": (112, 19 * 1024),
+    "lstm_fwd_persistent_bf_kernel<2,2,2,2,true>": (88, 19 * 1024),     # round 6: two fp16 planes, three products (the default narrow tile)
     # cfg2 at S = 64: two 4-sequence tiles per workgroup; recipe width 320: <6,4>; H = 256: <4,4> (the one tile RCCL fits beside)
     "lstm_bwd_persistent_q4_kernel<8,8>": (192, 81 * 1024),
     "lstm_bwd_persistent_q4_kernel<6,4>": (160, 9 * 1024),
@@ -47,7 +48,8 @@ BUDGETS = {
     "lstm_bwd_persistent_ksplit_kernel<4>": (232, 34 * 1024),
     "lstm_bwd_persistent_ksplit_mux_kernel<4>": (248, 35 * 1024),
     "lstm_fwd_persistent_kernel<4,1,4,false,true>": (208, 35 * 1024),
-    "lstm_fwd_persistent_bf_kernel<4,4,1,2>": (192, 35 * 1024),
+    "lstm_fwd_persistent_bf_kernel<4,4,1,2,false>": (192, 35 * 1024),
+    "lstm_fwd_persistent_bf_kernel<4,4,2,2,true>": (216, 35 * 1024),    # round 6: the wide tile on two fp16 planes (fp32-class; replaces the fp32-input tile)
     "lstm_fwd_persistent_mux_kernel<4,4,true>": (224, 35 * 1024),
 }
 
@@ -85,8 +87,8 @@ def test_side_stream_gemm_fits_beside_the_cfg2_backward_tile(table):
     """net.cpp's overlap rule: the weight-gradient GEMMs (gemm_f32_split_bf16_kernel, 256 threads = one wave per SIMD) run on the
     side stream UNDER the next-lower layer's backward recurrence (q4<8,4>, two waves per SIMD, one workgroup on every CU)."""
     q4 = table["lstm_bwd_persistent_q4_kernel<8,4>"]
-    side = [r for n, r in table.items() if n.startswith("gemm_f32_split_bf16_kernel<")]
-    assert len(side) == 8
+    side = [r for n, r in table.items() if n.startswith(("gemm_f32_split_bf16_kernel<", "gemm_f32_split_f16_kernel<"))]
+    assert len(side) == 16
     for g in side:
         assert g["max_threads"] == 256 and g["vgprs"] <= 168
         assert 2 * alloc(q4["vgprs"]) + alloc(g["vgprs"]) <= SIMD_VGPRS, (q4["vgprs"], g["vgprs"])
@@ -96,10 +98,11 @@ def test_side_stream_gemm_fits_beside_the_cfg2_backward_tile(table):
 
 
 def test_two_narrow_forward_workgroups_per_cu_and_the_early_gemm_beside_one(table):
-    bf = table["lstm_fwd_persistent_bf_kernel<2,2,3,3>"]
-    assert 4 * alloc(bf["vgprs"]) <= SIMD_VGPRS and 2 * bf["lds"] <= CU_LDS          # --num-sequence 64 at 512 cells: two per CU
-    g = max(r["vgprs"] for n, r in table.items() if n.startswith("gemm_f32_split_bf16_kernel<"))
-    assert 2 * alloc(bf["vgprs"]) + alloc(g) <= SIMD_VGPRS                              # "the middle first": one GEMM workgroup beside ONE tile
+    for name in ("lstm_fwd_persistent_bf_kernel<2,2,3,3,false>", "lstm_fwd_persistent_bf_kernel<2,2,2,2,true>"):
+        bf = table[name]
+        assert 4 * alloc(bf["vgprs"]) <= SIMD_VGPRS and 2 * bf["lds"] <= CU_LDS          # --num-sequence 64 at 512 cells: two per CU
+        g = max(r["vgprs"] for n, r in table.items() if n.startswith(("gemm_f32_split_bf16_kernel<", "gemm_f32_split_f16_kernel<")))
+        assert 2 * alloc(bf["vgprs"]) + alloc(g) <= SIMD_VGPRS                              # "the middle first": one GEMM workgroup beside ONE tile
 
 
 def test_exchange_schedule_table(table):
