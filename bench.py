@@ -59,6 +59,16 @@ def flops_per_frame(cfg) -> float:
     return total
 
 
+def gemm_products() -> int:
+    """Matrix-pipe products per fp32 product of the dense GEMMs in the library's current arithmetic mode (gemm.hip): 0 = the
+    f32-input MFMA (EESEN_GEMM_MODE=f32), 6 = three bf16 planes per operand (split), 3 = two fp16 planes per operand (half: the
+    default since round 6)."""
+    import ctypes as C
+    m = C.c_int(-1)
+    _lib.check(_lib.load().eesen_get_gemm_mode(C.byref(m)))
+    return {0: 0, 1: 6, 2: 3}[m.value]
+
+
 def fwd_rec_products(cfg, S: int, forward_mode: int = 0) -> int:
     """How the FORWARD recurrent product of this configuration is executed (lstm_persistent.hip: bf_plan): 0 = on the fp32-input
     MFMA; n > 0 = on the bf16 pipe as n bf16 products per fp32 product -- 6 for the fp32-class 3-way split the narrow tile takes
@@ -69,32 +79,38 @@ def fwd_rec_products(cfg, S: int, forward_mode: int = 0) -> int:
     H = cfg["H"]
     if forward_mode == 1 and H % 256 == 0 and H <= 1024:
         return 2
+    if os.environ.get("EESEN_FWD_SPLIT", "1") == "0":
+        return 0
+    f16 = os.environ.get("EESEN_FWD_F16", "1") != "0"   # round 6: two fp16 planes per operand, three products -- narrow AND wide tiles
     narrow = H % 8 == 0 and S > 16 and (H // 32 + 7) // 8 <= 2
-    if narrow and os.environ.get("EESEN_FWD_SPLIT", "1") != "0":
-        return 6
+    if narrow:
+        return 3 if f16 else 6
+    if f16 and H % 256 == 0 and H <= 1024:
+        return 3
     return 0
 
 
-def pipe_bound(cfg, split_gemm: bool = True, fwd_products: int = 0) -> dict:
+def pipe_bound(cfg, gemm_prod: int = 3, fwd_products: int = 0) -> dict:
     """The step's flops by matrix pipe and the time the two pipes need for them at their peaks.  Per layer and direction the
     recurrence kernels execute the forward and the backward recurrent product (8 H^2 per frame each).  The backward one runs on
     the fp32 pipe (v_mfma_f32_16x16x4_f32 / 4x4x1); the forward one too, unless `fwd_products` says it runs on the bf16 pipe as that
-    many bf16 products per fp32 product (fwd_rec_products).  Everything else is GEMM: on the bf16 pipe as six bf16 products per
-    fp32 product (the exact 3-way split), or on the fp32 pipe in EESEN_GEMM_MODE=f32.  frac = bound / measured time is <= 1 by
-    construction."""
+    many 16-bit products per fp32 product (fwd_rec_products).  Everything else is GEMM: on the 16-bit pipe as `gemm_prod` products per
+    fp32 product (3: two fp16 planes per operand, the default; 6: three bf16 planes), or on the fp32 pipe (0: EESEN_GEMM_MODE=f32).
+    The bf16 and fp16 MFMA forms have the same dense peak.  frac = bound / measured time is <= 1 by construction."""
     nd = 2 if cfg["kind"].startswith("BiLstm") else 1
     rec = float(cfg["layers"]) * nd * 16.0 * cfg["H"] * cfg["H"]
     gemm = flops_per_frame(cfg) - rec
     rec_f32 = rec if not fwd_products else rec / 2
     rec_bf16 = 0.0 if not fwd_products else fwd_products * rec / 2
+    split_gemm = gemm_prod > 0
     if split_gemm:
-        bf16 = 6.0 * gemm + rec_bf16
+        bf16 = float(gemm_prod) * gemm + rec_bf16
         sec = rec_f32 / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
     else:
         bf16 = rec_bf16
         sec = (rec_f32 + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
     return {"f32_pipe_flops_per_frame": rec_f32 + (0.0 if split_gemm else gemm), "gemm_flops_per_frame_fp32_equivalent": gemm,
-            "bf16_pipe_executed_flops_per_frame": bf16, "forward_recurrence_bf16_products": fwd_products, "bound_us_per_frame": 1e6 * sec}
+            "bf16_pipe_executed_flops_per_frame": bf16, "gemm_products": gemm_prod, "forward_recurrence_bf16_products": fwd_products, "bound_us_per_frame": 1e6 * sec}
 
 
 def ctc_block(cfg, batch, ctc_ph: dict, K: int) -> dict:
@@ -346,7 +362,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
             "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
             "bf16_recurrence_layers": net.Bf16RecurrenceLayers(),
             "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
-            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, True, fwd_rec_products(cfg, batch.S, int(forward_bf16)))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
+            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, gemm_products(), fwd_rec_products(cfg, batch.S, int(forward_bf16)))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
 
@@ -697,24 +713,31 @@ def main():
     # chain) instead of the default 3-way bf16 split (fp32-class accuracy on the bf16 matrix pipe, tests/test_gpu_gemm.py) -- so
     # that both arithmetic modes are on record from the same box and process.
     f32_only = None
-    if world == 1 and not args.main_only and os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"):
+    bf16_split = None
+    if world == 1 and not args.main_only and gemm_products() == 3:
         lib = _lib.load()
-        _lib.check(lib.eesen_set_gemm_mode(0))
-        try:
-            main_net, net = net, make_net()          # schedule defaults (gating, side-stream occupancy) follow the mode
-            for _ in range(2):
-                step()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            barrier()
-            dt2 = time.perf_counter() - t2
-            f32_only = {"ms_per_step": 1e3 * dt2 / args.steps, "frames_per_s": float(batch.T * batch.S) * args.steps / dt2,
-                        "gemm": "v_mfma_f32_32x32x2_f32 (EESEN_GEMM_MODE=f32)"}
-            net = main_net
-        finally:
-            _lib.check(lib.eesen_set_gemm_mode(-1))
+        main_net = net
+        for mode, label in ((0, "v_mfma_f32_32x32x2_f32 (EESEN_GEMM_MODE=f32)"),
+                            (1, "three bf16 planes per operand, six products on v_mfma_f32_32x32x16_bf16 (EESEN_GEMM_MODE=split: the default of rounds 2-5)")):
+            _lib.check(lib.eesen_set_gemm_mode(mode))
+            try:
+                net = make_net()          # schedule defaults (gating, side-stream occupancy) follow the mode
+                for _ in range(2):
+                    step()
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                barrier()
+                dt2 = time.perf_counter() - t2
+                rec = {"ms_per_step": 1e3 * dt2 / args.steps, "frames_per_s": float(batch.T * batch.S) * args.steps / dt2, "gemm": label}
+                if mode == 0:
+                    f32_only = rec
+                else:
+                    bf16_split = rec
+            finally:
+                net = main_net
+                _lib.check(lib.eesen_set_gemm_mode(-1))
 
     # Not the headline: the same K steps with the features already RESIDENT in HBM (what rounds 1-4 reported as `value`): what the
     # per-step H2D costs the step is the difference (the copy and the interleave of minibatch n + 1 run on the feeder's stream under
@@ -738,7 +761,8 @@ def main():
         fpf = flops_per_frame(cfg)
         fwd_mode = {"f32": 0, "bf16": 1, "bf16-gemm": 2}[args.forward_precision]
         fprod = fwd_rec_products(cfg, batch.S, fwd_mode)
-        pb = pipe_bound(cfg, os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1"), fprod)
+        gprod = gemm_products()
+        pb = pipe_bound(cfg, gprod, fprod)
         nd = 2 if cfg["kind"].startswith("BiLstm") else 1
         H, S, T, nl = cfg["H"], batch.S, batch.T, cfg["layers"]
         # per-launch algorithmic work of the three kernels that carry the step (DESIGN.md "kernels")
@@ -753,7 +777,8 @@ def main():
         # tile would be chosen (16-sequence tiles leave half the CUs idle), H a multiple of 128 up to 512, whole 4-sequence tiles
         q4 = (persistent and H % 128 == 0 and H <= 512 and S % 4 == 0 and S > 8 and 2 * ((H + 15) // 16) * nd * ((S + 15) // 16) <= 256
               and os.environ.get("EESEN_BWD_Q4", "1") != "0")
-        split = os.environ.get("EESEN_GEMM_MODE") in (None, "", "split", "1")
+        split = gprod > 0
+        gk = "gemm_f32_split_f16" if gprod == 3 else "gemm_f32_split_bf16"
         bf16_fwd = args.forward_precision != "f32"
         # the main-stream input->gates GEMMs take the 256 x 256-tile flavour when the shape holds >= 16 whole big tiles (gemm.hip)
         # (layer 1's K = 40 is not a multiple of 16 and takes the 128 x 128 flavour; the name is that of the layers that dominate)
@@ -763,12 +788,13 @@ def main():
         # figure below is their summed time per layer (the middle part's duration is that of a kernel sharing the chip)
         mid_first = persistent and nd == 2 and nl > 1 and H <= 512 and os.environ.get("EESEN_FWD_MID", "1") != "0" and os.environ.get("EESEN_OVERLAP", "1") != "0"
         gemm_name = ("gemm_f32_mfma_kernel" if not split and not bf16_fwd else
-                     ("gemm_f32_split_bf16_big_kernel" if big else "gemm_f32_split_bf16_kernel")) + \
-                    ("(input->gates: 2 ends + gemm_f32_split_bf16_kernel middle under the recurrence)" if mid_first and split and not bf16_fwd else "(input->gates)")
+                     ((gk + "_big_kernel") if big else ("gemm_f32_split_bf16_kernel" if bf16_fwd else gk + "_kernel"))) + \
+                    (f"(input->gates: 2 ends + {gk}_kernel middle under the recurrence)" if mid_first and split and not bf16_fwd else "(input->gates)")
         bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn
         # the forward recurrence on the bf16 pipe (lstm_fwd_persistent_bf_kernel): the fp32-class 3-way split of the narrow tile (six
         # products), or config 4's bf16 forward (m_t one plane, W_m hi + lo: two products)
-        fwd_name = "lstm_fwd_" + kn if not fprod else f"lstm_fwd_persistent_bf_kernel<AP={3 if fprod == 6 else 1}, WP={3 if fprod == 6 else fprod}>"
+        fwd_name = "lstm_fwd_" + kn if not fprod else {6: "lstm_fwd_persistent_bf_kernel<AP=3, WP=3> (bf16 planes)", 3: "lstm_fwd_persistent_bf_kernel<AP=2, WP=2, F16> (fp16 planes)",
+                                                        2: "lstm_fwd_persistent_bf_kernel<AP=1, WP=2> (bf16 forward)"}[fprod]
         kern = {
             fwd_name: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32" if not fprod else "bf16", products=fprod or 1),
             bwd_name: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
@@ -778,7 +804,7 @@ def main():
             k["avg_us"] = 1e6 * k["total_s"] / k["launches"]
             k["achieved"] = k["flops"] / (k["total_s"] / k["launches"]) / 1e12      # fp32-equivalent (algorithmic) TFLOP/s
             # what the matrix pipe EXECUTES: the split GEMM runs six bf16 products per fp32 product (one with bf16-rounded forward operands)
-            k["executed"] = k["achieved"] * (1 if k["pipe"] == "f32" else k.get("products", 1 if bf16_fwd else 6))
+            k["executed"] = k["achieved"] * (1 if k["pipe"] == "f32" else k.get("products", 1 if bf16_fwd else gprod))
             k["peak"] = PEAK_F32_MFMA_TFLOPS if k["pipe"] == "f32" else PEAK_BF16_MFMA_TFLOPS
             k["frac"] = k["executed"] / k["peak"]                                     # never above 1: executed flops over that pipe's peak
         dom = max(kern, key=lambda n: kern[n]["total_s"])
@@ -826,7 +852,7 @@ def main():
                              "the kernel's SIMD-cycles from the committed PMC pass; whole_step is the step's total FLOPs over its time"),
                     "whole_step": {"achieved": fpf * value / world / 1e12, "unit": "TFLOP/s fp32-equivalent", "flops_per_frame": fpf,
                                    **pb, "frac": pb["bound_us_per_frame"] * 1e-6 * value / world,
-                                   "note": "frac = (recurrence flops / fp32-MFMA peak + 6 x GEMM flops / bf16-MFMA peak) / measured time: the step against BOTH matrix pipes at their peaks, <= 1 by construction (the GEMMs run as six bf16 products per fp32 product); see config.f32_mfma_gemm_only for the all-f32 step"},
+                                   "note": "frac = (fp32-pipe recurrence flops / fp32-MFMA peak + products x (GEMM + 16-bit-pipe recurrence) flops / 16-bit MFMA peak) / measured time: the step against BOTH matrix pipes at their peaks, <= 1 by construction (gemm_products per fp32 product: 3 = two fp16 planes, 6 = three bf16 planes); see config.f32_mfma_gemm_only / config.bf16_split_gemm for the same step in the other arithmetic modes"},
                     "other_kernels": {n: ({"achieved_fp32_equivalent": v["achieved"], "executed": v["executed"], "pipe": v["pipe"], "peak": v["peak"],
                                            "frac": v["frac"], "avg_launch_us": v["avg_us"]})
                                       for n, v in kern.items() if n != dom}}
@@ -844,7 +870,7 @@ def main():
             C_ = CuMatrix(Mg, Ng, dev, zero=False)
             lib = _lib.load()
             gg = {}
-            for mode, name in ((0, "f32_mfma"), (1, "bf16_split")):
+            for mode, name in ((0, "f32_mfma"), (1, "bf16_split"), (2, "f16_planes")):
                 _lib.check(lib.eesen_set_gemm_mode(mode))
                 ms = C.c_float()
                 _lib.check(lib.eesen_op_gemm_bench(dev, 1, 1, Mg, Ng, Kg, C.c_void_p(A_.ptr), A_.stride, C.c_void_p(B_.ptr), B_.stride,
@@ -853,10 +879,14 @@ def main():
                 if mode == 0:
                     gg[name] = {"kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS,
                                 "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * ms.value}
-                else:   # six bf16 MFMA products per fp32 product: the matrix pipe executes 6x the useful flops
+                elif mode == 1:   # six bf16 MFMA products per fp32 product: the matrix pipe executes 6x the useful flops
                     gg[name] = {"kernel": "gemm_f32_split_bf16_kernel (6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block)",
                                 "achieved_fp32_equivalent": tf, "executed_bf16": 6 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": 6 * tf / PEAK_BF16_MFMA_TFLOPS, "vs_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * ms.value}
+                else:             # two fp16 planes per operand, three products (the default): 3x the useful flops
+                    gg[name] = {"kernel": "gemm_f32_split_f16_kernel (3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block; operand bounds measured outside the timed launches)",
+                                "achieved_fp32_equivalent": tf, "executed_f16": 3 * tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": 3 * tf / PEAK_BF16_MFMA_TFLOPS, "vs_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": 1e3 * ms.value}
             _lib.check(lib.eesen_set_gemm_mode(-1))
             roofline["gate_gemm_standalone"] = dict(shape=[Mg, Ng, Kg], **gg)
             del A_, B_, C_
@@ -894,11 +924,16 @@ def main():
                        "h2d": "inside the timed step: S host matrices -> pinned slot -> one PCIe copy -> time-major interleave on the device (feeder), double-buffered",
                        "device_resident_frames_per_s": resident["frames_per_s"] if resident else None,
                        "device_resident_ms_per_step": resident["ms_per_step"] if resident else None,
-                       "gemm_arithmetic": ("f32-input MFMA (exact fp32 fmaf chain)" if os.environ.get("EESEN_GEMM_MODE") in ("f32", "0") else
-                                           "fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross products on v_mfma_f32_32x32x16_bf16 with fp32 "
-                                           "accumulation (error <= 2^-23 |ab| per product = one fp32 rounding; measured against fp64 equal to the fp32 chain, "
-                                           "tests/test_gpu_gemm.py); recurrence, CTC and update in plain fp32"),
-                       "f32_mfma_gemm_only": f32_only},
+                       "gemm_arithmetic": {0: "f32-input MFMA (exact fp32 fmaf chain)",
+                                           6: "fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross products on v_mfma_f32_32x32x16_bf16 with fp32 "
+                                              "accumulation (error <= 2^-23 |ab| per product = one fp32 rounding; measured against fp64 equal to the fp32 chain, "
+                                              "tests/test_gpu_gemm.py); recurrence, CTC and update in plain fp32",
+                                           3: "fp32 operands held as TWO fp16 planes (round to nearest at both levels: hi + lo = the value to within 2^-24), each row of "
+                                              "op(A) / column of op(B) times the power of two its own largest magnitude asks for (measured on the device), 3 of the 4 "
+                                              "cross products on v_mfma_f32_32x32x16_f16 with fp32 accumulation (error ~ 3 * 2^-24 |ab| per product; measured against "
+                                              "fp64 equal to the fp32 chain on every shape of tests/test_gpu_gemm.py); the forward recurrence on the same planes; "
+                                              "backward recurrence, CTC and update in plain fp32"}[gprod],
+                       "f32_mfma_gemm_only": f32_only, "bf16_split_gemm": bf16_split},
             "phase_ms_per_step": {k: 1e3 * v / K for k, v in {**phases, **{'ctc_' + a: b for a, b in ctc_ph.items()}}.items()},
             "roofline": roofline,
         }

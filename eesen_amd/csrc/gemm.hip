@@ -47,8 +47,11 @@ struct GemmParams {
   int gm;       // > 0: XCD-aware tile map with row groups of gm tiles (see tile_of); 0: row-major
   int bm, bn;   // output tile of the kernel flavour being launched (128 x 128, or 256 x 256 for the big split kernel)
   int nprod;    // split kernel: 6 = fp32-class (hi/mid/lo cross products), 1 = bf16 x bf16 only (operands rounded to bf16)
-  const float* amax_a;   // two-plane fp16 kernel: device words holding an upper bound of max |A| / max |B| (the operand scales)
+  // two-plane fp16 kernel: device words holding upper bounds of the operands' magnitudes (they set the power-of-two scales):
+  // a_vec = 1: one word per M index (row of op(A)), else one word for the whole operand; b_vec: the same per N index
+  const float* amax_a;
   const float* amax_b;
+  int a_vec, b_vec;
   GemmGate gate;  // gate.cnt == nullptr: ordinary GEMM
 };
 
@@ -145,10 +148,11 @@ __device__ __forceinline__ void store_tile(float (*T)[BM + LDP], int tid, const 
 
 // C/D map of the 32x32 MFMA (all input types): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // row_w / col_w: offset of this wave's BMW x BNW blocks inside the workgroup's tile.
-// SCALED (two-plane fp16 kernel): the accumulators hold 2^(sa + sb) times the products; ua = 2^-sa, ub = 2^-sb (exact).
+// SCALED (two-plane fp16 kernel): accumulator (row, col) holds 2^(sa[row] + sb[col]) times the products; inv[r] = 2^-sa of the tile's
+// row r, inv[TM + c] = 2^-sb of its column c (exact powers of two, in LDS).
 template <int BMW, int BNW, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 (&acc)[BMW][BNW], int m0, int n0, int split, int row_w,
-                                              int col_w, int lr, int lk, float ua = 1.f, float ub = 1.f) {
+                                              int col_w, int lr, int lk, const float* inv = nullptr, int tm = 0) {
   float* C = p.C;
   size_t ldc = p.ldc;
   const bool partial = p.splits > 1;
@@ -163,12 +167,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x16 
       const int col = n0 + col_w + ni * 32 + lr;
       if (col >= p.N) continue;
       const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+      const float ub = SCALED ? inv[tm + col_w + ni * 32 + lr] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + row_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int rl = row_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + rl;
         if (row >= p.M) continue;
         float* dst = C + (size_t)row * ldc + col;
-        const float a = SCALED ? acc[mi][ni][r] * ua * ub : acc[mi][ni][r];
+        const float a = SCALED ? acc[mi][ni][r] * inv[rl] * ub : acc[mi][ni][r];
         if (partial) {
           *dst = a;
         } else {
@@ -366,8 +372,8 @@ using GeoBigH = SplitGeo<256, 256, 2, 4, 2>;
 
 // The power of two that brings an operand whose largest magnitude is *amax into [2^14, 2^15), and its inverse (both exact; an
 // all-zero operand gets 2^126 and 2^-126).  Uniform: scalar loads.
-__device__ __forceinline__ void half_scale(const float* amax, float& scale, float& inv) {
-  const int e = (int)((__builtin_bit_cast(unsigned, *amax) >> 23) & 0xffu);   // biased exponent of the bound
+__device__ __forceinline__ void half_scale(float amax, float& scale, float& inv) {
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);   // biased exponent of the bound
   const int s = min(max(127 + 14 + 127 - e, 1), 253);   // (253: the inverse stays a normal number)
   scale = __builtin_bit_cast(float, (unsigned)s << 23);
   inv = __builtin_bit_cast(float, (unsigned)(254 - s) << 23);
@@ -482,11 +488,11 @@ __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char*
   if (PL == 3) *reinterpret_cast<uint2*>(dst + 2 * PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
 }
 template <int PL, bool KC, bool GUARD, int THREADS, int ROWS>
-__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend, float scale) {
+__device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend, const float (&scale)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     SplitUnit u;
-    split_stage_a<PL, KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend, scale);
+    split_stage_a<PL, KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend, scale[i]);
     split_stage_b<PL>(u);
     split_stage_c<PL, KC, THREADS, ROWS>(u, base, i, tid);
   }
@@ -554,8 +560,20 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     split_load<A_KC, TH, TM>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
     split_load<B_KC, TH, TN>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
   };
-  float sa = 1.f, sb = 1.f, ua = 1.f, ub = 1.f;   // two fp16 planes: the operands' power-of-two scales and their inverses
-  if constexpr (PL == 2) { half_scale(p.amax_a, sa, ua); half_scale(p.amax_b, sb, ub); }
+  // two fp16 planes: the power-of-two scales of the rows this thread brings in (its two units per operand and k-tile sit in fixed
+  // rows), from the operands' bounds -- one word per row of op(A) / column of op(B), or one for the whole operand
+  float sa[2] = {1.f, 1.f}, sb[2] = {1.f, 1.f};
+  if constexpr (PL == 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int row, q;
+      float inv;
+      unit_of<A_KC, TH, TM>(tid, i, row, q);
+      half_scale(p.amax_a[p.a_vec ? min(m0 + row, p.M - 1) : 0], sa[i], inv);
+      unit_of<B_KC, TH, TN>(tid, i, row, q);
+      half_scale(p.amax_b[p.b_vec ? min(n0 + row, p.N - 1) : 0], sb[i], inv);
+    }
+  }
   auto store = [&](int t, const float4 (&ra)[2], const float4 (&rb)[2]) {
     const int st = (t & 1) * G::STAGE;
     split_store<PL, A_KC, GUARD, TH, TM>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend, sa);
@@ -638,8 +656,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u);
       __builtin_amdgcn_sched_barrier(0);
-      if (u < 2) split_stage_a<PL, A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend, sa);
-      else split_stage_a<PL, B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend, sb);
+      if (u < 2) split_stage_a<PL, A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend, sa[u]);
+      else split_stage_a<PL, B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend, sb[u - 2]);
       EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u + 1);
@@ -687,7 +705,18 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
     step(kt, ra0, rb0, kt + 1 < nk, kt + 3 < nk);
     if (kt + 1 < nk) step(kt + 1, ra1, rb1, kt + 2 < nk, kt + 4 < nk);
   }
-  gemm_epilogue<BMW, BNW, PL == 2>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk, ua, ub);
+  if constexpr (PL == 2) {   // the inverse scales of the tile's rows and columns, through LDS (the k loop's last barrier has passed)
+    static_assert(TH == TM + TN, "one thread per tile row / column");
+    float* inv = reinterpret_cast<float*>(lds);
+    float sc, iv;
+    if (tid < TM) half_scale(p.amax_a[p.a_vec ? min(m0 + tid, p.M - 1) : 0], sc, iv);
+    else half_scale(p.amax_b[p.b_vec ? min(n0 + tid - TM, p.N - 1) : 0], sc, iv);
+    inv[tid] = iv;
+    __syncthreads();
+    gemm_epilogue<BMW, BNW, true>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk, inv, TM);
+  } else {
+    gemm_epilogue<BMW, BNW>(p, acc, m0, n0, split, wm * (TM / G::WGM), wn * (TN / G::WGN), lr, lk);
+  }
 }
 
 template <bool A_KC, bool B_KC, bool GUARD>
@@ -716,30 +745,64 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_split_f16_big_kernel(GemmPara
   gemm_split_body<GeoBigH, A_KC, B_KC, false, false>(p);
 }
 
-// max |x| over a [rows x cols] matrix (row stride ld) into *out, which the caller has zeroed: non-negative floats order like their
-// bit patterns, so one unsigned atomic max per wave does it.  NaN / Inf bit patterns win, and the GEMM then produces what an fp32
-// GEMM would: NaN / Inf.
-__global__ __launch_bounds__(256) void amax_abs_kernel(const float* __restrict__ P, long rows, int cols, int ld, unsigned* __restrict__ out) {
-  unsigned m = 0;
-  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cols == ld) {   // one flat array
-    const long n4 = rows * cols / 4;
-    for (long i = t0; i < n4; i += stride) {
-      const uint4 v = reinterpret_cast<const uint4*>(P)[i];
-      m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+// Operand bounds of the two-plane kernels.  One pass over a [R x C] matrix (row stride ld): ROWS: out_rows[r] = max_c |P[r][c]|
+// (one wave per row, plain stores); COLS: part_cols[block][c] = max over the block's rows of |P[r][c]| (LDS atomics: non-negative
+// floats order like their bit patterns), folded over the blocks by amax_fold_kernel; ALL: *out_all = max of everything (one atomic
+// per block; the caller zeroes the word).  NaN / Inf bit patterns win, and the GEMM then produces what an fp32 GEMM would.
+template <bool ROWS, bool COLS, bool ALL>
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, long R, int C, int ld, unsigned* __restrict__ out_rows,
+                                                   unsigned* __restrict__ part_cols, unsigned* __restrict__ out_all) {
+  extern __shared__ unsigned smax[];   // COLS: C words; ALL: + 4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (COLS) {
+    for (int c = tid; c < C; c += 256) smax[c] = 0u;
+    __syncthreads();
+  }
+  unsigned all = 0u;
+  const bool vec = (C & 3) == 0 && (ld & 3) == 0;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    const float* row = P + r * ld;
+    unsigned m = 0u;
+    if (vec) {
+      for (int c = lane * 4; c < C; c += 256) {
+        uint4 v = *reinterpret_cast<const uint4*>(row + c);
+        v.x &= 0x7fffffffu; v.y &= 0x7fffffffu; v.z &= 0x7fffffffu; v.w &= 0x7fffffffu;
+        m = max(max(m, v.x), max(max(v.y, v.z), v.w));
+        if (COLS) { atomicMax(&smax[c], v.x); atomicMax(&smax[c + 1], v.y); atomicMax(&smax[c + 2], v.z); atomicMax(&smax[c + 3], v.w); }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const unsigned v = __builtin_bit_cast(unsigned, row[c]) & 0x7fffffffu;
+        m = max(m, v);
+        if (COLS) atomicMax(&smax[c], v);
+      }
     }
-  } else {
-    const int c4 = (cols + 3) / 4;
-    for (long i = t0; i < rows * c4; i += stride) {
-      const long r = i / c4;
-      const int c = (int)(i % c4) * 4;
-      const float* src = P + r * ld + c;
-      for (int j = 0; j < 4 && c + j < cols; ++j) m = max(m, __builtin_bit_cast(unsigned, src[j]) & 0x7fffffffu);
+    if (ROWS || ALL) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+      if (ROWS && lane == 0) out_rows[r] = m;
+      all = max(all, m);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if (COLS) {
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) part_cols[(size_t)blockIdx.x * C + c] = smax[c];
+  }
+  if (ALL) {   // one atomic per block (the launcher gives four words of LDS)
+    unsigned* red = smax + (COLS ? C : 0);
+    __syncthreads();
+    if (lane == 0) red[wave] = all;
+    __syncthreads();
+    if (tid == 0) { const unsigned m = max(max(red[0], red[1]), max(red[2], red[3])); if (m) atomicMax(out_all, m); }
+  }
+}
+// out[c] = max_b part[b][c]
+__global__ __launch_bounds__(256) void amax_fold_kernel(const unsigned* __restrict__ part, int nb, int C, unsigned* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  unsigned m = 0u;
+  for (int b = 0; b < nb; ++b) m = max(m, part[(size_t)b * C + c]);
+  out[c] = m;
 }
 
 // C = alpha * sum_s ws[s] + beta * C + bias
@@ -778,32 +841,63 @@ void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float
   EESEN_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), st));
   amax_abs_accumulate(st, P, rows, cols, ld, out);
 }
+static int amax_blocks(long rows) { return (int)std::max<long>(1, std::min<long>((rows + 3) / 4, kAmaxBlocks)); }
 void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out) {
   if (rows <= 0 || cols <= 0) return;
-  const long quads = cols == ld ? rows * cols / 4 : rows * ((cols + 3) / 4);
-  const int blocks = (int)std::max<long>(1, std::min<long>((quads + 1023) / 1024, 2048));   // >= 4 float4 per thread, <= 8 blocks per CU
-  hipLaunchKernelGGL(amax_abs_kernel, dim3(blocks), dim3(256), 0, st, P, rows, cols, ld, reinterpret_cast<unsigned*>(out));
+  if (cols == ld && cols < 1024 && (rows * cols) % 1024 == 0) { rows = rows * cols / 1024; cols = ld = 1024; }   // short contiguous rows: as one flat array
+  hipLaunchKernelGGL((amax_kernel<false, false, true>), dim3(amax_blocks(rows)), dim3(256), 4 * sizeof(unsigned), st, P, rows, cols, ld, static_cast<unsigned*>(nullptr),
+                     static_cast<unsigned*>(nullptr), reinterpret_cast<unsigned*>(out));
   check_launch("amax_abs");
 }
+void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld, float* out_rows, float* out_cols, float* ws) {
+  if (rows <= 0 || cols <= 0) return;
+  EESEN_REQUIRE(!out_cols || (ws && (size_t)cols * sizeof(float) <= 64 * 1024), EESEN_ERR_INVALID, "amax: column bounds need a workspace and <= 16384 columns");
+  const int nb = amax_blocks(rows);
+  unsigned* r = reinterpret_cast<unsigned*>(out_rows);
+  unsigned* w = reinterpret_cast<unsigned*>(ws);
+  if (out_rows && out_cols) hipLaunchKernelGGL((amax_kernel<true, true, false>), dim3(nb), dim3(256), (size_t)cols * sizeof(unsigned), st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
+  else if (out_cols) hipLaunchKernelGGL((amax_kernel<false, true, false>), dim3(nb), dim3(256), (size_t)cols * sizeof(unsigned), st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
+  else if (out_rows) hipLaunchKernelGGL((amax_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
+  check_launch("amax_rows_cols");
+  if (out_cols) {
+    hipLaunchKernelGGL(amax_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, w, nb, cols, reinterpret_cast<unsigned*>(out_cols));
+    check_launch("amax_fold");
+  }
+}
 
-// Operand bounds for a two-plane call whose caller passed none: a ring of device words, one pair per call.  A slot is reused after
-// kRing calls, far beyond what any stream of this library has in flight; the Net passes its own slots and never comes here.
-static const float* ring_amax(hipStream_t st, const float* P, long rows, int cols, int ld) {
-  constexpr int kRing = 4096, kDevs = 16;
+// Operand bounds for a two-plane call whose caller passed none: measured here, one word per row of op(A) / column of op(B), in an
+// arena of device words handed out round-robin.  A slot is reused after kArena floats' worth of calls, far beyond what any stream of
+// this library has in flight; the Net passes its own buffers and never comes here.
+static GemmBound arena_bound(hipStream_t st, const float* P, bool kc, int R, int K, int ld) {   // op(X) is [R x K]; kc: stored [R x K], else [K x R]
+  constexpr size_t kArena = (size_t)16 << 20, kDevs = 16;
   static std::mutex mu;
-  static float* ring[kDevs] = {nullptr};   // never freed: lives as long as the process's HIP context
-  static unsigned next[kDevs] = {0};
+  static float* arena[kDevs] = {nullptr};   // never freed: lives as long as the process's HIP context
+  static size_t next[kDevs] = {0};
   int dev = 0;
   EESEN_HIP_CHECK(hipGetDevice(&dev));
-  EESEN_REQUIRE(dev >= 0 && dev < kDevs, EESEN_ERR_INVALID, "gemm: device index beyond the amax ring table");
+  EESEN_REQUIRE(dev >= 0 && dev < (int)kDevs, EESEN_ERR_INVALID, "gemm: device index beyond the bounds arena table");
+  const size_t need = (size_t)R + (kc ? 0 : (size_t)kAmaxBlocks * R);
+  if (!kc && (size_t)R * sizeof(float) > 64 * 1024) {   // more columns than the LDS pass takes: one word for the operand
+    float* slot;
+    { std::lock_guard<std::mutex> lk(mu);
+      if (!arena[dev]) EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&arena[dev]), kArena * sizeof(float)));
+      if (next[dev] + 1 > kArena) next[dev] = 0;
+      slot = arena[dev] + next[dev]; next[dev] += 1; }
+    amax_abs(st, P, K, R, ld, slot);
+    return GemmBound{slot, 0};
+  }
+  EESEN_REQUIRE(need <= kArena, EESEN_ERR_INVALID, "gemm: operand too large for the bounds arena");
   float* slot;
   {
     std::lock_guard<std::mutex> lk(mu);
-    if (!ring[dev]) EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ring[dev]), kRing * sizeof(float)));
-    slot = ring[dev] + (next[dev]++ % kRing);
+    if (!arena[dev]) EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&arena[dev]), kArena * sizeof(float)));
+    if (next[dev] + need > kArena) next[dev] = 0;
+    slot = arena[dev] + next[dev];
+    next[dev] += need;
   }
-  amax_abs(st, P, rows, cols, ld, slot);
-  return slot;
+  if (kc) amax_rows_cols(st, P, R, K, ld, slot, nullptr, nullptr);
+  else amax_rows_cols(st, P, K, R, ld, nullptr, slot, slot + R);
+  return GemmBound{slot, 1};
 }
 
 // Row-group height of the XCD-aware tile map (0 = plain row-major) and the grid it needs.  Groups of 8 tile-rows once
@@ -821,7 +915,7 @@ static int xcd_group_rows(int tiles_m, int tiles_n, unsigned* grid_x) {
 
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws, size_t ws_floats,
-              int extra_lds_bytes, bool bf16_operands, const float* amax_a, const float* amax_b) {
+              int extra_lds_bytes, bool bf16_operands, GemmBound bound_a, GemmBound bound_b) {
   if (M <= 0 || N <= 0) return;
   EESEN_REQUIRE((lda % 4) == 0 && (ldb % 4) == 0, EESEN_ERR_INVALID, "gemm: leading dimensions must be multiples of 4");
   EESEN_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, EESEN_ERR_INVALID, "gemm: operands must be 16-byte aligned");
@@ -829,9 +923,12 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   const bool half = gemm_mode() == 2 && !bf16_operands;   // two fp16 planes: needs a bound of each operand's largest magnitude
   GemmParams p;
   p.amax_a = p.amax_b = nullptr;
+  p.a_vec = p.b_vec = 0;
   if (half) {
-    p.amax_a = amax_a ? amax_a : ring_amax(st, A, a_kc ? M : K, a_kc ? K : M, lda);
-    p.amax_b = amax_b ? amax_b : ring_amax(st, B, b_kc ? N : K, b_kc ? K : N, ldb);
+    if (!bound_a.p) bound_a = arena_bound(st, A, a_kc, M, K, lda);
+    if (!bound_b.p) bound_b = arena_bound(st, B, b_kc, N, K, ldb);
+    p.amax_a = bound_a.p; p.a_vec = bound_a.per_index;
+    p.amax_b = bound_b.p; p.b_vec = bound_b.per_index;
   }
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -917,7 +1014,7 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
 }
 
 void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                       int ldc, const float* bias, const GemmGate& gate, const float* amax_a, const float* amax_b) {
+                       int ldc, const float* bias, const GemmGate& gate, GemmBound bound_a, GemmBound bound_b) {
   EESEN_REQUIRE((M % BM) == 0 && (N % BN) == 0 && (K % BK) == 0, EESEN_ERR_INVALID, "gated GEMM needs whole tiles");
   EESEN_REQUIRE(gate.ndir * gate.nz * kShards <= 64, EESEN_ERR_INVALID, "gated GEMM: too many counter groups");
   GemmParams p;
@@ -927,8 +1024,8 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   p.splits = 1; p.k_chunk = K; p.tiles_n = N / BN; p.tiles_m = M / BM;
   p.gate = gate;
   p.nprod = 6;
-  p.amax_a = amax_a; p.amax_b = amax_b;
-  EESEN_REQUIRE(gemm_mode() != 2 || (amax_a && amax_b), EESEN_ERR_INVALID, "gated GEMM on fp16 planes needs both operand bounds (A is still being written)");
+  p.amax_a = bound_a.p; p.amax_b = bound_b.p; p.a_vec = bound_a.per_index; p.b_vec = bound_b.per_index;
+  EESEN_REQUIRE(gemm_mode() != 2 || (bound_a.p && bound_b.p), EESEN_ERR_INVALID, "gated GEMM on fp16 planes needs both operand bounds (A is still being written)");
   p.bm = p.bn = BM;
   unsigned gx = (unsigned)(p.tiles_m * p.tiles_n);
   p.gm = xcd_group_rows(p.tiles_m, p.tiles_n, &gx);

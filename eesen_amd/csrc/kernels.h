@@ -11,13 +11,18 @@ namespace eesen {
 // else [K x N].  All base pointers 16-byte aligned and all leading dimensions multiples of 4.
 // `ws`/`ws_floats`: split-K workspace (may be null => no split).  Replaces the cublasSgemm behind
 // CuMatrixBase::AddMatMat (/root/reference/src/gpucompute/cuda-matrix.cc:604-639).
+// Mode 2 (two fp16 planes): a bound of an operand's magnitudes, in device words -- per_index = 1: one word per M index of op(A) /
+// N index of op(B) (the bound of that row / column: the scale is then the dot product's own), 0: one word for the whole operand.
+// p = null: measured by a pass over the operand before the launch.  Ignored by the other modes.
+struct GemmBound {
+  const float* p = nullptr;
+  int per_index = 0;
+};
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
               size_t ws_floats, int extra_lds_bytes = 0,   // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
               bool bf16_operands = false,                  // round both operands to bf16, one bf16 MFMA product, fp32 accumulate
-              // mode 2 only: device words holding (a bound of) max |A| / max |B| over at least the operand; null = measured here
-              // by a pass over the operand (amax_abs) before the launch
-              const float* amax_a = nullptr, const float* amax_b = nullptr);
+              GemmBound bound_a = {}, GemmBound bound_b = {});
 
 // Arithmetic of every gemm_f32 / gemm_f32_nt_gated call: 0 = f32-input MFMA, 1 = 3-way bf16 split (six products), 2 = two fp16
 // planes (three products; gemm.hip); -1 = follow EESEN_GEMM_MODE.  Process-wide.
@@ -27,6 +32,10 @@ void set_gemm_mode(int mode);
 // *out = max |P[r][c]| over a [rows x cols] matrix with row stride ld (amax_abs zeroes the word first; _accumulate folds into it)
 void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
 void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
+// one pass: out_rows[r] = max_c |P[r][c]| and / or out_cols[c] = max_r |P[r][c]| (either may be null; out_cols needs a workspace
+// `ws` of kAmaxBlocks * cols floats and cols <= 16384)
+constexpr int kAmaxBlocks = 512;
+void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld, float* out_rows, float* out_cols, float* ws);
 
 // Arrival counters of the persistent recurrence kernels (lstm_persistent.hip): per (direction, sequence tile) group 8
 // shards (shard = blockIdx.x & 7), one 128-byte line each; a shard counts workgroups-in-shard x completed steps.
@@ -48,7 +57,7 @@ struct GemmGate {
   int spin_limit;
 };
 void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                       int ldc, const float* bias, const GemmGate& gate, const float* amax_a = nullptr, const float* amax_b = nullptr);
+                       int ldc, const float* bias, const GemmGate& gate, GemmBound bound_a = {}, GemmBound bound_b = {});
 
 // ---------------------------------------------------------------------------------------- lstm.hip
 struct LstmLayerDev {

@@ -368,7 +368,7 @@ void Net::finalize() {
   if (tn.overlap < 0)
     for (const Layer& L : layers)
       if (L.is_lstm() && L.H > 512) overlap = false;
-  amax.reserve(1 + 4 * layers.size());
+  amax.reserve(1 + layers.size());
   EESEN_HIP_CHECK(hipMemsetAsync(amax.p, 0, amax.cap * sizeof(float), st));
   EESEN_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(amax.p), 0x3f800000, 1, st));   // word 0 = 1.0f
   finalized = true;
@@ -376,19 +376,34 @@ void Net::finalize() {
   sync();
 }
 
-// max |W| of every weight matrix a GEMM multiplies with, after a parameter change (mode 2 of gemm.hip only)
+// one pass over a [rows x cols] matrix: the bounds of its rows and of its columns (gemm.hip: amax_rows_cols)
+void Net::measure(const float* Pm, long nrows, int cols, int ld, DevBuf<float>& out_rows, DevBuf<float>& out_cols) {
+  out_rows.reserve((size_t)nrows);
+  out_cols.reserve((size_t)cols);
+  amax_ws.reserve((size_t)kAmaxBlocks * cols);
+  amax_rows_cols(st, Pm, nrows, cols, ld, out_rows.p, out_cols.p, amax_ws.p);
+}
+bool Net::x_is_bounded(int li) const {
+  if (li == 0) return false;
+  const Layer& Pv = layers[li - 1];   // behind an LSTM layer without forward dropout (mask = 1 / (1 - p)), or an activation / softmax layer
+  return (Pv.is_lstm() && !Pv.cur_fwd_drop) || Pv.is_activation() || Pv.kind == EESEN_LAYER_SOFTMAX;
+}
+// the bounds of every weight matrix a GEMM multiplies with (mode 2 of gemm.hip) and max |W_m| (the fp16-plane recurrence), after a
+// parameter change
 void Net::ensure_weight_amax() {
-  if (wamax_valid) return;
-  EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_W), 0, layers.size() * sizeof(float), st));
-  EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_WM), 0, layers.size() * sizeof(float), st));
+  const bool mode2 = gemm_mode() == 2;
+  const bool need_w = mode2 && !wamax_valid;
+  if (wm_valid && !need_w) return;
+  if (!wm_valid) EESEN_HIP_CHECK(hipMemsetAsync(am_wm(0), 0, layers.size() * sizeof(float), st));
   for (size_t li = 0; li < layers.size(); ++li) {
-    const Layer& L = layers[li];
+    Layer& L = layers[li];
     if (L.is_lstm()) {
-      amax_abs_accumulate(st, params.p + L.p_off + L.off_wx, (long)L.ndir * 4 * L.H, pad4(L.din), pad4(L.din), am(li, AM_W));
-      amax_abs_accumulate(st, params.p + L.p_off + L.off_wm, (long)L.ndir * 4 * L.H, L.H, L.H, am(li, AM_WM));
-    } else if (L.kind == EESEN_LAYER_AFFINE) amax_abs_accumulate(st, params.p + L.p_off + L.off_w, L.dout, pad4(L.din), pad4(L.din), am(li, AM_W));
+      if (need_w) measure(params.p + L.p_off + L.off_wx, (long)L.ndir * 4 * L.H, pad4(L.din), pad4(L.din), L.bw.rows, L.bw.cols);
+      if (!wm_valid) amax_abs_accumulate(st, params.p + L.p_off + L.off_wm, (long)L.ndir * 4 * L.H, L.H, L.H, am_wm((int)li));
+    } else if (L.kind == EESEN_LAYER_AFFINE && need_w) measure(params.p + L.p_off + L.off_w, L.dout, pad4(L.din), pad4(L.din), L.bw.rows, L.bw.cols);
   }
-  wamax_valid = true;
+  wm_valid = true;
+  if (mode2) wamax_valid = true;
 }
 
 long Net::num_params() const {
@@ -405,7 +420,7 @@ void Net::init_accu() {  // InitAdaBuffers (bilstm-layer.h:66-100, affine-trans-
 }
 
 void Net::refresh_derived() {
-  wamax_valid = false;
+  wamax_valid = wm_valid = false;
   for (Layer& L : layers)
     if (L.is_lstm())
       for (int dir = 0; dir < L.ndir; ++dir)
@@ -524,7 +539,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
   d.fwd_split = net.tn.fwd_split;
   d.fwd_f16 = net.tn.fwd_f16 && net.tn.fwd_split;   // (EESEN_FWD_SPLIT=0 is the master switch: the fp32-input MFMA kernels)
-  d.wm_amax = net.amax.p ? const_cast<Net&>(net).am((int)(&L - net.layers.data()), Net::AM_WM) : nullptr;
+  d.wm_amax = net.amax.p ? const_cast<Net&>(net).am_wm((int)(&L - net.layers.data())) : nullptr;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.fwd_narrow2 = net.tn.fwd_narrow2; d.fwd_t16_small = net.tn.fwd_t16_small; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
 }
@@ -697,24 +712,18 @@ void Net::forward_pass() {
   bool g_gated = false;  // the current layer's input GEMM was launched gated on the side stream
   int gated_rows = 0;    // ... for its first gated_rows rows (whole 128-row tiles); the rest is a plain GEMM
   int mid_r0 = 0, mid_r1 = 0;   // rows [mid_r0, mid_r1) of the current layer's input GEMM already ran on the side stream (see plan_mid)
-  // two-plane fp16 GEMMs: the bound of the current activation x (null in the other modes)
-  // (measured also when this pass itself runs on bf16-rounded operands: Backpropagate's GEMMs read the words)
+  // two-plane fp16 GEMMs: the bounds of the current activation x and of the layer's weights (null in the other modes: unused)
+  // (measured also when this pass itself runs on bf16-rounded operands: Backpropagate's GEMMs read them)
   const bool half = gemm_mode() == 2;
   ensure_weight_amax();
-  const float* x_amax = nullptr;
   amx_valid = half;
-  if (half) {
-    EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_X), 0, layers.size() * sizeof(float), st));
-    amax_abs_accumulate(st, x, rows, layers[0].din, ldx, am(0, AM_X));
-    x_amax = am(0, AM_X);
-  }
   for (Layer& L : layers) {
     const int li_ = (int)(&L - layers.data());
-    const float* w_amax = half ? am(li_, AM_W) : nullptr;
-    if (half && li_ > 0 && L.trainable()) {   // the input of a GEMM layer: bounded by 1 behind an LSTM layer (|m| = |o tanh c| < 1) or an
-      const Layer& Pv = layers[li_ - 1];      // activation / softmax layer; measured behind an affine layer or forward dropout (mask = 1 / (1 - p))
-      if ((Pv.is_lstm() && !Pv.cur_fwd_drop) || Pv.is_activation() || Pv.kind == EESEN_LAYER_SOFTMAX) x_amax = am_one();
-      else { amax_abs_accumulate(st, x, rows, L.din, ldx, am(li_, AM_X)); x_amax = am(li_, AM_X); }
+    GemmBound x_amax, w_amax;
+    if (half && L.trainable()) {
+      if (x_is_bounded(li_)) x_amax = bound_one();
+      else { measure(x, rows, L.din, ldx, L.bx.rows, L.bx.cols); x_amax = GemmBound{L.bx.rows.p, 1}; }
+      w_amax = GemmBound{L.bw.rows.p, 1};
     }
     if (L.is_lstm()) {
       const int H = L.H, nd = L.ndir, ldY = nd * H, ldG = nd * 4 * H;
@@ -814,7 +823,7 @@ void Net::forward_pass() {
         // (this layer's output is the operand: no forward dropout here, so it is bounded by 1; the weights' word was written on `st`
         // before ev_gate_reset, which the side stream has just waited for)
         gemm_f32_nt_gated(st2, gated_rows, ldG2, ldY, L.Y.p + (size_t)S * ldY, ldY, params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din),
-                          nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate, half ? am_one() : nullptr, half ? am(li_ + 1, AM_W) : nullptr);
+                          nxt->G.p, ldG2, params.p + nxt->p_off + nxt->off_bias, gate, half ? bound_one() : GemmBound{}, half ? GemmBound{nxt->bw.rows.p, 1} : GemmBound{});
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
         g_gated = true;
@@ -840,7 +849,7 @@ void Net::forward_pass() {
         gemm_f32(st2, true, true, mid_r1 - mid_r0, ldG2, nxt->din, 1.f, L.Y.p + (size_t)S * ldY + (size_t)mid_r0 * ldY, ldY,
                  params.p + nxt->p_off + nxt->off_wx, pad4(nxt->din), 0.f, nxt->G.p + (size_t)mid_r0 * ldG2, ldG2,
                  params.p + nxt->p_off + nxt->off_bias, nullptr, 0, /* a token of extra LDS: the 128 x 128 flavour */ 64, fwd_bf16,
-                 half ? am_one() : nullptr, half ? am(li_ + 1, AM_W) : nullptr);
+                 half ? bound_one() : GemmBound{}, half ? GemmBound{nxt->bw.rows.p, 1} : GemmBound{});
         timer.end(st2, tj_);
         EESEN_HIP_CHECK(hipEventRecord(ev_gate_done, st2));
       } }
@@ -950,25 +959,13 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
   float* d = dA.p;
   int ld_d = pad4(Kout);
   float* dn = dB.p;
-  // two-plane fp16 GEMMs: operand bounds (weights: ensure_weight_amax; layer inputs: the words Propagate left; gradients: measured here)
+  // two-plane fp16 GEMMs: operand bounds (weights: ensure_weight_amax; layer inputs: what Propagate measured; gradients: measured here)
   const bool half = gemm_mode() == 2;
   ensure_weight_amax();
-  if (half) EESEN_HIP_CHECK(hipMemsetAsync(am(0, AM_D), 0, layers.size() * sizeof(float), st));
-  auto x_bound = [&](int li) -> const float* {   // as forward_pass chose it
-    if (!half) return nullptr;
-    if (!amx_valid) return nullptr;   // the mode changed between Propagate and here: measured at the call (gemm.hip)
-    if (li == 0) return am(0, AM_X);
-    const Layer& Pv = layers[li - 1];
-    return ((Pv.is_lstm() && !Pv.cur_fwd_drop) || Pv.is_activation() || Pv.kind == EESEN_LAYER_SOFTMAX) ? am_one() : am(li, AM_X);
+  auto x_cols = [&](int li) -> GemmBound {   // the layer's input as the B operand of its weight-gradient GEMM: per input column
+    if (!half || !amx_valid) return GemmBound{};   // (the mode changed between Propagate and here: measured at the call, gemm.hip)
+    return x_is_bounded(li) ? bound_one() : GemmBound{layers[li].bx.cols.p, 1};
   };
-  if (const Layer& Lb = layers.back(); Lb.out_nb) {   // the caller's out_diff has the file's columns: the padded cells get zeros
-    EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
-    for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, out_diff + (size_t)b * Lb.out_hf, ldd, d + (size_t)b * Lb.out_hi, ld_d, rows, Lb.out_hf);
-  } else {
-    if (ld_d != Kout) EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
-    copy2d(st, out_diff, ldd, d, ld_d, rows, Kout);
-  }
-
   for (int li = (int)layers.size() - 1; li >= 0; --li) {
     Layer& L = layers[li];
     // this layer's input activation
@@ -992,16 +989,15 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
       continue;
     } else if (L.kind == EESEN_LAYER_AFFINE) {
       { const int ti_ = timer.begin(st, 4);
-      const float* d_amax = nullptr;
-      if (half) { amax_abs_accumulate(st, d, rows, L.dout, ld_d, am(li, AM_D)); d_amax = am(li, AM_D); }
+      if (half) measure(d, rows, L.dout, ld_d, L.bd.rows, L.bd.cols);
       if (want_in) {  // in_diff = out_diff * W  (affine-trans-layer.h:171)
         if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
         gemm_f32(st, true, false, rows, L.din, L.dout, 1.f, d, ld_d, params.p + L.p_off + L.off_w, pad4(L.din), 0.f, dn, ld_n,
-                 nullptr, nullptr, 0, 0, false, d_amax, half ? am(li, AM_W) : nullptr);
+                 nullptr, nullptr, 0, 0, false, half ? GemmBound{L.bd.rows.p, 1} : GemmBound{}, half ? GemmBound{L.bw.cols.p, 1} : GemmBound{});
       }
       // gradients (computed inside Update in the reference, affine-trans-layer.h:182-183)
       gemm_f32(st, false, false, L.dout, L.din, rows, 1.f, d, ld_d, x, ldx, 0.f, fr + L.off_w, pad4(L.din), nullptr, ws.p, ws_floats, 0, false,
-               d_amax, x_bound(li));
+               half ? GemmBound{L.bd.cols.p, 1} : GemmBound{}, x_cols(li));
       col_sums(st, d, rows, L.dout, ld_d, fr + L.off_b, ws.p, ws_floats);
       timer.end(st, ti_); }
       bucket_allreduce(li, st);
@@ -1032,14 +1028,14 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
         for (int step = 0; step < T; ++step) lstm_bwd_step(st, v, step, d, ld_d, DGl, DCF.p);
       check_launch("lstm_bwd");
       timer.end(st, ti_); }
-      const float* dg_amax = nullptr;   // one pass over the gate gradients for the (up to four) GEMMs that multiply them
-      if (half) { const int ti_ = timer.begin(st, 4); amax_abs_accumulate(st, DGl, rows, ldG, ldG, am(li, AM_D)); dg_amax = am(li, AM_D); timer.end(st, ti_); }
+      // one pass over the gate gradients for the (up to four) GEMMs that multiply them: per frame (input gradient) and per gate column
+      if (half) { const int ti_ = timer.begin(st, 4); measure(DGl, rows, ldG, ldG, L.bd.rows, L.bd.cols); timer.end(st, ti_); }
       EESEN_HIP_CHECK(hipEventRecord(ev_rec, st));
       if (want_in) {  // in_diff = DGIFO_fw * Wx_fw + DGIFO_bw * Wx_bw  (:502, :593) as one K = ndir*4H contraction
         const int ti_ = timer.begin(st, 4);
         if (ld_n != L.din) EESEN_HIP_CHECK(hipMemsetAsync(dn, 0, (size_t)rows * ld_n * sizeof(float), st));
         gemm_f32(st, true, false, rows, L.din, ldG, 1.f, DGl, ldG, params.p + L.p_off + L.off_wx, pad4(L.din), 0.f, dn, ld_n,
-                 nullptr, nullptr, 0, 0, false, dg_amax, half ? am(li, AM_W) : nullptr);
+                 nullptr, nullptr, 0, 0, false, half ? GemmBound{L.bd.rows.p, 1} : GemmBound{}, half ? GemmBound{L.bw.cols.p, 1} : GemmBound{});
         timer.end(st, ti_);
         // The input-gradient GEMM is on the critical path (the next-lower recurrence waits for it), the weight-gradient GEMMs
         // are not: they start behind it instead of beside it (measured: step 44.15 -> 42.97 ms)
@@ -1062,12 +1058,13 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
       { const int ti_ = timer.begin(sg, 4);
       // W_x gradient, both directions stacked: DGIFO^T * x  (:505, :596)
       gemm_f32(sg, false, false, ldG, L.din, rows, 1.f, DGl, ldG, x, ldx, 0.f, fr + L.off_wx, pad4(L.din), nullptr, ws2.p, need_ws, side_lds, false,
-               dg_amax, x_bound(li));
+               half ? GemmBound{L.bd.cols.p, 1} : GemmBound{}, x_cols(li));
       // W_m gradient per direction: DGIFO^T * m shifted one step toward the recurrence source (:506, :597)
       for (int dir = 0; dir < nd; ++dir)
         gemm_f32(sg, false, false, 4 * H, H, rows, 1.f, DGl + (size_t)dir * 4 * H, ldG,
                  L.Y.p + (size_t)(dir == 0 ? 0 : 2 * S) * ldY + (size_t)dir * H, ldY, 0.f,
-                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, need_ws, side_lds, false, dg_amax, half ? am_one() : nullptr);
+                 fr + L.off_wm + (size_t)dir * 4 * H * H, H, nullptr, ws2.p, need_ws, side_lds, false,
+                 half ? GemmBound{L.bd.cols.p + (size_t)dir * 4 * H, 1} : GemmBound{}, half ? bound_one() : GemmBound{});
       lstm_bias_peep_grads(sg, v, DGl, fr + L.off_bias, fr + L.off_peep, ws2.p, need_ws);
       timer.end(sg, ti_); }
       bucket_allreduce(li, sg);  // this layer's gradients are complete: sum them over the ranks under the lower layers' backward pass

@@ -36,6 +36,8 @@ struct Layer {
   // AffineTransform
   size_t off_w = 0, off_b = 0;
   DevBuf<float> out;  // affine / softmax output [rows x pad4(dout)]
+  // operand bounds of the two-plane GEMMs (Net::amax): per row / per column of the weights, the input activation, the gradient
+  struct Bounds { DevBuf<float> rows, cols; } bw, bx, bd;
   // Dropout options of BiLstm(Parallel) in model-file token order (bilstm-layer.h:331-373): ForwardDropoutFactor,
   // ForwardTimeStepDropout, ForwardSequenceDropout, RecurrentTimeStepDropout, RecurrentSequenceDropout, RNNDrop,
   // NoMemLossDropout, RecurrentDropoutFactor, TwiddleForward (booleans stored as 0 / 1)
@@ -158,17 +160,22 @@ struct Net {
   void set_dropout_masks(int layer, const float* fwd, long fwd_n, const float* rec, int rec_rows, long rec_n, int coin);
   void get_dropout_masks(int layer, float* fwd_host, float* rec_host, int* info4);
   size_t ws_floats = 0;
-  // Operand bounds of the two-plane fp16 GEMMs (gemm.hip, mode 2): device words holding max |x| of a tensor, or a bound the
-  // structure gives (word 0 = 1.0: LSTM outputs, sigmoid / tanh / softmax outputs).  Per layer li: [W] the weight matrix its GEMMs
-  // multiply with (W_x / W; measured after every parameter change), [X] its input activation (measured in Propagate when not
-  // bounded by 1, reused by Backpropagate), [D] the gradient it multiplies in Backpropagate (DG of an LSTM layer, out_diff of an affine
-  // one; measured there).  The GEMM of a PART of a tensor takes the whole tensor's word, so results do not depend on how a GEMM is cut.
-  DevBuf<float> amax;
-  bool wamax_valid = false;
-  bool amx_valid = false;     // the [X] words are those of the last Propagate
-  enum { AM_W = 0, AM_X = 1, AM_D = 2, AM_WM = 3 };   // AM_WM: max |W_m| of an LSTM layer (the fp16-plane forward recurrence, lstm_persistent.hip)
-  float* am(int li, int k) { return amax.p + 1 + (size_t)k * layers.size() + li; }
-  const float* am_one() const { return amax.p; }
+  // Operand bounds of the two-plane fp16 GEMMs (gemm.hip, mode 2; kernels.h: GemmBound).  Every GEMM operand is scaled per row of
+  // op(A) / column of op(B) by the power of two that its own bound asks for, so a dot product's precision does not depend on what
+  // the rest of the tensor holds.  Per layer (Layer::bw / bx / bd): the bounds of the rows AND of the columns of [W] the weight matrix
+  // its GEMMs multiply with (W_x / W; measured after every parameter change), [X] its input activation (measured in Propagate where the
+  // structure gives no bound, reused by Backpropagate), [D] the gradient it multiplies in Backpropagate (DG of an LSTM layer, out_diff
+  // of an affine one) -- one pass per tensor (amax_rows_cols).  What the structure bounds takes one word: `amax[0]` = 1.0 for LSTM
+  // outputs (|m| = |o tanh c| < 1) and sigmoid / tanh / softmax outputs.  amax[1 + li]: max |W_m| of LSTM layer li (the fp16-plane
+  // forward recurrence, lstm_persistent.hip).  The GEMM of a PART of a tensor takes the same words, so results do not depend on how a
+  // GEMM is cut.
+  DevBuf<float> amax, amax_ws;
+  bool wamax_valid = false, wm_valid = false;
+  bool amx_valid = false;     // the [X] bounds are those of the last Propagate
+  float* am_wm(int li) { return amax.p + 1 + li; }
+  GemmBound bound_one() const { return GemmBound{amax.p, 0}; }
+  bool x_is_bounded(int li) const;                    // layer li's input needs no measurement (bounded by 1)
+  void measure(const float* P, long rows, int cols, int ld, DevBuf<float>& out_rows, DevBuf<float>& out_cols);
   void ensure_weight_amax();
   PhaseTimer timer;
   // data-parallel exchange (comm.cpp): with a communicator attached, Backpropagate sums every layer's fresh gradients

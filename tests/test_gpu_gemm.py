@@ -20,7 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(1, 1, 256, 256, 64), (1, 1, 1000, 2048, 1024), (1, 0, 700, 300, 4096), (0, 0, 2048, 512, 32000), (0, 0, 184, 40, 8000),
           (0, 1, 257, 130, 50), (1, 1, 33, 46, 1024), (1, 0, 640, 1024, 46), (0, 0, 128, 128, 17), (1, 1, 129, 127, 19),
           # whole 256 x 256 tiles, >= 16 of them: the eight-wave flavour of the split kernel (all four layouts, split-K, short K)
-          (1, 1, 1024, 1024, 512), (1, 0, 2048, 512, 4096), (0, 0, 1024, 1024, 8000), (0, 1, 1280, 1024, 48), (1, 1, 4096, 256, 16)]
+          (1, 1, 1024, 1024, 512), (1, 0, 2048, 512, 4096), (0, 0, 1024, 1024, 8000), (0, 1, 1280, 1024, 48), (1, 1, 4096, 256, 16),
+          # short K, many outputs, every layout: where a PER-TENSOR scale of the fp16 planes showed (3x the fp32 chain's error: an element 2^-20 of
+          # its tensor's largest meeting a large partner); the scales are per row of op(A) / column of op(B)
+          (0, 0, 4096, 256, 16), (1, 0, 2048, 512, 16), (0, 1, 1024, 1024, 32)]
 
 
 def _run(gpu, mode, a_kc, b_kc, A, B, C0, bias, alpha, beta):
@@ -69,7 +72,7 @@ def test_split_mode_is_as_accurate_as_the_fp32_chain(gpu, report, a_kc, b_kc, M,
     report(dict(a_kc=a_kc, b_kc=b_kc, M=M, N=N, K=K, err_f32_mfma=err[0], err_bf16_split=err[1], err_f16_planes=err[2]))
     assert err[0] < 4e-6                      # fp32 chain vs fp64, normalised by sum |a||b|: round-off class (grows slowly with K)
     assert err[1] < max(1.5 * err[0], 2.4e-7), f"split {err[1]:.3g} vs fp32 chain {err[0]:.3g}"
-    assert err[2] < max(4.0 * err[0], 4e-7), f"fp16 planes {err[2]:.3g} vs fp32 chain {err[0]:.3g}"
+    assert err[2] < max(1.5 * err[0], 4e-7), f"fp16 planes {err[2]:.3g} vs fp32 chain {err[0]:.3g}"
 
 
 def test_fp16_planes_keep_what_fp16_range_would_lose(gpu):

@@ -416,12 +416,16 @@ def test_two_narrow_forward_workgroups_per_cu(gpu, over, monkeypatch):
         assert ri["fwd_persistent"] == ri["bwd_persistent"] == ri["lstm_layers"] == cfg["layers"] and net.recoveries == 0, ri
         for r in res:
             assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
-        return res[0]
+        fwd = net.Plan()["layers"][-1]["forward"]
+        return res[0] + ((fwd["kernel"], fwd["workgroups_per_cu"]),)
 
     base = run()
     monkeypatch.setenv("EESEN_FWD_NARROW2", "0")
     wide = run()
-    assert not np.array_equal(wide[0], base[0])          # another kernel really ran
+    # another kernel really ran: the narrow tile, two workgroups per CU, against the wide 16 x 16 tile.  (Round 6: both are instantiations
+    # of the fp16-plane kernel -- the same products in the same order per output, so the outputs may now agree bit for bit, where
+    # rounds 4-5 compared the bf16-plane narrow tile with the fp32-input wide one.)
+    assert base[2] != wide[2] and base[2][1] == 2 and wide[2][1] == 1, (base[2], wide[2])
     assert rel_err(base[0], wide[0]) < 2e-6 and rel_err(base[1], wide[1]) < 1e-4
 
 

@@ -223,11 +223,14 @@ def test_bench_pipe_bound_keeps_every_fraction_at_or_below_one():
     from eesen_amd import synth
     for name in ("cfg1", "cfg2", "cfg4", "cfg5"):
         cfg = synth.config(name)
-        pb = bench.pipe_bound(cfg)
-        assert pb["f32_pipe_flops_per_frame"] + pb["gemm_flops_per_frame_fp32_equivalent"] == pytest.approx(bench.flops_per_frame(cfg))
-        assert pb["bf16_pipe_executed_flops_per_frame"] == pytest.approx(6 * pb["gemm_flops_per_frame_fp32_equivalent"])
-        lower = pb["f32_pipe_flops_per_frame"] / (bench.PEAK_F32_MFMA_TFLOPS * 1e12) + \
-            pb["bf16_pipe_executed_flops_per_frame"] / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
-        assert pb["bound_us_per_frame"] == pytest.approx(1e6 * lower)
-        # the all-f32 arithmetic (EESEN_GEMM_MODE=f32) is bounded by the fp32 pipe alone, and more tightly
-        assert bench.pipe_bound(cfg, split_gemm=False)["bound_us_per_frame"] > pb["bound_us_per_frame"]
+        for prod in (3, 6):   # two fp16 planes (the default since round 6) / three bf16 planes per operand
+            pb = bench.pipe_bound(cfg, prod)
+            assert pb["f32_pipe_flops_per_frame"] + pb["gemm_flops_per_frame_fp32_equivalent"] == pytest.approx(bench.flops_per_frame(cfg))
+            assert pb["bf16_pipe_executed_flops_per_frame"] == pytest.approx(prod * pb["gemm_flops_per_frame_fp32_equivalent"])
+            lower = pb["f32_pipe_flops_per_frame"] / (bench.PEAK_F32_MFMA_TFLOPS * 1e12) + \
+                pb["bf16_pipe_executed_flops_per_frame"] / (bench.PEAK_BF16_MFMA_TFLOPS * 1e12)
+            assert pb["bound_us_per_frame"] == pytest.approx(1e6 * lower)
+            # the all-f32 arithmetic (EESEN_GEMM_MODE=f32) is bounded by the fp32 pipe alone, and more tightly
+            assert bench.pipe_bound(cfg, 0)["bound_us_per_frame"] > pb["bound_us_per_frame"]
+        # the forward recurrence on the 16-bit pipe moves its half of the recurrent flops there
+        assert bench.pipe_bound(cfg, 3, 3)["bound_us_per_frame"] < bench.pipe_bound(cfg, 3, 0)["bound_us_per_frame"]
