@@ -64,6 +64,7 @@ def gemm_products() -> int:
     f32-input MFMA (EESEN_GEMM_MODE=f32), 6 = three bf16 planes per operand (split), 3 = two fp16 planes per operand (half: the
     default since round 6)."""
     import ctypes as C
+    from eesen_amd import _lib
     m = C.c_int(-1)
     _lib.check(_lib.load().eesen_get_gemm_mode(C.byref(m)))
     return {0: 0, 1: 6, 2: 3}[m.value]

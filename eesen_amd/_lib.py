@@ -108,6 +108,7 @@ SIGNATURES = {
     "eesen_dev_free": (_i, [_i, _vp]),
     "eesen_dev_copy": (_i, [_i, _vp, _vp, _l, _i]),
     "eesen_op_log_sub_prior": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _f]),
+    "eesen_op_amax_rows_cols": (_i, [_i, _vp, C.c_long, _i, _i, _vp, _vp]),
     "eesen_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _pf]),
     "eesen_op_gemm": (_i, [_i, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, _vp]),
     "eesen_op_gemm_async": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, C.c_long, _i]),

@@ -396,4 +396,16 @@ int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, con
   });
 }
 
+int eesen_op_amax_rows_cols(int device, const float* m_dev, long rows, int cols, int ld, float* out_rows_dev, float* out_cols_dev) {
+  return guard([&] {
+    REQ_PTR(m_dev);
+    EESEN_REQUIRE(rows > 0 && cols > 0 && ld >= cols, EESEN_ERR_INVALID, "bad matrix shape");
+    EESEN_HIP_CHECK(hipSetDevice(device));
+    DevBuf<float> ws;
+    if (out_cols_dev) ws.reserve((size_t)kAmaxBlocks * cols);
+    amax_rows_cols(nullptr, m_dev, rows, cols, ld, out_rows_dev, out_cols_dev, ws.p);
+    EESEN_HIP_CHECK(hipStreamSynchronize(nullptr));
+  });
+}
+
 }  // extern "C"

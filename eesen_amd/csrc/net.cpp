@@ -966,6 +966,14 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
     if (!half || !amx_valid) return GemmBound{};   // (the mode changed between Propagate and here: measured at the call, gemm.hip)
     return x_is_bounded(li) ? bound_one() : GemmBound{layers[li].bx.cols.p, 1};
   };
+  if (const Layer& Lb = layers.back(); Lb.out_nb) {   // the caller's out_diff has the file's columns: the padded cells get zeros
+    EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
+    for (int b = 0; b < Lb.out_nb; ++b) copy2d(st, out_diff + (size_t)b * Lb.out_hf, ldd, d + (size_t)b * Lb.out_hi, ld_d, rows, Lb.out_hf);
+  } else {
+    if (ld_d != Kout) EESEN_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)rows * ld_d * sizeof(float), st));
+    copy2d(st, out_diff, ldd, d, ld_d, rows, Kout);
+  }
+
   for (int li = (int)layers.size() - 1; li >= 0; --li) {
     Layer& L = layers[li];
     // this layer's input activation

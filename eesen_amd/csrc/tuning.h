@@ -15,7 +15,10 @@
 //                                    kernels on layers of <= 512 cells whose backward pass takes a 4- / 8-sequence tile; off beside
 //                                    the 16-sequence tiles, e.g. --num-sequence 64 at 512 cells)
 //   EESEN_SPIN_LIMIT        400000   bound of the in-kernel hand-off spins (x10 with a communicator attached); 0 in tests forces a time-out
-//   EESEN_GEMM_MODE         split    f32: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain) instead of the 3-way bf16 split
+//   EESEN_GEMM_MODE         half     arithmetic of every dense GEMM (gemm.hip): half = two fp16 planes per operand, three products on
+//                                    v_mfma_f32_32x32x16_f16, per-row / per-column power-of-two scales measured on the device (round 6);
+//                                    split = three bf16 planes, six products (the default of rounds 2-5); f32 = v_mfma_f32_32x32x2_f32
+//                                    (an exact fp32 fmaf chain).  All three fp32-class against fp64 (tests/test_gpu_gemm.py)
 //   EESEN_HOST_FEATURE_PIPES unset   (trainers) run recognised feature pipes as host processes instead of on the device
 //   ---- A/B arms of the tests --------------------------------------------------------------------------------------------
 //   EESEN_BWD_Q4            1        0: 8-sequence backward tile instead of the 4 x 32 tile (H <= 512)
@@ -25,8 +28,10 @@
 //   EESEN_BWD_KSPLIT        1        0: 16 x 16 backward tile instead of the K-split kernel (wide layers)
 //   EESEN_FWD_MUX           1        0: two sequence windows instead of the time-multiplexed forward kernel (S = 64 at H = 1024)
 //   EESEN_BWD_MUX           1        0: the same for the K-split backward kernel
-//   EESEN_FWD_SPLIT         1        0: narrow forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of
-//                                    the 3-way bf16 split of both operands (fp32-class: six products, one fp32 rounding per product)
+//   EESEN_FWD_SPLIT         1        0: forward recurrence on the fp32-input MFMA (bit-identical to the per-step kernels) instead of on
+//                                    16-bit planes of both operands (fp32-class; which planes: EESEN_FWD_F16)
+//   EESEN_FWD_F16           1        0: the narrow forward tile on three bf16 planes / six products (rounds 4-5) and the wide tile on the
+//                                    fp32-input MFMA, instead of both on two fp16 planes / three products (round 6)
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_CTC_WAVES         0        n: the CTC lattice sweep as n wavefronts per lattice where that instantiation exists (read when a
 //                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 16 / 16 for rows of 512 / 1024 /
@@ -41,7 +46,7 @@
 //   EESEN_GATE_FWD          auto     next layer's input GEMM gated under the forward recurrence (auto: f32 GEMM mode only)
 //   EESEN_FWD_MID           1        0: the next layer's input GEMM waits for the whole forward recurrence (no early middle part):
 //                                    what counter-collecting runs (rocprofv3 --pmc lets ONE kernel run at a time) must set
-//   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 split / 32 f32)
+//   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 half and split / 32 f32)
 //   ---- diagnostics -------------------------------------------------------------------------------------------------------
 //   EESEN_TRACE             0        1: in-kernel s_memtime timeline of workgroup 0, printed when the Net is destroyed
 //   EESEN_PRINT_FLIGHT      unset    print the measured increment flight and the derived first-poll delays

@@ -410,6 +410,12 @@ int eesen_op_log_sub_prior(int device, void* stream, float* m_dev, int rows, int
 int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, const float* A, int lda,
                         const float* B, int ldb, float* C, int ldc, int iters, float* avg_ms);
 
+/* The operand bounds of the two-plane GEMM arithmetic (eesen_set_gemm_mode(2), csrc/gemm.hip: amax_rows_cols), as the Net measures
+ * them: out_rows[r] = max_c |m[r][c]| (rows floats) and / or out_cols[c] = max_r |m[r][c]| (cols floats) of a device matrix with row
+ * stride ld, in ONE pass; either output may be NULL.  Device pointers; cols <= 16384 when out_cols is asked for.  Synchronises.
+ * No counterpart in the reference (its GEMM is cublasSgemm, src/gpucompute/cuda-matrix.cc:604-639): exported for the tests. */
+int eesen_op_amax_rows_cols(int device, const float* m_dev, long rows, int cols, int ld, float* out_rows_dev, float* out_cols_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,29 @@ def test_fp16_planes_keep_what_fp16_range_would_lose(gpu):
         gpu.eesen_set_gemm_mode(-1)
 
 
+@pytest.mark.parametrize("rows,cols,ld", [(768, 1024, 1024), (1024, 40, 40), (600, 46, 48), (1600, 4096, 4096), (7, 13, 16), (32000, 2048, 2048), (240, 2048, 2048),
+                                          (3, 16384, 16384), (5000, 4, 4)])
+def test_operand_bounds_pass(gpu, rows, cols, ld):
+    """amax_rows_cols (one pass: row maxima by one wave per row, column maxima through LDS atomic max + a fold over the blocks) against
+    numpy: exact (a maximum of magnitudes involves no rounding), with NaN-free inputs spanning many decades, rows-only / columns-only /
+    both, padded rows (ld > cols: the pad must not be read)."""
+    from eesen_amd.api import CuMatrix
+    rng = np.random.default_rng(rows + cols)
+    m = (rng.standard_normal((rows, ld)) * np.exp(rng.uniform(-20, 20, (rows, ld)))).astype(np.float32)
+    m[:, cols:] = 1e30                      # the pad columns hold garbage that would win every maximum
+    m[rows // 2, :cols] = 0.0               # an all-zero row
+    m[:, cols // 2] = 0.0                   # an all-zero column
+    d = CuMatrix.from_numpy(m)
+    assert d.stride == ld
+    want_r = np.abs(m[:, :cols]).max(1); want_c = np.abs(m[:, :cols]).max(0)
+    for do_r, do_c in ((1, 1), (1, 0), (0, 1)):
+        r = CuMatrix(1, rows); c = CuMatrix(1, cols)
+        rc = gpu.eesen_op_amax_rows_cols(0, C.c_void_p(d.ptr), rows, cols, ld, C.c_void_p(r.ptr) if do_r else None, C.c_void_p(c.ptr) if do_c else None)
+        assert rc == 0, gpu.eesen_last_error()
+        if do_r: assert np.array_equal(r.numpy()[0], want_r)
+        if do_c: assert np.array_equal(c.numpy()[0], want_c)
+
+
 def test_training_step_in_split_mode_meets_the_same_parity_bar(gpu):
     """One full step (small_bi) with every GEMM in split mode against the oracle, at the 1e-4 bar of the fp32 path, and the
     distance between the two modes' gradients."""
