@@ -746,10 +746,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_split_f16_big_kernel(GemmPara
 }
 
 // Operand bounds of the two-plane kernels.  One pass over a [R x C] matrix (row stride ld): ROWS: out_rows[r] = max_c |P[r][c]|
-// (one wave per row, plain stores); COLS: part_cols[block][c] = max over the block's rows of |P[r][c]| (LDS atomics: non-negative
-// floats order like their bit patterns), folded over the blocks by amax_fold_kernel; ALL: *out_all = max of everything (one atomic
-// per block; the caller zeroes the word).  NaN / Inf bit patterns win, and the GEMM then produces what an fp32 GEMM would.
-template <bool ROWS, bool COLS, bool ALL>
+// (one wave per row, plain stores); COLS: part_cols[block][c] = max over the block's rows of |P[r][c]|, folded over the blocks by
+// amax_fold_kernel; ALL: *out_all = max of everything (one atomic per block; the caller zeroes the word).  Non-negative floats order
+// like their bit patterns, so every maximum is an unsigned integer maximum.  NaN / Inf bit patterns win, and the GEMM then produces what
+// an fp32 GEMM would.  CJ > 0 (rows of whole float4s, C <= 1024 CJ): a lane owns the SAME columns (lane * 4 + 256 j) in every row its wave
+// visits, so the column maxima live in registers and the row's CJ loads are all in flight together; CJ = 0: any shape, column maxima
+// through LDS atomics.
+template <bool ROWS, bool COLS, bool ALL, int CJ>
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, long R, int C, int ld, unsigned* __restrict__ out_rows,
                                                    unsigned* __restrict__ part_cols, unsigned* __restrict__ out_all) {
   extern __shared__ unsigned smax[];   // COLS: C words; ALL: + 4
@@ -759,16 +762,25 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, 
     __syncthreads();
   }
   unsigned all = 0u;
-  const bool vec = (C & 3) == 0 && (ld & 3) == 0;
+  constexpr int NJ = CJ > 0 ? CJ : 1;
+  uint4 cm[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) cm[j] = make_uint4(0u, 0u, 0u, 0u);
   for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
     const float* row = P + r * ld;
     unsigned m = 0u;
-    if (vec) {
-      for (int c = lane * 4; c < C; c += 256) {
-        uint4 v = *reinterpret_cast<const uint4*>(row + c);
-        v.x &= 0x7fffffffu; v.y &= 0x7fffffffu; v.z &= 0x7fffffffu; v.w &= 0x7fffffffu;
-        m = max(max(m, v.x), max(max(v.y, v.z), v.w));
-        if (COLS) { atomicMax(&smax[c], v.x); atomicMax(&smax[c + 1], v.y); atomicMax(&smax[c + 2], v.z); atomicMax(&smax[c + 3], v.w); }
+    if (CJ > 0) {
+      uint4 v[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        v[j] = c < C ? *reinterpret_cast<const uint4*>(row + c) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        v[j].x &= 0x7fffffffu; v[j].y &= 0x7fffffffu; v[j].z &= 0x7fffffffu; v[j].w &= 0x7fffffffu;
+        m = max(max(m, v[j].x), max(max(v[j].y, v[j].z), v[j].w));
+        if (COLS) { cm[j].x = max(cm[j].x, v[j].x); cm[j].y = max(cm[j].y, v[j].y); cm[j].z = max(cm[j].z, v[j].z); cm[j].w = max(cm[j].w, v[j].w); }
       }
     } else {
       for (int c = lane; c < C; c += 64) {
@@ -785,6 +797,13 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, 
     }
   }
   if (COLS) {
+    if (CJ > 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < C) { atomicMax(&smax[c], cm[j].x); atomicMax(&smax[c + 1], cm[j].y); atomicMax(&smax[c + 2], cm[j].z); atomicMax(&smax[c + 3], cm[j].w); }
+      }
+    }
     __syncthreads();
     for (int c = tid; c < C; c += 256) part_cols[(size_t)blockIdx.x * C + c] = smax[c];
   }
@@ -796,13 +815,22 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, 
     if (tid == 0) { const unsigned m = max(max(red[0], red[1]), max(red[2], red[3])); if (m) atomicMax(out_all, m); }
   }
 }
-// out[c] = max_b part[b][c]
+// out[c] = max_b part[b][c]: a block folds 64 columns; its four waves take interleaved groups of eight partial rows (eight loads in
+// flight per lane), then fold across the waves through LDS
 __global__ __launch_bounds__(256) void amax_fold_kernel(const unsigned* __restrict__ part, int nb, int C, unsigned* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  unsigned m = 0u;
-  for (int b = 0; b < nb; ++b) m = max(m, part[(size_t)b * C + c]);
-  out[c] = m;
+  __shared__ unsigned red[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  unsigned m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (c < C)
+    for (int b = g * 8; b < nb; b += 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (b + k < nb) m[k] = max(m[k], part[(size_t)(b + k) * C + c]);
+    }
+  red[g][cl] = max(max(max(m[0], m[1]), max(m[2], m[3])), max(max(m[4], m[5]), max(m[6], m[7])));
+  __syncthreads();
+  if (g == 0 && c < C) out[c] = max(max(red[0][cl], red[1][cl]), max(red[2][cl], red[3][cl]));
 }
 
 // C = alpha * sum_s ws[s] + beta * C + bias
@@ -842,28 +870,46 @@ void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float
   amax_abs_accumulate(st, P, rows, cols, ld, out);
 }
 static int amax_blocks(long rows) { return (int)std::max<long>(1, std::min<long>((rows + 3) / 4, kAmaxBlocks)); }
+// CJ of amax_kernel for this shape (0: the generic path)
+static int amax_cj(int cols, int ld) {
+  if ((cols & 3) || (ld & 3) || cols > 4096) return 0;
+  const int need = (cols + 1023) / 1024;   // 256 columns per j step x 4 floats
+  return need <= 1 ? 1 : need <= 2 ? 2 : 4;
+}
+#define EESEN_AMAX_LAUNCH(R_, C_, A_, LDS)                                                                                                     \
+  do {                                                                                                                                         \
+    switch (cj) {                                                                                                                              \
+      case 1: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 4>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;              \
+      case 2: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 8>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;              \
+      case 4: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 16>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;             \
+      default: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 0>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a);                    \
+    }                                                                                                                                          \
+  } while (0)
 void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out) {
   if (rows <= 0 || cols <= 0) return;
   if (cols == ld && cols < 1024 && (rows * cols) % 1024 == 0) { rows = rows * cols / 1024; cols = ld = 1024; }   // short contiguous rows: as one flat array
-  hipLaunchKernelGGL((amax_kernel<false, false, true>), dim3(amax_blocks(rows)), dim3(256), 4 * sizeof(unsigned), st, P, rows, cols, ld, static_cast<unsigned*>(nullptr),
-                     static_cast<unsigned*>(nullptr), reinterpret_cast<unsigned*>(out));
+  const int nb = amax_blocks(rows), cj = amax_cj(cols, ld);
+  unsigned *r = nullptr, *w = nullptr, *a = reinterpret_cast<unsigned*>(out);
+  EESEN_AMAX_LAUNCH(false, false, true, 4 * sizeof(unsigned));
   check_launch("amax_abs");
 }
 void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld, float* out_rows, float* out_cols, float* ws) {
   if (rows <= 0 || cols <= 0) return;
   EESEN_REQUIRE(!out_cols || (ws && (size_t)cols * sizeof(float) <= 64 * 1024), EESEN_ERR_INVALID, "amax: column bounds need a workspace and <= 16384 columns");
-  const int nb = amax_blocks(rows);
+  const int nb = amax_blocks(rows), cj = amax_cj(cols, ld);
   unsigned* r = reinterpret_cast<unsigned*>(out_rows);
   unsigned* w = reinterpret_cast<unsigned*>(ws);
-  if (out_rows && out_cols) hipLaunchKernelGGL((amax_kernel<true, true, false>), dim3(nb), dim3(256), (size_t)cols * sizeof(unsigned), st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
-  else if (out_cols) hipLaunchKernelGGL((amax_kernel<false, true, false>), dim3(nb), dim3(256), (size_t)cols * sizeof(unsigned), st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
-  else if (out_rows) hipLaunchKernelGGL((amax_kernel<true, false, false>), dim3(nb), dim3(256), 0, st, P, rows, cols, ld, r, w, static_cast<unsigned*>(nullptr));
+  unsigned* a = nullptr;
+  if (out_rows && out_cols) EESEN_AMAX_LAUNCH(true, true, false, (size_t)cols * sizeof(unsigned));
+  else if (out_cols) EESEN_AMAX_LAUNCH(false, true, false, (size_t)cols * sizeof(unsigned));
+  else if (out_rows) EESEN_AMAX_LAUNCH(true, false, false, 0);
   check_launch("amax_rows_cols");
   if (out_cols) {
-    hipLaunchKernelGGL(amax_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, w, nb, cols, reinterpret_cast<unsigned*>(out_cols));
+    hipLaunchKernelGGL(amax_fold_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, w, nb, cols, reinterpret_cast<unsigned*>(out_cols));
     check_launch("amax_fold");
   }
 }
+#undef EESEN_AMAX_LAUNCH
 
 // Operand bounds for a two-plane call whose caller passed none: measured here, one word per row of op(A) / column of op(B), in an
 // arena of device words handed out round-robin.  A slot is reused after kArena floats' worth of calls, far beyond what any stream of

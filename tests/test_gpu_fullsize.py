@@ -163,7 +163,9 @@ def test_cfg5_full_length_layer_persistent_equals_per_step_kernels(gpu, monkeypa
         del net, ctc, out, diff, idf
     # (round 6: the wide forward tile runs on two fp16 planes per operand -- fp32-class, another summation order: 2e-6 like the narrow
     # tile's; EESEN_FWD_SPLIT=0 keeps the fp32-input kernel, which is bit-identical to the per-step one)
+    # in_diff: at T = 3000 the CTC stage turns last-bit differences of ln y into 1e-3-class differences of gamma (|alpha| ~ 3e3: the
+    # reference's own fp32-vs-fp64 floor for in_diff is 1.6-2.5e-2 here); measured 2.3e-3.  Gradient tensors sum them out.
     e = [rel_err(res["1"][k], res["0"][k]) for k in range(4)]
-    assert e[0] < 2e-6 and e[1] < 1e-6 and e[2] < 1e-4 and e[3] < 1e-4, e
+    assert e[0] < 2e-6 and e[1] < 1e-6 and e[2] < 6e-3 and e[3] < 1e-4, e
     vm = valid_mask(batch.lens, batch.T, batch.S)
     assert np.all(np.isfinite(res["1"][3])) and np.all(res["1"][2][~vm] == 0)
