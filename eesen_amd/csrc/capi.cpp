@@ -374,15 +374,11 @@ int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, con
     EESEN_HIP_CHECK(hipEventCreate(&e1));
     // the operand bounds of the two-plane mode are measured once, outside the timed loop (the Net keeps them per tensor)
     DevBuf<float> am;
-    am.reserve((size_t)M + N + (size_t)kAmaxBlocks * std::max(M, N));
+    am.reserve((size_t)M + N + (size_t)kAmaxBlocks * 16384);
     GemmBound ba{am.p, 1}, bb{am.p + M, 1};
     float* aws = am.p + M + N;
-    const bool wide = (size_t)std::max(a_kc ? 0 : M, b_kc ? 0 : N) * sizeof(float) > 64 * 1024;   // beyond the column pass: one word per operand
-    if (wide) { amax_abs(nullptr, A, a_kc ? M : K, a_kc ? K : M, lda, am.p); amax_abs(nullptr, B, b_kc ? N : K, b_kc ? K : N, ldb, am.p + 1); ba = GemmBound{am.p, 0}; bb = GemmBound{am.p + 1, 0}; }
-    else {
-      if (a_kc) amax_rows_cols(nullptr, A, M, K, lda, am.p, nullptr, nullptr); else amax_rows_cols(nullptr, A, K, M, lda, nullptr, am.p, aws);
-      if (b_kc) amax_rows_cols(nullptr, B, N, K, ldb, am.p + M, nullptr, nullptr); else amax_rows_cols(nullptr, B, K, N, ldb, nullptr, am.p + M, aws);
-    }
+    if (a_kc) amax_rows_cols(nullptr, A, M, K, lda, am.p, nullptr, nullptr); else amax_rows_cols(nullptr, A, K, M, lda, nullptr, am.p, aws);
+    if (b_kc) amax_rows_cols(nullptr, B, N, K, ldb, am.p + M, nullptr, nullptr); else amax_rows_cols(nullptr, B, K, N, ldb, nullptr, am.p + M, aws);
     for (int i = 0; i < 2; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, ba, bb);
     EESEN_HIP_CHECK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, ba, bb);
@@ -402,7 +398,7 @@ int eesen_op_amax_rows_cols(int device, const float* m_dev, long rows, int cols,
     EESEN_REQUIRE(rows > 0 && cols > 0 && ld >= cols, EESEN_ERR_INVALID, "bad matrix shape");
     EESEN_HIP_CHECK(hipSetDevice(device));
     DevBuf<float> ws;
-    if (out_cols_dev) ws.reserve((size_t)kAmaxBlocks * cols);
+    if (out_cols_dev) ws.reserve((size_t)kAmaxBlocks * 16384);
     amax_rows_cols(nullptr, m_dev, rows, cols, ld, out_rows_dev, out_cols_dev, ws.p);
     EESEN_HIP_CHECK(hipStreamSynchronize(nullptr));
   });

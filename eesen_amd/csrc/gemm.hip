@@ -745,92 +745,130 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_split_f16_big_kernel(GemmPara
   gemm_split_body<GeoBigH, A_KC, B_KC, false, false>(p);
 }
 
-// Operand bounds of the two-plane kernels.  One pass over a [R x C] matrix (row stride ld): ROWS: out_rows[r] = max_c |P[r][c]|
-// (one wave per row, plain stores); COLS: part_cols[block][c] = max over the block's rows of |P[r][c]|, folded over the blocks by
-// amax_fold_kernel; ALL: *out_all = max of everything (one atomic per block; the caller zeroes the word).  Non-negative floats order
-// like their bit patterns, so every maximum is an unsigned integer maximum.  NaN / Inf bit patterns win, and the GEMM then produces what
-// an fp32 GEMM would.  CJ > 0 (rows of whole float4s, C <= 1024 CJ): a lane owns the SAME columns (lane * 4 + 256 j) in every row its wave
-// visits, so the column maxima live in registers and the row's CJ loads are all in flight together; CJ = 0: any shape, column maxima
-// through LDS atomics.
-template <bool ROWS, bool COLS, bool ALL, int CJ>
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ P, long R, int C, int ld, unsigned* __restrict__ out_rows,
-                                                   unsigned* __restrict__ part_cols, unsigned* __restrict__ out_all) {
-  extern __shared__ unsigned smax[];   // COLS: C words; ALL: + 4
+// Operand bounds of the two-plane kernels.  One pass over a [R x C] matrix (row stride ld): ROWS: out_rows[r] = max_c |P[r][c]|;
+// COLS: part_cols[block][c] = max over the block's rows of |P[r][c]|, folded over the blocks by amax_fold_kernel; ALL: *out_all = max of
+// everything (one atomic per block; the caller zeroes the word).  Non-negative floats order like their bit patterns, so every maximum
+// is an unsigned integer maximum.  NaN / Inf bit patterns win, and the GEMM then produces what an fp32 GEMM would.
+// VEC (rows of whole float4s): the matrix is cut into column slabs of 1024; a wave stays on ONE slab (global wave id % slabs) and walks
+// rows, two at a time, so a lane owns the same 16 columns in every row it sees: the column maxima live in 16 registers, eight 16-byte
+// loads are in flight per lane, and 50-odd registers let 32 waves share a CU.  With more than one slab the row maxima of the slabs
+// meet through one atomic per (wave, row) -- out_rows is zeroed by the launcher then.  !VEC: any shape, one wave per row, column maxima
+// through LDS atomics (small matrices only).
+constexpr int kAmaxWaves = 16;   // waves per block (8 waves per CU streamed 3.6 TB/s)
+template <bool ROWS, bool COLS, bool ALL, bool VEC>
+__global__ __launch_bounds__(kAmaxWaves * 64) void amax_kernel(const float* __restrict__ P, long R, int C, int ld, unsigned* __restrict__ out_rows,
+                                                               unsigned* __restrict__ part_cols, unsigned* __restrict__ out_all, int row_acc) {
+  extern __shared__ unsigned smax[];   // COLS: Cp words; ALL: + kAmaxWaves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cp = (C + 3) & ~3;   // the partial rows are padded to whole 16-byte words (amax_fold_kernel)
   if (COLS) {
-    for (int c = tid; c < C; c += 256) smax[c] = 0u;
+    for (int c = tid; c < Cp; c += kAmaxWaves * 64) smax[c] = 0u;
     __syncthreads();
   }
   unsigned all = 0u;
-  constexpr int NJ = CJ > 0 ? CJ : 1;
-  uint4 cm[NJ];
+  if (VEC) {
+    const int nslab = (C + 1023) / 1024;
+    const long gw = (long)blockIdx.x * kAmaxWaves + wave, nw = (long)gridDim.x * kAmaxWaves;
+    const int slab = (int)(gw % nslab);
+    const int c0 = slab * 1024 + lane * 4;
+    uint4 cm[4];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) cm[j] = make_uint4(0u, 0u, 0u, 0u);
-  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
-    const float* row = P + r * ld;
-    unsigned m = 0u;
-    if (CJ > 0) {
-      uint4 v[NJ];
+    for (int j = 0; j < 4; ++j) cm[j] = make_uint4(0u, 0u, 0u, 0u);
+    const long rstep = nw / nslab;          // (the launcher makes the grid's waves a multiple of the slabs)
+    for (long r = gw / nslab; r < R; r += 2 * rstep) {
+      const bool two = r + rstep < R;
+      const float* row0 = P + r * ld;
+      const float* row1 = P + (two ? r + rstep : r) * ld;
+      uint4 v[8];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int c = lane * 4 + 256 * j;
-        v[j] = c < C ? *reinterpret_cast<const uint4*>(row + c) : make_uint4(0u, 0u, 0u, 0u);
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 256 * j;
+        v[j] = c < C ? *reinterpret_cast<const uint4*>(row0 + c) : make_uint4(0u, 0u, 0u, 0u);
+        v[4 + j] = c < C ? *reinterpret_cast<const uint4*>(row1 + c) : make_uint4(0u, 0u, 0u, 0u);
       }
+      unsigned m0 = 0u, m1 = 0u;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < 8; ++j) {
         v[j].x &= 0x7fffffffu; v[j].y &= 0x7fffffffu; v[j].z &= 0x7fffffffu; v[j].w &= 0x7fffffffu;
-        m = max(max(m, v[j].x), max(max(v[j].y, v[j].z), v[j].w));
-        if (COLS) { cm[j].x = max(cm[j].x, v[j].x); cm[j].y = max(cm[j].y, v[j].y); cm[j].z = max(cm[j].z, v[j].z); cm[j].w = max(cm[j].w, v[j].w); }
+        const unsigned mj = max(max(v[j].x, v[j].y), max(v[j].z, v[j].w));
+        if (j < 4) m0 = max(m0, mj); else m1 = max(m1, mj);
+        if (COLS) { uint4& q = cm[j & 3]; q.x = max(q.x, v[j].x); q.y = max(q.y, v[j].y); q.z = max(q.z, v[j].z); q.w = max(q.w, v[j].w); }
       }
-    } else {
+      if (ROWS || ALL) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m0 = max(m0, (unsigned)__shfl_xor((int)m0, o)); m1 = max(m1, (unsigned)__shfl_xor((int)m1, o)); }
+        if (ROWS && lane == 0) {
+          if (nslab > 1 || row_acc) { atomicMax(&out_rows[r], m0); if (two) atomicMax(&out_rows[r + rstep], m1); }
+          else { out_rows[r] = m0; if (two) out_rows[r + rstep] = m1; }
+        }
+        all = max(all, max(m0, m1));
+      }
+    }
+    if (COLS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 256 * j;
+        if (c < C) { atomicMax(&smax[c], cm[j].x); atomicMax(&smax[c + 1], cm[j].y); atomicMax(&smax[c + 2], cm[j].z); atomicMax(&smax[c + 3], cm[j].w); }
+      }
+    }
+  } else {
+    for (long r = (long)blockIdx.x * kAmaxWaves + wave; r < R; r += (long)gridDim.x * kAmaxWaves) {
+      const float* row = P + r * ld;
+      unsigned m = 0u;
       for (int c = lane; c < C; c += 64) {
         const unsigned v = __builtin_bit_cast(unsigned, row[c]) & 0x7fffffffu;
         m = max(m, v);
         if (COLS) atomicMax(&smax[c], v);
       }
-    }
-    if (ROWS || ALL) {
+      if (ROWS || ALL) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-      if (ROWS && lane == 0) out_rows[r] = m;
-      all = max(all, m);
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (ROWS && lane == 0) { if (row_acc) atomicMax(&out_rows[r], m); else out_rows[r] = m; }
+        all = max(all, m);
+      }
     }
   }
   if (COLS) {
-    if (CJ > 0) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int c = lane * 4 + 256 * j;
-        if (c < C) { atomicMax(&smax[c], cm[j].x); atomicMax(&smax[c + 1], cm[j].y); atomicMax(&smax[c + 2], cm[j].z); atomicMax(&smax[c + 3], cm[j].w); }
-      }
-    }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) part_cols[(size_t)blockIdx.x * C + c] = smax[c];
+    for (int c = tid; c < Cp; c += kAmaxWaves * 64) part_cols[(size_t)blockIdx.x * Cp + c] = smax[c];
   }
-  if (ALL) {   // one atomic per block (the launcher gives four words of LDS)
-    unsigned* red = smax + (COLS ? C : 0);
+  if (ALL) {   // one atomic per block (the launcher gives kAmaxWaves words of LDS)
+    unsigned* red = smax + (COLS ? Cp : 0);
     __syncthreads();
     if (lane == 0) red[wave] = all;
     __syncthreads();
-    if (tid == 0) { const unsigned m = max(max(red[0], red[1]), max(red[2], red[3])); if (m) atomicMax(out_all, m); }
+    if (tid == 0) {
+      unsigned m = 0u;
+      for (int w = 0; w < kAmaxWaves; ++w) m = max(m, red[w]);
+      if (m) atomicMax(out_all, m);
+    }
   }
 }
-// out[c] = max_b part[b][c]: a block folds 64 columns; its four waves take interleaved groups of eight partial rows (eight loads in
-// flight per lane), then fold across the waves through LDS
-__global__ __launch_bounds__(256) void amax_fold_kernel(const unsigned* __restrict__ part, int nb, int C, unsigned* __restrict__ out) {
-  __shared__ unsigned red[4][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  unsigned m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  if (c < C)
-    for (int b = g * 8; b < nb; b += 32) {
+// out[c] = max_b part[b][c]: a block folds 64 columns as 16 column quads x 16 groups of partial rows (16-byte loads, eight in flight per
+// lane), then across the groups through LDS.  C is a multiple of 4 here (the launcher pads the partial rows).
+__global__ __launch_bounds__(256) void amax_fold_kernel(const unsigned* __restrict__ part, int nb, int Cp, int C, unsigned* __restrict__ out) {
+  __shared__ uint4 red[16][16];
+  const int cq = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  uint4 m = make_uint4(0u, 0u, 0u, 0u);
+  if (c < Cp)
+    for (int b = g; b < nb; b += 16 * 8) {
+      uint4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (b + k < nb) m[k] = max(m[k], part[(size_t)(b + k) * C + c]);
+      for (int k = 0; k < 8; ++k) v[k] = b + 16 * k < nb ? *reinterpret_cast<const uint4*>(part + (size_t)(b + 16 * k) * Cp + c) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { m.x = max(m.x, v[k].x); m.y = max(m.y, v[k].y); m.z = max(m.z, v[k].z); m.w = max(m.w, v[k].w); }
     }
-  red[g][cl] = max(max(max(m[0], m[1]), max(m[2], m[3])), max(max(m[4], m[5]), max(m[6], m[7])));
+  red[g][cq] = m;
   __syncthreads();
-  if (g == 0 && c < C) out[c] = max(max(red[0][cl], red[1][cl]), max(red[2][cl], red[3][cl]));
+  if (g == 0 && c < Cp) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const uint4 o = red[k][cq]; m.x = max(m.x, o.x); m.y = max(m.y, o.y); m.z = max(m.z, o.z); m.w = max(m.w, o.w); }
+    if (c + 0 < C) out[c + 0] = m.x;
+    if (c + 1 < C) out[c + 1] = m.y;
+    if (c + 2 < C) out[c + 2] = m.z;
+    if (c + 3 < C) out[c + 3] = m.w;
+  }
 }
 
 // C = alpha * sum_s ws[s] + beta * C + bias
@@ -869,44 +907,51 @@ void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float
   EESEN_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), st));
   amax_abs_accumulate(st, P, rows, cols, ld, out);
 }
-static int amax_blocks(long rows) { return (int)std::max<long>(1, std::min<long>((rows + 3) / 4, kAmaxBlocks)); }
-// CJ of amax_kernel for this shape (0: the generic path)
-static int amax_cj(int cols, int ld) {
-  if ((cols & 3) || (ld & 3) || cols > 4096) return 0;
-  const int need = (cols + 1023) / 1024;   // 256 columns per j step x 4 floats
-  return need <= 1 ? 1 : need <= 2 ? 2 : 4;
-}
-#define EESEN_AMAX_LAUNCH(R_, C_, A_, LDS)                                                                                                     \
-  do {                                                                                                                                         \
-    switch (cj) {                                                                                                                              \
-      case 1: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 4>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;              \
-      case 2: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 8>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;              \
-      case 4: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 16>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a); break;             \
-      default: hipLaunchKernelGGL((amax_kernel<R_, C_, A_, 0>), dim3(nb), dim3(256), LDS, st, P, rows, cols, ld, r, w, a);                    \
-    }                                                                                                                                          \
+// blocks of amax_kernel for [rows x cols]: about two (row, 1024-column slab) units per wave, at most kAmaxBlocks, and a whole number of
+// slabs' worth of waves (a wave stays on one slab: kAmaxWaves * blocks must be a multiple of the slabs -- 16 is, up to 16 slabs)
+static int amax_blocks(long rows, int slabs) { return (int)std::max<long>(1, std::min<long>((rows * slabs + 2 * kAmaxWaves - 1) / (2 * kAmaxWaves), kAmaxBlocks)); }
+#define EESEN_AMAX_LAUNCH(R_, C_, A_, LDS)                                                                                                        \
+  do {                                                                                                                                            \
+    if (vec) hipLaunchKernelGGL((amax_kernel<R_, C_, A_, true>), dim3(nb), dim3(kAmaxWaves * 64), LDS, st, Pc, rows, cc, ld, r, w, a, racc);     \
+    else hipLaunchKernelGGL((amax_kernel<R_, C_, A_, false>), dim3(nb), dim3(kAmaxWaves * 64), LDS, st, Pc, rows, cc, ld, r, w, a, racc);        \
   } while (0)
+constexpr int kAmaxSlabCols = 16384;   // columns one launch takes (16 slabs of 1024; 64 KB of LDS for the column maxima)
 void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out) {
   if (rows <= 0 || cols <= 0) return;
   if (cols == ld && cols < 1024 && (rows * cols) % 1024 == 0) { rows = rows * cols / 1024; cols = ld = 1024; }   // short contiguous rows: as one flat array
-  const int nb = amax_blocks(rows), cj = amax_cj(cols, ld);
   unsigned *r = nullptr, *w = nullptr, *a = reinterpret_cast<unsigned*>(out);
-  EESEN_AMAX_LAUNCH(false, false, true, 4 * sizeof(unsigned));
+  const int racc = 0;
+  const bool vec = (cols & 3) == 0 && (ld & 3) == 0;
+  for (int c0 = 0; c0 < cols; c0 += kAmaxSlabCols) {
+    const float* Pc = P + c0;
+    const int cc = std::min(kAmaxSlabCols, cols - c0), nb = amax_blocks(rows, vec ? (cc + 1023) / 1024 : 1);
+    EESEN_AMAX_LAUNCH(false, false, true, kAmaxWaves * sizeof(unsigned));
+  }
   check_launch("amax_abs");
 }
 void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld, float* out_rows, float* out_cols, float* ws) {
   if (rows <= 0 || cols <= 0) return;
-  EESEN_REQUIRE(!out_cols || (ws && (size_t)cols * sizeof(float) <= 64 * 1024), EESEN_ERR_INVALID, "amax: column bounds need a workspace and <= 16384 columns");
-  const int nb = amax_blocks(rows), cj = amax_cj(cols, ld);
+  EESEN_REQUIRE(!out_cols || ws, EESEN_ERR_INVALID, "amax: column bounds need a workspace");
   unsigned* r = reinterpret_cast<unsigned*>(out_rows);
   unsigned* w = reinterpret_cast<unsigned*>(ws);
   unsigned* a = nullptr;
-  if (out_rows && out_cols) EESEN_AMAX_LAUNCH(true, true, false, (size_t)cols * sizeof(unsigned));
-  else if (out_cols) EESEN_AMAX_LAUNCH(false, true, false, (size_t)cols * sizeof(unsigned));
-  else if (out_rows) EESEN_AMAX_LAUNCH(true, false, false, 0);
-  check_launch("amax_rows_cols");
-  if (out_cols) {
-    hipLaunchKernelGGL(amax_fold_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, w, nb, cols, reinterpret_cast<unsigned*>(out_cols));
-    check_launch("amax_fold");
+  const bool vec = (cols & 3) == 0 && (ld & 3) == 0;
+  // the row maxima of several column slabs meet through atomics: start from zero
+  const bool multi = out_rows && ((vec && cols > 1024) || cols > kAmaxSlabCols);
+  if (multi) EESEN_HIP_CHECK(hipMemsetAsync(out_rows, 0, (size_t)rows * sizeof(float), st));
+  for (int c0 = 0; c0 < cols; c0 += kAmaxSlabCols) {
+    const float* Pc = P + c0;
+    const int cc = std::min(kAmaxSlabCols, cols - c0), racc = multi ? 1 : 0;
+    const int nb = amax_blocks(rows, vec ? (cc + 1023) / 1024 : 1);
+    const int cp = (cc + 3) & ~3;
+    if (out_rows && out_cols) EESEN_AMAX_LAUNCH(true, true, false, (size_t)cp * sizeof(unsigned));
+    else if (out_cols) EESEN_AMAX_LAUNCH(false, true, false, (size_t)cp * sizeof(unsigned));
+    else if (out_rows) EESEN_AMAX_LAUNCH(true, false, false, 0);
+    check_launch("amax_rows_cols");
+    if (out_cols) {
+      hipLaunchKernelGGL(amax_fold_kernel, dim3((cp + 63) / 64), dim3(256), 0, st, w, nb, cp, cc, reinterpret_cast<unsigned*>(out_cols) + c0);
+      check_launch("amax_fold");
+    }
   }
 }
 #undef EESEN_AMAX_LAUNCH
@@ -922,16 +967,7 @@ static GemmBound arena_bound(hipStream_t st, const float* P, bool kc, int R, int
   int dev = 0;
   EESEN_HIP_CHECK(hipGetDevice(&dev));
   EESEN_REQUIRE(dev >= 0 && dev < (int)kDevs, EESEN_ERR_INVALID, "gemm: device index beyond the bounds arena table");
-  const size_t need = (size_t)R + (kc ? 0 : (size_t)kAmaxBlocks * R);
-  if (!kc && (size_t)R * sizeof(float) > 64 * 1024) {   // more columns than the LDS pass takes: one word for the operand
-    float* slot;
-    { std::lock_guard<std::mutex> lk(mu);
-      if (!arena[dev]) EESEN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&arena[dev]), kArena * sizeof(float)));
-      if (next[dev] + 1 > kArena) next[dev] = 0;
-      slot = arena[dev] + next[dev]; next[dev] += 1; }
-    amax_abs(st, P, K, R, ld, slot);
-    return GemmBound{slot, 0};
-  }
+  const size_t need = (((size_t)R + 3) & ~(size_t)3) + (kc ? 0 : (size_t)kAmaxBlocks * kAmaxSlabCols);
   EESEN_REQUIRE(need <= kArena, EESEN_ERR_INVALID, "gemm: operand too large for the bounds arena");
   float* slot;
   {
@@ -942,7 +978,7 @@ static GemmBound arena_bound(hipStream_t st, const float* P, bool kc, int R, int
     next[dev] += need;
   }
   if (kc) amax_rows_cols(st, P, R, K, ld, slot, nullptr, nullptr);
-  else amax_rows_cols(st, P, K, R, ld, nullptr, slot, slot + R);
+  else amax_rows_cols(st, P, K, R, ld, nullptr, slot, slot + ((R + 3) & ~3));
   return GemmBound{slot, 1};
 }
 

@@ -33,7 +33,7 @@ void set_gemm_mode(int mode);
 void amax_abs(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
 void amax_abs_accumulate(hipStream_t st, const float* P, long rows, int cols, int ld, float* out);
 // one pass: out_rows[r] = max_c |P[r][c]| and / or out_cols[c] = max_r |P[r][c]| (either may be null; out_cols needs a workspace
-// `ws` of kAmaxBlocks * cols floats and cols <= 16384)
+// `ws` of kAmaxBlocks * min(16384, pad4(cols)) floats)
 constexpr int kAmaxBlocks = 512;
 void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld, float* out_rows, float* out_cols, float* ws);
 
@@ -113,7 +113,15 @@ struct LstmLayerDev {
   // the 3-way split would be, and on the wide 16 x 16 tile.  wm_amax: device word holding max |W_m| of this layer (both directions).
   int fwd_f16 = 0;
   const float* wm_amax = nullptr;
+  // the K-split backward tile of wide layers on two fp16 planes per operand (round 6; tuning.h: EESEN_BWD_F16): DGH = the gate gradients a
+  // second time, as planes with a per-(producer, sequence) power of two ([T*S x ndir*4H] words of 4 bytes: the fp32 rows' bytes), EX = the
+  // inverse powers' exponents ([T][ndir][ceil(S/16)][H/16][16] bytes); both null: not offered (lstm_bwd_planes_floats)
+  int bwd_f16 = 0;
+  unsigned char* DGH = nullptr;
+  float* EX = nullptr;
 };
+// floats of LstmLayerDev::EX this layer shape needs when its backward pass may take the fp16-plane K-split tile (0: it will not)
+size_t lstm_bwd_planes_ex_floats(const LstmLayerDev& L);
 float handoff_flight_ns();
 // The share of the device's CUs this PROCESS sizes its persistent grids against: 1/n (EESEN_GPU_SHARE, or set by a communicator
 // that found n of its ranks on this device: comm.cpp).  Process-wide.

@@ -418,6 +418,7 @@ __device__ __forceinline__ void half_scale(const float* amax, float& scale, floa
   scale = __uint_as_float((unsigned)s << 23);
   inv = __uint_as_float((unsigned)(254 - s) << 23);
 }
+__device__ __forceinline__ void half_scale(float amax, float& scale, float& inv) { half_scale(&amax, scale, inv); }
 __device__ __forceinline__ unsigned rne_f16(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }   // v_cvt_f16_f32: round to nearest even
 __device__ __forceinline__ float f16_bits_to_f32(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 __device__ __forceinline__ unsigned rne_bf16(float x) {   // round-to-nearest-even bf16 (gemm.hip: rne_bf16_bits), in the low 16 bits
@@ -1512,6 +1513,276 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 }
 
 // ------------------------------------------------------------------------------------------------
+// The K-split backward tile on TWO fp16 PLANES per operand (round 6; LstmLayerDev::bwd_f16, EESEN_BWD_F16).  The fp32-input MFMA
+// chain above is 3.4 of the step's 7.1 us (128 v_mfma_f32_16x16x4_f32 per wave, two waves per SIMD).  Two fp16 planes of W_m^T take
+// the fp32 rows' registers (128 per lane) and three v_mfma_f32_16x16x32_f16 products per 32-wide k block replace 8 x 1 fp32 ones:
+// 48 MFMAs of 16 cycles per wave and step.  What stood in the way: the A operand is the gate
+// gradient this very kernel produces step by step -- no bound is known before the launch, and fp16 has 5 exponent bits.  So the
+// PRODUCER scales: the 16 threads that finish one sequence's 16 cells (one DPP row) take the maximum of their 64 gate gradients,
+// derive the power of two that brings it into [2^14, 2^15), publish the gradients a second time as two fp16 planes of the scaled
+// values (LstmLayerDev::DGH: the fp32 row's bytes, per 8 k values [8 x hi][8 x lo]) and the inverse power in LstmLayerDev::EX
+// (its biased exponent, one BYTE per sequence: [t][dir][16-sequence tile][producer][16] -- a 128-byte line holds eight producers of ONE
+// tile and ONE K quarter, whose consumers have waited for all of them; a line that also held another tile's bytes could be read, and
+// cached by an XCD's L2, before those were written); the fp32 gradients still go to DG for the GEMMs and the bias / peephole passes.  The CONSUMER's
+// 32-wide k block lies inside one producer's 64 values, so its three products carry ONE power per output row: they go through a
+// temporary accumulator that is folded into the running one with the row's inverse power (4 FMAs per block and 16-unit tile).
+// Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product ~ 3 * 2^-24 |ab|
+// (gemm.hip, "half" mode, has the argument); padding frames publish zeros (scale 2^126: 0 stays 0).
+// Shapes: as the fp32 K-split tile with an even number of k blocks per wave (H = 512, 1024).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_row_max16(float v) {   // maximum over the 16 lanes of a DPP row, in every lane of it
+  v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+  v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x140, 0xf, 0xf, true)));   // row_mirror
+  return v;
+}
+template <int CPW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
+                                                                               float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
+                                                                               unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
+  constexpr int KU = 4, ST = 16, UW = 64, NT = 4;
+  __shared__ float red[NW][ST][48 + 1];    // partial sums of the three sibling blocks, per wave
+  __shared__ float red2[NW][ST][16 + 1];   // ... of the own block
+  __shared__ int s_go, s_fail;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = L.H, S = L.S, T = L.T;
+  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H, KQ = K4 / KU;
+  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
+  const int uu = bx / KU, ku = bx % KU;
+  const int um0 = uu * UW, uc0 = um0 + ku * 16;            // units of the MFMA outputs / of the cell update
+  const int s0 = L.s_begin + bz * ST;
+  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);
+  const int g = dir * R.nz + bz, ngroups = R.ndir * R.nz, nub = H / UW;
+  const unsigned nprod = (unsigned)(H / KU / 16);          // producers of one K quarter
+  const int NP = H / 16;                                   // producers (16-unit groups) per direction
+  const int NZ = (S + ST - 1) / ST, zt = s0 / ST;          // 16-sequence tiles of the whole batch / this workgroup's
+  static_assert(CPW % 2 == 0, "pass 2 takes the k blocks in pairs");
+  unsigned* wait_cnt = cnt + (size_t)(g * KU + ku) * kShards * kShardStride;
+  unsigned* pub_cnt = cnt + (size_t)(g * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
+
+  const int li = lane & 15, kq = lane >> 4;
+  const int sa = s0 + li;
+  // this wave's part of W_m^T as two fp16 planes of 2^s W (s from the layer's max |W_m|): 64 unit rows x its CPW blocks of the K quarter
+  float wscale, winv;
+  half_scale(L.wm_amax, wscale, winv);
+  f32x4 bh[NT][CPW], bl[NT][CPW];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int ut = n == 3 ? ku : n + (n >= ku ? 1 : 0);
+    const float* Br = L.WmT + ((size_t)dir * H + um0 + ut * 16 + li) * K4 + (size_t)ku * KQ;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      float w[8];
+      ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, KQ, true, w);
+      f32x4 ph, pl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float w0 = w[2 * j] * wscale, w1 = w[2 * j + 1] * wscale;     // exact (a power of two)
+        const unsigned h0 = rne_f16(w0), h1 = rne_f16(w1);
+        const unsigned l0 = rne_f16(w0 - f16_bits_to_f32(h0)), l1 = rne_f16(w1 - f16_bits_to_f32(h1));
+        ph[j] = __uint_as_float(h0 | (h1 << 16));
+        pl[j] = __uint_as_float(l0 | (l1 << 16));
+      }
+      bh[n][c] = ph; bl[n][c] = pl;
+    }
+  }
+  const int es = tid >> 4, eu = tid & 15;
+  const int s_e = s0 + es, u_e = uc0 + eu;
+  const bool e_act = tid < ST * 16;            // the cell waves: whole DPP rows of 16 threads per sequence
+  const bool e_ok = e_act && s_e < s_end;
+  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+  int len = 0;
+  if (e_ok) {
+    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+    len = L.lens[s_e];
+  }
+  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
+  const size_t gcol = (size_t)dir * K4 + u_e * 4;
+  const size_t ycol = (size_t)dir * H + u_e;
+  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dy = 0.f, c_t = 0.f, c_p = 0.f;
+  {
+    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
+    if (e_ok) {
+      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
+      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
+      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
+      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
+    }
+  }
+  if (tid == 0) s_fail = 0;   // (the first barrier of step 1 orders it)
+  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
+  __amdgpu_buffer_rsrc_t rDH = make_rsrc(reinterpret_cast<const float*>(L.DGH));   // the planes: the fp32 rows' bytes, the same offsets
+  const __amdgpu_buffer_rsrc_t rEX = make_rsrc(L.EX);     // bytes
+  int tbS = 0;
+
+  for (int step = 0; step < T; ++step) {
+    const int t = dir == 0 ? T - 1 - step : step;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    if (chunk < T && step % chunk == 0) {
+      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
+      tbS = tb * S;
+      rDG = make_rsrc(DG + (size_t)tbS * ldG);
+      rDH = make_rsrc(reinterpret_cast<const float*>(L.DGH) + (size_t)tbS * ldG);
+    }
+    float dm_in = 0.f;
+    EESEN_STAMP(0);
+    if (step > 0) {
+      if (wave == EESEN_POLL_WAVE) {
+        const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
+        if (lane == 0) s_go = go ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_go) return;
+      EESEN_STAMP(1);
+      f32x4 acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
+      constexpr unsigned kOob = 0x80000000u;
+      f32x4 ah[CPW], al[CPW];
+      unsigned iv[CPW];   // the inverse powers' exponent bytes of the four sequences this lane's accumulator registers hold (C/D map: row = 4 * kq + reg)
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int blk = wave + c * NW;                     // 32-wide k block of the quarter: inside producer ku * nprod + blk / 2
+        const bool ok = sa < s_end && blk * 32 < KQ;
+        const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
+        ah[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, kSc1);
+        al[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, kSc1);
+        const int prod = ku * (int)nprod + blk / 2;
+        const bool iok = blk * 32 < KQ;
+        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * ST + 4 * kq) : kOob, 0, kSc1);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      // pass 1: the siblings' three blocks (three chains interleaved); per k block lo x hi', hi x lo', hi x hi' into a temporary, folded
+      // into the accumulator with the producer's inverse power
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        f32x4 tmp[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), zero4, 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bl[n][c]), tmp[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), tmp[n], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ivr = __uint_as_float(((iv[c] >> (8 * r)) & 0xffu) << 23);
+#pragma unroll
+          for (int n = 0; n < 3; ++n) acc[n][r] = fmaf(tmp[n][r], ivr, acc[n][r]);
+        }
+      }
+      // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][n * 16 + li] = acc[n][r] * winv;
+      __syncthreads();
+      unsigned long long* px = PX + ((size_t)((size_t)(step & 1) * ngroups + g) * nub + uu) * (KU * KU * 256);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int o = tid + h * (NW * 64);
+        if (o < ST * 48) {
+          const int sq = o / 48, uc = o % 48, n = uc >> 4, dst = n + (n >= ku ? 1 : 0);
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
+          px_put(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, (unsigned)step);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the stores leave BEFORE pass 2 (nothing waits for them)
+      // pass 2: the own block, two k blocks at a time (two independent chains); half way through, the siblings' words are read
+      // SPECULATIVELY (see the fp32 kernel)
+      unsigned long long sw[KU] = {};
+#pragma unroll
+      for (int c = 0; c < CPW; c += 2) {
+        f32x4 tmp[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), zero4, 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bl[3][c + d]), tmp[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), tmp[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[3][r] = fmaf(tmp[d][r], __uint_as_float(((iv[c + d] >> (8 * r)) & 0xffu) << 23), acc[3][r]);
+        if (c == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (e_ok) px_load<KU>(px, ku, es * 16 + eu, sw);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red2[wave][4 * kq + r][li] = acc[3][r] * winv;
+      EESEN_STAMP(2);
+      __syncthreads();
+      if (e_ok) {   // the three siblings' partial sums: they run in lockstep with this workgroup, the words left them a pass ago
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dm_in += red2[w][es][eu];
+        if (!px_take<KU>(px, ku, es * 16 + eu, (unsigned)step, err, spin_limit, sw, dm_in)) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_fail = 1;
+        }
+      }
+      EESEN_STAMP(3);
+    }
+    if (e_act) {
+      const float dm = dy + dm_in;
+      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
+      const float h = tanhf_(c_t);
+      const float dh = (1.f - h * h) * (dm * o);
+      float dob = o * (1.f - o) * (dm * h);
+      const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
+      float df = f * (1.f - f) * (dc * c_p);
+      float di = i * (1.f - i) * (dc * g_);
+      float dg = (1.f - g_ * g_) * (dc * i);
+      float carry = dc * f;
+      if (t >= len || !e_ok) { dg = di = df = dob = 0.f; carry = 0.f; }
+      // the sequence's 64 gate gradients of this workgroup (16 threads = one DPP row): their power of two, then the planes
+      float sc, inv;
+      half_scale(dpp_row_max16(fmaxf(fmaxf(fabsf(dg), fabsf(di)), fmaxf(fabsf(df), fabsf(dob)))), sc, inv);
+      if (e_ok) {
+        const f32x4 out = {dg, di, df, dob};
+        const unsigned o32 = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rDG, o32, 0, kSc1);
+        const float x0 = dg * sc, x1 = di * sc, x2 = df * sc, x3 = dob * sc;      // exact
+        const unsigned h0 = rne_f16(x0), h1 = rne_f16(x1), h2 = rne_f16(x2), h3 = rne_f16(x3);
+        const unsigned l0 = rne_f16(x0 - f16_bits_to_f32(h0)), l1 = rne_f16(x1 - f16_bits_to_f32(h1));
+        const unsigned l2 = rne_f16(x2 - f16_bits_to_f32(h2)), l3 = rne_f16(x3 - f16_bits_to_f32(h3));
+        // per 8 k values (two units) 32 bytes: [8 x hi][8 x lo]; this unit's four gates are the first or the second half of each
+        const unsigned oh = (o32 & ~31u) + (unsigned)(u_e & 1) * 8u;
+        f32x2_t ph = {__uint_as_float(h0 | (h1 << 16)), __uint_as_float(h2 | (h3 << 16))};
+        f32x2_t pl = {__uint_as_float(l0 | (l1 << 16)), __uint_as_float(l2 | (l3 << 16))};
+        __builtin_amdgcn_raw_buffer_store_b64(ph, rDH, oh, 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b64(pl, rDH, oh + 16u, 0, kSc1);
+        if (eu == 0)
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(__float_as_uint(inv) >> 23), rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * ST + es), 0, kSc1);
+        dcf = carry; dn_i = di; dn_f = df;
+      }
+    }
+    if (step + 1 < T) {
+      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s_fail) return;
+      EESEN_STAMP(4);
+      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e_ok) {  // next step's operands, issued after the publish
+        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
+        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
+        c_t = c_p;
+        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K-split backward, TWO sequence tiles per workgroup (time-multiplexed): BASELINE config 5 (S = 64 at H = 1024).
 // 64 sequences need 512 K-split workgroups -- two windows of 32, one launch after the other, 2 x 7.8 us per time step.  Here one
 // launch covers all four tiles: a workgroup keeps its W_m^T slice ONCE and steps two independent chains, tile 2g and 2g + 1 of
@@ -1970,6 +2241,13 @@ static const void* bwd_q4_fn(int cpw, int stq) {
   switch (cpw) { case 8: return EESEN_Q4_FN(8); case 6: return EESEN_Q4_FN(6); case 4: return EESEN_Q4_FN(4); default: return EESEN_Q4_FN(2); }
 #undef EESEN_Q4_FN
 }
+static const void* bwd_ksplit_h_fn(int cpw) {
+  switch (cpw) {
+    case 4: return reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_h_kernel<4>);
+    case 2: return reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_h_kernel<2>);
+    default: return nullptr;
+  }
+}
 static const void* bwd_ksplit_fn(int cpw, bool mux) {
   switch (cpw) {
     case 4: return mux ? reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_mux_kernel<4>) : reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_kernel<4>);
@@ -2132,6 +2410,16 @@ size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   return (size_t)2 * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096 * 2;
 }
 
+// the fp16-plane K-split tile applies (shape and switches; the buffers are the caller's to hand over)
+static bool bwd_planes_shape(const LstmLayerDev& L) {
+  if (!L.bwd_f16 || !L.bwd_ksplit || L.wm_amax == nullptr) return false;
+  const int cpw = (4 * L.H / 4) / (32 * NW);
+  return lstm_bwd_ksplit_px_floats(L) != 0 && (cpw == 2 || cpw == 4) && (4 * L.H / 4) % (32 * NW) == 0;
+}
+size_t lstm_bwd_planes_ex_floats(const LstmLayerDev& L) {
+  return bwd_planes_shape(L) ? ((size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 16) * 16 + 3) / 4 : 0;   // one byte per (t, dir, tile, producer, sequence)
+}
+
 RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
   RecPlan P;
   const int nch = (4 * L0.H + 31) / 32;
@@ -2188,6 +2476,24 @@ RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
       const void* fn = bwd_ksplit_fn(cpw, false);
       return fn != nullptr && fits(fn, grid, NW * 64);
     };
+    // Round 6: the same tile on two fp16 planes per operand (lstm_bwd_persistent_ksplit_h_kernel) where the caller handed over the
+    // plane and exponent buffers; batches that need two windows take two launches of it (faster than one multiplexed fp32 launch)
+    if (bwd_planes_shape(L0) && (assume_px || (L0.DGH && L0.EX))) {
+      const void* fnh = bwd_ksplit_h_fn(cpw);
+      auto hfits = [&](int Sw) {
+        dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(Sw, 16));
+        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
+        return c1 <= (size_t)kCtlHalf && fnh != nullptr && fits(fnh, grid, NW * 64);
+      };
+      const int nwh = pick_windows(L0.S, 16, hfits);
+      if (nwh > 0 && (nwh == 1 || ((size_t)(L0.S / nwh) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
+        const dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(L0.S / nwh, 16));
+        P.kind = kRecBwdKsplit; P.fn = fnh; P.cpw = cpw; P.seq_tile = 16; P.units = 64; P.windows = nwh;
+        snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_h_kernel<%d>", cpw);
+        plan_resources(P, grid);
+        return P;
+      }
+    }
     const int nwin = pick_windows(L0.S, 16, kfits);
     // Two windows: one launch that time-multiplexes two sequence tiles per workgroup instead (lstm_bwd_persistent_ksplit_mux_kernel;
     // LstmLayerDev::bwd_mux = 0 / EESEN_BWD_MUX=0: the two launches, one after the other)

@@ -380,7 +380,7 @@ void Net::finalize() {
 void Net::measure(const float* Pm, long nrows, int cols, int ld, DevBuf<float>& out_rows, DevBuf<float>& out_cols) {
   out_rows.reserve((size_t)nrows);
   out_cols.reserve((size_t)cols);
-  amax_ws.reserve((size_t)kAmaxBlocks * cols);
+  amax_ws.reserve((size_t)kAmaxBlocks * std::min(16384, (cols + 3) & ~3));   // (one launch takes <= 16384 columns: amax_rows_cols)
   amax_rows_cols(st, Pm, nrows, cols, ld, out_rows.p, out_cols.p, amax_ws.p);
 }
 bool Net::x_is_bounded(int li) const {
@@ -539,6 +539,7 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.fwd_bf16 = net.fwd_bf16_rec ? 1 : 0;
   d.fwd_split = net.tn.fwd_split;
   d.fwd_f16 = net.tn.fwd_f16 && net.tn.fwd_split;   // (EESEN_FWD_SPLIT=0 is the master switch: the fp32-input MFMA kernels)
+  d.bwd_f16 = net.tn.bwd_f16 && net.tn.fwd_split;
   d.wm_amax = net.amax.p ? const_cast<Net&>(net).am_wm((int)(&L - net.layers.data())) : nullptr;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.fwd_narrow2 = net.tn.fwd_narrow2; d.fwd_t16_small = net.tn.fwd_t16_small; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;
@@ -1016,6 +1017,12 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
       if (persistent) {  // wide layers: partial-sum exchange space of the K-split backward kernel (shared by the layers: their passes are serial)
         const size_t need = lstm_bwd_ksplit_px_floats(v);
         if (need) { bwd_px.reserve(need); v.PX = bwd_px.p; v.px_floats = bwd_px.cap; }
+        if (const size_t ex = lstm_bwd_planes_ex_floats(v)) {   // the fp16-plane form: planes of the gate gradients + inverse powers (shared by the layers)
+          bwd_dgh.reserve((size_t)rows * ldG);
+          bwd_ex.reserve(ex);
+          v.DGH = reinterpret_cast<unsigned char*>(bwd_dgh.p);
+          v.EX = bwd_ex.p;
+        }
       }
       EESEN_REQUIRE(in_train || !L.has_dropout(), EESEN_ERR_STATE, "Can't backpropagate a dropout layer in test mode (bilstm-parallel-layer.h:425)");
       if (L.cur_fwd_drop) mul_elements(st, d, ld_d, L.fmask.p, ldY, d, ld_d, rows, ldY);  // out_diff_drop, :892-896

@@ -121,6 +121,7 @@ struct Net {
   // backward scratch
   DevBuf<float> DGb[2], DCF, dA, dB, ws, ws2;
   DevBuf<float> bwd_px;       // partial-sum exchange space of the K-split backward kernel (wide layers)
+  DevBuf<float> bwd_dgh, bwd_ex;   // ... of its fp16-plane form: the gate gradients as planes, the inverse powers (LstmLayerDev::DGH / EX)
   hipStream_t st2 = nullptr;  // side stream: weight-gradient GEMMs under the next layer's recurrence
   hipEvent_t ev_rec = nullptr, ev_grad[2] = {nullptr, nullptr};
   bool overlap = true;

@@ -55,7 +55,11 @@ int eesen_device_count(int* count);
  *   1  3-way bf16 split: every fp32 operand is EXACTLY hi + mid + lo (three bf16), six of the nine cross products run on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; error <= 2^-23 |a*b| per product, i.e. fp32-GEMM class, at 2.67x the
  *      f32 matrix rate (gfx950 runs f32 MFMA at 1/16 of the bf16 rate and has no TF32 form);
- *  -1  follow the environment (EESEN_GEMM_MODE=f32|split; split when unset), the initial state. */
+ *   2  two fp16 planes (round 6, the default): every fp32 operand is hi + lo (fp16, round to nearest at both levels: equal to
+ *      the value to within 2^-24), each row of op(A) / column of op(B) scaled by the exact power of two its own largest magnitude
+ *      asks for (measured on the device), three of the four cross products on v_mfma_f32_32x32x16_f16 with fp32 accumulation;
+ *      error ~ 3 * 2^-24 |a*b| per product -- the same class -- at 1.58x the rate of mode 1;
+ *  -1  follow the environment (EESEN_GEMM_MODE=f32|split|half; half when unset), the initial state. */
 int eesen_set_gemm_mode(int mode);
 int eesen_get_gemm_mode(int* mode);
 
@@ -412,7 +416,7 @@ int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, con
 
 /* The operand bounds of the two-plane GEMM arithmetic (eesen_set_gemm_mode(2), csrc/gemm.hip: amax_rows_cols), as the Net measures
  * them: out_rows[r] = max_c |m[r][c]| (rows floats) and / or out_cols[c] = max_r |m[r][c]| (cols floats) of a device matrix with row
- * stride ld, in ONE pass; either output may be NULL.  Device pointers; cols <= 16384 when out_cols is asked for.  Synchronises.
+ * stride ld, in ONE pass; either output may be NULL.  Device pointers.  Synchronises.
  * No counterpart in the reference (its GEMM is cublasSgemm, src/gpucompute/cuda-matrix.cc:604-639): exported for the tests. */
 int eesen_op_amax_rows_cols(int device, const float* m_dev, long rows, int cols, int ld, float* out_rows_dev, float* out_cols_dev);
 

@@ -108,7 +108,7 @@ def test_fp16_planes_keep_what_fp16_range_would_lose(gpu):
 
 
 @pytest.mark.parametrize("rows,cols,ld", [(768, 1024, 1024), (1024, 40, 40), (600, 46, 48), (1600, 4096, 4096), (7, 13, 16), (32000, 2048, 2048), (240, 2048, 2048),
-                                          (3, 16384, 16384), (5000, 4, 4)])
+                                          (3, 16384, 16384), (5000, 4, 4), (32000, 8192, 8192), (100, 5000, 5000), (64, 4100, 4104)])
 def test_operand_bounds_pass(gpu, rows, cols, ld):
     """amax_rows_cols (one pass: row maxima by one wave per row, column maxima through LDS atomic max + a fold over the blocks) against
     numpy: exact (a maximum of magnitudes involves no rounding), with NaN-free inputs spanning many decades, rows-only / columns-only /
