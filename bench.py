@@ -91,7 +91,17 @@ def fwd_rec_products(cfg, S: int, forward_mode: int = 0) -> int:
     return 0
 
 
-def pipe_bound(cfg, gemm_prod: int = 3, fwd_products: int = 0) -> dict:
+def bwd_rec_products(cfg) -> int:
+    """How the BACKWARD recurrent product runs: 0 = on the fp32-input MFMA (narrow layers: the 4 x 32 tile; any layer with
+    EESEN_BWD_F16=0 / EESEN_FWD_SPLIT=0); 3 = the K-split tile of wide layers (768 < H <= 1024, H % 256 == 0) on two fp16 planes per
+    operand (lstm_bwd_persistent_ksplit_h_kernel, round 6)."""
+    if os.environ.get("EESEN_PERSISTENT", "1") == "0" or os.environ.get("EESEN_FWD_SPLIT", "1") == "0" or os.environ.get("EESEN_BWD_F16", "1") == "0":
+        return 0
+    H = cfg["H"]
+    return 3 if H == 1024 and os.environ.get("EESEN_BWD_KSPLIT", "1") != "0" else 0
+
+
+def pipe_bound(cfg, gemm_prod: int = 3, fwd_products: int = 0, bwd_products: int = 0) -> dict:
     """The step's flops by matrix pipe and the time the two pipes need for them at their peaks.  Per layer and direction the
     recurrence kernels execute the forward and the backward recurrent product (8 H^2 per frame each).  The backward one runs on
     the fp32 pipe (v_mfma_f32_16x16x4_f32 / 4x4x1); the forward one too, unless `fwd_products` says it runs on the bf16 pipe as that
@@ -101,8 +111,8 @@ def pipe_bound(cfg, gemm_prod: int = 3, fwd_products: int = 0) -> dict:
     nd = 2 if cfg["kind"].startswith("BiLstm") else 1
     rec = float(cfg["layers"]) * nd * 16.0 * cfg["H"] * cfg["H"]
     gemm = flops_per_frame(cfg) - rec
-    rec_f32 = rec if not fwd_products else rec / 2
-    rec_bf16 = 0.0 if not fwd_products else fwd_products * rec / 2
+    rec_f32 = (0.0 if fwd_products else rec / 2) + (0.0 if bwd_products else rec / 2)
+    rec_bf16 = (fwd_products + bwd_products) * rec / 2
     split_gemm = gemm_prod > 0
     if split_gemm:
         bf16 = float(gemm_prod) * gemm + rec_bf16
@@ -111,7 +121,8 @@ def pipe_bound(cfg, gemm_prod: int = 3, fwd_products: int = 0) -> dict:
         bf16 = rec_bf16
         sec = (rec_f32 + gemm) / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12)
     return {"f32_pipe_flops_per_frame": rec_f32 + (0.0 if split_gemm else gemm), "gemm_flops_per_frame_fp32_equivalent": gemm,
-            "bf16_pipe_executed_flops_per_frame": bf16, "gemm_products": gemm_prod, "forward_recurrence_bf16_products": fwd_products, "bound_us_per_frame": 1e6 * sec}
+            "bf16_pipe_executed_flops_per_frame": bf16, "gemm_products": gemm_prod, "forward_recurrence_bf16_products": fwd_products, "backward_recurrence_f16_products": bwd_products,
+            "bound_us_per_frame": 1e6 * sec}
 
 
 def ctc_block(cfg, batch, ctc_ph: dict, K: int) -> dict:
@@ -363,7 +374,7 @@ def secondary_leg(name: str, dev: int, steps: int = 3, warmup: int = 1, forward_
             "dtype": ("bf16-fwd/f32" if int(forward_bf16) == 1 else "bf16-fwd-gemm-only/f32") if forward_bf16 else "f32",
             "bf16_recurrence_layers": net.Bf16RecurrenceLayers(),
             "whole_step_tflops_fp32_equivalent": fpf * frames / dt / 1e12,
-            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, gemm_products(), fwd_rec_products(cfg, batch.S, int(forward_bf16)))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
+            "whole_step_frac_of_pipe_roofline": pipe_bound(cfg, gemm_products(), fwd_rec_products(cfg, batch.S, int(forward_bf16)), bwd_rec_products(cfg))["bound_us_per_frame"] * 1e-6 * frames / dt,   # both pipes at peak, <= 1 (pipe_bound)
             "flops_per_frame": fpf, "persistent_layers": {"fwd": info["fwd_persistent"], "bwd": info["bwd_persistent"], "of": info["lstm_layers"]},
             "recoveries": net.recoveries, "ctc_minibatches_dropped": ctc.Dropped()}
 
@@ -763,7 +774,7 @@ def main():
         fwd_mode = {"f32": 0, "bf16": 1, "bf16-gemm": 2}[args.forward_precision]
         fprod = fwd_rec_products(cfg, batch.S, fwd_mode)
         gprod = gemm_products()
-        pb = pipe_bound(cfg, gprod, fprod)
+        pb = pipe_bound(cfg, gprod, fprod, bwd_rec_products(cfg))
         nd = 2 if cfg["kind"].startswith("BiLstm") else 1
         H, S, T, nl = cfg["H"], batch.S, batch.T, cfg["layers"]
         # per-launch algorithmic work of the three kernels that carry the step (DESIGN.md "kernels")
@@ -791,14 +802,14 @@ def main():
         gemm_name = ("gemm_f32_mfma_kernel" if not split and not bf16_fwd else
                      ((gk + "_big_kernel") if big else ("gemm_f32_split_bf16_kernel" if bf16_fwd else gk + "_kernel"))) + \
                     (f"(input->gates: 2 ends + {gk}_kernel middle under the recurrence)" if mid_first and split and not bf16_fwd else "(input->gates)")
-        bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else "lstm_bwd_" + kn
+        bwd_name = "lstm_bwd_persistent_q4_kernel" if q4 else ("lstm_bwd_persistent_ksplit_h_kernel (fp16 planes)" if persistent and bwd_rec_products(cfg) else "lstm_bwd_" + kn)
         # the forward recurrence on the bf16 pipe (lstm_fwd_persistent_bf_kernel): the fp32-class 3-way split of the narrow tile (six
         # products), or config 4's bf16 forward (m_t one plane, W_m hi + lo: two products)
         fwd_name = "lstm_fwd_" + kn if not fprod else {6: "lstm_fwd_persistent_bf_kernel<AP=3, WP=3> (bf16 planes)", 3: "lstm_fwd_persistent_bf_kernel<AP=2, WP=2, F16> (fp16 planes)",
                                                         2: "lstm_fwd_persistent_bf_kernel<AP=1, WP=2> (bf16 forward)"}[fprod]
         kern = {
             fwd_name: dict(total_s=phases["recurrence_fwd"], launches=n_rec, flops=rec_flops, pipe="f32" if not fprod else "bf16", products=fprod or 1),
-            bwd_name: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops, pipe="f32"),
+            bwd_name: dict(total_s=phases["recurrence_bwd"], launches=n_rec, flops=rec_flops, pipe="f32" if not bwd_rec_products(cfg) else "bf16", products=bwd_rec_products(cfg) or 1),
             gemm_name: dict(total_s=phases["input_gemm"], launches=nl * K, flops=gemm_flops, pipe="f32" if (not split and not bf16_fwd) else "bf16"),
         }
         for k in kern.values():

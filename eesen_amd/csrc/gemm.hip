@@ -957,18 +957,19 @@ void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld,
 #undef EESEN_AMAX_LAUNCH
 
 // Operand bounds for a two-plane call whose caller passed none: measured here, one word per row of op(A) / column of op(B), in an
-// arena of device words handed out round-robin.  A slot is reused after kArena floats' worth of calls, far beyond what any stream of
-// this library has in flight; the Net passes its own buffers and never comes here.
+// arena of device words handed out round-robin.  A slot is reused after kArena floats' worth of bounds -- at most an eighth of it per
+// operand, so never within one call, and far beyond what any stream of this library has in flight; the Net passes its own buffers and
+// never comes here.
 static GemmBound arena_bound(hipStream_t st, const float* P, bool kc, int R, int K, int ld) {   // op(X) is [R x K]; kc: stored [R x K], else [K x R]
-  constexpr size_t kArena = (size_t)16 << 20, kDevs = 16;
+  constexpr size_t kArena = (size_t)4 << 20, kDevs = 16;
   static std::mutex mu;
   static float* arena[kDevs] = {nullptr};   // never freed: lives as long as the process's HIP context
   static size_t next[kDevs] = {0};
   int dev = 0;
   EESEN_HIP_CHECK(hipGetDevice(&dev));
   EESEN_REQUIRE(dev >= 0 && dev < (int)kDevs, EESEN_ERR_INVALID, "gemm: device index beyond the bounds arena table");
-  const size_t need = (((size_t)R + 3) & ~(size_t)3) + (kc ? 0 : (size_t)kAmaxBlocks * kAmaxSlabCols);
-  EESEN_REQUIRE(need <= kArena, EESEN_ERR_INVALID, "gemm: operand too large for the bounds arena");
+  const size_t need = ((size_t)R + 3) & ~(size_t)3;
+  EESEN_REQUIRE(need <= kArena / 8, EESEN_ERR_INVALID, "gemm: operand too large for the bounds arena");
   float* slot;
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -978,7 +979,12 @@ static GemmBound arena_bound(hipStream_t st, const float* P, bool kc, int R, int
     next[dev] += need;
   }
   if (kc) amax_rows_cols(st, P, R, K, ld, slot, nullptr, nullptr);
-  else amax_rows_cols(st, P, K, R, ld, nullptr, slot, slot + ((R + 3) & ~3));
+  else {   // the column pass's partial rows: stream-ordered scratch of this call
+    float* ws = nullptr;
+    EESEN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&ws), (size_t)kAmaxBlocks * std::min<size_t>(need, kAmaxSlabCols) * sizeof(float), st));
+    amax_rows_cols(st, P, K, R, ld, nullptr, slot, ws);
+    EESEN_HIP_CHECK(hipFreeAsync(ws, st));
+  }
   return GemmBound{slot, 1};
 }
 

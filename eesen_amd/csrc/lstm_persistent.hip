@@ -1529,6 +1529,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 // Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product ~ 3 * 2^-24 |ab|
 // (gemm.hip, "half" mode, has the argument); padding frames publish zeros (scale 2^126: 0 stays 0).
 // Shapes: as the fp32 K-split tile with an even number of k blocks per wave (H = 512, 1024).
+// (Costing probes, never in the product build: -DEESEN_PROBE_KH=1 no plane stores, 2 no exponent loads, 4 no exponent stores.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dpp_row_max16(float v) {   // maximum over the 16 lanes of a DPP row, in every lane of it
   v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
@@ -1545,6 +1546,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
   __shared__ float red[NW][ST][48 + 1];    // partial sums of the three sibling blocks, per wave
   __shared__ float red2[NW][ST][16 + 1];   // ... of the own block
   __shared__ int s_go, s_fail;
+  __shared__ float park[6][ST * 16];       // the cell threads' peephole weights (loop-invariant) and carries (d_c f, d_i, d_f): read once per step, and the register file is full
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = L.H, S = L.S, T = L.T;
@@ -1592,14 +1594,17 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
   const int s_e = s0 + es, u_e = uc0 + eu;
   const bool e_act = tid < ST * 16;            // the cell waves: whole DPP rows of 16 threads per sequence
   const bool e_ok = e_act && s_e < s_end;
-  float p_i = 0.f, p_f = 0.f, p_o = 0.f;
   int len = 0;
-  if (e_ok) {
-    const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
-    p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
-    len = L.lens[s_e];
+  if (e_act) {
+    float p_i = 0.f, p_f = 0.f, p_o = 0.f;
+    if (e_ok) {
+      const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
+      p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
+      len = L.lens[s_e];
+    }
+    park[0][tid] = p_i; park[1][tid] = p_f; park[2][tid] = p_o;
+    park[3][tid] = 0.f; park[4][tid] = 0.f; park[5][tid] = 0.f;
   }
-  float dcf = 0.f, dn_i = 0.f, dn_f = 0.f;
   const size_t gcol = (size_t)dir * K4 + u_e * 4;
   const size_t ycol = (size_t)dir * H + u_e;
   float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1653,7 +1658,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         ah[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, kSc1);
         al[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, kSc1);
         const int prod = ku * (int)nprod + blk / 2;
+#if defined(EESEN_PROBE_KH) && (EESEN_PROBE_KH & 2)
+        const bool iok = false;
+#else
         const bool iok = blk * 32 < KQ;
+#endif
         iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * ST + 4 * kq) : kOob, 0, kSc1);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
@@ -1737,7 +1746,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       const float h = tanhf_(c_t);
       const float dh = (1.f - h * h) * (dm * o);
       float dob = o * (1.f - o) * (dm * h);
-      const float dc = dh + dcf + dn_i * p_i + dn_f * p_f + dob * p_o;
+      const float dc = dh + park[3][tid] + park[4][tid] * park[0][tid] + park[5][tid] * park[1][tid] + dob * park[2][tid];
       float df = f * (1.f - f) * (dc * c_p);
       float di = i * (1.f - i) * (dc * g_);
       float dg = (1.f - g_ * g_) * (dc * i);
@@ -1758,11 +1767,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         const unsigned oh = (o32 & ~31u) + (unsigned)(u_e & 1) * 8u;
         f32x2_t ph = {__uint_as_float(h0 | (h1 << 16)), __uint_as_float(h2 | (h3 << 16))};
         f32x2_t pl = {__uint_as_float(l0 | (l1 << 16)), __uint_as_float(l2 | (l3 << 16))};
+#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 1)
         __builtin_amdgcn_raw_buffer_store_b64(ph, rDH, oh, 0, kSc1);
         __builtin_amdgcn_raw_buffer_store_b64(pl, rDH, oh + 16u, 0, kSc1);
+#endif
+#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 4)
         if (eu == 0)
           __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(__float_as_uint(inv) >> 23), rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * ST + es), 0, kSc1);
-        dcf = carry; dn_i = di; dn_f = df;
+#endif
+        park[3][tid] = carry; park[4][tid] = di; park[5][tid] = df;
       }
     }
     if (step + 1 < T) {

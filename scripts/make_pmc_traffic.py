@@ -47,8 +47,12 @@ def main(tag, commit, switches):
            "config": {"config": "cfg2", "T": 1000, "S": 32}, "bytes_per_launch": {}, "mfma_busy": {}, "kernels": {},
            "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per dispatch (profiled launches: rocprofv3 --pmc lets ONE kernel run at a time)"}
     for key, prefix, fmul in (("lstm_bwd_persistent_q4_kernel", "lstm_bwd_persistent_q4_kernel", 2.0), ("lstm_fwd_persistent_kernel", "lstm_fwd_persistent_kernel", 2.0),
-                              ("lstm_fwd_persistent_bf_kernel<AP=3, WP=3>", "lstm_fwd_persistent_bf_kernel<2, 2, 3, 3>", 2.0),
-                              ("gemm_f32_split_bf16_big_kernel(input->gates)", "gemm_f32_split_bf16_big_kernel<true, false>", 1.59)):
+                              ("lstm_fwd_persistent_bf_kernel<AP=3, WP=3> (bf16 planes)", "lstm_fwd_persistent_bf_kernel<2, 2, 3, 3, false>", 2.0),
+                              ("lstm_fwd_persistent_bf_kernel<AP=2, WP=2, F16> (fp16 planes)", "lstm_fwd_persistent_bf_kernel<2, 2, 2, 2, true>", 2.0),
+                              ("gemm_f32_split_f16_big_kernel(input->gates)", "gemm_f32_split_f16_big_kernel<true, true>", 1.59),
+                              ("gemm_f32_split_f16_big_kernel(input gradient)", "gemm_f32_split_f16_big_kernel<true, false>", 1.59),
+                              ("amax_kernel(gate gradients)", "amax_kernel<true, true, false, true>", 2.0),
+                              ("gemm_f32_split_bf16_big_kernel(input->gates)", "gemm_f32_split_bf16_big_kernel<true, true>", 1.59)):
         name, r = find(fw, prefix)
         if r:
             out["bytes_per_launch"][key] = (fmul * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
@@ -57,7 +61,7 @@ def main(tag, commit, switches):
         if r and r.get("GRBM_GUI_ACTIVE"):
             out["mfma_busy"][key] = r["SQ_VALU_MFMA_BUSY_CYCLES"] / (r["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     out["bytes_per_launch"]["lstm_bwd_persistent_kernel"] = out["bytes_per_launch"].get("lstm_bwd_persistent_q4_kernel")
-    out["bytes_per_launch"]["gemm_f32_mfma_kernel(input->gates)"] = out["bytes_per_launch"].get("gemm_f32_split_bf16_big_kernel(input->gates)")
+    out["bytes_per_launch"]["gemm_f32_mfma_kernel(input->gates)"] = out["bytes_per_launch"].get("gemm_f32_split_f16_big_kernel(input->gates)")
     # the WIDE configurations (round 6: scripts/collect_profiles_wide.sh): per configuration the recurrence kernels' traffic per launch
     # against their algorithmic bytes, and their matrix-pipe occupancy -- quoted by bench.py's secondary legs
     wide = {}

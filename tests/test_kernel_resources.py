@@ -60,10 +60,8 @@ def test_no_kernel_spills_vector_registers_or_uses_scratch(table):
     m/n-contiguous flavours of the 256 x 256 split GEMM spill 3 / 6 registers in their prologue (they run at the same 203-206 TF
     as the flavour without, profiles/r05_bench_line.json), and three guarded instantiations of the non-default f32-MFMA GEMM
     (EESEN_GEMM_MODE=f32) keep a small indexed array in scratch."""
-    allowed_spill = {"gemm_f32_split_bf16_big_kernel<false,true>": 4, "gemm_f32_split_bf16_big_kernel<true,false>": 8,
-                     "lstm_bwd_persistent_ksplit_h_kernel<4>": 4}      # (two 8-byte values parked in scratch once per step)
+    allowed_spill = {"gemm_f32_split_bf16_big_kernel<false,true>": 4, "gemm_f32_split_bf16_big_kernel<true,false>": 8}
     allowed_scratch = {"gemm_f32_split_bf16_big_kernel<false,true>": 32, "gemm_f32_split_bf16_big_kernel<true,false>": 32,
-                       "lstm_bwd_persistent_ksplit_h_kernel<4>": 32,
                        "gemm_f32_mfma_kernel<false,false,false>": 96, "gemm_f32_mfma_kernel<false,true,false>": 64, "gemm_f32_mfma_kernel<true,false,false>": 64}
     assert len(table) >= 140
     bad = []
@@ -73,7 +71,7 @@ def test_no_kernel_spills_vector_registers_or_uses_scratch(table):
     assert not bad, bad
     # every recurrence / CTC kernel: none at all
     for n, r in table.items():
-        if n.startswith(("lstm_", "ctc_")) and n not in allowed_spill:
+        if n.startswith(("lstm_", "ctc_")):
             assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
 
 
