@@ -1518,12 +1518,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 // the fp32 rows' registers (128 per lane) and three v_mfma_f32_16x16x32_f16 products per 32-wide k block replace 8 x 1 fp32 ones:
 // 48 MFMAs of 16 cycles per wave and step.  What stood in the way: the A operand is the gate
 // gradient this very kernel produces step by step -- no bound is known before the launch, and fp16 has 5 exponent bits.  So the
-// PRODUCER scales: the 16 threads that finish one sequence's 16 cells (one DPP row) take the maximum of their 64 gate gradients,
-// derive the power of two that brings it into [2^14, 2^15), publish the gradients a second time as two fp16 planes of the scaled
+// PRODUCER scales: a wave of the cell phase (four sequences x 16 cells: four DPP rows) takes the maximum of its 256 gate gradients,
+// derives the power of two that brings it into [2^14, 2^15), publishes the gradients a second time as two fp16 planes of the scaled
 // values (LstmLayerDev::DGH: the fp32 row's bytes, per 8 k values [8 x hi][8 x lo]) and the inverse power in LstmLayerDev::EX
-// (its biased exponent, one BYTE per sequence: [t][dir][16-sequence tile][producer][16] -- a 128-byte line holds eight producers of ONE
-// tile and ONE K quarter, whose consumers have waited for all of them; a line that also held another tile's bytes could be read, and
-// cached by an XCD's L2, before those were written); the fp32 gradients still go to DG for the GEMMs and the bias / peephole passes.  The CONSUMER's
+// (its biased exponent, one BYTE per wave of the producer = per four sequences x 64 values: [t][dir][16-sequence tile][producer][8], four
+// bytes used -- a 128-byte line holds the 16 producers of ONE tile and ONE K quarter, whose consumers have waited for all of them; a
+// line that also held another quarter's bytes could be read, and cached by an XCD's L2, before those were written); the fp32 gradients
+// still go to DG for the GEMMs and the bias / peephole passes, stored LAST and left in flight by the drain in front of the publish.  The CONSUMER's
 // 32-wide k block lies inside one producer's 64 values, so its three products carry ONE power per output row: they go through a
 // temporary accumulator that is folded into the running one with the row's inverse power (4 FMAs per block and 16-unit tile).
 // Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product ~ 3 * 2^-24 |ab|
@@ -1649,7 +1650,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
       constexpr unsigned kOob = 0x80000000u;
       f32x4 ah[CPW], al[CPW];
-      unsigned iv[CPW];   // the inverse powers' exponent bytes of the four sequences this lane's accumulator registers hold (C/D map: row = 4 * kq + reg)
+      unsigned iv[CPW];   // the inverse powers' exponent bytes of the producer's four 4-sequence groups (this lane's accumulator registers hold group kq: C/D map row = 4 * kq + reg)
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int blk = wave + c * NW;                     // 32-wide k block of the quarter: inside producer ku * nprod + blk / 2
@@ -1663,7 +1664,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 #else
         const bool iok = blk * 32 < KQ;
 #endif
-        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * ST + 4 * kq) : kOob, 0, kSc1);
+        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 8) : kOob, 0, kSc1);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1678,12 +1679,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bl[n][c]), tmp[n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), tmp[n], 0, 0, 0);
+        const float ivc = __uint_as_float(((iv[c] >> (8 * kq)) & 0xffu) << 23);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ivr = __uint_as_float(((iv[c] >> (8 * r)) & 0xffu) << 23);
+        for (int n = 0; n < 3; ++n)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) acc[n][r] = fmaf(tmp[n][r], ivr, acc[n][r]);
-        }
+          for (int r = 0; r < 4; ++r) acc[n][r] = fmaf(tmp[n][r], ivc, acc[n][r]);
       }
       // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
 #pragma unroll
@@ -1717,9 +1717,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 #pragma unroll
         for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), tmp[d], 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < 2; ++d) {
+          const float ivc = __uint_as_float(((iv[c + d] >> (8 * kq)) & 0xffu) << 23);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[3][r] = fmaf(tmp[d][r], __uint_as_float(((iv[c + d] >> (8 * r)) & 0xffu) << 23), acc[3][r]);
+          for (int r = 0; r < 4; ++r) acc[3][r] = fmaf(tmp[d][r], ivc, acc[3][r]);
+        }
         if (c == 0) {
           __builtin_amdgcn_sched_barrier(0);
           if (e_ok) px_load<KU>(px, ku, es * 16 + eu, sw);
@@ -1752,13 +1754,22 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       float dg = (1.f - g_ * g_) * (dc * i);
       float carry = dc * f;
       if (t >= len || !e_ok) { dg = di = df = dob = 0.f; carry = 0.f; }
-      // the sequence's 64 gate gradients of this workgroup (16 threads = one DPP row): their power of two, then the planes
+      // the power of two of this wave's four sequences x 64 gate gradients (four DPP rows of 16 threads), then the planes
       float sc, inv;
-      half_scale(dpp_row_max16(fmaxf(fmaxf(fabsf(dg), fabsf(di)), fmaxf(fabsf(df), fabsf(dob)))), sc, inv);
+      {
+        const float rm = dpp_row_max16(fmaxf(fmaxf(fabsf(dg), fabsf(di)), fmaxf(fabsf(df), fabsf(dob))));
+        const int ri = (int)__float_as_uint(rm);
+        const float wm = fmaxf(fmaxf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 0)), __uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 16))),
+                               fmaxf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 32)), __uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 48))));
+        half_scale(wm, sc, inv);
+      }
+#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 4)
+      if (lane == 0 && s0 + 4 * wave < s_end)   // one byte per wave: [t][dir][tile][producer][8]: group `wave` of the producer's four
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(__float_as_uint(inv) >> 23), rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * 8 + wave), 0, kSc1);
+#endif
       if (e_ok) {
         const f32x4 out = {dg, di, df, dob};
         const unsigned o32 = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(out, rDG, o32, 0, kSc1);
         const float x0 = dg * sc, x1 = di * sc, x2 = df * sc, x3 = dob * sc;      // exact
         const unsigned h0 = rne_f16(x0), h1 = rne_f16(x1), h2 = rne_f16(x2), h3 = rne_f16(x3);
         const unsigned l0 = rne_f16(x0 - f16_bits_to_f32(h0)), l1 = rne_f16(x1 - f16_bits_to_f32(h1));
@@ -1771,15 +1782,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         __builtin_amdgcn_raw_buffer_store_b64(ph, rDH, oh, 0, kSc1);
         __builtin_amdgcn_raw_buffer_store_b64(pl, rDH, oh + 16u, 0, kSc1);
 #endif
-#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 4)
-        if (eu == 0)
-          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(__float_as_uint(inv) >> 23), rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * ST + es), 0, kSc1);
-#endif
+        // the fp32 gradients LAST: nobody reads them before the kernel ends (the GEMMs and the bias / peephole passes do), so the
+        // drain in front of the publish leaves this one store in flight (s_waitcnt vmcnt(1) below)
+        __builtin_amdgcn_raw_buffer_store_b128(out, rDG, o32, 0, kSc1);
         park[3][tid] = carry; park[4][tid] = di; park[5][tid] = df;
       }
     }
     if (step + 1 < T) {
-      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // everything but the newest store: the fp32 gradients (see above)
       __syncthreads();
       if (s_fail) return;
       EESEN_STAMP(4);
@@ -2430,7 +2440,7 @@ static bool bwd_planes_shape(const LstmLayerDev& L) {
   return lstm_bwd_ksplit_px_floats(L) != 0 && (cpw == 2 || cpw == 4) && (4 * L.H / 4) % (32 * NW) == 0;
 }
 size_t lstm_bwd_planes_ex_floats(const LstmLayerDev& L) {
-  return bwd_planes_shape(L) ? ((size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 16) * 16 + 3) / 4 : 0;   // one byte per (t, dir, tile, producer, sequence)
+  return bwd_planes_shape(L) ? ((size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 16) * 8 + 3) / 4 : 0;   // eight bytes per (t, dir, tile, producer): four used
 }
 
 RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
