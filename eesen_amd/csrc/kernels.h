@@ -115,7 +115,7 @@ struct LstmLayerDev {
   const float* wm_amax = nullptr;
   // the K-split backward tile of wide layers on two fp16 planes per operand (round 6; tuning.h: EESEN_BWD_F16): DGH = the gate gradients a
   // second time, as planes with a per-(producer, sequence) power of two ([T*S x ndir*4H] words of 4 bytes: the fp32 rows' bytes), EX = the
-  // inverse powers' exponents ([T][ndir][ceil(S/16)][H/16][16] bytes); both null: not offered (lstm_bwd_planes_floats)
+  // inverse powers ([T][ndir][ceil(S/16)][H/16][4 groups of 4 sequences] words of 16 bytes); both null: not offered (lstm_bwd_planes_floats)
   int bwd_f16 = 0;
   unsigned char* DGH = nullptr;
   float* EX = nullptr;

@@ -1520,11 +1520,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 // gradient this very kernel produces step by step -- no bound is known before the launch, and fp16 has 5 exponent bits.  So the
 // PRODUCER scales: a wave of the cell phase (four sequences x 16 cells: four DPP rows) takes the maximum of its 256 gate gradients,
 // derives the power of two that brings it into [2^14, 2^15), publishes the gradients a second time as two fp16 planes of the scaled
-// values (LstmLayerDev::DGH: the fp32 row's bytes, per 8 k values [8 x hi][8 x lo]) and the inverse power in LstmLayerDev::EX
-// (its biased exponent, one BYTE per wave of the producer = per four sequences x 64 values: [t][dir][16-sequence tile][producer][8], four
-// bytes used -- a 128-byte line holds the 16 producers of ONE tile and ONE K quarter, whose consumers have waited for all of them; a
-// line that also held another quarter's bytes could be read, and cached by an XCD's L2, before those were written); the fp32 gradients
-// still go to DG for the GEMMs and the bias / peephole passes, stored LAST and left in flight by the drain in front of the publish.  The CONSUMER's
+// values (LstmLayerDev::DGH: where a cell's four fp32 gradients sit in DG, its 16 bytes hold [4 x hi][4 x lo]: one whole-word store per
+// lane) and the inverse power in LstmLayerDev::EX (one 16-byte word per wave of the producer = per four sequences x 64 values:
+// [t][dir][16-sequence tile][producer][4] -- a 128-byte line holds two producers of ONE tile and ONE K quarter, whose consumers have
+// waited for both; a line that also held another quarter's words could be read, and cached by an XCD's L2, before those were
+// written); the fp32 gradients still go to DG for the GEMMs and the bias / peephole passes, stored LAST and left in flight by the
+// drain in front of the publish.  The CONSUMER's
 // 32-wide k block lies inside one producer's 64 values, so its three products carry ONE power per output row: they go through a
 // temporary accumulator that is folded into the running one with the row's inverse power (4 FMAs per block and 16-unit tile).
 // Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product ~ 3 * 2^-24 |ab|
@@ -1656,15 +1657,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         const int blk = wave + c * NW;                     // 32-wide k block of the quarter: inside producer ku * nprod + blk / 2
         const bool ok = sa < s_end && blk * 32 < KQ;
         const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
-        ah[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, kSc1);
-        al[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, kSc1);
+        // two units' blocks of [4 x hi][4 x lo]: the hi halves of both make the A fragment's eight hi values, the lo halves its eight lo
+        const f32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, kSc1);
+        const f32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, kSc1);
+        ah[c] = f32x4{u0[0], u0[1], u1[0], u1[1]};
+        al[c] = f32x4{u0[2], u0[3], u1[2], u1[3]};
         const int prod = ku * (int)nprod + blk / 2;
 #if defined(EESEN_PROBE_KH) && (EESEN_PROBE_KH & 2)
         const bool iok = false;
 #else
         const bool iok = blk * 32 < KQ;
 #endif
-        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 8) : kOob, 0, kSc1);
+        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 64 + kq * 16) : kOob, 0, kSc1);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1679,7 +1683,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bl[n][c]), tmp[n], 0, 0, 0);
 #pragma unroll
         for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), tmp[n], 0, 0, 0);
-        const float ivc = __uint_as_float(((iv[c] >> (8 * kq)) & 0xffu) << 23);
+        const float ivc = __uint_as_float(iv[c]);
 #pragma unroll
         for (int n = 0; n < 3; ++n)
 #pragma unroll
@@ -1718,7 +1722,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), tmp[d], 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const float ivc = __uint_as_float(((iv[c + d] >> (8 * kq)) & 0xffu) << 23);
+          const float ivc = __uint_as_float(iv[c + d]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[3][r] = fmaf(tmp[d][r], ivc, acc[3][r]);
         }
@@ -1764,8 +1768,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         half_scale(wm, sc, inv);
       }
 #if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 4)
-      if (lane == 0 && s0 + 4 * wave < s_end)   // one byte per wave: [t][dir][tile][producer][8]: group `wave` of the producer's four
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(__float_as_uint(inv) >> 23), rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * 8 + wave), 0, kSc1);
+      if (lane == 0 && s0 + 4 * wave < s_end) {   // one 16-byte word per wave (a whole-word write-through store; sub-dword ones cost 900 ticks of drain): [t][dir][tile][producer][4 groups]
+        const f32x4 iv4 = {inv, inv, inv, inv};
+        __builtin_amdgcn_raw_buffer_store_b128(iv4, rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * 64 + wave * 16), 0, kSc1);
+      }
 #endif
       if (e_ok) {
         const f32x4 out = {dg, di, df, dob};
@@ -1774,13 +1780,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         const unsigned h0 = rne_f16(x0), h1 = rne_f16(x1), h2 = rne_f16(x2), h3 = rne_f16(x3);
         const unsigned l0 = rne_f16(x0 - f16_bits_to_f32(h0)), l1 = rne_f16(x1 - f16_bits_to_f32(h1));
         const unsigned l2 = rne_f16(x2 - f16_bits_to_f32(h2)), l3 = rne_f16(x3 - f16_bits_to_f32(h3));
-        // per 8 k values (two units) 32 bytes: [8 x hi][8 x lo]; this unit's four gates are the first or the second half of each
-        const unsigned oh = (o32 & ~31u) + (unsigned)(u_e & 1) * 8u;
-        f32x2_t ph = {__uint_as_float(h0 | (h1 << 16)), __uint_as_float(h2 | (h3 << 16))};
-        f32x2_t pl = {__uint_as_float(l0 | (l1 << 16)), __uint_as_float(l2 | (l3 << 16))};
+        // this unit's 16 bytes (where its fp32 gradients sit in DG): [4 x hi][4 x lo] -- ONE whole-word store per lane, the 16 lanes of a
+        // row cover 256 contiguous bytes (two 8-byte stores with holes between the lanes' pieces cost 1400 ticks of drain)
+        const f32x4 pp = {__uint_as_float(h0 | (h1 << 16)), __uint_as_float(h2 | (h3 << 16)), __uint_as_float(l0 | (l1 << 16)), __uint_as_float(l2 | (l3 << 16))};
 #if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 1)
-        __builtin_amdgcn_raw_buffer_store_b64(ph, rDH, oh, 0, kSc1);
-        __builtin_amdgcn_raw_buffer_store_b64(pl, rDH, oh + 16u, 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b128(pp, rDH, o32, 0, kSc1);
 #endif
         // the fp32 gradients LAST: nobody reads them before the kernel ends (the GEMMs and the bias / peephole passes do), so the
         // drain in front of the publish leaves this one store in flight (s_waitcnt vmcnt(1) below)
@@ -2440,7 +2444,7 @@ static bool bwd_planes_shape(const LstmLayerDev& L) {
   return lstm_bwd_ksplit_px_floats(L) != 0 && (cpw == 2 || cpw == 4) && (4 * L.H / 4) % (32 * NW) == 0;
 }
 size_t lstm_bwd_planes_ex_floats(const LstmLayerDev& L) {
-  return bwd_planes_shape(L) ? ((size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 16) * 8 + 3) / 4 : 0;   // eight bytes per (t, dir, tile, producer): four used
+  return bwd_planes_shape(L) ? (size_t)L.T * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 16) * 16 : 0;   // 64 bytes per (t, dir, tile, producer)
 }
 
 RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
