@@ -1658,8 +1658,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         const bool ok = sa < s_end && blk * 32 < KQ;
         const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
         // two units' blocks of [4 x hi][4 x lo]: the hi halves of both make the A fragment's eight hi values, the lo halves its eight lo
-        const f32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, kSc1);
-        const f32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, kSc1);
+        // (PLAIN loads, like ld8_sc1 above: every line is read for the first time in this launch, and the 16 workgroups of an XCD that
+        // read the same quarter share one fabric fetch through its L2; with L1-bypassing sc1 loads each pulled its own copy: 25 GB/s per CU)
+        const f32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, 0);
+        const f32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, 0);
         ah[c] = f32x4{u0[0], u0[1], u1[0], u1[1]};
         al[c] = f32x4{u0[2], u0[3], u1[2], u1[3]};
         const int prod = ku * (int)nprod + blk / 2;
@@ -1668,7 +1670,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 #else
         const bool iok = blk * 32 < KQ;
 #endif
-        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 64 + kq * 16) : kOob, 0, kSc1);
+        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 64 + kq * 16) : kOob, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1776,13 +1778,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       if (e_ok) {
         const f32x4 out = {dg, di, df, dob};
         const unsigned o32 = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
-        const float x0 = dg * sc, x1 = di * sc, x2 = df * sc, x3 = dob * sc;      // exact
-        const unsigned h0 = rne_f16(x0), h1 = rne_f16(x1), h2 = rne_f16(x2), h3 = rne_f16(x3);
-        const unsigned l0 = rne_f16(x0 - f16_bits_to_f32(h0)), l1 = rne_f16(x1 - f16_bits_to_f32(h1));
-        const unsigned l2 = rne_f16(x2 - f16_bits_to_f32(h2)), l3 = rne_f16(x3 - f16_bits_to_f32(h3));
+        const f32x2_t x01 = {dg * sc, di * sc}, x23 = {df * sc, dob * sc};         // exact
+        const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);   // v_cvt_pk_f16_f32: round to nearest even
+        const f32x2_t r01 = {x01[0] - (float)h01[0], x01[1] - (float)h01[1]}, r23 = {x23[0] - (float)h23[0], x23[1] - (float)h23[1]};   // exact
+        const f16x2_t l01 = __builtin_convertvector(r01, f16x2_t), l23 = __builtin_convertvector(r23, f16x2_t);
         // this unit's 16 bytes (where its fp32 gradients sit in DG): [4 x hi][4 x lo] -- ONE whole-word store per lane, the 16 lanes of a
         // row cover 256 contiguous bytes (two 8-byte stores with holes between the lanes' pieces cost 1400 ticks of drain)
-        const f32x4 pp = {__uint_as_float(h0 | (h1 << 16)), __uint_as_float(h2 | (h3 << 16)), __uint_as_float(l0 | (l1 << 16)), __uint_as_float(l2 | (l3 << 16))};
+        const f32x4 pp = {__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23)};
 #if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 1)
         __builtin_amdgcn_raw_buffer_store_b128(pp, rDH, o32, 0, kSc1);
 #endif
