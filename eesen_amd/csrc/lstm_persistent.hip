@@ -1650,20 +1650,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
       const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
       constexpr unsigned kOob = 0x80000000u;
-      f32x4 ah[CPW], al[CPW];
+      f32x4 u0[CPW], u1[CPW];   // per k block two units' words of [4 x hi][4 x lo]; regrouped into the A fragments at their use (below)
       unsigned iv[CPW];   // the inverse powers' exponent bytes of the producer's four 4-sequence groups (this lane's accumulator registers hold group kq: C/D map row = 4 * kq + reg)
+      // the inverse powers first (four bytes per lane and k block: back long before the planes; the first fold needs them)
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int blk = wave + c * NW;                     // 32-wide k block of the quarter: inside producer ku * nprod + blk / 2
-        const bool ok = sa < s_end && blk * 32 < KQ;
-        const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
-        // two units' blocks of [4 x hi][4 x lo]: the hi halves of both make the A fragment's eight hi values, the lo halves its eight lo
-        // (PLAIN loads, like ld8_sc1 above: every line is read for the first time in this launch, and the 16 workgroups of an XCD that
-        // read the same quarter share one fabric fetch through its L2; with L1-bypassing sc1 loads each pulled its own copy: 25 GB/s per CU)
-        const f32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, 0);
-        const f32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, 0);
-        ah[c] = f32x4{u0[0], u0[1], u1[0], u1[1]};
-        al[c] = f32x4{u0[2], u0[3], u1[2], u1[3]};
         const int prod = ku * (int)nprod + blk / 2;
 #if defined(EESEN_PROBE_KH) && (EESEN_PROBE_KH & 2)
         const bool iok = false;
@@ -1672,19 +1664,35 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 #endif
         iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 64 + kq * 16) : kOob, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int blk = wave + c * NW;
+        const bool ok = sa < s_end && blk * 32 < KQ;
+        const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
+        // (PLAIN loads, like ld8_sc1 above: every line is read for the first time in this launch, and the 16 workgroups of an XCD that
+        // read the same quarter share one fabric fetch through its L2; with L1-bypassing sc1 loads each pulled its own copy: 25 GB/s per CU)
+        u0[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, 0);
+        u1[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA -- and nothing that reads a loaded register (the
+                                          // regrouping moves: they would wait for every load) on this side of the fence
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      // the hi halves of both units make the A fragment's eight hi values, the lo halves its eight lo (same lane -> k assignment as W's planes)
+      auto frag_hi = [&](int c) { return f32x4{u0[c][0], u0[c][1], u1[c][0], u1[c][1]}; };
+      auto frag_lo = [&](int c) { return f32x4{u0[c][2], u0[c][3], u1[c][2], u1[c][3]}; };
       // pass 1: the siblings' three blocks (three chains interleaved); per k block lo x hi', hi x lo', hi x hi' into a temporary, folded
       // into the accumulator with the producer's inverse power
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         f32x4 tmp[3];
+        const f32x4 ahc = frag_hi(c), alc = frag_lo(c);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), zero4, 0, 0, 0);
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, alc), __builtin_bit_cast(f16x8_t, bh[n][c]), zero4, 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bl[n][c]), tmp[n], 0, 0, 0);
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ahc), __builtin_bit_cast(f16x8_t, bl[n][c]), tmp[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c]), __builtin_bit_cast(f16x8_t, bh[n][c]), tmp[n], 0, 0, 0);
+        for (int n = 0; n < 3; ++n) tmp[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ahc), __builtin_bit_cast(f16x8_t, bh[n][c]), tmp[n], 0, 0, 0);
         const float ivc = __uint_as_float(iv[c]);
 #pragma unroll
         for (int n = 0; n < 3; ++n)
@@ -1716,12 +1724,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 #pragma unroll
       for (int c = 0; c < CPW; c += 2) {
         f32x4 tmp[2];
+        const f32x4 ah2[2] = {frag_hi(c), frag_hi(c + 1)}, al2[2] = {frag_lo(c), frag_lo(c + 1)};
 #pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), zero4, 0, 0, 0);
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al2[d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), zero4, 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bl[3][c + d]), tmp[d], 0, 0, 0);
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah2[d]), __builtin_bit_cast(f16x8_t, bl[3][c + d]), tmp[d], 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah[c + d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), tmp[d], 0, 0, 0);
+        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah2[d]), __builtin_bit_cast(f16x8_t, bh[3][c + d]), tmp[d], 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const float ivc = __uint_as_float(iv[c + d]);

@@ -16,5 +16,5 @@ for line in sys.stdin:
 run bwd_f32 EESEN_BWD_F16=0 EESEN_TRACE=1
 run bwd_f16 EESEN_BWD_F16=1 EESEN_TRACE=1
 run bwd_f16_again EESEN_BWD_F16=1
-for n in 1 4 7; do run probe$n EESEN_HIP_LIBRARY=$PWD/eesen_amd/lib/variants/libeesen_hip_khprobe$n.so EESEN_TRACE=1; done
+for n in 4 7; do run probe$n EESEN_HIP_LIBRARY=$PWD/eesen_amd/lib/variants/libeesen_hip_khprobe$n.so EESEN_TRACE=1; done
 cat $O/ledger.log
