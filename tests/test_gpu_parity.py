@@ -517,6 +517,39 @@ def test_backward_tiles_agree_and_are_deterministic(gpu, over, monkeypatch):
     assert not np.array_equal(res["1"][0][1], res["0"][0][1])     # two different kernels ran
     assert rel_err(res["1"][0][0], res["0"][0][0]) < 1e-5 and rel_err(res["1"][0][1], res["0"][0][1]) < 1e-5
 
+@pytest.mark.parametrize("over", [dict(T=24, layers=2, H=1024), dict(T=20, layers=1, H=1024, S=64), dict(T=20, layers=1, H=1024, S=24)])
+def test_wide_backward_tile_on_fp16_planes(gpu, over, monkeypatch):
+    """lstm_bwd_persistent_ksplit_h_kernel (round 6, EESEN_BWD_F16): the K-split backward tile of 1024-cell layers with W_m^T and the
+    gate gradients as two fp16 planes each (three products), the gate gradients published a second time as planes with a power of
+    two per wave of their producer.  Against the fp32-input K-split tile (EESEN_BWD_F16=0; at S = 64 its time-multiplexed form) on
+    the same inputs: input gradient and every parameter gradient within 2e-5 (fp32-class products, another summation order), each arm
+    bit-identical run after run, every layer pass persistent, no recovery; ragged sequence tiles (S = 24) included."""
+    from eesen_amd.api import Net, Ctc, CuMatrix
+    cfg = synth.config("cfg2"); cfg.update(over)
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    res, kern = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EESEN_BWD_F16", mode)
+        net = Net.from_layers(layers); ctc = Ctc()
+        runs = []
+        for _ in range(3):
+            net.SetSeqLengths(batch.lens)
+            out = net.Propagate(batch.feats)
+            diff = ctc.EvalParallel(batch.lens, out, batch.labels)
+            idf = CuMatrix(batch.T * batch.S, cfg["D"])
+            net.BackpropagateNoUpdate(diff, idf)
+            runs.append((idf.numpy(), net.GetGrads()))
+        info = net.RecurrenceInfo()
+        assert info["bwd_persistent"] == info["lstm_layers"] == cfg["layers"] and net.recoveries == 0, (mode, info)
+        for r in runs:
+            assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]), mode
+        res[mode] = runs[0]
+        kern[mode] = net.Plan()["layers"][-1]["backward"]["kernel"]
+    assert "ksplit_h" in kern["1"] and "ksplit_h" not in kern["0"] and "ksplit" in kern["0"], kern
+    assert np.isfinite(res["1"][1]).all() and np.abs(res["1"][1]).max() > 0
+    assert rel_err(res["1"][0], res["0"][0]) < 2e-5 and rel_err(res["1"][1], res["0"][1]) < 2e-5
+
+
 @pytest.mark.parametrize("over", [dict(T=40, layers=2), dict(T=33, layers=1, H=256, S=24), dict(T=36, layers=2, S=64),
                                   dict(T=33, layers=2, H=320, D=120, S=32), dict(T=33, layers=2, H=320, D=120, S=64), dict(T=33, layers=1, S=52)])
 def test_two_sequence_tiles_per_backward_workgroup(gpu, over, monkeypatch):
