@@ -32,3 +32,10 @@ for f in ("r06_bench_real_rccl_world1", "r06_bench_two_ranks_persistent", "r06_b
     except Exception as e:
         print(f, "FAILED", e)
 PY
+# the recipe-shape leg at --num-sequence 10 / 32 under the arithmetic switches (where does S = 10 stand against round 5's 20.4 ms?)
+for ns in 10 32; do
+  for e in "EESEN_GEMM_MODE=half" "EESEN_GEMM_MODE=split" "EESEN_GEMM_MODE=split EESEN_FWD_F16=0" "EESEN_GEMM_MODE=half EESEN_FWD_F16=0"; do
+    echo "recipe S=$ns $e: $(env $e timeout 200 python scripts/recipe_ab.py $ns 2>/dev/null | tail -1)" >> $O/recipe_ab.log
+  done
+done
+cat $O/recipe_ab.log
