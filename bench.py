@@ -940,9 +940,9 @@ def main():
                                            6: "fp32 operands split exactly into 3 bf16 terms, 6 of the 9 cross products on v_mfma_f32_32x32x16_bf16 with fp32 "
                                               "accumulation (error <= 2^-23 |ab| per product = one fp32 rounding; measured against fp64 equal to the fp32 chain, "
                                               "tests/test_gpu_gemm.py); recurrence, CTC and update in plain fp32",
-                                           3: "fp32 operands held as TWO fp16 planes (round to nearest at both levels: hi + lo = the value to within 2^-24), each row of "
+                                           3: "fp32 operands held as TWO fp16 planes (round to nearest at both levels: hi + lo = the value to within 2^-22), each row of "
                                               "op(A) / column of op(B) times the power of two its own largest magnitude asks for (measured on the device), 3 of the 4 "
-                                              "cross products on v_mfma_f32_32x32x16_f16 with fp32 accumulation (error ~ 3 * 2^-24 |ab| per product; measured against "
+                                              "cross products on v_mfma_f32_32x32x16_f16 with fp32 accumulation (error <= 3 * 2^-22 |ab| per product, the '3xTF32' arithmetic; measured against "
                                               "fp64 equal to the fp32 chain on every shape of tests/test_gpu_gemm.py); the forward recurrence on the same planes; "
                                               "backward recurrence, CTC and update in plain fp32"}[gprod],
                        "f32_mfma_gemm_only": f32_only, "bf16_split_gemm": bf16_split},

@@ -325,17 +325,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_gated_kernel(GemmParams 
 // are 64 B apart modulo the bank window so that the ds_write_b64 of a k-contiguous loader do not collide either.
 //
 // Round 6: the same body on TWO fp16 planes ("half" mode, PL = 2).  With round-to-nearest at both levels an fp32 value a is
-// hi + lo to within 2^-24 |a| (hi = fp16(a): 11 bits, |a - hi| <= 2^-12 |a|; lo = fp16(a - hi): |a - hi - lo| <= 2^-24 |a| -- the
-// residual is signed, which is worth one bit per level), so
-//     a*b ~ hi*hi' + (hi*lo' + lo*hi'),   |error| <= ~3 * 2^-24 |a*b|   (dropped lo*lo' <= 2^-24 |ab|; two representation errors)
-// THREE products on v_mfma_f32_32x32x16_f16 instead of six on the bf16 form of the same rate, and two planes to split instead
-// of three.  What fp16 lacks is exponent range (5 bits): every operand is multiplied by a power of two that brings ITS largest
-// magnitude into [2^14, 2^15) (half_scale: from a device word holding max |x| or a bound of it -- amax_abs below, or a bound
-// the caller knows, e.g. 1 for an LSTM output), and the epilogue multiplies the two powers back out -- both exact.  hi is then
-// a normal fp16 number down to 2^-29 of the tensor's largest element, lo down to 2^-17 of it; below that they are fp16
-// DENORMALS, which the gfx950 MFMA multiplies exactly (no flush; asserted on the device by tests/test_gpu_gemm.py), so the
-// absolute error of an element never exceeds 2^-40 of the tensor's largest.  Measured against fp64 the two-plane kernel is as
-// accurate as the three-plane one (profiles/r06_gemm_accuracy.json).
+// hi + lo to within 2^-22 |a| (hi = fp16(a): 11 bits, |a - hi| <= 2^-11 |a|; lo = fp16(a - hi): |a - hi - lo| <= 2^-22 |a| -- the
+// worst case; the residuals of two roundings to nearest rarely both sit at half an ulp: 2^-23 is the largest seen over 2 x 10^5
+// random values, tests/test_half_planes_math.py), so
+//     a*b ~ hi*hi' + (hi*lo' + lo*hi'),   |error| <= 3 * 2^-22 |a*b|   (dropped lo*lo' <= 2^-22 |ab|; two representation errors)
+// -- the arithmetic of "3xTF32" (an 11-bit big part and an 11-bit small part, three products): a worst-case bound 12 times the
+// three-bf16-plane split's 2^-23, random in sign from element to element, and MEASURED against fp64 over K-long dot products (where
+// the fp32 accumulation's own rounding dominates either way) equal to the fp32 chain and to the six-product kernel on every shape
+// of tests/test_gpu_gemm.py (profiles/r06_gemm_accuracy.json).  THREE products on v_mfma_f32_32x32x16_f16 instead of six on the
+// bf16 form of the same rate, and two planes to split instead of three.  What fp16 lacks is exponent range (5 bits): every row of
+// op(A) / column of op(B) is multiplied by the power of two that brings ITS largest magnitude into [2^14, 2^15) (half_scale: from
+// device words holding those maxima -- amax_rows_cols below -- or a bound the caller knows, e.g. 1 for an LSTM output), and the
+// epilogue multiplies the two powers back out -- both exact.  Where the residual a 2^s - hi falls below fp16's smallest normal
+// number (2^-14) lo is an fp16 DENORMAL, which the gfx950 MFMA multiplies exactly (no flush; asserted on the device by
+// tests/test_gpu_gemm.py): |a - (hi + lo) 2^-s| <= max(2^-22 |a|, 2^-39 x the row's largest) -- full precision for every element
+// within 2^-15 of its row's largest, an absolute floor 2^-39 of it below that.
 constexpr int kSplitMinW = 3;   // workgroups per CU of the 128 x 128 split kernel; measured: 171 -> 178 TF with two tiles of prefetch, 189 with three workgroups per CU
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

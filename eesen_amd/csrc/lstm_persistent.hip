@@ -397,8 +397,8 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_kernel(LstmLayerD
 //        rounding of m_t is noise.)  Gate pre-activations, cell state, activations and everything stored for the backward
 //        pass (G, C, Y) stay fp32; the backward pass is the fp32 one.
 //   <AP = 2, WP = 2, F16>  (round 6) fp32-class arithmetic on TWO fp16 planes per operand and three products: with round-to-nearest
-//        at both levels an fp32 value is hi + lo to within 2^-24 (gemm.hip, mode 2, has the argument), the dropped lo x lo' is
-//        <= 2^-24 |ab|.  fp16 has 5 exponent bits, so both operands carry an exact power of two: m_t times 2^14 (|m| = |o tanh c| < 1,
+//        at both levels an fp32 value is hi + lo to within 2^-22 (gemm.hip, mode 2, has the argument and the measurements), the dropped
+//        lo x lo' is <= 2^-22 |ab|.  fp16 has 5 exponent bits, so both operands carry an exact power of two: m_t times 2^14 (|m| = |o tanh c| < 1,
 //        so its planes sit in fp16's top binades; what falls into the denormal range is multiplied exactly by the MFMA), W_m times
 //        the power that brings max |W_m| of the layer (LstmLayerDev::wm_amax, measured by the host after every parameter change)
 //        into [2^14, 2^15); the accumulators are multiplied by the inverse on their way to the cell.  12 MFMAs per wave and step at
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_kernel(Lst
 // drain in front of the publish.  The CONSUMER's
 // 32-wide k block lies inside one producer's 64 values, so its three products carry ONE power per output row: they go through a
 // temporary accumulator that is folded into the running one with the row's inverse power (4 FMAs per block and 16-unit tile).
-// Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product ~ 3 * 2^-24 |ab|
+// Same roles, hand-offs and partial-sum exchange as lstm_bwd_persistent_ksplit_kernel.  Error per product <= 3 * 2^-22 |ab|
 // (gemm.hip, "half" mode, has the argument); padding frames publish zeros (scale 2^126: 0 stays 0).
 // Shapes: as the fp32 K-split tile with an even number of k blocks per wave (H = 512, 1024).
 // (Costing probes, never in the product build: -DEESEN_PROBE_KH=1 no plane stores, 2 no exponent loads, 4 no exponent stores.)

@@ -56,9 +56,10 @@ int eesen_device_count(int* count);
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; error <= 2^-23 |a*b| per product, i.e. fp32-GEMM class, at 2.67x the
  *      f32 matrix rate (gfx950 runs f32 MFMA at 1/16 of the bf16 rate and has no TF32 form);
  *   2  two fp16 planes (round 6, the default): every fp32 operand is hi + lo (fp16, round to nearest at both levels: equal to
- *      the value to within 2^-24), each row of op(A) / column of op(B) scaled by the exact power of two its own largest magnitude
+ *      the value to within 2^-22), each row of op(A) / column of op(B) scaled by the exact power of two its own largest magnitude
  *      asks for (measured on the device), three of the four cross products on v_mfma_f32_32x32x16_f16 with fp32 accumulation;
- *      error ~ 3 * 2^-24 |a*b| per product -- the same class -- at 1.58x the rate of mode 1;
+ *      error <= 3 * 2^-22 |a*b| per product (the "3xTF32" arithmetic; measured against fp64 equal to modes 0 and 1,
+ *      tests/test_gpu_gemm.py) at 1.58x the rate of mode 1;
  *  -1  follow the environment (EESEN_GEMM_MODE=f32|split|half; half when unset), the initial state. */
 int eesen_set_gemm_mode(int mode);
 int eesen_get_gemm_mode(int* mode);

@@ -2,8 +2,9 @@
 
 Mode 0 (f32-input MFMA) is an exact fp32 fmaf chain.  Mode 1 splits every fp32 operand into three bf16 terms and runs
 six bf16 MFMA products with fp32 accumulation; its error bound is 2^-23 |a*b| per product, the class of ONE fp32 rounding.
-Mode 2 (round 6) holds every operand as two fp16 planes (round to nearest at both levels: 2^-24 relative), scaled by a power
-of two so that its largest magnitude sits in fp16's top binades, and runs three fp16 MFMA products: ~3 * 2^-24 |a*b| per product.
+Mode 2 (round 6) holds every operand as two fp16 planes (round to nearest at both levels: 2^-22 relative in the worst case), every row /
+column scaled by a power of two so that its largest magnitude sits in fp16's top binades, and runs three fp16 MFMA products: <= 3 * 2^-22
+|a*b| per product (the "3xTF32" arithmetic).
 The test measures all three against fp64, normalised by sum_k |a||b| (the quantity round-off scales with), over every operand
 layout, ragged shapes, split-K shapes and the bias / alpha / beta epilogue, and requires the plane modes to be as accurate
 as the fp32 chain."""
