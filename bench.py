@@ -727,35 +727,29 @@ def main():
     f32_only = None
     bf16_split = None
     if world == 1 and not args.main_only and gemm_products() == 3:
-        lib = _lib.load()
-        main_net = net
-        for mode, label in ((0, "v_mfma_f32_32x32x2_f32 (EESEN_GEMM_MODE=f32)"),
-                            (1, "three bf16 planes per operand, six products on v_mfma_f32_32x32x16_bf16 (EESEN_GEMM_MODE=split: the default of rounds 2-5)")):
-            _lib.check(lib.eesen_set_gemm_mode(mode))
+        # Each in its OWN process (this script with --main-only and EESEN_GEMM_MODE set): a second Net of another arithmetic inside this
+        # process measured 40.1-41.3 ms for the six-product mode where a process of its own measures 35.8 (the step time of that mode is
+        # bimodal with where the Net's buffers land, scripts/leg_artifact.py) -- a comparison must not depend on that draw.  This process
+        # idles meanwhile.
+        import subprocess
+        for mode, env_mode, label in ((0, "f32", "v_mfma_f32_32x32x2_f32 (EESEN_GEMM_MODE=f32)"),
+                                      (1, "split", "three bf16 planes per operand, six products on v_mfma_f32_32x32x16_bf16 (EESEN_GEMM_MODE=split: the default of "
+                                                   "rounds 2-5; the recurrences as in the headline)")):
             try:
-                # two fresh Nets, the faster one counts: a Net's step time is bimodal with where its buffers happen to land (seen with the
-                # six-product GEMMs: 35.7 / 40.4 ms in one process, scripts/leg_artifact.py), and a comparison leg must not be the slow draw
-                tries = []
-                for _ in range(2):
-                    net = make_net()          # schedule defaults (gating, side-stream occupancy) follow the mode
-                    for _ in range(2):
-                        step()
-                    barrier()
-                    t2 = time.perf_counter()
-                    for _ in range(args.steps):
-                        step()
-                    barrier()
-                    tries.append(time.perf_counter() - t2)
-                dt2 = min(tries)
-                rec = {"ms_per_step": 1e3 * dt2 / args.steps, "frames_per_s": float(batch.T * batch.S) * args.steps / dt2, "gemm": label,
-                       "ms_per_step_of_two_nets": [1e3 * t / args.steps for t in tries]}
-                if mode == 0:
-                    f32_only = rec
-                else:
-                    bf16_split = rec
-            finally:
-                net = main_net
-                _lib.check(lib.eesen_set_gemm_mode(-1))
+                cmd = [sys.executable, os.path.abspath(__file__), "--main-only", "--steps", str(args.steps), "--warmup", str(max(2, args.warmup)), "--config", args.config,
+                       "--forward-precision", args.forward_precision]
+                for k in ("T", "H", "S", "layers"):
+                    if getattr(args, k):
+                        cmd += ["--" + k, str(getattr(args, k))]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "EESEN_GEMM_MODE": env_mode})
+                d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+                rec = {"ms_per_step": d2["ms_per_step"], "frames_per_s": d2["value"], "gemm": label, "how": "its own process: " + " ".join(cmd[1:]) + f" with EESEN_GEMM_MODE={env_mode}"}
+            except Exception as e:   # noqa: BLE001 -- a comparison leg must never take the measurement down
+                rec = {"error": str(e)}
+            if mode == 0:
+                f32_only = rec
+            else:
+                bf16_split = rec
 
     # Not the headline: the same K steps with the features already RESIDENT in HBM (what rounds 1-4 reported as `value`): what the
     # per-step H2D costs the step is the difference (the copy and the interleave of minibatch n + 1 run on the feeder's stream under
