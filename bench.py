@@ -453,6 +453,19 @@ def recipe_leg(dev: int, num_sequence: int, n_utts: int = 120, frame_limit: int 
             "persistent_layer_passes": {"fwd": pers[0], "bwd": pers[1], "of": pers[2]}, "recoveries": net.recoveries}
 
 
+def secondary_legs(dev: int) -> dict:
+    """name -> callable: the other single-GPU BASELINE configurations and the reference's own recipe shape (config.secondary)."""
+    # (10 / 5 timed steps: three were inside the box-to-box noise for comparing the cfg4 legs with each other)
+    return {"cfg2_S64": lambda: secondary_leg("cfg2", dev, steps=10, warmup=2, over=dict(S=64)),
+            "cfg4": lambda: secondary_leg("cfg4", dev, steps=10, warmup=2),
+            "cfg4_bf16_forward": lambda: secondary_leg("cfg4", dev, steps=10, warmup=2, forward_bf16=True),
+            "cfg5": lambda: secondary_leg("cfg5", dev, steps=4, warmup=1),
+            "wsj_recipe_shape_S10": lambda: recipe_leg(dev, 10), "wsj_recipe_shape_S20": lambda: recipe_leg(dev, 20),
+            # the same shape with the minibatch this part wants (INTEGRATION.md "Which --num-sequence"): the frame limit raised
+            # so that --num-sequence is what bounds a minibatch
+            "wsj_recipe_shape_S32": lambda: recipe_leg(dev, 32, 256, 100000), "wsj_recipe_shape_S64": lambda: recipe_leg(dev, 64, 256, 100000)}
+
+
 def check_full_cfg3(comm, dev: int, rank: int, world: int, all_reduce) -> dict:
     """--check full_cfg3 (N = 8): SURVEY.md section 8e's parity statement through the REAL exchange.  Rank r runs shard r of the global
     minibatch of BASELINE configs[2] (256 utterances, T = 1000, 4 x 512; the interleaved deal of eesen_amd.parallel.shard_batch) with
@@ -549,7 +562,11 @@ def main():
                     help="N = 8 only: before the timed steps, the eight shards of BASELINE configs[2]'s global minibatch (256 utterances) through the "
                          "communicator -- the all-reduced gradient against tests/golden/full_cfg3.npz (ONE reference process at --num-sequence "
                          "256) at the fixture's bars; the result goes into the line as config.check_full_cfg3")
+    ap.add_argument("--leg", default=None, help="(internal) run ONE leg of config.secondary in this process and print its record as a JSON line")
     args = ap.parse_args()
+    if args.leg:
+        print(json.dumps(secondary_legs(0)[args.leg]()), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
     # stdout carries exactly ONE JSON line: everything else that C libraries print there (RCCL prints its version banner on
@@ -988,17 +1005,14 @@ def main():
             # the other single-GPU BASELINE configurations and the reference's own recipe shape, driver-timed in the same run
             del net, feats_dev, diff, feeder
             sec = {}
-            # (10 / 5 timed steps: three were inside the box-to-box noise for comparing the cfg4 legs with each other)
-            for name, fn in (("cfg2_S64", lambda: secondary_leg("cfg2", dev, steps=10, warmup=2, over=dict(S=64))),
-                             ("cfg4", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2)),
-                             ("cfg4_bf16_forward", lambda: secondary_leg("cfg4", dev, steps=10, warmup=2, forward_bf16=True)),
-                             ("cfg5", lambda: secondary_leg("cfg5", dev, steps=4, warmup=1)),
-                             ("wsj_recipe_shape_S10", lambda: recipe_leg(dev, 10)), ("wsj_recipe_shape_S20", lambda: recipe_leg(dev, 20)),
-                             # the same shape with the minibatch this part wants (INTEGRATION.md "Which --num-sequence"): the frame limit raised
-                             # so that --num-sequence is what bounds a minibatch
-                             ("wsj_recipe_shape_S32", lambda: recipe_leg(dev, 32, 256, 100000)), ("wsj_recipe_shape_S64", lambda: recipe_leg(dev, 64, 256, 100000))):
+            # Every leg in a process of its OWN (this script with --leg NAME): a Net's step time depends on what the process allocated and
+            # freed before it -- measured: cfg4 71.1-72.1 ms after one allocation history, 77.5 after another; the recipe leg at
+            # --num-sequence 10 19.5 / 23.7 -- and a trainer is one Net per process.  This process has released its own Net and idles meanwhile.
+            import subprocess
+            for name in secondary_legs(dev):
                 try:
-                    sec[name] = fn()
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name], capture_output=True, text=True, timeout=900)
+                    sec[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
                 except Exception as e:  # noqa: BLE001
                     sec[name] = {"error": str(e)}
             line["config"]["secondary"] = sec
