@@ -39,6 +39,20 @@ def _bench(args, env_extra, timeout=900):
     return json.loads(lines[0]), r.stderr
 
 
+def test_bench_secondary_leg_runs_as_a_process_of_its_own(gpu):
+    """`bench.py --leg NAME` (round 6): what the default bench run starts once per leg of config.secondary -- a Net's step time depends on
+    its process's allocation history, so every leg gets a fresh process.  One JSON record on stdout, every layer pass persistent."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--leg", "wsj_recipe_shape_S10"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert 5.0 < d["ms_per_minibatch"] < 100.0 and d["recoveries"] == 0
+    assert d["persistent_layer_passes"]["fwd"] == d["persistent_layer_passes"]["bwd"] == d["persistent_layer_passes"]["of"] > 0
+
+
 def test_bench_line_describes_the_real_rccl_at_world_size_one(gpu):
     """The self-describing N > 1 line with the REAL librccl, at the only world size a one-GPU box offers:
     `config.comm` names the library the linker resolved (not the stand-in), its version, the one rank RCCL itself counts, the
