@@ -565,12 +565,15 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_persistent_bf_kernel(LstmLay
     __syncthreads();
     EESEN_STAMP(2);
     if (e_act) {
+      // the eight waves' partial sums: ALL eight LDS reads in flight, then the sum in the same order (hipcc kept two in flight and
+      // waited for each in turn: eight ~100-cycle round trips on the step's critical path)
+      float4 pv[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) pv[w] = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
+      __builtin_amdgcn_sched_barrier(0);
       float4 pre = gx;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const float4 v = *reinterpret_cast<const float4*>(&red[w][es][eu * 4]);
-        pre.x += v.x; pre.y += v.y; pre.z += v.z; pre.w += v.w;
-      }
+      for (int w = 0; w < NW; ++w) { pre.x += pv[w].x; pre.y += pv[w].y; pre.z += pv[w].z; pre.w += pv[w].w; }
       float g = tanhf_(pre.x);
       float i = sigmoidf_(pre.y + p_i * cprev);
       float f = sigmoidf_(pre.z + p_f * cprev);
@@ -1219,9 +1222,14 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_q4_kernel(LstmLay
     EESEN_STAMP(2);
     __syncthreads();
     if (e_ok) {
+      // (all sixteen LDS reads in flight, then the sum in the same order: see the forward kernel)
+      float ra[NW], rb[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { ra[w] = red[w][(es >> 2) * 8 + (es & 3)][eu]; rb[w] = red[w][(es >> 2) * 8 + 4 + (es & 3)][eu]; }
+      __builtin_amdgcn_sched_barrier(0);
       float dm = dyc;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) dm += red[w][(es >> 2) * 8 + (es & 3)][eu] + red[w][(es >> 2) * 8 + 4 + (es & 3)][eu];
+      for (int w = 0; w < NW; ++w) dm += ra[w] + rb[w];
       const float g = gtc.x, i = gtc.y, f = gtc.z, o = gtc.w;
       const float h = tanhf_(ctc);
       const float dh = (1.f - h * h) * (dm * o);
@@ -1711,9 +1719,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
         const int o = tid + h * (NW * 64);
         if (o < ST * 48) {
           const int sq = o / 48, uc = o % 48, n = uc >> 4, dst = n + (n >= ku ? 1 : 0);
+          float rv[NW];   // (all eight LDS reads in flight, then the sum in the same order)
+#pragma unroll
+          for (int w = 0; w < NW; ++w) rv[w] = red[w][sq][uc];
           float v = 0.f;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
+          for (int w = 0; w < NW; ++w) v += rv[w];
           px_put(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, (unsigned)step);
         }
       }
@@ -1748,8 +1759,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
       EESEN_STAMP(2);
       __syncthreads();
       if (e_ok) {   // the three siblings' partial sums: they run in lockstep with this workgroup, the words left them a pass ago
+        float rv[NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) dm_in += red2[w][es][eu];
+        for (int w = 0; w < NW; ++w) rv[w] = red2[w][es][eu];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dm_in += rv[w];
         if (!px_take<KU>(px, ku, es * 16 + eu, (unsigned)step, err, spin_limit, sw, dm_in)) {
           __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           s_fail = 1;

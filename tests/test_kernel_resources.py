@@ -38,7 +38,7 @@ BUDGETS = {
     # cfg2 (4 x 512, S = 32): backward 4 x 32 tile, forward narrow bf16-pipe tile, the side-stream / early-middle GEMM flavour
     "lstm_bwd_persistent_q4_kernel<8,4>": (168, 74 * 1024),
     "lstm_fwd_persistent_bf_kernel<2,2,3,3,false>": (112, 19 * 1024),
-    "lstm_fwd_persistent_bf_kernel<2,2,2,2,true>": (88, 19 * 1024),     # round 6: two fp16 planes, three products (the default narrow tile)
+    "lstm_fwd_persistent_bf_kernel<2,2,2,2,true>": (96, 19 * 1024),     # round 6: two fp16 planes, three products (the default narrow tile)
     # cfg2 at S = 64: two 4-sequence tiles per workgroup; recipe width 320: <6,4>; H = 256: <4,4> (the one tile RCCL fits beside)
     "lstm_bwd_persistent_q4_kernel<8,8>": (192, 81 * 1024),
     "lstm_bwd_persistent_q4_kernel<6,4>": (160, 9 * 1024),
