@@ -117,7 +117,6 @@ struct LstmLayerDev {
   // second time, as planes with a per-(producer, sequence) power of two ([T*S x ndir*4H] words of 4 bytes: the fp32 rows' bytes), EX = the
   // inverse powers ([T][ndir][ceil(S/16)][H/16][4 groups of 4 sequences] words of 16 bytes); both null: not offered (lstm_bwd_planes_floats)
   int bwd_f16 = 0;
-  int bwd_k8 = 0;   // ... with K split eight ways instead of four (half the operand fetch per workgroup; tuning.h: EESEN_BWD_K8)
   unsigned char* DGH = nullptr;
   float* EX = nullptr;
 };

@@ -1835,305 +1835,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_h_kernel(L
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fp16-plane K-split tile with K split KU ways (round 6, last session): KU = 4 is the tile above; KU = 8 (LstmLayerDev::bwd_k8,
-// EESEN_BWD_K8) holds 128 units x ONE EIGHTH of K -- the same 256 KB of W_m^T, the same 48 MFMAs per wave and step -- and fetches 32 KB
-// of planes per step instead of 64: the fp16-plane step is bound by that fetch (64 KB arriving over 1.8 us with 0.65 us of MFMA under
-// it), not by the MFMAs any more.  The price: seven sibling blocks of partial sums instead of three (7 x 2 KB per workgroup and step
-// through the tagged-word exchange), summed tile by tile without an accumulator array.
-// ------------------------------------------------------------------------------------------------
-template <int KU>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_persistent_ksplit_hk_kernel(LstmLayerDev L, const float* __restrict__ dY, int lddy,
-                                                                               float* __restrict__ DG, unsigned long long* __restrict__ PX, unsigned* cnt,
-                                                                               unsigned* err, int spin_limit, Role R, int chunk, unsigned long long* trace) {
-  constexpr int ST = 16, UW = 16 * KU, NT = KU, CPW = 16 / KU;   // H = 1024: K / KU = 4096 / KU gate gradients in 8 waves x CPW blocks of 32
-  constexpr int TB = 4 / CPW;                                     // sibling tiles per batch: four independent MFMA chains (tiles x k blocks) at a time
-  __shared__ float red[NW][ST][(KU - 1) * 16 + 1];   // partial sums of the KU - 1 sibling blocks, per wave
-  __shared__ float red2[NW][ST][16 + 1];   // ... of the own block
-  __shared__ int s_go, s_fail;
-  __shared__ float park[6][ST * 16];       // the cell threads' peephole weights (loop-invariant) and carries (d_c f, d_i, d_f): read once per step, and the register file is full
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = L.H, S = L.S, T = L.T;
-  const int ldY = L.ndir * H, ldG = L.ndir * 4 * H, K4 = 4 * H, KQ = K4 / KU;
-  const int bx = R.unit_group(blockIdx.x), dir = R.dir(blockIdx.x), bz = R.seq_group(blockIdx.x);
-  const int uu = bx / KU, ku = bx % KU;
-  const int um0 = uu * UW, uc0 = um0 + ku * 16;            // units of the MFMA outputs / of the cell update
-  const int s0 = L.s_begin + bz * ST;
-  const int s_end = L.s_begin + (L.s_count ? L.s_count : S);
-  const int g = dir * R.nz + bz, ngroups = R.ndir * R.nz, nub = H / UW;
-  const unsigned nprod = (unsigned)(H / KU / 16);          // producers of one K quarter
-  const int NP = H / 16;                                   // producers (16-unit groups) per direction
-  const int NZ = (S + ST - 1) / ST, zt = s0 / ST;          // 16-sequence tiles of the whole batch / this workgroup's
-  static_assert(CPW % 2 == 0 && CPW * TB == 4, "KU = 4 or 8");
-  unsigned* wait_cnt = cnt + (size_t)(g * KU + ku) * kShards * kShardStride;
-  unsigned* pub_cnt = cnt + (size_t)(g * KU + uc0 / (H / KU)) * kShards * kShardStride + (size_t)(((uc0 / 16) % (int)nprod) & (kShards - 1)) * kShardStride;
-
-  const int li = lane & 15, kq = lane >> 4;
-  const int sa = s0 + li;
-  // this wave's part of W_m^T as two fp16 planes of 2^s W (s from the layer's max |W_m|): 64 unit rows x its CPW blocks of the K quarter
-  float wscale, winv;
-  half_scale(L.wm_amax, wscale, winv);
-  f32x4 bh[NT][CPW], bl[NT][CPW];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int ut = n == NT - 1 ? ku : n + (n >= ku ? 1 : 0);
-    const float* Br = L.WmT + ((size_t)dir * H + um0 + ut * 16 + li) * K4 + (size_t)ku * KQ;
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      float w[8];
-      ld8_plain(Br, (wave + c * NW) * 32 + kq * 8, KQ, true, w);
-      f32x4 ph, pl;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float w0 = w[2 * j] * wscale, w1 = w[2 * j + 1] * wscale;     // exact (a power of two)
-        const unsigned h0 = rne_f16(w0), h1 = rne_f16(w1);
-        const unsigned l0 = rne_f16(w0 - f16_bits_to_f32(h0)), l1 = rne_f16(w1 - f16_bits_to_f32(h1));
-        ph[j] = __uint_as_float(h0 | (h1 << 16));
-        pl[j] = __uint_as_float(l0 | (l1 << 16));
-      }
-      bh[n][c] = ph; bl[n][c] = pl;
-    }
-  }
-  const int es = tid >> 4, eu = tid & 15;
-  const int s_e = s0 + es, u_e = uc0 + eu;
-  const bool e_act = tid < ST * 16;            // the cell waves: whole DPP rows of 16 threads per sequence
-  const bool e_ok = e_act && s_e < s_end;
-  int len = 0;
-  if (e_act) {
-    float p_i = 0.f, p_f = 0.f, p_o = 0.f;
-    if (e_ok) {
-      const float* pp = L.peep + (size_t)dir * 3 * H + u_e;
-      p_i = pp[0]; p_f = pp[H]; p_o = pp[2 * H];
-      len = L.lens[s_e];
-    }
-    park[0][tid] = p_i; park[1][tid] = p_f; park[2][tid] = p_o;
-    park[3][tid] = 0.f; park[4][tid] = 0.f; park[5][tid] = 0.f;
-  }
-  const size_t gcol = (size_t)dir * K4 + u_e * 4;
-  const size_t ycol = (size_t)dir * H + u_e;
-  float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dy = 0.f, c_t = 0.f, c_p = 0.f;
-  {
-    const int t0 = dir == 0 ? T - 1 : 0, tp0 = dir == 0 ? t0 - 1 : t0 + 1;
-    if (e_ok) {
-      gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t0 * S + s_e) * ldG + gcol);
-      dy = dY[(size_t)(t0 * S + s_e) * lddy + ycol];
-      c_t = L.C[(size_t)((t0 + 1) * S + s_e) * ldY + ycol];
-      c_p = L.C[(size_t)((tp0 + 1) * S + s_e) * ldY + ycol];
-    }
-  }
-  if (tid == 0) s_fail = 0;   // (the first barrier of step 1 orders it)
-  __amdgpu_buffer_rsrc_t rDG = make_rsrc(DG);   // re-based once per chunk of steps (gate gradients beyond 2 GB), see lstm_bwd_persistent_kernel
-  __amdgpu_buffer_rsrc_t rDH = make_rsrc(reinterpret_cast<const float*>(L.DGH));   // the planes: the fp32 rows' bytes, the same offsets
-  const __amdgpu_buffer_rsrc_t rEX = make_rsrc(L.EX);     // bytes
-  int tbS = 0;
-
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? T - 1 - step : step;
-    const int tn = dir == 0 ? t + 1 : t - 1;
-    if (chunk < T && step % chunk == 0) {
-      const int tb = dir == 0 ? max(0, T - step - chunk) : max(0, step - 1);
-      tbS = tb * S;
-      rDG = make_rsrc(DG + (size_t)tbS * ldG);
-      rDH = make_rsrc(reinterpret_cast<const float*>(L.DGH) + (size_t)tbS * ldG);
-    }
-    float dm_in = 0.f;
-    EESEN_STAMP(0);
-    if (step > 0) {
-      if (wave == EESEN_POLL_WAVE) {
-        const bool go = wait_counters(wait_cnt, nprod, (unsigned)step, err, spin_limit, lane, L.poll_delay);
-        if (lane == 0) s_go = go ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_go) return;
-      EESEN_STAMP(1);
-      f32x4 acc3 = {0.f, 0.f, 0.f, 0.f};   // the own block's partial sums
-      const size_t arow = ((size_t)(tn * S - tbS + sa) * ldG + (size_t)dir * K4 + (size_t)ku * KQ) * 4;
-      constexpr unsigned kOob = 0x80000000u;
-      f32x4 u0[CPW], u1[CPW];   // per k block two units' words of [4 x hi][4 x lo]; regrouped into the A fragments at their use (below)
-      unsigned iv[CPW];   // the inverse powers' exponent bytes of the producer's four 4-sequence groups (this lane's accumulator registers hold group kq: C/D map row = 4 * kq + reg)
-      // the inverse powers first (four bytes per lane and k block: back long before the planes; the first fold needs them)
-#pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        const int blk = wave + c * NW;                     // 32-wide k block of the quarter: inside producer ku * nprod + blk / 2
-        const int prod = ku * (int)nprod + blk / 2;
-#if defined(EESEN_PROBE_KH) && (EESEN_PROBE_KH & 2)
-        const bool iok = false;
-#else
-        const bool iok = blk * 32 < KQ;
-#endif
-        iv[c] = __builtin_amdgcn_raw_buffer_load_b32(rEX, iok ? (unsigned)((((size_t)(tn * L.ndir + dir) * NZ + zt) * NP + prod) * 64 + kq * 16) : kOob, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < CPW; ++c) {
-        const int blk = wave + c * NW;
-        const bool ok = sa < s_end && blk * 32 < KQ;
-        const unsigned off = (unsigned)(arow + (size_t)(blk * 32 + kq * 8) * 4);
-        // (PLAIN loads, like ld8_sc1 above: every line is read for the first time in this launch, and the 16 workgroups of an XCD that
-        // read the same quarter share one fabric fetch through its L2; with L1-bypassing sc1 loads each pulled its own copy: 25 GB/s per CU)
-        u0[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off : kOob, 0, 0);
-        u1[c] = __builtin_amdgcn_raw_buffer_load_b128(rDH, ok ? off + 16u : kOob, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // all loads in flight BEFORE the first MFMA -- and nothing that reads a loaded register (the
-                                          // regrouping moves: they would wait for every load) on this side of the fence
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      // the hi halves of both units make the A fragment's eight hi values, the lo halves its eight lo (same lane -> k assignment as W's planes)
-      auto frag_hi = [&](int c) { return f32x4{u0[c][0], u0[c][1], u1[c][0], u1[c][1]}; };
-      auto frag_lo = [&](int c) { return f32x4{u0[c][2], u0[c][3], u1[c][2], u1[c][3]}; };
-      // pass 1: the siblings' KU - 1 blocks, TB tiles at a time: per tile and k block lo x hi', hi x lo', hi x hi' into a temporary (TB x CPW = 4
-      // independent chains), folded with the producer's inverse power; a tile's sum goes to LDS at once (no accumulator array: the register
-      // file is full)
-#pragma unroll
-      for (int n0 = 0; n0 < NT - 1; n0 += TB) {
-        f32x4 tmp[TB][CPW];
-#pragma unroll
-        for (int d = 0; d < TB; ++d)
-#pragma unroll
-          for (int c = 0; c < CPW; ++c)
-            if (n0 + d < NT - 1) tmp[d][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, frag_lo(c)), __builtin_bit_cast(f16x8_t, bh[n0 + d][c]), zero4, 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < TB; ++d)
-#pragma unroll
-          for (int c = 0; c < CPW; ++c)
-            if (n0 + d < NT - 1) tmp[d][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, frag_hi(c)), __builtin_bit_cast(f16x8_t, bl[n0 + d][c]), tmp[d][c], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < TB; ++d)
-#pragma unroll
-          for (int c = 0; c < CPW; ++c)
-            if (n0 + d < NT - 1) tmp[d][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, frag_hi(c)), __builtin_bit_cast(f16x8_t, bh[n0 + d][c]), tmp[d][c], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < TB; ++d)
-          if (n0 + d < NT - 1) {
-            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-              const float ivc = __uint_as_float(iv[c]);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) a4[r] = fmaf(tmp[d][c][r], ivc, a4[r]);
-            }
-            // C/D map of the 16x16 MFMA: col = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][(n0 + d) * 16 + li] = a4[r] * winv;
-          }
-      }
-      __syncthreads();
-      unsigned long long* px = PX + ((size_t)((size_t)(step & 1) * ngroups + g) * nub + uu) * (KU * KU * 256);
-#pragma unroll
-      for (int h = 0; h < (ST * (KU - 1) * 16 + NW * 64 - 1) / (NW * 64); ++h) {
-        const int o = tid + h * (NW * 64);
-        if (o < ST * (KU - 1) * 16) {
-          const int sq = o / ((KU - 1) * 16), uc = o % ((KU - 1) * 16), n = uc >> 4, dst = n + (n >= ku ? 1 : 0);
-          float v = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) v += red[w][sq][uc];
-          px_put(px + (size_t)(dst * KU + ku) * 256 + sq * 16 + (uc & 15), v, (unsigned)step);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // the stores leave BEFORE pass 2 (nothing waits for them)
-      // pass 2: the own block, two k blocks at a time (two independent chains); half way through, the siblings' words are read
-      // SPECULATIVELY (see the fp32 kernel)
-      unsigned long long sw[KU] = {};
-#pragma unroll
-      for (int c = 0; c < CPW; c += 2) {
-        f32x4 tmp[2];
-        const f32x4 ah2[2] = {frag_hi(c), frag_hi(c + 1)}, al2[2] = {frag_lo(c), frag_lo(c + 1)};
-#pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al2[d]), __builtin_bit_cast(f16x8_t, bh[NT - 1][c + d]), zero4, 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah2[d]), __builtin_bit_cast(f16x8_t, bl[NT - 1][c + d]), tmp[d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) tmp[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah2[d]), __builtin_bit_cast(f16x8_t, bh[NT - 1][c + d]), tmp[d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const float ivc = __uint_as_float(iv[c + d]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc3[r] = fmaf(tmp[d][r], ivc, acc3[r]);
-        }
-        if (c == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (e_ok) px_load<KU>(px, ku, es * 16 + eu, sw);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red2[wave][4 * kq + r][li] = acc3[r] * winv;
-      EESEN_STAMP(2);
-      __syncthreads();
-      if (e_ok) {   // the three siblings' partial sums: they run in lockstep with this workgroup, the words left them a pass ago
-#pragma unroll
-        for (int w = 0; w < NW; ++w) dm_in += red2[w][es][eu];
-        if (!px_take<KU>(px, ku, es * 16 + eu, (unsigned)step, err, spin_limit, sw, dm_in)) {
-          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_fail = 1;
-        }
-      }
-      EESEN_STAMP(3);
-    }
-    if (e_act) {
-      const float dm = dy + dm_in;
-      const float g_ = gt.x, i = gt.y, f = gt.z, o = gt.w;
-      const float h = tanhf_(c_t);
-      const float dh = (1.f - h * h) * (dm * o);
-      float dob = o * (1.f - o) * (dm * h);
-      const float dc = dh + park[3][tid] + park[4][tid] * park[0][tid] + park[5][tid] * park[1][tid] + dob * park[2][tid];
-      float df = f * (1.f - f) * (dc * c_p);
-      float di = i * (1.f - i) * (dc * g_);
-      float dg = (1.f - g_ * g_) * (dc * i);
-      float carry = dc * f;
-      if (t >= len || !e_ok) { dg = di = df = dob = 0.f; carry = 0.f; }
-      // the power of two of this wave's four sequences x 64 gate gradients (four DPP rows of 16 threads), then the planes
-      float sc, inv;
-      {
-        const float rm = dpp_row_max16(fmaxf(fmaxf(fabsf(dg), fabsf(di)), fmaxf(fabsf(df), fabsf(dob))));
-        const int ri = (int)__float_as_uint(rm);
-        const float wm = fmaxf(fmaxf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 0)), __uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 16))),
-                               fmaxf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 32)), __uint_as_float((unsigned)__builtin_amdgcn_readlane(ri, 48))));
-        half_scale(wm, sc, inv);
-      }
-#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 4)
-      if (lane == 0 && s0 + 4 * wave < s_end) {   // one 16-byte word per wave (a whole-word write-through store; sub-dword ones cost 900 ticks of drain): [t][dir][tile][producer][4 groups]
-        const f32x4 iv4 = {inv, inv, inv, inv};
-        __builtin_amdgcn_raw_buffer_store_b128(iv4, rEX, (unsigned)((((size_t)(t * L.ndir + dir) * NZ + zt) * NP + uc0 / 16) * 64 + wave * 16), 0, kSc1);
-      }
-#endif
-      if (e_ok) {
-        const f32x4 out = {dg, di, df, dob};
-        const unsigned o32 = (unsigned)(((size_t)(t * S - tbS + s_e) * ldG + gcol) * 4);
-        const f32x2_t x01 = {dg * sc, di * sc}, x23 = {df * sc, dob * sc};         // exact
-        const f16x2_t h01 = __builtin_convertvector(x01, f16x2_t), h23 = __builtin_convertvector(x23, f16x2_t);   // v_cvt_pk_f16_f32: round to nearest even
-        const f32x2_t r01 = {x01[0] - (float)h01[0], x01[1] - (float)h01[1]}, r23 = {x23[0] - (float)h23[0], x23[1] - (float)h23[1]};   // exact
-        const f16x2_t l01 = __builtin_convertvector(r01, f16x2_t), l23 = __builtin_convertvector(r23, f16x2_t);
-        // this unit's 16 bytes (where its fp32 gradients sit in DG): [4 x hi][4 x lo] -- ONE whole-word store per lane, the 16 lanes of a
-        // row cover 256 contiguous bytes (two 8-byte stores with holes between the lanes' pieces cost 1400 ticks of drain)
-        const f32x4 pp = {__builtin_bit_cast(float, h01), __builtin_bit_cast(float, h23), __builtin_bit_cast(float, l01), __builtin_bit_cast(float, l23)};
-#if !defined(EESEN_PROBE_KH) || !(EESEN_PROBE_KH & 1)
-        __builtin_amdgcn_raw_buffer_store_b128(pp, rDH, o32, 0, kSc1);
-#endif
-        // the fp32 gradients LAST: nobody reads them before the kernel ends (the GEMMs and the bias / peephole passes do), so the
-        // drain in front of the publish leaves this one store in flight (s_waitcnt vmcnt(1) below)
-        __builtin_amdgcn_raw_buffer_store_b128(out, rDG, o32, 0, kSc1);
-        park[3][tid] = carry; park[4][tid] = di; park[5][tid] = df;
-      }
-    }
-    if (step + 1 < T) {
-      if (tid < ST * 16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // everything but the newest store: the fp32 gradients (see above)
-      __syncthreads();
-      if (s_fail) return;
-      EESEN_STAMP(4);
-      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (e_ok) {  // next step's operands, issued after the publish
-        const int t2 = dir == 0 ? t - 1 : t + 1, tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-        gt = *reinterpret_cast<const float4*>(L.G + (size_t)(t2 * S + s_e) * ldG + gcol);
-        dy = dY[(size_t)(t2 * S + s_e) * lddy + ycol];
-        c_t = c_p;
-        c_p = L.C[(size_t)((tp2 + 1) * S + s_e) * ldY + ycol];
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // K-split backward, TWO sequence tiles per workgroup (time-multiplexed): BASELINE config 5 (S = 64 at H = 1024).
 // 64 sequences need 512 K-split workgroups -- two windows of 32, one launch after the other, 2 x 7.8 us per time step.  Here one
 // launch covers all four tiles: a workgroup keeps its W_m^T slice ONCE and steps two independent chains, tile 2g and 2g + 1 of
@@ -2592,7 +2293,6 @@ static const void* bwd_q4_fn(int cpw, int stq) {
   switch (cpw) { case 8: return EESEN_Q4_FN(8); case 6: return EESEN_Q4_FN(6); case 4: return EESEN_Q4_FN(4); default: return EESEN_Q4_FN(2); }
 #undef EESEN_Q4_FN
 }
-static const void* bwd_ksplit_hk8_fn() { return reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_hk_kernel<8>); }
 static const void* bwd_ksplit_h_fn(int cpw) {
   switch (cpw) {
     case 4: return reinterpret_cast<const void*>(&lstm_bwd_persistent_ksplit_h_kernel<4>);
@@ -2758,9 +2458,8 @@ size_t lstm_bwd_ksplit_px_floats(const LstmLayerDev& L) {
   const int ncu = share_of_cus();
   const long blocks16 = (long)cdiv(L.H, 16) * L.ndir * cdiv(L.S, 16);
   if (2 * blocks16 <= ncu && L.S > 8) return 0;   // the 8-sequence / 4 x 32 tiles are taken there
-  // the largest window the launcher may pick is the whole batch; per (slot, group, unit block) KU x KU blocks of 16 x 16 words of 8 bytes:
-  // 16 blocks of 64 units with KU = 4, 8 blocks of 128 units with KU = 8 (the fp16-plane tile with K split eight ways): twice the space
-  return (size_t)2 * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096 * 2 * (L.bwd_k8 ? 2 : 1);
+  // the largest window the launcher may pick is the whole batch
+  return (size_t)2 * L.ndir * cdiv(L.S, 16) * (size_t)(L.H / 64) * 4096 * 2;
 }
 
 // the fp16-plane K-split tile applies (shape and switches; the buffers are the caller's to hand over)
@@ -2832,20 +2531,17 @@ RecPlan lstm_bwd_plan(const LstmLayerDev& L0, bool assume_px) {
     // Round 6: the same tile on two fp16 planes per operand (lstm_bwd_persistent_ksplit_h_kernel) where the caller handed over the
     // plane and exponent buffers; batches that need two windows take two launches of it (faster than one multiplexed fp32 launch)
     if (bwd_planes_shape(L0) && (assume_px || (L0.DGH && L0.EX))) {
-      const bool k8 = L0.bwd_k8 && L0.H == 1024;   // K split eight ways: half the operand fetch per workgroup (lstm_bwd_persistent_ksplit_hk_kernel<8>)
-      const int KUh = k8 ? 8 : 4;
-      const void* fnh = k8 ? bwd_ksplit_hk8_fn() : bwd_ksplit_h_fn(cpw);
+      const void* fnh = bwd_ksplit_h_fn(cpw);
       auto hfits = [&](int Sw) {
         dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(Sw, 16));
-        const size_t c1 = (size_t)grid.y * grid.z * KUh * kShards * kShardStride;
+        const size_t c1 = (size_t)grid.y * grid.z * 4 * kShards * kShardStride;
         return c1 <= (size_t)kCtlHalf && fnh != nullptr && fits(fnh, grid, NW * 64);
       };
       const int nwh = pick_windows(L0.S, 16, hfits);
       if (nwh > 0 && (nwh == 1 || ((size_t)(L0.S / nwh) * L0.ndir * 4 * L0.H * sizeof(float)) % 128 == 0)) {
         const dim3 grid(L0.H / 64 * 4, L0.ndir, cdiv(L0.S / nwh, 16));
-        P.kind = kRecBwdKsplit; P.fn = fnh; P.cpw = k8 ? 2 : cpw; P.seq_tile = 16; P.units = 16 * KUh; P.windows = nwh;
-        if (k8) snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_hk_kernel<8>");
-        else snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_h_kernel<%d>", cpw);
+        P.kind = kRecBwdKsplit; P.fn = fnh; P.cpw = cpw; P.seq_tile = 16; P.units = 64; P.windows = nwh;
+        snprintf(P.kernel, sizeof(P.kernel), "lstm_bwd_persistent_ksplit_h_kernel<%d>", cpw);
         plan_resources(P, grid);
         return P;
       }
@@ -2911,7 +2607,7 @@ bool lstm_bwd_persistent(hipStream_t st, const LstmLayerDev& L0, const float* dY
       if (P.kind == kRecBwdKsplitMux) { L.s_begin = 0; L.s_count = 0; }
       else { L.s_count = L0.S / P.windows; L.s_begin = w * L.s_count; }
       // counters: one set per (direction, 16-sequence tile) and K quarter -- the multiplexed launch covers every tile of the batch
-      const size_t c1 = (size_t)L0.ndir * (P.kind == kRecBwdKsplitMux ? cdiv(L0.S, 16) : (int)grid.z) * (P.units == 128 ? 8 : 4) * kShards * kShardStride;
+      const size_t c1 = (size_t)L0.ndir * (P.kind == kRecBwdKsplitMux ? cdiv(L0.S, 16) : (int)grid.z) * 4 * kShards * kShardStride;
       EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * c1, st));
       EESEN_HIP_CHECK(hipMemsetAsync(L.PX, 0, sizeof(float) * px_need, st));
       if (P.kind == kRecBwdKsplitMux) plan_launch(st, P, grid, L, dY, lddy, DG, px, cnt, err, spin_limit, role, chunk);

@@ -540,7 +540,6 @@ static LstmLayerDev lstm_view(const Net& net, const Layer& L) {
   d.fwd_split = net.tn.fwd_split;
   d.fwd_f16 = net.tn.fwd_f16 && net.tn.fwd_split;   // (EESEN_FWD_SPLIT=0 is the master switch: the fp32-input MFMA kernels)
   d.bwd_f16 = net.tn.bwd_f16 && net.tn.fwd_split;
-  d.bwd_k8 = net.tn.bwd_k8;
   d.wm_amax = net.amax.p ? const_cast<Net&>(net).am_wm((int)(&L - net.layers.data())) : nullptr;
   d.xcd_map = net.tn.xcd_map; d.fwd_mux = net.tn.fwd_mux; d.bwd_q4 = net.tn.bwd_q4; d.bwd_q4_st8 = net.tn.bwd_q4_st8; d.fwd_narrow2 = net.tn.fwd_narrow2; d.fwd_t16_small = net.tn.fwd_t16_small; d.bwd_ksplit = net.tn.bwd_ksplit; d.bwd_mux = net.tn.bwd_mux;
   return d;

@@ -35,8 +35,6 @@
 //   EESEN_BWD_F16           1        0: the K-split backward tile of wide layers on the fp32-input MFMA (and its time-multiplexed form at
 //                                    S = 64) instead of on two fp16 planes per operand, the gate gradients published a second time as
 //                                    planes with a per-(producer, sequence) power of two (round 6)
-//   EESEN_BWD_K8            0        1: that tile with K split EIGHT ways (128 units x an eighth of K per workgroup: half the operand fetch,
-//                                    seven sibling blocks of partial sums instead of three)
 //   EESEN_XCD_MAP           1        0: plain workgroup -> role map instead of the XCD-aware one
 //   EESEN_CTC_WAVES         0        n: the CTC lattice sweep as n wavefronts per lattice where that instantiation exists (read when a
 //                                    Ctc is created; 0: one wave up to 256 lattice positions, 4 / 8 / 16 / 16 for rows of 512 / 1024 /
@@ -77,7 +75,7 @@ struct Tuning {
   int overlap = -1, gate_fwd = -1, side_lds_kb = -1;   // -1: decided by the Net (see above)
   int spin_limit = 400000;
   bool spin_limit_set = false;
-  int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1, fwd_f16 = 1, bwd_f16 = 1, bwd_k8 = 0;
+  int bwd_q4 = 1, bwd_q4_st8 = 1, fwd_narrow2 = 1, fwd_t16_small = 1, bwd_ksplit = 1, fwd_mux = 1, bwd_mux = 1, xcd_map = 1, fwd_mid = 1, fwd_split = 1, fwd_f16 = 1, bwd_f16 = 1;
   int comm_defer = -1;   // -1: decided per minibatch from the backward plans (Net::exchange_deferred_for_minibatch)
   int trace = 0;
   bool print_flight = false;
@@ -106,7 +104,6 @@ struct Tuning {
     t.fwd_split = num("EESEN_FWD_SPLIT", 1);
     t.fwd_f16 = num("EESEN_FWD_F16", 1);
     t.bwd_f16 = num("EESEN_BWD_F16", 1);
-    t.bwd_k8 = num("EESEN_BWD_K8", 0);
     t.xcd_map = num("EESEN_XCD_MAP", 1);
     t.comm_defer = num("EESEN_COMM_DEFER", -1);
     t.trace = num("EESEN_TRACE", 0);

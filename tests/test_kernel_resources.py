@@ -47,8 +47,7 @@ BUDGETS = {
     # cfg4 / cfg5 (1024 cells): K-split backward (+ its time-multiplexed form at S = 64), wide forward fp32 / bf16 / multiplexed
     "lstm_bwd_persistent_ksplit_kernel<4>": (232, 34 * 1024),
     "lstm_bwd_persistent_ksplit_mux_kernel<4>": (248, 35 * 1024),
-    "lstm_bwd_persistent_ksplit_h_kernel<4>": (256, 40 * 1024),
-    "lstm_bwd_persistent_ksplit_hk_kernel<8>": (248, 72 * 1024),    # ... with K split eight ways (EESEN_BWD_K8)     # round 6: the K-split tile on two fp16 planes (fills the register file)
+    "lstm_bwd_persistent_ksplit_h_kernel<4>": (256, 40 * 1024),     # round 6: the K-split tile on two fp16 planes (fills the register file)
     "lstm_fwd_persistent_kernel<4,1,4,false,true>": (208, 35 * 1024),
     "lstm_fwd_persistent_bf_kernel<4,4,1,2,false>": (192, 35 * 1024),
     "lstm_fwd_persistent_bf_kernel<4,4,2,2,true>": (216, 35 * 1024),    # round 6: the wide tile on two fp16 planes (fp32-class; replaces the fp32-input tile)
