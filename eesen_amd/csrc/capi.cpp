@@ -379,20 +379,6 @@ int eesen_op_gemm_bench(int device, int a_kc, int b_kc, int M, int N, int K, con
     float* aws = am.p + M + N;
     if (a_kc) amax_rows_cols(nullptr, A, M, K, lda, am.p, nullptr, nullptr); else amax_rows_cols(nullptr, A, K, M, lda, nullptr, am.p, aws);
     if (b_kc) amax_rows_cols(nullptr, B, N, K, ldb, am.p + M, nullptr, nullptr); else amax_rows_cols(nullptr, B, K, N, ldb, nullptr, am.p + M, aws);
-    // EESEN_GEMM_PRE=1|2: B (and A) as planes split ahead of the timed loop, as the Net holds them per tensor
-    DevBuf<float> pa, pb;
-    const char* pre_e = getenv("EESEN_GEMM_PRE");
-    const int pre = pre_e ? atoi(pre_e) : 0;
-    if (gemm_mode() == 2 && pre >= 1 && (b_kc || K % 2 == 0)) {
-      pb.reserve((size_t)(b_kc ? N : K) * ldb);
-      gemm_planes(nullptr, B, b_kc ? N : K, b_kc ? K : N, ldb, !b_kc, bb, pb.p);
-      bb.planes = pb.p;
-    }
-    if (gemm_mode() == 2 && pre >= 2 && (a_kc || K % 2 == 0)) {
-      pa.reserve((size_t)(a_kc ? M : K) * lda);
-      gemm_planes(nullptr, A, a_kc ? M : K, a_kc ? K : M, lda, !a_kc, ba, pa.p);
-      ba.planes = pa.p;
-    }
     for (int i = 0; i < 2; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, ba, bb);
     EESEN_HIP_CHECK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < iters; ++i) gemm_f32(nullptr, a_kc != 0, b_kc != 0, M, N, K, 1.f, A, lda, B, ldb, 0.f, C, ldc, nullptr, ws.p, ws.cap, 0, false, ba, bb);

@@ -395,7 +395,7 @@ __device__ __forceinline__ void unit_of(int tid, int i, int& row, int& q) {
 // Branch-free on purpose (see load_tile): a guarded load makes hipcc wait for every load separately, which serialises the
 // HBM latency of the four loads of a k-tile.  Out-of-range rows / k are clamped to a valid address here; the store side zeroes
 // them -- AFTER the MFMA block, so that nothing touches the loaded registers (and waits for them) before it.
-template <bool KC, int THREADS, int ROWS, bool PRE = false>
+template <bool KC, int THREADS, int ROWS>
 __device__ __forceinline__ void split_load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, int tid,
                                            float4 (&v)[2]) {
 #pragma unroll
@@ -409,7 +409,7 @@ __device__ __forceinline__ void split_load(const float* __restrict__ P, int ld, 
       v[i] = *reinterpret_cast<const float4*>(P + (size_t)min(r, R - 1) * ld + kc);
     } else {
       const float* col = P + min(r, R - 1);
-      const int kl = PRE ? (max(kend - 1, 0) | 1) : max(kend - 1, 0);   // (planes: the lo words of the last row pair sit in row kend | 1)
+      const int kl = max(kend - 1, 0);
       v[i].x = col[(size_t)min(k + 0, kl) * ld];
       v[i].y = col[(size_t)min(k + 1, kl) * ld];
       v[i].z = col[(size_t)min(k + 2, kl) * ld];
@@ -442,28 +442,8 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b) {
 __device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
 __device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
 // PL = 3: bf16 planes by truncation (scale unused).  PL = 2: fp16 planes by rounding, of the operand times `scale` (half_scale).
-// PRE (two fp16 planes only): the operand was split ahead of the GEMM (planes_kernel below) and `v` holds plane words, not floats --
-//   KC: a row's k-quad is 16 bytes = its four hi halves, then its four lo halves;
-//   !KC: rows k, k + 1 (k even) of the plane matrix hold (hi[k], hi[k+1]) and (lo[k], lo[k+1]) of every column
-// -- so the stage is a renaming (and, guarded, a select): no arithmetic on the SIMD's issue port at all.
-template <int PL, bool KC, bool GUARD, int THREADS, int ROWS, bool PRE = false>
+template <int PL, bool KC, bool GUARD, int THREADS, int ROWS>
 __device__ __forceinline__ void split_stage_a(SplitUnit& u, const float4& v, int i, int tid, int R, int r0, int k0, int kend, float scale) {
-  if constexpr (PRE) {
-    static_assert(PL == 2, "planes ahead of the GEMM exist for the two-plane kernels only");
-    unsigned w[4] = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
-    if (GUARD) {   // (k beyond K inside a valid quad / pair: zeros written by planes_kernel)
-      int row, q;
-      unit_of<KC, THREADS, ROWS>(tid, i, row, q);
-      const bool ok = r0 + row < R;
-      const int k = k0 + q * 4;
-      const bool v0 = ok && k < kend, v1 = KC ? v0 : (ok && k + 2 < kend);
-      w[0] = v0 ? w[0] : 0u; w[1] = v0 ? w[1] : 0u;
-      w[2] = v1 ? w[2] : 0u; w[3] = v1 ? w[3] : 0u;
-    }
-    if (KC) { u.ph[0] = w[0]; u.ph[1] = w[1]; u.pm[0] = w[2]; u.pm[1] = w[3]; }
-    else { u.ph[0] = w[0]; u.pm[0] = w[1]; u.ph[1] = w[2]; u.pm[1] = w[3]; }
-    return;
-  }
   float x[4] = {v.x, v.y, v.z, v.w};
   if (GUARD) {
     int row, q;
@@ -511,13 +491,13 @@ __device__ __forceinline__ void split_stage_c(const SplitUnit& u, unsigned char*
   *reinterpret_cast<uint2*>(dst + PS) = make_uint2(u.pm[0], u.pm[1]);
   if (PL == 3) *reinterpret_cast<uint2*>(dst + 2 * PS) = make_uint2(pack_hi16(u.r[0], u.r[1]), pack_hi16(u.r[2], u.r[3]));
 }
-template <int PL, bool KC, bool GUARD, int THREADS, int ROWS, bool PRE = false>
+template <int PL, bool KC, bool GUARD, int THREADS, int ROWS>
 __device__ __forceinline__ void split_store(unsigned char* base, int tid, const float4 (&v)[2], int R, int r0, int k0, int kend, const float (&scale)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     SplitUnit u;
-    split_stage_a<PL, KC, GUARD, THREADS, ROWS, PRE>(u, v[i], i, tid, R, r0, k0, kend, scale[i]);
-    if constexpr (!PRE) split_stage_b<PL>(u);
+    split_stage_a<PL, KC, GUARD, THREADS, ROWS>(u, v[i], i, tid, R, r0, k0, kend, scale[i]);
+    split_stage_b<PL>(u);
     split_stage_c<PL, KC, THREADS, ROWS>(u, base, i, tid);
   }
 }
@@ -553,13 +533,9 @@ __device__ __forceinline__ void bf16_store(unsigned char* base, int tid, const f
   }
 }
 
-// PRE: 0 = both operands are fp32 matrices, split here; 1 = B arrives as planes (p.B points at them: same addresses, same ldb);
-// 2 = A and B both do.
-template <class G, bool A_KC, bool B_KC, bool GUARD, bool GATED, int PRE = 0>
+template <class G, bool A_KC, bool B_KC, bool GUARD, bool GATED>
 __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   constexpr int TM = G::TM, TN = G::TN, TH = G::THREADS, BMW = G::BMW, BNW = G::BNW, PL = G::PL;
-  constexpr bool APRE = PRE == 2, BPRE = PRE >= 1;
-  static_assert(PRE == 0 || PL == 2, "planes ahead of the GEMM: two-plane kernels only");
   // stage s: A planes at s * STAGE, B planes at s * STAGE + OP_A (indexed as an array, so the accesses stay ds_* ones)
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -585,8 +561,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
 
   // tile t of the k loop: HBM -> registers / registers -> split -> LDS stage / LDS stage -> NMFMA MFMAs
   auto load = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
-    split_load<A_KC, TH, TM, APRE>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
-    split_load<B_KC, TH, TN, BPRE>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
+    split_load<A_KC, TH, TM>(p.A, p.lda, p.M, m0, kbeg + t * SBK, kend, tid, ra);
+    split_load<B_KC, TH, TN>(p.B, p.ldb, p.N, n0, kbeg + t * SBK, kend, tid, rb);
   };
   // two fp16 planes: the power-of-two scales of the rows this thread brings in (its two units per operand and k-tile sit in fixed
   // rows), from the operands' bounds -- one word per row of op(A) / column of op(B), or one for the whole operand
@@ -604,8 +580,8 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
   }
   auto store = [&](int t, const float4 (&ra)[2], const float4 (&rb)[2]) {
     const int st = (t & 1) * G::STAGE;
-    split_store<PL, A_KC, GUARD, TH, TM, APRE>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend, sa);
-    split_store<PL, B_KC, GUARD, TH, TN, BPRE>(&lds[st + G::OP_A], tid, rb, p.N, n0, kbeg + t * SBK, kend, sb);
+    split_store<PL, A_KC, GUARD, TH, TM>(&lds[st], tid, ra, p.M, m0, kbeg + t * SBK, kend, sa);
+    split_store<PL, B_KC, GUARD, TH, TN>(&lds[st + G::OP_A], tid, rb, p.N, n0, kbeg + t * SBK, kend, sb);
   };
   // smallest terms first: hi*lo' + lo*hi' + mid*mid', then hi*mid' + mid*hi', then hi*hi' (two planes: hi*lo' + lo*hi', then hi*hi');
   // the output blocks in turn, so that dependent MFMAs are BMW * BNW issues apart
@@ -684,17 +660,14 @@ __device__ __forceinline__ void gemm_split_body(const GemmParams& p) {
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u);
       __builtin_amdgcn_sched_barrier(0);
-      const bool pre_u = u < 2 ? APRE : BPRE;   // (a unit that arrives as planes has nothing to compute: its brackets stay empty)
-      if (u < 2) split_stage_a<PL, A_KC, GUARD, TH, TM, APRE>(su, ra[u], u, tid, p.M, m0, k1, kend, sa[u]);
-      else split_stage_a<PL, B_KC, GUARD, TH, TN, BPRE>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend, sb[u - 2]);
-      if (!pre_u) EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
+      if (u < 2) split_stage_a<PL, A_KC, GUARD, TH, TM>(su, ra[u], u, tid, p.M, m0, k1, kend, sa[u]);
+      else split_stage_a<PL, B_KC, GUARD, TH, TN>(su, rb[u - 2], u - 2, tid, p.N, n0, k1, kend, sb[u - 2]);
+      EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.ph[0], su.ph[1]);
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u + 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!pre_u) {
-        split_stage_b<PL>(su);
-        EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.pm[0], su.pm[1]);
-      }
+      split_stage_b<PL>(su);
+      EESEN_PIN6(su.r[0], su.r[1], su.r[2], su.r[3], su.pm[0], su.pm[1]);
       __builtin_amdgcn_sched_barrier(0);
       group(3 * u + 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -763,65 +736,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_split_bf16_big_kernel(GemmPar
   gemm_split_body<GeoBig, A_KC, B_KC, false, false>(p);
 }
 
-// the same three kernels on two fp16 planes (three products); PRE: operands that arrive as planes (gemm_split_body)
-template <bool A_KC, bool B_KC, bool GUARD, int PRE = 0>
+// the same three kernels on two fp16 planes (three products)
+template <bool A_KC, bool B_KC, bool GUARD>
 __global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_f16_kernel(GemmParams p) {
-  gemm_split_body<GeoSmallH, A_KC, B_KC, GUARD, false, PRE>(p);
+  gemm_split_body<GeoSmallH, A_KC, B_KC, GUARD, false>(p);
 }
-template <int PRE = 0>
 __global__ __launch_bounds__(256, kSplitMinW) void gemm_f32_split_f16_gated_kernel(GemmParams p) {
-  gemm_split_body<GeoSmallH, true, true, false, true, PRE>(p);
+  gemm_split_body<GeoSmallH, true, true, false, true>(p);
 }
-template <bool A_KC, bool B_KC, int PRE = 0>
+template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 2) void gemm_f32_split_f16_big_kernel(GemmParams p) {
-  gemm_split_body<GeoBigH, A_KC, B_KC, false, false, PRE>(p);
-}
-
-// An operand of the two-plane kernels split AHEAD of the GEMM: every element a of a [R x C] fp32 matrix (row stride ld) becomes
-// hi = fp16(a 2^s), lo = fp16(a 2^s - hi) -- the same two roundings, in the same order, as split_stage_a / _b perform inside the GEMM,
-// so a GEMM on planes is bit-identical to the GEMM on the matrix -- with s from the same bound words (half_scale).  The planes take the
-// matrix's place: the same number of bytes, the same ld, the GEMM computes the same addresses.
-//   KQ (the GEMM's k runs along the rows' columns; the scale belongs to the ROW): the 16 bytes of a column quad hold its four hi
-//      halves, then its four lo halves; columns C .. ld - 1 are written as zeros.
-//   !KQ (k runs down the rows; the scale belongs to the COLUMN): rows 2i, 2i + 1 become a row of (hi[2i][c], hi[2i+1][c]) words and a
-//      row of (lo[2i][c], lo[2i+1][c]) words (R even).
-// A GEMM's tiles re-split the same element once per tile that reads it -- N / 256 times for an A operand; here it happens once, in a
-// pass at HBM speed, and the GEMM's inner loop is left with loads, LDS writes and MFMAs.
-template <bool KQ>
-__global__ __launch_bounds__(256) void planes_kernel(const float* __restrict__ P, long R, int C, int ld, const float* __restrict__ bound,
-                                                     int per_index, unsigned* __restrict__ out) {
-  const int nq = ld >> 2;
-  const long units = (KQ ? R : (R >> 1)) * nq;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < units; i += (long)gridDim.x * 256) {
-    const long r = i / nq;
-    const int c = (int)(i - r * nq) << 2;
-    if (KQ) {
-      float sc, iv;
-      half_scale(bound[per_index ? r : 0], sc, iv);
-      float4 v = *reinterpret_cast<const float4*>(P + r * ld + c);
-      float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = c + j < C ? x[j] : 0.f;
-      uint4 o;
-      o.x = pack_f16(x[0], x[1]); o.y = pack_f16(x[2], x[3]);
-      o.z = pack_f16(x[0] - f16_lo(o.x), x[1] - f16_hi(o.x)); o.w = pack_f16(x[2] - f16_lo(o.y), x[3] - f16_hi(o.y));
-      *reinterpret_cast<uint4*>(out + r * ld + c) = o;
-    } else {
-      const float4 v0 = *reinterpret_cast<const float4*>(P + (2 * r) * ld + c), v1 = *reinterpret_cast<const float4*>(P + (2 * r + 1) * ld + c);
-      const float a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
-      unsigned h[4], l[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float sc, iv;
-        half_scale(bound[per_index ? min(c + j, C - 1) : 0], sc, iv);
-        const float xa = c + j < C ? a[j] * sc : 0.f, xb = c + j < C ? b[j] * sc : 0.f;
-        h[j] = pack_f16(xa, xb);
-        l[j] = pack_f16(xa - f16_lo(h[j]), xb - f16_hi(h[j]));
-      }
-      *reinterpret_cast<uint4*>(out + (2 * r) * ld + c) = make_uint4(h[0], h[1], h[2], h[3]);
-      *reinterpret_cast<uint4*>(out + (2 * r + 1) * ld + c) = make_uint4(l[0], l[1], l[2], l[3]);
-    }
-  }
+  gemm_split_body<GeoBigH, A_KC, B_KC, false, false>(p);
 }
 
 // Operand bounds of the two-plane kernels.  One pass over a [R x C] matrix (row stride ld): ROWS: out_rows[r] = max_c |P[r][c]|;
@@ -1035,17 +960,6 @@ void amax_rows_cols(hipStream_t st, const float* P, long rows, int cols, int ld,
 }
 #undef EESEN_AMAX_LAUNCH
 
-void gemm_planes(hipStream_t st, const float* P, long rows, int cols, int ld, bool k_along_rows, GemmBound bound, float* out) {
-  if (rows <= 0 || cols <= 0) return;
-  EESEN_REQUIRE(bound.p && (ld & 3) == 0 && ((((uintptr_t)P | (uintptr_t)out)) & 15) == 0, EESEN_ERR_INVALID, "planes: a bound, 16-byte alignment and ld % 4 == 0 are required");
-  EESEN_REQUIRE(!k_along_rows || (rows & 1) == 0, EESEN_ERR_INVALID, "planes with k along the rows pair the rows: an even number of them");
-  const long units = (k_along_rows ? rows / 2 : rows) * (long)(ld / 4);
-  const int nb = (int)std::max<long>(1, std::min<long>((units + 255) / 256, 256 * 16));
-  if (k_along_rows) hipLaunchKernelGGL((planes_kernel<false>), dim3(nb), dim3(256), 0, st, P, rows, cols, ld, bound.p, bound.per_index, reinterpret_cast<unsigned*>(out));
-  else hipLaunchKernelGGL((planes_kernel<true>), dim3(nb), dim3(256), 0, st, P, rows, cols, ld, bound.p, bound.per_index, reinterpret_cast<unsigned*>(out));
-  check_launch("planes");
-}
-
 // Operand bounds for a two-plane call whose caller passed none: measured here, one word per row of op(A) / column of op(B), in an
 // arena of device words handed out round-robin.  A slot is reused after kArena floats' worth of bounds -- at most an eighth of it per
 // operand, so never within one call, and far beyond what any stream of this library has in flight; the Net passes its own buffers and
@@ -1102,28 +1016,11 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   GemmParams p;
   p.amax_a = p.amax_b = nullptr;
   p.a_vec = p.b_vec = 0;
-  int pre = 0;   // operands that arrive as planes: 1 = B, 2 = A and B (the flavours that are built; A alone is read as the matrix)
-  float* scratch_planes[2] = {nullptr, nullptr};
   if (half) {
     if (!bound_a.p) bound_a = arena_bound(st, A, a_kc, M, K, lda);
     if (!bound_b.p) bound_b = arena_bound(st, B, b_kc, N, K, ldb);
     p.amax_a = bound_a.p; p.a_vec = bound_a.per_index;
     p.amax_b = bound_b.p; p.b_vec = bound_b.per_index;
-    // EESEN_GEMM_PRE=1|2 (tests and probes): callers that brought no planes get them built here, per call, in stream-ordered scratch
-    static const int force_pre = [] { const char* e = getenv("EESEN_GEMM_PRE"); return e ? atoi(e) : 0; }();
-    auto scratch = [&](const float* Pm, bool kc, int R, int ld_, GemmBound& b, float*& hold) {
-      if (b.planes || (!kc && (K & 1))) return;
-      const long rws = kc ? R : K;
-      EESEN_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&hold), (size_t)rws * ld_ * sizeof(float), st));
-      gemm_planes(st, Pm, rws, kc ? K : R, ld_, !kc, b, hold);
-      b.planes = hold;
-    };
-    if (force_pre >= 1) scratch(B, b_kc, N, ldb, bound_b, scratch_planes[1]);
-    if (force_pre >= 2) scratch(A, a_kc, M, lda, bound_a, scratch_planes[0]);
-    const bool b_ok = bound_b.planes && (b_kc || (K & 1) == 0), a_ok = bound_a.planes && (a_kc || (K & 1) == 0);
-    pre = b_ok ? (a_ok ? 2 : 1) : 0;
-    if (pre >= 1) B = bound_b.planes;
-    if (pre >= 2) A = bound_a.planes;
   }
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -1166,17 +1063,10 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<AK, BKC, false>), grid, block, extra_lds_bytes, st, p);     \
   } while (0)
   if (big && half) {
-#define EESEN_BIG_LAUNCH(AK, BKC)                                                                                     \
-  do {                                                                                                                \
-    if (pre == 2) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<AK, BKC, 2>), grid, block, 0, st, p);             \
-    else if (pre == 1) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<AK, BKC, 1>), grid, block, 0, st, p);        \
-    else hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<AK, BKC, 0>), grid, block, 0, st, p);                      \
-  } while (0)
-    if (a_kc && b_kc) EESEN_BIG_LAUNCH(true, true);
-    else if (a_kc && !b_kc) EESEN_BIG_LAUNCH(true, false);
-    else if (!a_kc && b_kc) EESEN_BIG_LAUNCH(false, true);
-    else EESEN_BIG_LAUNCH(false, false);
-#undef EESEN_BIG_LAUNCH
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<true, true>), grid, block, 0, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<true, false>), grid, block, 0, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_split_f16_big_kernel<false, false>), grid, block, 0, st, p);
   } else if (big) {   // K and k_chunk are multiples of 16: every split is made of whole k-tiles, every tile is interior
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, true>), grid, block, 0, st, p);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_split_bf16_big_kernel<true, false>), grid, block, 0, st, p);
@@ -1190,12 +1080,8 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
     const bool sg = (M % BM) != 0 || (N % BN) != 0 || (K % k_chunk) != 0 || (k_chunk % 16) != 0;
 #define EESEN_SPLIT_LAUNCH(AK, BKC)                                                                                   \
   do {                                                                                                                \
-    if (half && sg && pre == 2) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, true, 2>), grid, block, extra, st, p);   \
-    else if (half && sg && pre == 1) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, true, 1>), grid, block, extra, st, p); \
-    else if (half && sg) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, true, 0>), grid, block, extra, st, p);  \
-    else if (half && pre == 2) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, false, 2>), grid, block, extra, st, p); \
-    else if (half && pre == 1) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, false, 1>), grid, block, extra, st, p); \
-    else if (half) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, false, 0>), grid, block, extra, st, p);      \
+    if (half && sg) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, true>), grid, block, extra, st, p);        \
+    else if (half) hipLaunchKernelGGL((gemm_f32_split_f16_kernel<AK, BKC, false>), grid, block, extra, st, p);        \
     else if (sg) hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, true>), grid, block, extra, st, p);          \
     else hipLaunchKernelGGL((gemm_f32_split_bf16_kernel<AK, BKC, false>), grid, block, extra, st, p);                 \
   } while (0)
@@ -1210,8 +1096,6 @@ void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float a
   else EESEN_GEMM_LAUNCH(false, false);
 #undef EESEN_GEMM_LAUNCH
   check_launch("gemm_f32_mfma");
-  for (float* sp : scratch_planes)
-    if (sp) EESEN_HIP_CHECK(hipFreeAsync(sp, st));
   if (splits > 1) {
     const size_t total = (size_t)M * N;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
@@ -1242,10 +1126,7 @@ void gemm_f32_nt_gated(hipStream_t st, int M, int N, int K, const float* A, int 
   // fit a CU (2 x 60 KB), which always leaves room for one 512-thread recurrence workgroup (20 KB LDS, 192 VGPRs/SIMD
   // next to 2 x 112) whatever the dispatch order.
   constexpr int gate_lds = 26 * 1024;
-  if (gemm_mode() == 2 && bound_b.planes) {   // the weights as planes (the activations are still being written: split in the kernel)
-    p.B = bound_b.planes;
-    hipLaunchKernelGGL(gemm_f32_split_f16_gated_kernel<1>, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmallH::STAGE), st, p);
-  } else if (gemm_mode() == 2) hipLaunchKernelGGL(gemm_f32_split_f16_gated_kernel<0>, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmallH::STAGE), st, p);
+  if (gemm_mode() == 2) hipLaunchKernelGGL(gemm_f32_split_f16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmallH::STAGE), st, p);
   else if (gemm_mode() == 1) hipLaunchKernelGGL(gemm_f32_split_bf16_gated_kernel, dim3(gx), dim3(256), std::max(0, gate_lds + 33792 - 2 * GeoSmall::STAGE), st, p);
   else hipLaunchKernelGGL(gemm_f32_mfma_gated_kernel, dim3(gx), dim3(256), gate_lds, st, p);
   check_launch("gemm_f32_mfma_gated");

@@ -14,16 +14,10 @@ namespace eesen {
 // Mode 2 (two fp16 planes): a bound of an operand's magnitudes, in device words -- per_index = 1: one word per M index of op(A) /
 // N index of op(B) (the bound of that row / column: the scale is then the dot product's own), 0: one word for the whole operand.
 // p = null: measured by a pass over the operand before the launch.  Ignored by the other modes.
-// planes != null (mode 2): the operand ALSO exists as two fp16 planes, split ahead of the call with these very bounds (gemm_planes):
-// the kernel reads them in the matrix's place (same ld) and splits nothing.  Honoured for B alone or for A and B together.
 struct GemmBound {
   const float* p = nullptr;
   int per_index = 0;
-  const float* planes = nullptr;
 };
-// The planes of a [rows x cols] matrix (row stride ld) for a GEMM whose k index runs along its columns (k_along_rows = false: `bound`
-// per row or one word) or down its rows (true: `bound` per column or one word; rows even).  `out`: rows x ld words.
-void gemm_planes(hipStream_t st, const float* P, long rows, int cols, int ld, bool k_along_rows, GemmBound bound, float* out);
 void gemm_f32(hipStream_t st, bool a_kc, bool b_kc, int M, int N, int K, float alpha, const float* A, int lda,
               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
               size_t ws_floats, int extra_lds_bytes = 0,   // extra_lds_bytes: unused dynamic LDS = occupancy cap per CU
