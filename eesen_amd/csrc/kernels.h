@@ -91,6 +91,7 @@ struct LstmLayerDev {
   // first-poll delay of the persistent kernels' hand-off waits in wall-clock ticks of 10 ns; set by the host from the measured
   // increment flight of the device (handoff_flight_ns)
   int poll_delay = 0;
+  int poll_raw = 0;   // 1: poll_delay is an experimenter's value (EESEN_POLL_NS): the launchers apply no per-plan factor to it
   // progress milestone of the narrow forward persistent kernel (null: none; two words): when every workgroup of a (direction, sequence
   // tile) group has published step `milestone_step`, the group's first workgroup adds 1 to milestone[0], and the last group sets
   // milestone[1] -- the host starts the GEMM that consumes this pass's rows for the frames both directions have finished by then

@@ -2108,6 +2108,9 @@ float handoff_flight_ns() {
   std::sort(ns, ns + 5);
   (void)hipFree(flags);
   (void)hipFree(out);
+  // (the median of five.  The measurement has two modes on an MI355X -- 370-420 ns and 550-620 ns, by where the dispatcher puts the two
+  // workgroups; some boxes read the far one every time -- and a step's time does not depend on which one its process measured: net.cpp
+  // uses the delays tuned on this part whenever the reading is in that range, and the reading itself only as a plausibility check)
   cache[dev] = (float)std::min(2000.0, std::max(100.0, ns[2]));
   return cache[dev];
 }
@@ -2434,6 +2437,10 @@ bool lstm_fwd_persistent(hipStream_t st, const LstmLayerDev& L0, unsigned* cnt, 
     LstmLayerDev L = L0;
     L.s_count = L0.S / P.windows;
     L.s_begin = w * L.s_count;
+    // Two workgroups per CU (the narrow tile at --num-sequence 64): a step takes a quarter longer and its increments land later -- the
+    // first poll 700 ns after the publish instead of 400.  Swept on the final kernels (round 6, cfg2 at S = 64, ms per step at a first
+    // poll after 300 / 400 / 500 / 600 / 700 / 850 ns: 52.8 / 52.0 / 51.0-51.7 / 51.4 / 51.0 / 51.4; profiles/r06_poll_sweep.log).
+    if (P.wgs_per_cu >= 2 && !L0.poll_raw) L.poll_delay = L0.poll_delay * 7 / 4;
     EESEN_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * grid.y * grid.z * kShards * kShardStride, st));
     if (after_reset && P.windows == 1) EESEN_HIP_CHECK(hipEventRecord(after_reset, st));  // a gated consumer may start polling from here on
     plan_launch(st, P, grid, L, cnt, err, spin_limit, trace, role);

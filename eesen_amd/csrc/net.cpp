@@ -152,24 +152,31 @@ Net::Net(int dev, void* stream) : device(dev) {
   }
   ctl.reserve(kCtlWords);
   EESEN_HIP_CHECK(hipMemset(ctl.p, 0, kCtlWords * sizeof(unsigned)));
-  // First-poll delays of the recurrence kernels' hand-off waits = the MEASURED flight of an agent-scope increment between two CUs
-  // of this device (lstm_persistent.hip: handoff_flight_ns) times a dimensionless factor per wait kind.  The factors restate round
-  // 2's hand-tuned optima (s_sleep 20 forward / 14 backward at ~2.1 GHz = 610 / 430 ns, against ~610 ns of flight on those boxes:
-  // "about one flight"; the K-split kernel's sibling exchange has no counter to wait on any more); a chip that clocks or
-  // routes differently gets proportionally different delays instead of another box's constants.  Measured on a box with
-  // derived delays anywhere between 12 and 21 units: the step does not move (39.2-39.3 ms) -- the optimum is flat, the
-  // measurement only has to land in it.  EESEN_POLL_NS="fwd,bwd" overrides (experiments).
+  // First-poll delays of the recurrence kernels' hand-off waits.  Rounds 2-5 derived them from the MEASURED flight of an agent-scope
+  // increment between two CUs of this device (lstm_persistent.hip: handoff_flight_ns) times a factor per wait kind (1.0 forward, 0.7
+  // backward: round 2's hand-tuned s_sleep constants restated), so that a chip that clocks or routes differently gets proportionally
+  // different delays.  EESEN_POLL_NS="fwd,bwd" overrides (experiments).
   {
-    constexpr float kFactorFwd = 1.0f, kFactorBwd = 0.7f;
+    // Round 6 swept the delays again on the final kernels (profiles/r06_poll_sweep.log; cfg2, ms per step): forward 0 / 100 / 200 / 300 /
+    // 400 / 600 ns at the best backward value 33.8 / 32.5 / 32.4 / 31.7 / 31.4 / 31.7; backward 0 / 100 / 200 / 280 / 420 / 500 / 600 /
+    // 700 / 1000 ns at forward 400: 33.1 / 32.0 / 32.0 / 31.6 / 31.4 / 31.55 / 31.8 / 32.0 / 32.9 -- with the weight-gradient GEMMs of the
+    // layer above on the side stream the increments take longer to land: 420 ns there, 280 where the recurrence has the chip to itself
+    // (cfg2 at S = 64, cfg4, cfg5: at or within noise of the best of 140-560).  And the MEASUREMENT turned out to have two modes on this
+    // part (370-420 and 550-620 ns: where the dispatcher puts the ping-pong's two workgroups; one box read the far mode in every process)
+    // while the step does not care which one was read (fixed delays, readings of 398-591 ns: 36.0-36.15 ms): scaling the delays with
+    // the reading made a far-mode process 0.3-0.9 ms slower per step for nothing.  So: the delays tuned on the MI355X, in ns, whenever the
+    // reading is in the part's own range; scaled by reading / 400 only outside it (another clock, another fabric).
+    constexpr float kFwdNs = 400.f, kBwdNs = 280.f, kBwdSideNs = 420.f, kRefFlightNs = 400.f;
     flight_ns = handoff_flight_ns();
-    auto ticks = [&](float factor) { return std::min(300, std::max(0, (int)std::lround(factor * flight_ns / 10.f))); };
-    delay_fwd = ticks(kFactorFwd); delay_bwd = ticks(kFactorBwd);
+    const float fscale = flight_ns >= 300.f && flight_ns <= 700.f ? 1.f : flight_ns / kRefFlightNs;
+    auto ticks = [&](float ns) { return std::min(300, std::max(0, (int)std::lround(fscale * ns / 10.f))); };
+    delay_fwd = ticks(kFwdNs); delay_bwd = ticks(kBwdNs); delay_bwd_side = ticks(kBwdSideNs);
     if (const char* e = tn.poll_ns) {
       int a = -1, b2 = -1;
-      if (sscanf(e, "%d,%d", &a, &b2) == 2) { delay_fwd = a / 10; delay_bwd = b2 / 10; }
+      if (sscanf(e, "%d,%d", &a, &b2) == 2) { delay_fwd = a / 10; delay_bwd = delay_bwd_side = b2 / 10; poll_raw = 1; }
     }
     if (tn.print_flight)
-      fprintf(stderr, "eesen_hip: increment flight %.0f ns; first-poll delays forward %d0, backward %d0 ns\n", flight_ns, delay_fwd, delay_bwd);
+      fprintf(stderr, "eesen_hip: increment flight %.0f ns; first-poll delays forward %d0, backward %d0 (beside side-stream GEMMs %d0) ns\n", flight_ns, delay_fwd, delay_bwd, delay_bwd_side);
   }
 }
 
@@ -798,6 +805,7 @@ void Net::forward_pass() {
       { const int ti_ = timer.begin(st, 1);
       LstmLayerDev v = lstm_view(*this, L);
       v.poll_delay = delay_fwd;
+      v.poll_raw = poll_raw;
       if (plan_mid) {
         mile.reserve(32);
         EESEN_HIP_CHECK(hipMemsetAsync(mile.p, 0, 2 * sizeof(unsigned), st));
@@ -1013,7 +1021,8 @@ void Net::backpropagate_impl(const float* out_diff, int ldd, float* in_diff, int
     } else {
       const int H = L.H, nd = L.ndir, ldG = nd * 4 * H, ldY = nd * H;
       LstmLayerDev v = lstm_view(*this, L);
-      v.poll_delay = delay_bwd;
+      v.poll_delay = overlap ? delay_bwd_side : delay_bwd;   // (beside side-stream GEMMs the hand-off's increments land later: see the constructor)
+      v.poll_raw = poll_raw;
       if (persistent) {  // wide layers: partial-sum exchange space of the K-split backward kernel (shared by the layers: their passes are serial)
         const size_t need = lstm_bwd_ksplit_px_floats(v);
         if (need) { bwd_px.reserve(need); v.PX = bwd_px.p; v.px_floats = bwd_px.cap; }

@@ -137,7 +137,7 @@ struct Net {
   int info_fwd_persistent = 0, info_bwd_persistent = 0, info_lstm_layers = 0;   // of the last Propagate / Backpropagate (tests)
   int spin_limit = 400000;
   float flight_ns = 0.f;      // measured increment flight between two CUs of this device
-  int delay_fwd = 61, delay_bwd = 43;   // first-poll delays derived from it, wall-clock ticks of 10 ns
+  int delay_fwd = 61, delay_bwd = 43, delay_bwd_side = 64, poll_raw = 0;   // first-poll delays derived from it, wall-clock ticks of 10 ns
   int recoveries = 0;         // times a timed-out persistent kernel made the net fall back to the per-step kernels
   DevBuf<unsigned long long> trace;  // EESEN_TRACE=1 debug timeline
   void check_device_error(bool consumer);

@@ -52,8 +52,8 @@
 //   EESEN_SIDE_LDS_KB       auto     occupancy cap of the side-stream GEMMs (unused dynamic LDS; auto: 48 half and split / 32 f32)
 //   ---- diagnostics -------------------------------------------------------------------------------------------------------
 //   EESEN_TRACE             0        1: in-kernel s_memtime timeline of workgroup 0, printed when the Net is destroyed
-//   EESEN_PRINT_FLIGHT      unset    print the measured increment flight and the derived first-poll delays
-//   EESEN_POLL_NS           unset    "fwd,bwd": first-poll delays in ns instead of the derived ones
+//   EESEN_PRINT_FLIGHT      unset    print the measured increment flight and the first-poll delays in use
+//   EESEN_POLL_NS           unset    "fwd,bwd": first-poll delays in ns instead of the tuned ones (400 / 280, 420 beside side-stream GEMMs; net.cpp)
 //   ---- data-parallel exchange (comm.cpp) ----------------------------------------------------------------------------------
 //   EESEN_RCCL_LIBRARY      librccl.so.1   library to dlopen for the nccl* entry points (tests: the stand-in)
 //   EESEN_COMM_TIMEOUT_S    600      watchdog: seconds after which an unfinished collective aborts the communicator
