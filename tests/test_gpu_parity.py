@@ -612,6 +612,38 @@ def test_persistent_kernel_gives_up_loudly_instead_of_hanging(gpu, monkeypatch, 
     assert np.array_equal(out, ok.Propagate(batch.feats).numpy())
 
 
+def test_first_poll_delays_do_not_follow_a_bimodal_reading(gpu, monkeypatch, capfd):
+    """The hand-off waits' first-poll delays (csrc/net.cpp): the values tuned on the MI355X -- 400 ns forward, 280 backward, 420 beside
+    side-stream GEMMs -- whenever the increment flight the Net measures at creation is in the part's own range (300-700 ns: the reading has
+    two modes, 370-420 and 550-620 ns, that the step time does not share; round 6 scaled the delays with it and lost 0.3-0.9 ms per step
+    in far-mode processes); EESEN_POLL_NS overrides both backward values; results are the same bits whatever the delays."""
+    import re
+    from eesen_amd.api import Net
+    cfg = synth.config("small_bi")
+    layers = synth.make_model(**cfg); batch = synth.make_batch(**cfg)
+    monkeypatch.setenv("EESEN_PRINT_FLIGHT", "1")
+
+    def make():
+        net = Net.from_layers(layers)
+        m = re.search(r"increment flight (\d+) ns; first-poll delays forward (\d+), backward (\d+) \(beside side-stream GEMMs (\d+)\) ns", capfd.readouterr().err)
+        assert m, "the Net did not report its delays"
+        net.SetSeqLengths(batch.lens)
+        return net, tuple(int(g) for g in m.groups())
+
+    net, (flight, fwd, bwd, side) = make()
+    assert 100 <= flight <= 2000
+    if 300 <= flight <= 700:
+        assert (fwd, bwd, side) == (400, 280, 420)
+    else:   # another clock / fabric: everything scales with the reading
+        assert abs(fwd - flight) <= 10 and abs(bwd - 0.7 * flight) <= 10 and abs(side - 1.05 * flight) <= 10
+    base = net.Propagate(batch.feats).numpy()
+    monkeypatch.setenv("EESEN_POLL_NS", "50,900")
+    net2, (_, fwd2, bwd2, side2) = make()
+    assert (fwd2, bwd2, side2) == (50, 900, 900)
+    assert np.array_equal(net2.Propagate(batch.feats).numpy(), base)
+    assert net2.RecurrenceInfo()["fwd_persistent"] == net.RecurrenceInfo()["fwd_persistent"] > 0
+
+
 @pytest.mark.parametrize("kind,H,S,T", [("BiLstmParallel", 10, 8, 30), ("LstmParallel", 7, 4, 21), ("BiLstmParallel", 150, 16, 40)])
 def test_cell_counts_that_are_not_multiples_of_4(gpu, kind, H, S, T, tmp_path):
     """The kernels fetch the recurrent state four cells at a time; the reference takes any <CellDim>.  The library pads such a layer
