@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void ctc_error_diff_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunk = (T + frames - 1) / frames;
-  const int wid = blockIdx.x * 4 + w;                       // wave -> (utterance, chunk of frames), utterance fastest
+  const int wid = blockIdx.x * (blockDim.x >> 6) + w;       // wave -> (utterance, chunk of frames), utterance fastest; 4, 2 or 1 waves per workgroup (the launcher: by K)
   if (wid >= nchunk * S) return;
   const int s = wid % S, t0 = (wid / S) * frames;
   const int t1 = min(T, t0 + frames);
@@ -483,19 +483,23 @@ void ctc_error_diff(hipStream_t st, const float* probs, int ld, int T, int S, in
                     const float* pzx, float* diff, int ldd) {
   const int rows = T * S;
   if (rows <= 0) return;
-  const size_t smem = (size_t)4 * 2 * K * sizeof(float);
+  // Every wave stages 2 K floats (per class: the running maximum and the sum of exp(v - max)) in LDS and the waves of a workgroup do not
+  // talk to each other: four waves per workgroup up to 5120 classes (160 KB), two up to 10240, one up to 20480 -- word-piece inventories;
+  // the reference itself takes any K (ctc-loss.cc:116-129: a [T x K] matrix), beyond 20480 this pass would need a second sweep per frame.
+  const int nwb = K <= 5120 ? 4 : K <= 10240 ? 2 : 1;
+  const size_t smem = (size_t)nwb * 2 * K * sizeof(float);
   // frames per wave: 8 where that still leaves >= 16384 waves (64 per CU: measured, cfg5 0.50 -> 0.37 ms), one for small
   // minibatches (cfg2's 32 000 frames: 3 per wave measured slower than 1)
   const int frames = std::max(1, std::min(8, rows / 16384));
   if (smem > 64 * 1024) {  // word / BPE targets (K in the thousands): ask for more than the default 64 KB of dynamic LDS (160 KB per CU)
-    EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: too many classes for the gradient pass (8 K floats of LDS per workgroup exceed 160 KB)");
+    EESEN_REQUIRE(smem <= 160 * 1024, EESEN_ERR_INVALID, "ctc: more than 20480 classes: the gradient pass keeps 2 K floats per wave in LDS (160 KB per workgroup)");
   }
   auto launch = [&](auto kern) {
     // (asked for on every such launch: the grant is per device and per kernel, a process-wide "already granted" table was neither
     // -- a second device skipped the call and its launch failed; the call is a host-side table update, microseconds)
     if (smem > 64 * 1024)
       EESEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, 4)), dim3(256), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
+    hipLaunchKernelGGL(kern, dim3(cdiv(cdiv(T, frames) * S, nwb)), dim3(64 * nwb), smem, st, probs, ld, T, S, K, Lpad, lens, lablens, labx, alpha,
                        beta, pzx, diff, ldd, frames);
   };
   EESEN_REQUIRE(Lpad <= 4096, EESEN_ERR_INVALID, "ctc: expanded label length above 4096");

@@ -274,7 +274,7 @@ int eesen_ctc_destroy(eesen_ctc_t* ctc);
  * objective / frame counters reported by eesen_ctc_report.  Every sequence needs >= 1 label and a
  * feasible alignment is the caller's business (ln p ~ -1e30 otherwise, as in the reference).
  * Limits (EESEN_ERR_INVALID beyond them; the reference has none): at most 2047 labels per sequence -- expanded label sequences
- * of up to 4096 lattice positions -- and at most 5120 classes. */
+ * of up to 4096 lattice positions -- and at most 20480 classes (5120 before round 6's closing change). */
 int eesen_ctc_eval_parallel(eesen_ctc_t* ctc, const int* frame_num_utt, int S, const float* net_out_dev,
                             int rows, int K, int ld, const int* label_ids, const int* label_off,
                             float* diff_dev, int diff_ld, float* pzx_host);

@@ -946,13 +946,20 @@ def test_recovery_from_a_timed_out_persistent_kernel(gpu, monkeypatch, capfd):
     assert np.array_equal(bad.GetParams(), ref.GetParams())
 
 
-def test_ctc_with_thousands_of_classes(gpu):
-    """Word / BPE-sized output layers: the gradient pass stages 4 * (L' + K) floats in LDS per workgroup, beyond the default 64 KB
-    of dynamic LDS at K ~ 4000 (the kernel then asks for up to 160 KB)."""
+@pytest.mark.parametrize("K", [5000, 5121, 9000, 20480])
+def test_ctc_with_thousands_of_classes(gpu, K):
+    """Word / BPE-sized output layers: the gradient pass keeps 2 K floats per wave in LDS -- beyond the default 64 KB of dynamic LDS per
+    workgroup at K ~ 2000 (the kernel then asks for up to 160 KB), four waves per workgroup up to 5120 classes, two up to 10240, one up to
+    20480 (csrc/ctc.hip: ctc_error_diff); more than that is refused with a message."""
     from eesen_amd.api import CuMatrix, Ctc
+    from eesen_amd._lib import EesenError
     from oracle import net as onet
-    S, T, K = 3, 30, 5000
+    S, T = 3, 30
     lens, probs, labels = _random_ctc_case(S, T, K, 8, seed=99)
+    if K == 20480:
+        lens2, probs2, labels2 = _random_ctc_case(S, 4, K + 1, 2, seed=5)
+        with pytest.raises(EesenError, match="more than 20480 classes"):
+            Ctc().EvalParallel(lens2, CuMatrix.from_numpy(probs2), labels2)
     ids = np.concatenate(labels); off = np.concatenate([[0], np.cumsum([len(l) for l in labels])]).astype(np.int32)
     want = onet.ctc_eval_parallel(probs, T, S, lens, ids, off, "f32")
     ctc = Ctc()
